@@ -1,0 +1,235 @@
+"""numpy front end of the C oracle (oracle/ee_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; nothing under edge-enhancement_amd/ may import it.
+
+Each wrapper takes and returns numpy arrays; reference citations live next to
+the C functions.  Fixed 3x3 weights are produced by `gaussian_kernel` /
+`sobel_kernel`, restating utils/core.py:58-84 in numpy float64 exactly as the
+reference does, then cast to float32 as core.py:164,177,180 do.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libee_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ee_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.orc_ce_f32.restype = ctypes.c_double
+        _lib.orc_kl_f32.restype = ctypes.c_double
+        _lib.orc_softce_f64.restype = ctypes.c_double
+        _lib.orc_mse_f32.restype = ctypes.c_double
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+
+
+# ---- fixed weights (utils/core.py:58-84) -----------------------------------
+def gaussian_kernel(k=3, mu=0, sigma=1, normalize=True):
+    g1 = np.linspace(-1, 1, k)
+    x, y = np.meshgrid(g1, g1)
+    d = (x ** 2 + y ** 2) ** 0.5
+    g2 = np.exp(-(d - mu) ** 2 / (2 * sigma ** 2))
+    g2 = g2 / (2 * np.pi * sigma ** 2)
+    if normalize:
+        g2 = g2 / np.sum(g2)
+    return g2
+
+
+def sobel_kernel(k=3):
+    r = np.linspace(-(k // 2), k // 2, k)
+    x, y = np.meshgrid(r, r)
+    den = x ** 2 + y ** 2
+    den[:, k // 2] = 1
+    return x / den
+
+
+def edge_weights(sigma=1.0, mu=0.0):
+    g = gaussian_kernel(3, mu, sigma).astype(np.float32).reshape(9)
+    s = sobel_kernel(3)
+    return g, s.astype(np.float32).reshape(9), s.T.astype(np.float32).reshape(9).copy()
+
+
+# ---- PGD family -------------------------------------------------------------
+def pgd_init(x0, noise, lo=0.0, hi=1.0):
+    x0, noise = _f32(x0), _f32(noise)
+    x = np.empty_like(x0)
+    lib().orc_pgd_init_f32(_p(x), _p(x0), _p(noise), c_l(x0.size), c_f(lo), c_f(hi))
+    return x
+
+
+def pgd_step(x, g, x0, alpha, eps, lo=0.0, hi=1.0, direction=1):
+    x = _f32(x).copy()
+    g, x0 = _f32(g), _f32(x0)
+    lib().orc_pgd_step_f32(_p(x), _p(g), _p(x0), c_l(x.size), c_f(alpha), c_f(eps), c_f(lo), c_f(hi),
+                           c_i(direction))
+    return x
+
+
+def fgsm_step(x, g, alpha, lo=0.0, hi=1.0, direction=1):
+    x, g = _f32(x), _f32(g)
+    out = np.empty_like(x)
+    lib().orc_fgsm_step_f32(_p(out), _p(x), _p(g), c_l(x.size), c_f(alpha), c_f(lo), c_f(hi), c_i(direction))
+    return out
+
+
+def add_clamp(x, delta, lo=0.0, hi=1.0):
+    x, delta = _f32(x), _f32(delta)
+    out = np.empty_like(x)
+    lib().orc_add_clamp_f32(_p(out), _p(x), _p(delta), c_l(x.size), c_f(lo), c_f(hi))
+    return out
+
+
+def freeat_update(delta, g, alpha, eps):
+    delta = _f32(delta).copy()
+    g = _f32(g)
+    lib().orc_freeat_update_f32(_p(delta), _p(g), c_l(g.size), c_f(alpha), c_f(eps))
+    return delta
+
+
+def avmix(x, x0, wgt, gamma):
+    x, x0 = _f32(x), _f32(x0)
+    wgt = np.ascontiguousarray(wgt, dtype=np.float64).reshape(-1)
+    out = np.empty_like(x)
+    B = x.shape[0]
+    lib().orc_avmix_f32(_p(out), _p(x), _p(x0), _p(wgt), c_l(B), c_l(x.size // B), c_f(gamma))
+    return out
+
+
+# ---- edge filter ------------------------------------------------------------
+def edge125_fwd(x, alpha, high, sigma=1.0, want_internals=False):
+    x = _f32(x)
+    B, C, H, W = x.shape
+    g9, sx9, sy9 = edge_weights(sigma)
+    edge = np.empty((B, 1, H, W), np.float32)
+    if want_internals:
+        mag, gx, gy = (np.empty((B, 1, H, W), np.float32) for _ in range(3))
+    else:
+        mag = gx = gy = None
+    lib().orc_edge125_fwd_f32(_p(x), c_i(B), c_i(C), c_i(H), c_i(W), _p(g9), _p(sx9), _p(sy9),
+                              c_f(alpha), c_f(high), _p(edge), _p(mag), _p(gx), _p(gy))
+    return (edge, mag, gx, gy) if want_internals else edge
+
+
+def edge125_bwd(x, u, alpha, high, sigma=1.0):
+    x, u = _f32(x), _f32(u)
+    B, C, H, W = x.shape
+    g9, sx9, sy9 = edge_weights(sigma)
+    out = np.empty((B, 1, H, W), np.float32)
+    lib().orc_edge125_bwd_f32(_p(x), _p(u), c_i(B), c_i(C), c_i(H), c_i(W), _p(g9), _p(sx9), _p(sy9),
+                              c_f(alpha), c_f(high), _p(out))
+    return out
+
+
+def frontend_fwd(x, x_hfs, alpha, high, w, sigma=1.0):
+    x, x_hfs = _f32(x), _f32(x_hfs)
+    B, C, H, W = x.shape
+    g9, sx9, sy9 = edge_weights(sigma)
+    x_in = np.empty_like(x)
+    gate = np.empty(x.shape, np.uint8)
+    edge = np.empty((B, 1, H, W), np.float32)
+    lib().orc_frontend_fwd_f32(_p(x), _p(x_hfs), c_i(B), c_i(C), c_i(H), c_i(W), _p(g9), _p(sx9), _p(sy9),
+                               c_f(alpha), c_f(high), c_f(w), _p(x_in), _p(gate), _p(edge))
+    return x_in, gate, edge
+
+
+def frontend_bwd(g_in, gate, x, alpha, high, w, sigma=1.0):
+    g_in, x = _f32(g_in), _f32(x)
+    gate = np.ascontiguousarray(gate, dtype=np.uint8)
+    B, C, H, W = x.shape
+    g9, sx9, sy9 = edge_weights(sigma)
+    g_hfs = np.empty_like(x)
+    g_edge = np.empty((B, 1, H, W), np.float32)
+    lib().orc_frontend_bwd_f32(_p(g_in), _p(gate), _p(x), c_i(B), c_i(C), c_i(H), c_i(W), _p(g9), _p(sx9),
+                               _p(sy9), c_f(alpha), c_f(high), c_f(w), _p(g_hfs), _p(g_edge))
+    return g_hfs, g_edge
+
+
+# ---- losses -----------------------------------------------------------------
+def ce(logits, y, mean=False, want_grad=True):
+    z = _f32(logits)
+    y = np.ascontiguousarray(y, dtype=np.int64)
+    B, K = z.shape
+    d = np.empty_like(z) if want_grad else None
+    v = lib().orc_ce_f32(_p(z), _p(y), c_i(B), c_i(K), c_i(1 if mean else 0), _p(d))
+    return v, d
+
+
+def kl_batchmean(zq, zp):
+    zq, zp = _f32(zq), _f32(zp)
+    B, K = zq.shape
+    dq, dp = np.empty_like(zq), np.empty_like(zp)
+    v = lib().orc_kl_f32(_p(zq), _p(zp), c_i(B), c_i(K), _p(dq), _p(dp))
+    return v, dq, dp
+
+
+def softce(z, t, scale):
+    z = _f32(z)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    B, K = z.shape
+    dz = np.empty((B, K), np.float64)
+    v = lib().orc_softce_f64(_p(z), _p(t), c_i(B), c_i(K), ctypes.c_double(scale), _p(dz))
+    return v, dz
+
+
+def mse(a, b):
+    a, b = _f32(a), _f32(b)
+    da = np.empty_like(a)
+    v = lib().orc_mse_f32(_p(a), _p(b), c_l(a.size), _p(da))
+    return v, da
+
+
+def topk(logits, y, k):
+    z = _f32(logits)
+    y = np.ascontiguousarray(y, dtype=np.int64)
+    B, K = z.shape
+    idx = np.empty((B, k), np.int64)
+    correct = np.zeros(k, np.int64)
+    lib().orc_topk_i64(_p(z), _p(y), c_i(B), c_i(K), c_i(k), _p(idx), _p(correct))
+    return idx, correct
+
+
+def label_smoothing(onehot, factor, num_classes):
+    """utils/attacks.py:444-445 (AVmixup._label_smoothing), float32 like the reference."""
+    onehot = _f32(onehot)
+    return onehot * np.float32(factor) + (onehot - np.float32(1.0)) * np.float32((factor - 1) / float(num_classes - 1))
+
+
+def hfs_mask(w, h, r):
+    """utils/core.py:23-42 HighFreqSuppress.templete()."""
+    temp = np.zeros((w, h), "float32")
+    cw, ch = w // 2, h // 2
+    dw = r if w % 2 == 0 else r + 1
+    dh = r if h % 2 == 0 else r + 1
+    temp[cw - r:cw + dw, ch - r:ch + dh] = 1.0
+    temp = np.roll(temp, -cw, axis=0)
+    temp = np.roll(temp, -ch, axis=1)
+    return temp

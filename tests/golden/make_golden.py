@@ -1,0 +1,473 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    python tests/golden/make_golden.py
+
+How the reference is imported
+-----------------------------
+`utils/attacks.py` and `utils/core.py` import three modules this image lacks
+(`torch._six` via utils/_jit_internal.py:9, `cv2` at attacks.py:8 / core.py:10,
+`torchvision` in the model files).  They are registered in `sys.modules` as
+EMPTY `types.ModuleType` objects (only `torch._six.builtins`, needed by the
+import statement itself, is set).  Nothing computed below touches them, with
+ONE exception that is handled explicitly:
+
+* `get_thin_kernels()` (core.py:87-112) needs real `cv2.getRotationMatrix2D`
+  / `cv2.warpAffine`.  Every Canny class calls it in `__init__`.  It is
+  replaced by the analytically derived table `THIN_TABLE` below.
+  - `CannyFilter_step125_1.forward` (core.py:549-585) never reads
+    `weight_directional`, so its fixtures are unaffected by that table and are
+    genuinely pinned to the reference.
+  - `CannyFilter` / `CannyFilter_BPDA` fixtures DO depend on the table; they
+    are written to `canny_full_unpinned.npz` and are labelled
+    "parity unpinned" wherever they are used.
+
+The fixtures hold data only (inputs, seeds, outputs) - no reference source.
+"""
+import builtins
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+_six = types.ModuleType("torch._six")
+_six.builtins = builtins
+sys.modules["torch._six"] = _six
+sys.modules["cv2"] = types.ModuleType("cv2")
+_tv = types.ModuleType("torchvision")
+_tvm = types.ModuleType("torchvision.models")
+_tv.models = _tvm
+sys.modules["torchvision"] = _tv
+sys.modules["torchvision.models"] = _tvm
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "MNIST"))
+sys.path.insert(0, os.path.join(REF, "Tiny_ImageNet"))
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import utils.attacks as rattacks  # noqa: E402
+import utils.core as rcore  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# k*45 degrees -> (row, col) of the -1 neighbour in the 3x3 directional kernel
+# (centre is +1).  Derived from core.py:87-112 (rotation of [0,0,1,-1,-1] about
+# the centre, counter-clockwise in image coordinates); real cv2 unavailable.
+THIN_TABLE = {0: (1, 2), 1: (0, 2), 2: (0, 1), 3: (0, 0), 4: (1, 0), 5: (2, 0), 6: (2, 1), 7: (2, 2)}
+
+
+def derived_thin_kernels(start=0, end=360, step=45):
+    ks = []
+    for angle in range(start, end, step):
+        k = np.zeros((3, 3))
+        k[1, 1] = 1
+        r, c = THIN_TABLE[(angle // 45) % 8]
+        k[r, c] = -1
+        ks.append(k)
+    return ks
+
+
+rcore.get_thin_kernels = derived_thin_kernels
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+class Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+# --------------------------------------------------------------------------
+# 1. fixed weights and masks
+# --------------------------------------------------------------------------
+def gen_kernels():
+    out = {
+        "gauss_k3_mu0_s1": rcore.get_gaussian_kernel(3, 0, 1),
+        "gauss_k3_mu0_s2": rcore.get_gaussian_kernel(3, 0, 2.0),
+        "gauss_k5_mu0_s1": rcore.get_gaussian_kernel(5, 0, 1),
+        "gauss_k3_unnorm": rcore.get_gaussian_kernel(3, 0, 1, normalize=False),
+        "sobel_k3": rcore.get_sobel_kernel(3),
+        "sobel_k5": rcore.get_sobel_kernel(5),
+    }
+    for (w, h, r) in [(64, 64, 8), (28, 28, 4), (224, 224, 16), (7, 9, 2), (32, 32, 4)]:
+        m = rcore.HighFreqSuppress(w, h, r)
+        out["hfs_mask_%d_%d_%d" % (w, h, r)] = m.temp.numpy()[0, 0, :, :, 0].astype(np.uint8)
+    save("kernels", **out)
+
+
+# --------------------------------------------------------------------------
+# 2. CannyFilter_step125_1 forward + backward
+# --------------------------------------------------------------------------
+def rect_image(B, C, H, W, seed):
+    """Piece-wise constant image (MNIST-like): exercises mag == 0 -> NaN grads."""
+    rng = np.random.RandomState(seed)
+    x = np.zeros((B, C, H, W), np.float32)
+    for b in range(B):
+        for _ in range(3):
+            h0, w0 = rng.randint(0, H - 4), rng.randint(0, W - 4)
+            h1, w1 = rng.randint(h0 + 2, H), rng.randint(w0 + 2, W)
+            for c in range(C):
+                x[b, c, h0:h1, w0:w1] = np.float32(rng.choice([0.25, 0.5, 0.75, 1.0]))
+    return x
+
+
+def ramp_images(C, H, W, high):
+    """Horizontal ramps whose Sobel magnitude sits within a few ulp of `high`."""
+    xs = []
+    base = np.float32(high) / np.float32(4.0)
+    for k in range(-3, 4):
+        a = np.float32(base) * (np.float32(1.0) + np.float32(k) * np.float32(2.0 ** -23))
+        row = (np.arange(W, dtype=np.float32) * a).astype(np.float32)
+        xs.append(np.broadcast_to(row, (C, H, W)).copy())
+    return np.stack(xs).astype(np.float32)
+
+
+def run_edge125(x_np, alpha, high, seed_u):
+    filt = rcore.CannyFilter_step125_1(sigma=1, alpha=alpha)
+    x = torch.from_numpy(x_np.copy()).requires_grad_(True)
+    e = filt(x, low_threshold=high / 2, high_threshold=high, hysteresis=True)
+    g = torch.Generator().manual_seed(seed_u)
+    u = torch.randn(e.shape, generator=g)
+    (e * u).sum().backward()
+    return e.detach().numpy().astype(np.uint8), u.numpy(), x.grad.numpy()
+
+
+def gen_edge125():
+    # NOTE: every case has batch >= 2.  torch routes N == 1 small 3x3 convolutions through its
+    # im2col+GEMM path, whose summation order differs (by rounding noise) from the oneDNN direct
+    # convolution used for N > 1 - the shape class of every reference config (B = 50 / 100 / 256).
+    cases = {}
+    torch.manual_seed(0)
+    cases["rand_tiny"] = (torch.rand(2, 3, 64, 64).numpy(), 0.0, 76.0 / 255)
+    torch.manual_seed(0)
+    cases["rand_mnist"] = (torch.rand(2, 1, 28, 28).numpy(), 0.3, 51.0 / 255)
+    cases["rect_mnist"] = (rect_image(2, 1, 28, 28, 3), 0.3, 51.0 / 255)
+    cases["rect_rgb"] = (rect_image(2, 3, 32, 32, 4), 0.0, 76.0 / 255)
+    cases["ramp_thr"] = (ramp_images(3, 16, 16, 76.0 / 255), 0.0, 76.0 / 255)
+    torch.manual_seed(5)
+    cases["ragged"] = (torch.rand(2, 3, 17, 23).numpy(), 0.0, 76.0 / 255)
+    torch.manual_seed(6)
+    cases["two_ch"] = (torch.rand(3, 2, 5, 9).numpy(), 0.1, 0.2)
+    torch.manual_seed(7)
+    cases["one_px"] = (torch.rand(2, 3, 1, 1).numpy(), 0.0, 76.0 / 255)
+    torch.manual_seed(8)
+    cases["thin"] = (torch.rand(2, 1, 1, 40).numpy(), 0.0, 0.1)
+    torch.manual_seed(9)
+    # smooth image scaled so that many magnitudes exceed 1.001 (upper gate)
+    cases["big_mag"] = ((torch.rand(2, 3, 24, 24) * 6.0).numpy(), 0.0, 76.0 / 255)
+    out = {}
+    for name, (x, alpha, high) in cases.items():
+        e, u, gx = run_edge125(x, alpha, high, 11)
+        out[name + "__x"] = x.astype(np.float32)
+        out[name + "__alpha_high"] = np.array([alpha, high], np.float64)
+        out[name + "__edge"] = e
+        out[name + "__u"] = u
+        out[name + "__gx"] = gx
+        print("  edge125", name, x.shape, "edges", int(e.sum()), "nan grads", int(np.isnan(gx).sum()))
+    save("edge125", **out)
+
+
+# --------------------------------------------------------------------------
+# 3. the PGD / FGSM update, recorded step by step
+# --------------------------------------------------------------------------
+class TinyNet(nn.Module):
+    """A small differentiable classifier with exact-zero gradients (ReLU) so
+    that sign(0) = 0 is exercised.  Seeded; rebuilt identically in tests."""
+
+    def __init__(self, cin, hw, ncls, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w1 = nn.Parameter(torch.randn(8, cin, 3, 3, generator=g) * 0.5)
+        self.w2 = nn.Parameter(torch.randn(ncls, 8 * (hw // 2) * (hw // 2), generator=g) * 0.2)
+
+    def forward(self, x):
+        h = F.relu(F.conv2d(x, self.w1, padding=1))
+        h = F.avg_pool2d(h, 2)
+        return F.linear(h.flatten(1), self.w2)
+
+
+class Recorder(nn.Module):
+    """Wraps a model; records every input it is called with and the gradient
+    that later arrives at that input."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+        self.xs, self.gs = [], []
+
+    def forward(self, x):
+        self.xs.append(x.detach().clone().numpy())
+        if x.requires_grad:
+            x.register_hook(lambda g: self.gs.append(g.detach().clone().numpy()))
+        return self.m(x)
+
+
+def gen_pgd():
+    out = {}
+    B, C, HW, K = 3, 2, 8, 10
+    torch.manual_seed(21)
+    x0 = torch.rand(B, C, HW, HW)
+    # make some pixels sit on the [0,1] and eps-box borders
+    x0[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 0.001, 0.999])
+    y = torch.tensor([1, 0, 4])
+    eps, alpha, steps = 0.062745098039216, 0.007843137254902, 6
+    out["x0"], out["y"] = x0.numpy(), y.numpy()
+    out["eps_alpha"] = np.array([eps, alpha], np.float64)
+
+    # (a) untargeted PGD with random start
+    rec = Recorder(TinyNet(C, HW, K, 31))
+    torch.manual_seed(100)
+    xa = rattacks.PGD(rec, Args(random=True, epsilon=eps), x0, y, steps, alpha)
+    torch.manual_seed(100)
+    noise = torch.zeros_like(x0).uniform_(-eps, eps)
+    out["pgd_noise"] = noise.numpy()
+    out["pgd_xs"] = np.stack(rec.xs)
+    out["pgd_gs"] = np.stack(rec.gs)
+    out["pgd_final"] = xa.numpy()
+
+    # (b) untargeted PGD without random start, MNIST-like parameters
+    rec = Recorder(TinyNet(C, HW, K, 32))
+    xb = rattacks.PGD(rec, Args(random=False, epsilon=0.3), x0, y, 8, 0.01)
+    out["pgdb_xs"], out["pgdb_gs"], out["pgdb_final"] = np.stack(rec.xs), np.stack(rec.gs), xb.numpy()
+
+    # (c) targeted PGD (descent)
+    rec = Recorder(TinyNet(C, HW, K, 33))
+    torch.manual_seed(101)
+    xc, tl = rattacks.targeted_PGD(rec, Args(random=True, epsilon=eps), x0, y, steps, alpha, K, "cpu")
+    torch.manual_seed(101)
+    off = torch.randint(low=1, high=K, size=y.shape)
+    noise_c = torch.zeros_like(x0).uniform_(-eps, eps)
+    out["tpgd_offset"], out["tpgd_noise"] = off.numpy(), noise_c.numpy()
+    out["tpgd_target"] = tl.numpy()
+    out["tpgd_xs"], out["tpgd_gs"], out["tpgd_final"] = np.stack(rec.xs), np.stack(rec.gs), xc.numpy()
+
+    # (d) FGSM, both directions
+    for targeted in (False, True):
+        rec = Recorder(TinyNet(C, HW, K, 34))
+        xf = rattacks.FGSM(rec, x0, y, targeted=targeted, step_size=0.007)
+        tag = "fgsm_t" if targeted else "fgsm_u"
+        out[tag + "_g"], out[tag + "_final"] = rec.gs[0], xf.numpy()
+
+    # (e) a gradient with NaN / +-0 / inf entries through the PGD update lines
+    class FixedGrad(nn.Module):
+        def __init__(self, g):
+            super().__init__()
+            self.g = g
+
+        def forward(self, x):
+            # logits whose dCE/dx is dominated by self.g; NaNs are injected by hook
+            x.register_hook(lambda gr: self.g)
+            return (x * 0).flatten(1)[:, :K] + x.flatten(1)[:, :K]
+
+    gspec = torch.randn(B, C, HW, HW)
+    gspec[0, 0, 0, :6] = torch.tensor([float("nan"), 0.0, -0.0, float("inf"), -float("inf"), 1e-40])
+    xe = rattacks.PGD(FixedGrad(gspec), Args(random=False, epsilon=eps), x0, y, 1, alpha)
+    out["special_g"], out["special_final"] = gspec.numpy(), xe.numpy()
+    save("pgd_steps", **out)
+
+
+# --------------------------------------------------------------------------
+# 4. losses
+# --------------------------------------------------------------------------
+def gen_losses():
+    out = {}
+    for tag, (B, K, seed) in {"s": (4, 10, 2), "t": (16, 200, 3), "i": (5, 1000, 4)}.items():
+        torch.manual_seed(seed)
+        la = (torch.randn(B, K) * 2).requires_grad_(True)
+        lb = (torch.randn(B, K) * 2).requires_grad_(True)
+        y = torch.randint(0, K, (B,))
+        out[tag + "_la"], out[tag + "_lb"], out[tag + "_y"] = la.detach().numpy(), lb.detach().numpy(), y.numpy()
+
+        ce_sum = F.cross_entropy(la, y, reduction="sum")
+        (g_ce_sum,) = torch.autograd.grad(ce_sum, la)
+        ce_mean = F.cross_entropy(la, y)
+        (g_ce_mean,) = torch.autograd.grad(ce_mean, la)
+        out[tag + "_ce_sum"], out[tag + "_ce_sum_g"] = ce_sum.item(), g_ce_sum.numpy()
+        out[tag + "_ce_mean"], out[tag + "_ce_mean_g"] = ce_mean.item(), g_ce_mean.numpy()
+
+        tr = rattacks.Trades(beta=6.0)
+        kl = tr.criterion_kl(F.log_softmax(lb, dim=1), F.softmax(la, dim=-1))
+        g_kl_b, g_kl_a = torch.autograd.grad(kl, [lb, la])
+        out[tag + "_kl"], out[tag + "_kl_gq"], out[tag + "_kl_gp"] = kl.item(), g_kl_b.numpy(), g_kl_a.numpy()
+
+        mse = F.mse_loss(la, lb)
+        out[tag + "_mse"] = mse.item()
+
+        class _Opt:
+            def zero_grad(self):
+                pass
+
+        alp = rattacks.ALP(beta=0.5).loss(nn.Identity(), la, lb, y, _Opt())
+        ga, gb = torch.autograd.grad(alp, [la, lb])
+        out[tag + "_alp"], out[tag + "_alp_ga"], out[tag + "_alp_gb"] = alp.item(), ga.numpy(), gb.numpy()
+
+        # Trades.loss: model(x_adv) -> use a linear "model" so that logits_adv = lb-like
+        lin = nn.Linear(K, K, bias=False)
+        with torch.no_grad():
+            lin.weight.copy_(torch.eye(K))
+        xadv = lb.detach().clone()
+        tl = tr.loss(lin, la, xadv, y, _Opt())
+        (g_tl,) = torch.autograd.grad(tl, la)
+        out[tag + "_trades"], out[tag + "_trades_ga"] = tl.item(), g_tl.numpy()
+
+        ls = rattacks.LabelSmoothLoss(0.1)(la, y)
+        (g_ls,) = torch.autograd.grad(ls, la)
+        out[tag + "_lsmooth"], out[tag + "_lsmooth_g"] = ls.item(), g_ls.numpy()
+        out[tag + "_cle"] = rattacks.compute_loss_and_error(la, y, 0.2).item()
+        out[tag + "_pred"] = rattacks.predict_from_logits(la).numpy()
+
+        av = rattacks.AVmixup(Args(random=False, epsilon=0.1), 2.0, 1.0, 0.1, 0.01, 1, num_classes=K, device="cpu")
+        onehot = torch.eye(K)[y]
+        out[tag + "_smooth_l1"] = av._label_smoothing(onehot, 1.0).numpy()
+        out[tag + "_smooth_l2"] = av._label_smoothing(onehot, 0.1).numpy()
+        # soft-label loss used inside AVmixup.perturb (attacks.py:462-463) and by the driver
+        soft = av._label_smoothing(onehot, 0.1).double()
+        sl = -torch.sum(F.log_softmax(la, dim=1) * soft) / B
+        (g_sl,) = torch.autograd.grad(sl, la)
+        out[tag + "_softce_f64"], out[tag + "_softce_g"] = sl.item(), g_sl.numpy()
+        out[tag + "_l2norm"] = rattacks.l2_norm(la.detach().view(B, 1, 1, K)).numpy()
+    save("losses", **out)
+
+
+# --------------------------------------------------------------------------
+# 5. AVmixup.perturb / CW (targeted) end to end on TinyNet
+# --------------------------------------------------------------------------
+def gen_avmix_cw():
+    out = {}
+    B, C, HW, K = 4, 2, 8, 10
+    torch.manual_seed(41)
+    x0 = torch.rand(B, C, HW, HW)
+    y = torch.tensor([3, 1, 0, 7])
+    eps, alpha = 0.062745098039216, 0.003921568627451
+    out["x0"], out["y"] = x0.numpy(), y.numpy()
+    out["eps_alpha"] = np.array([eps, alpha], np.float64)
+
+    rec = Recorder(TinyNet(C, HW, K, 51))
+    av = rattacks.AVmixup(Args(random=True, epsilon=eps), 2.0, 1.0, 0.1, alpha, 5, num_classes=K, device="cpu")
+    torch.manual_seed(200)
+    np.random.seed(201)
+    xm, ym = av.perturb(rec, x0, torch.eye(K)[y])
+    torch.manual_seed(200)
+    noise = torch.zeros_like(x0).uniform_(-eps, eps)
+    np.random.seed(201)
+    beta = np.random.beta(1.0, 1.0, [B, 1, 1, 1])
+    out["av_noise"], out["av_beta"] = noise.numpy(), beta
+    out["av_xs"], out["av_gs"] = np.stack(rec.xs), np.stack(rec.gs)
+    out["av_x"], out["av_y"] = xm.numpy(), ym.numpy()
+    assert ym.dtype == torch.float64 and xm.dtype == torch.float32
+
+    # CW-Linf, targeted form (the only one that runs in the reference)
+    net = TinyNet(C, HW, K, 52)
+    tgt = torch.tensor([4, 2, 1, 8])
+    torch.manual_seed(202)
+    adv, p = rattacks.CWLinfAttack(x0, net(x0).argmax(1), net, eps, None, eps, max_iters=4, target=tgt,
+                                   n_class=K, cur_device="cpu")
+    torch.manual_seed(202)
+    rp = torch.FloatTensor(x0.shape).uniform_(-eps, eps)
+    out["cw_noise"], out["cw_target"] = rp.numpy(), tgt.numpy()
+    out["cw_adv"], out["cw_p"] = adv.detach().numpy(), p.detach().numpy()
+    save("avmix_cw", **out)
+
+
+# --------------------------------------------------------------------------
+# 6. end-to-end: reference models through reference PGD (weights re-seeded in tests)
+# --------------------------------------------------------------------------
+def state_checksum(model):
+    s = 0.0
+    for p in model.state_dict().values():
+        s += float(p.double().abs().sum())
+    return s
+
+
+def gen_e2e():
+    out = {}
+    from models_mnist.Net2 import Net_2
+    torch.manual_seed(7)
+    net = Net_2().eval()
+    out["net2_checksum"] = state_checksum(net)
+    torch.manual_seed(1)
+    x = torch.rand(6, 1, 28, 28)
+    y = torch.randint(0, 10, (6,))
+    torch.manual_seed(300)
+    xa = rattacks.PGD(net, Args(random=True, epsilon=0.3), x, y, 40, 0.01)
+    torch.manual_seed(300)
+    out["net2_noise"] = torch.zeros_like(x).uniform_(-0.3, 0.3).numpy()
+    with torch.no_grad():
+        out["net2_logits_clean"] = net(x).numpy()
+        out["net2_logits_adv"] = net(xa).numpy()
+    out["net2_x"], out["net2_y"], out["net2_xadv"] = x.numpy(), y.numpy(), xa.numpy()
+
+    # load resnet.py as a plain file: the package __init__ pulls in resnet_EE*.py,
+    # which need torchvision.transforms / turtle and hard-code .cuda()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_tiny_resnet", os.path.join(REF, "Tiny_ImageNet", "models_tinyimagenet", "resnet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    resnet18 = mod.resnet18
+    torch.manual_seed(8)
+    rn = resnet18().eval()
+    out["rn18_checksum"] = state_checksum(rn)
+    torch.manual_seed(2)
+    x = torch.rand(2, 3, 64, 64)
+    y = torch.randint(0, 200, (2,))
+    eps, alpha = 0.062745098039216, 0.007843137254902
+    torch.manual_seed(301)
+    xa = rattacks.PGD(rn, Args(random=True, epsilon=eps), x, y, 3, alpha)
+    torch.manual_seed(301)
+    out["rn18_noise"] = torch.zeros_like(x).uniform_(-eps, eps).numpy()
+    with torch.no_grad():
+        out["rn18_logits_clean"] = rn(x).numpy()
+        out["rn18_logits_adv"] = rn(xa).numpy()
+    out["rn18_x"], out["rn18_y"], out["rn18_xadv"] = x.numpy(), y.numpy(), xa.numpy()
+    save("e2e", **out)
+
+
+# --------------------------------------------------------------------------
+# 7. full Canny / BPDA (depends on the DERIVED thin-kernel table -> unpinned)
+# --------------------------------------------------------------------------
+def gen_canny_full():
+    out = {}
+    torch.manual_seed(12)
+    xs = {"rand_rgb": (torch.rand(2, 3, 32, 32).numpy(), 0.0, 38.0 / 255, 76.0 / 255),
+          "rand_mnist": (torch.rand(2, 1, 28, 28).numpy(), 0.3, 25.0 / 255, 51.0 / 255),
+          "rect_rgb": (rect_image(2, 3, 32, 32, 14), 0.0, 38.0 / 255, 76.0 / 255)}
+    for name, (x_np, alpha, low, high) in xs.items():
+        for cls_name in ("CannyFilter", "CannyFilter_BPDA"):
+            filt = getattr(rcore, cls_name)(sigma=1, alpha=alpha)
+            x = torch.from_numpy(x_np.copy()).requires_grad_(True)
+            e = filt(x, low_threshold=low, high_threshold=high, hysteresis=True)
+            g = torch.Generator().manual_seed(13)
+            u = torch.randn(e.shape, generator=g)
+            (e * u).sum().backward()
+            key = name + "__" + cls_name
+            out[key + "__edge"] = e.detach().numpy().astype(np.float32)
+            out[key + "__gx"] = x.grad.numpy()
+            out[name + "__u"] = u.numpy()
+            print("  canny_full", key, "edges", float(e.sum()), "nan", int(np.isnan(x.grad.numpy()).sum()))
+        out[name + "__x"] = x_np
+        out[name + "__alpha_low_high"] = np.array([alpha, low, high], np.float64)
+    save("canny_full_unpinned", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    gen_kernels()
+    gen_edge125()
+    gen_pgd()
+    gen_losses()
+    gen_avmix_cw()
+    gen_e2e()
+    gen_canny_full()
