@@ -1,0 +1,71 @@
+// ee_common.hpp - shared device/host helpers for libeeadv (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "eeadv.h"
+
+#define EE_API extern "C" __attribute__((visibility("default")))
+
+namespace ee {
+
+constexpr int kWave = 64;         // CDNA wavefront
+constexpr int kBlock = 256;       // 4 waves per workgroup
+constexpr int kMaxGrid = 256 * 8; // 256 CUs x 8 workgroups: cap, then grid-stride
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+// ---- timing hooks (ee_prof.hip) ---------------------------------------------------------------
+struct ProfScope {
+    int id;
+    hipStream_t stream;
+    void *slot;
+    ProfScope(int kernel_id, hipStream_t s);
+    ~ProfScope();
+};
+
+static inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? EE_OK : static_cast<int>(e);
+}
+
+// ---- device arithmetic with the reference's (torch) semantics ---------------------------------
+// torch.sign: sign(+-0) = 0, sign(NaN) = 0
+__device__ __forceinline__ float sgn(float g) { return static_cast<float>((g > 0.0f) - (g < 0.0f)); }
+// torch.max / torch.min (binary): NaN in either operand propagates
+__device__ __forceinline__ float tmax(float a, float b) { return (a != a || b != b) ? (a + b) : (a > b ? a : b); }
+__device__ __forceinline__ float tmin(float a, float b) { return (a != a || b != b) ? (a + b) : (a < b ? a : b); }
+// torch.clamp(v, lo, hi); NaN propagates
+__device__ __forceinline__ float tclamp(float v, float lo, float hi) {
+    float r = v < lo ? lo : v;
+    r = r > hi ? hi : r;
+    return (v != v) ? v : r;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- Philox4x32-10 ----------------------------------------------------------------------------
+struct Philox {
+    uint32_t k0, k1;
+    __device__ Philox(uint64_t seed) : k0(static_cast<uint32_t>(seed)), k1(static_cast<uint32_t>(seed >> 32)) {}
+    __device__ uint4 operator()(uint64_t ctr, uint32_t stream_id = 0) const {
+        uint32_t c0 = static_cast<uint32_t>(ctr), c1 = static_cast<uint32_t>(ctr >> 32), c2 = stream_id, c3 = 0;
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            const uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+// 24 random bits -> [0,1), as torch's uniform_ does for float
+__device__ __forceinline__ float u01(uint32_t r) { return static_cast<float>(r >> 8) * (1.0f / 16777216.0f); }
+
+}  // namespace ee

@@ -1,0 +1,83 @@
+"""ctypes binding of libeeadv.so (include/eeadv.h) - the only doorway from Python to the HIP kernels.
+
+The library is built in-tree by `make -C edge-enhancement_amd/csrc` (or `__graft_entry__.build()`).
+There is NO fallback: if the shared object is missing, fails to load, or lacks a symbol declared in
+include/eeadv.h, importing this module raises - a GPU run can never silently use a CPU path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libeeadv.so")
+
+c_f, c_d, c_i, c_l, c_p = ctypes.c_float, ctypes.c_double, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+c_u64 = ctypes.c_uint64
+
+# symbol -> argtypes, exactly the prototypes of include/eeadv.h (return type int unless listed in _RESTYPE)
+SIGNATURES = {
+    "ee_abi_version": [],
+    "ee_strerror": [c_i],
+    "ee_device_name": [],
+    "ee_pgd_init_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_p],
+    "ee_pgd_init_rng_f32": [c_p, c_p, c_l, c_f, c_i, c_u64, c_u64, c_f, c_f, c_p],
+    "ee_pgd_step_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_p],
+    "ee_fgsm_step_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_i, c_p],
+    "ee_add_clamp_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_p],
+    "ee_freeat_update_f32": [c_p, c_p, c_l, c_f, c_f, c_p],
+    "ee_avmix_f32": [c_p, c_p, c_p, c_p, c_l, c_l, c_f, c_p],
+    "ee_avmix_labels_f64": [c_p, c_p, c_p, c_l, c_l, c_f, c_f, c_p],
+    "ee_edge125_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_p, c_p, c_p],
+    "ee_edge125_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_p, c_p],
+    "ee_frontend_fwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
+    "ee_frontend_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_p, c_p, c_p],
+    "ee_pgd_step_bcast_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_f, c_f, c_f, c_f, c_i, c_p],
+    "ee_ce_f32": [c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p],
+    "ee_kl_f32": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
+    "ee_softce_f64": [c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p],
+    "ee_mse_f32": [c_p, c_p, c_l, c_f, c_p, c_p, c_p],
+    "ee_mse_num_partials": [c_l],
+    "ee_reduce_rows_f64": [c_p, c_l, c_d, c_p, c_p],
+    "ee_topk_i64": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "ee_add_square_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    "ee_add_square_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    "ee_prof_enable": [c_i],
+    "ee_prof_read": [c_i, c_p, c_p],
+    "ee_prof_reset": [],
+}
+_RESTYPE = {"ee_strerror": ctypes.c_char_p, "ee_device_name": ctypes.c_char_p, "ee_mse_num_partials": c_l}
+
+# kernel-family ids of include/eeadv.h (ee_prof_*)
+K_PGD_STEP, K_FRONTEND_FWD, K_FRONTEND_BWD, K_EDGE_FWD, K_EDGE_BWD, K_CE, K_PGD_STEP_BCAST = range(7)
+
+
+class EEError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libeeadv.so not found at %s - build it with `make -C edge-enhancement_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:  # header / library drift must be loud
+            raise ImportError("libeeadv.so does not export %s (stale build?)" % name) from exc
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_i)
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib.ee_strerror(rc)
+        raise EEError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", rc))
+
+
+def abi_version():
+    return lib.ee_abi_version()

@@ -1,0 +1,312 @@
+"""Tensor-level wrappers over the C ABI (include/eeadv.h).
+
+Every function takes ROCm tensors, checks device / dtype / contiguity / shape on the host (a wrong shape
+must never reach a kernel), and enqueues ONE library call on torch's current HIP stream.  Nothing here
+computes on the CPU and nothing falls back to torch ops: a CPU tensor raises.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+_INF = float("inf")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise N.EEError("%s is on %s: the eeadv kernels only run on a ROCm device (no CPU fallback)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _opt(t, dtype, name, shape=None):
+    return None if t is None else _chk(t, dtype, name, shape)
+
+
+# ---- fixed 3x3 weights (utils/core.py:58-84, restated in numpy float64 then cast like core.py:164,177,180) ----
+def gaussian_kernel_np(k=3, mu=0, sigma=1, normalize=True):
+    g1 = np.linspace(-1, 1, k)
+    x, y = np.meshgrid(g1, g1)
+    d = (x ** 2 + y ** 2) ** 0.5
+    g2 = np.exp(-(d - mu) ** 2 / (2 * sigma ** 2))
+    g2 = g2 / (2 * np.pi * sigma ** 2)
+    if normalize:
+        g2 = g2 / np.sum(g2)
+    return g2
+
+
+def sobel_kernel_np(k=3):
+    rng = np.linspace(-(k // 2), k // 2, k)
+    x, y = np.meshgrid(rng, rng)
+    den = x ** 2 + y ** 2
+    den[:, k // 2] = 1
+    return x / den
+
+
+class EdgeWeights:
+    """The 27 host floats every edge kernel takes (Gaussian, Sobel-x, Sobel-y)."""
+
+    def __init__(self, sigma=1.0, mu=0.0):
+        g = gaussian_kernel_np(3, mu, sigma).astype(np.float32).reshape(9)
+        s = sobel_kernel_np(3)
+        self.host = np.concatenate([g, s.astype(np.float32).reshape(9), s.T.astype(np.float32).reshape(9)])
+        self.host = np.ascontiguousarray(self.host, dtype=np.float32)
+        self.ptr = self.host.ctypes.data_as(ctypes.c_void_p)
+
+
+# ---- PGD family ------------------------------------------------------------------------------------------
+def pgd_init(x0, noise, lo=0.0, hi=1.0, out=None):
+    p0 = _chk(x0, torch.float32, "x0")
+    pn = _chk(noise, torch.float32, "noise", x0.shape)
+    out = torch.empty_like(x0) if out is None else out
+    po = _chk(out, torch.float32, "out", x0.shape)
+    N.check(N.lib.ee_pgd_init_f32(po, p0, pn, x0.numel(), lo, hi, _stream()), "ee_pgd_init_f32")
+    return out
+
+
+def pgd_init_rng(x0, scale, dist, seed, offset, lo=0.0, hi=1.0, out=None):
+    p0 = _chk(x0, torch.float32, "x0")
+    out = torch.empty_like(x0) if out is None else out
+    po = _chk(out, torch.float32, "out", x0.shape)
+    N.check(N.lib.ee_pgd_init_rng_f32(po, p0, x0.numel(), scale, dist, seed, offset, lo, hi, _stream()),
+            "ee_pgd_init_rng_f32")
+    return out
+
+
+def pgd_step_(x, g, x0, alpha, eps, lo=0.0, hi=1.0, direction=1):
+    """In place on x (attacks.py:25-27)."""
+    px = _chk(x, torch.float32, "x")
+    pg = _chk(g, torch.float32, "g", x.shape)
+    p0 = _chk(x0, torch.float32, "x0", x.shape)
+    N.check(N.lib.ee_pgd_step_f32(px, pg, p0, x.numel(), alpha, eps, lo, hi, direction, _stream()), "ee_pgd_step_f32")
+    return x
+
+
+def pgd_step_bcast_(x, g_lp, g_edge, x0, alpha, eps, lo=0.0, hi=1.0, direction=1):
+    B, C, H, W = x.shape
+    px = _chk(x, torch.float32, "x")
+    pl = _chk(g_lp, torch.float32, "g_lp", x.shape)
+    pe = _chk(g_edge, torch.float32, "g_edge", (B, 1, H, W))
+    p0 = _chk(x0, torch.float32, "x0", x.shape)
+    N.check(N.lib.ee_pgd_step_bcast_f32(px, pl, pe, p0, B, C, H * W, alpha, eps, lo, hi, direction, _stream()),
+            "ee_pgd_step_bcast_f32")
+    return x
+
+
+def fgsm_step(x, g, alpha, lo=0.0, hi=1.0, direction=1):
+    px = _chk(x, torch.float32, "x")
+    pg = _chk(g, torch.float32, "g", x.shape)
+    out = torch.empty_like(x)
+    N.check(N.lib.ee_fgsm_step_f32(_chk(out, torch.float32, "out"), px, pg, x.numel(), alpha, lo, hi, direction, _stream()),
+            "ee_fgsm_step_f32")
+    return out
+
+
+def add_clamp(x, delta, lo=0.0, hi=1.0):
+    px = _chk(x, torch.float32, "x")
+    pd = _chk(delta, torch.float32, "delta", x.shape)
+    out = torch.empty_like(x)
+    N.check(N.lib.ee_add_clamp_f32(_chk(out, torch.float32, "out"), px, pd, x.numel(), lo, hi, _stream()), "ee_add_clamp_f32")
+    return out
+
+
+def freeat_update_(delta, g, alpha, eps):
+    """delta[:n] updated in place, n = g.numel() (the live rows of the persistent noise buffer)."""
+    pd = _chk(delta, torch.float32, "delta")
+    pg = _chk(g, torch.float32, "g")
+    if g.numel() > delta.numel():
+        raise ValueError("gradient has more elements than the noise buffer")
+    N.check(N.lib.ee_freeat_update_f32(pd, pg, g.numel(), alpha, eps, _stream()), "ee_freeat_update_f32")
+    return delta
+
+
+def avmix(x, x0, wgt, gamma):
+    B = x.shape[0]
+    px = _chk(x, torch.float32, "x")
+    p0 = _chk(x0, torch.float32, "x0", x.shape)
+    pw = _chk(wgt, torch.float64, "wgt", (B,))
+    out = torch.empty_like(x)
+    N.check(N.lib.ee_avmix_f32(_chk(out, torch.float32, "out"), px, p0, pw, B, x.numel() // max(B, 1), gamma, _stream()),
+            "ee_avmix_f32")
+    return out
+
+
+def avmix_labels(labels, wgt, K, lambda1, lambda2):
+    B = labels.shape[0]
+    pl = _chk(labels, torch.int64, "labels", (B,))
+    pw = _chk(wgt, torch.float64, "wgt", (B,))
+    out = torch.empty((B, K), dtype=torch.float64, device=labels.device)
+    N.check(N.lib.ee_avmix_labels_f64(_chk(out, torch.float64, "out"), pl, pw, B, K, lambda1, lambda2, _stream()),
+            "ee_avmix_labels_f64")
+    return out
+
+
+# ---- edge filter / front end ---------------------------------------------------------------------------------
+def edge125_fwd(x, wts, alpha, high, want_mag=False):
+    B, C, H, W = x.shape
+    px = _chk(x, torch.float32, "x")
+    edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    mag = torch.empty_like(edge) if want_mag else None
+    N.check(N.lib.ee_edge125_fwd_f32(px, B, C, H, W, wts.ptr, alpha, high, _chk(edge, torch.float32, "edge"),
+                                     _opt(mag, torch.float32, "mag"), _stream()), "ee_edge125_fwd_f32")
+    return (edge, mag) if want_mag else edge
+
+
+def edge125_bwd(x, u, wts, alpha, high):
+    B, C, H, W = x.shape
+    px = _chk(x, torch.float32, "x")
+    pu = _chk(u, torch.float32, "u", (B, 1, H, W))
+    g = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_edge125_bwd_f32(px, pu, B, C, H, W, wts.ptr, alpha, high, _chk(g, torch.float32, "g"), _stream()),
+            "ee_edge125_bwd_f32")
+    return g
+
+
+def frontend_fwd(x, x_hfs, wts, alpha, high, w, want_edge=False):
+    B, C, H, W = x.shape
+    px = _chk(x, torch.float32, "x")
+    ph = _chk(x_hfs, torch.float32, "x_hfs", x.shape)
+    x_in = torch.empty_like(x)
+    gate = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device) if want_edge else None
+    N.check(N.lib.ee_frontend_fwd_f32(px, ph, B, C, H, W, wts.ptr, alpha, high, w, _chk(x_in, torch.float32, "x_in"),
+                                      _chk(gate, torch.uint8, "gate"), _opt(edge, torch.float32, "edge"), _stream()),
+            "ee_frontend_fwd_f32")
+    return x_in, gate, edge
+
+
+def frontend_bwd(g_in, gate, x, wts, alpha, high, w):
+    B, C, H, W = x.shape
+    pg = _chk(g_in, torch.float32, "g_in", x.shape)
+    pt = _chk(gate, torch.uint8, "gate", x.shape)
+    px = _chk(x, torch.float32, "x")
+    g_hfs = torch.empty_like(x)
+    g_edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_frontend_bwd_f32(pg, pt, px, B, C, H, W, wts.ptr, alpha, high, w, _chk(g_hfs, torch.float32, "g_hfs"),
+                                      _chk(g_edge, torch.float32, "g_edge"), _stream()), "ee_frontend_bwd_f32")
+    return g_hfs, g_edge
+
+
+# ---- losses ------------------------------------------------------------------------------------------------------
+def _reduce_rows(rows, scale):
+    out = torch.empty(1, dtype=torch.float64, device=rows.device)
+    N.check(N.lib.ee_reduce_rows_f64(_chk(rows, torch.float64, "rows"), rows.numel(), scale, _chk(out, torch.float64, "out"),
+                                     _stream()), "ee_reduce_rows_f64")
+    return out
+
+
+def ce(logits, labels, reduction="mean", smoothing=0.0, want_loss=True, want_grad=True):
+    """Returns (loss: 0-dim fp32 tensor or None, dlogits or None)."""
+    B, K = logits.shape
+    pz = _chk(logits, torch.float32, "logits")
+    py = _chk(labels, torch.int64, "labels", (B,))
+    gscale = 1.0 / B if reduction == "mean" else 1.0
+    rows = torch.empty(B, dtype=torch.float64, device=logits.device) if want_loss else None
+    d = torch.empty_like(logits) if want_grad else None
+    N.check(N.lib.ee_ce_f32(pz, py, B, K, smoothing, gscale, _opt(rows, torch.float64, "rows"), _opt(d, torch.float32, "d"),
+                            _stream()), "ee_ce_f32")
+    loss = _reduce_rows(rows, gscale)[0].to(torch.float32) if want_loss else None
+    return loss, d
+
+
+def kl_batchmean(zq, zp, want_loss=True, want_dq=True, want_dp=False):
+    B, K = zq.shape
+    pq = _chk(zq, torch.float32, "zq")
+    pp = _chk(zp, torch.float32, "zp", zq.shape)
+    rows = torch.empty(B, dtype=torch.float64, device=zq.device) if want_loss else None
+    dq = torch.empty_like(zq) if want_dq else None
+    dp = torch.empty_like(zq) if want_dp else None
+    N.check(N.lib.ee_kl_f32(pq, pp, B, K, 1.0 / B, _opt(rows, torch.float64, "rows"), _opt(dq, torch.float32, "dq"),
+                            _opt(dp, torch.float32, "dp"), _stream()), "ee_kl_f32")
+    loss = _reduce_rows(rows, 1.0 / B)[0].to(torch.float32) if want_loss else None
+    return loss, dq, dp
+
+
+def softce(z, t, scale, want_loss=True, want_grad=True):
+    """-sum(log_softmax(z) * t) * scale with float64 targets; loss and gradient are float64."""
+    B, K = z.shape
+    pz = _chk(z, torch.float32, "z")
+    pt = _chk(t, torch.float64, "t", z.shape)
+    rows = torch.empty(B, dtype=torch.float64, device=z.device) if want_loss else None
+    dz = torch.empty((B, K), dtype=torch.float64, device=z.device) if want_grad else None
+    N.check(N.lib.ee_softce_f64(pz, pt, B, K, scale, _opt(rows, torch.float64, "rows"), _opt(dz, torch.float64, "dz"),
+                                _stream()), "ee_softce_f64")
+    loss = _reduce_rows(rows, scale)[0] if want_loss else None
+    return loss, dz
+
+
+def mse(a, b, want_loss=True, want_grad=True):
+    pa = _chk(a, torch.float32, "a")
+    pb = _chk(b, torch.float32, "b", a.shape)
+    n = a.numel()
+    nb = N.lib.ee_mse_num_partials(n)
+    part = torch.empty(nb, dtype=torch.float64, device=a.device) if want_loss else None
+    da = torch.empty_like(a) if want_grad else None
+    N.check(N.lib.ee_mse_f32(pa, pb, n, 2.0 / n, _opt(part, torch.float64, "part"), _opt(da, torch.float32, "da"), _stream()),
+            "ee_mse_f32")
+    loss = _reduce_rows(part, 1.0 / n)[0].to(torch.float32) if want_loss else None
+    return loss, da
+
+
+def topk(logits, labels, k):
+    """(idx [B,k] int64, correct [k] int64 or None)."""
+    B, K = logits.shape
+    pz = _chk(logits, torch.float32, "logits")
+    idx = torch.empty((B, k), dtype=torch.int64, device=logits.device)
+    correct = torch.empty(k, dtype=torch.int64, device=logits.device) if labels is not None else None
+    N.check(N.lib.ee_topk_i64(pz, _opt(labels, torch.int64, "labels", (B,)), B, K, k, _chk(idx, torch.int64, "idx"),
+                              _opt(correct, torch.int64, "correct"), _stream()), "ee_topk_i64")
+    return idx, correct
+
+
+# ---- Add_Square ------------------------------------------------------------------------------------------------------
+def add_square_fwd(x, eps, stripe, sq_sign, sq_pos, sq_size):
+    B, C, H, W = x.shape
+    nq = int(sq_size.numel())
+    out = torch.empty_like(x)
+    N.check(N.lib.ee_add_square_fwd_f32(_chk(x, torch.float32, "x"), B, C, H, W, eps, _chk(stripe, torch.float32, "stripe", (B, C, 1, W)),
+                                        _chk(sq_sign, torch.float32, "sq_sign", (nq, C)), _chk(sq_pos, torch.int64, "sq_pos", (nq,)),
+                                        _chk(sq_size, torch.int32, "sq_size", (nq,)), nq, _chk(out, torch.float32, "out"), _stream()),
+            "ee_add_square_fwd_f32")
+    return out
+
+
+def add_square_bwd(g_out, x, eps, stripe, sq_sign, sq_pos, sq_size):
+    B, C, H, W = x.shape
+    nq = int(sq_size.numel())
+    g_x = torch.empty_like(x)
+    N.check(N.lib.ee_add_square_bwd_f32(_chk(g_out, torch.float32, "g_out", x.shape), _chk(x, torch.float32, "x"), B, C, H, W, eps,
+                                        _chk(stripe, torch.float32, "stripe", (B, C, 1, W)),
+                                        _chk(sq_sign, torch.float32, "sq_sign", (nq, C)), _chk(sq_pos, torch.int64, "sq_pos", (nq,)),
+                                        _chk(sq_size, torch.int32, "sq_size", (nq,)), nq, _chk(g_x, torch.float32, "g_x"), _stream()),
+            "ee_add_square_bwd_f32")
+    return g_x
+
+
+# ---- timing hooks ------------------------------------------------------------------------------------------------------
+def prof_enable(on=True):
+    N.check(N.lib.ee_prof_enable(1 if on else 0), "ee_prof_enable")
+
+
+def prof_reset():
+    N.check(N.lib.ee_prof_reset(), "ee_prof_reset")
+
+
+def prof_read(kernel_id):
+    ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+    N.check(N.lib.ee_prof_read(kernel_id, ctypes.byref(ms), ctypes.byref(cnt)), "ee_prof_read")
+    return ms.value, cnt.value

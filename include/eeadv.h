@@ -1,0 +1,200 @@
+/*
+ * eeadv.h - C ABI of libeeadv.so: the MI355X (gfx950) hot path of Edge-Enhancement adversarial training.
+ *
+ * The reference (Aiqz/Edge-Enhancement) is pure Python on PyTorch and has no FFI of its own; the
+ * "interface" each entry point replaces is therefore the group of ATen launches behind a few lines of
+ * utils/attacks.py / utils/core.py, cited per function (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd or a torch ROCm tensor's data_ptr()) unless a
+ *     parameter is documented "host"; tensors are dense, row-major NCHW / [B,K];
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is enqueued
+ *     asynchronously on it, nothing synchronises, so every call is hipGraph-capturable;
+ *   - return value: 0 = success, < 0 = EE_ERR_* (argument check failed, nothing was launched),
+ *     > 0 = the hipError_t reported by the launch;
+ *   - fp32 arithmetic follows the operation order of oracle/ee_oracle.c bit for bit (built with
+ *     -ffp-contract=off; IEEE division and square root), including sign(NaN) = sign(0) = 0 and the
+ *     0*inf = NaN gradient of the edge filter at zero magnitude.
+ */
+#ifndef EEADV_H
+#define EEADV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EE_OK 0
+#define EE_ERR_NULL (-1)        /* a required pointer is NULL */
+#define EE_ERR_SHAPE (-2)       /* a size / shape argument is out of range */
+#define EE_ERR_UNSUPPORTED (-3) /* valid request this build has no kernel for (e.g. C > 4) */
+#define EE_ERR_ALIGN (-4)       /* pointer not aligned to the element size */
+
+#define EEADV_ABI_VERSION 1
+
+int ee_abi_version(void);
+/* static string for an EE_ERR_* / hipError_t code returned by any entry point */
+const char *ee_strerror(int code);
+/* name of the device the library would launch on, or NULL (host pointer to a static buffer) */
+const char *ee_device_name(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * PGD / FGSM / free-AT element-wise updates                              (utils/attacks.py)
+ * ------------------------------------------------------------------------------------------- */
+
+/* attacks.py:15-17 (also :42-44, :454-456, :492-494):  x = clamp(x0 + noise, lo, hi).
+ * `noise` is caller-supplied (U(-eps,eps) for PGD, 0.001*randn for TRADES/ALP :250,:406 with
+ * lo = -inf, hi = +inf because those initialisations are not clamped). */
+int ee_pgd_init_f32(float *x, const float *x0, const float *noise, int64_t n, float lo, float hi, void *stream);
+
+/* same, with the noise drawn on the device: Philox4x32-10 keyed by (seed, offset), element i uses
+ * counter offset + i/4.  dist 0: U(-scale, scale)  (zeros_like(x).uniform_(-eps, eps), attacks.py:16);
+ * dist 1: scale * N(0,1)  (0.001 * randn, attacks.py:250).  Streams differ from torch's generators,
+ * so parity tests use ee_pgd_init_f32 with injected noise. */
+int ee_pgd_init_rng_f32(float *x, const float *x0, int64_t n, float scale, int dist, uint64_t seed,
+                        uint64_t offset, float lo, float hi, void *stream);
+
+/* attacks.py:25-27 (same body :52-54 :82-84 :257-259 :298-300 :318-320 :353-355 :414-416 :466-468
+ * :505-507), in place on x:
+ *     t = x + dir*alpha*sign(g);  t = max(t, x0 - eps);  t = min(t, x0 + eps);  x = clamp(t, lo, hi)
+ * dir = +1 ascent (untargeted), -1 descent (targeted).  16 B of HBM traffic per element. */
+int ee_pgd_step_f32(float *x, const float *g, const float *x0, int64_t n, float alpha, float eps, float lo,
+                    float hi, int dir, void *stream);
+
+/* attacks.py:121-126 FGSM:  out = clamp(x + dir*alpha*sign(g), lo, hi)   (no eps projection) */
+int ee_fgsm_step_f32(float *out, const float *x, const float *g, int64_t n, float alpha, float lo, float hi,
+                     int dir, void *stream);
+
+/* ImageNet/free_imagenet/AT_free_imagenet_ddp.py:289-290:  out = clamp(x + delta, lo, hi) */
+int ee_add_clamp_f32(float *out, const float *x, const float *delta, int64_t n, float lo, float hi,
+                     void *stream);
+
+/* AT_free_imagenet_ddp.py:305-307:  delta[0:n] = clamp(delta[0:n] + alpha*sign(g), -eps, eps) in place.
+ * The reference clamps the whole persistent buffer; rows beyond the batch are unchanged and already
+ * inside the box, so touching only the n live elements gives the same buffer. */
+int ee_freeat_update_f32(float *delta, const float *g, int64_t n, float alpha, float eps, void *stream);
+
+/* attacks.py:469-479 AVmixup vertex + per-sample mix.  wgt = float64[B] (numpy Beta(1,1) weights):
+ *     v = clamp(x0 + (x - x0)*gamma, 0, 1);   out = float(double(x0)*w_b + double(v)*(1 - w_b)) */
+int ee_avmix_f32(float *out, const float *x, const float *x0, const double *wgt, int64_t B, int64_t per_sample,
+                 float gamma, void *stream);
+
+/* attacks.py:475-478  mixed soft labels, float64 out[B,K]:
+ *     y = ls(onehot, l1)*w_b + ls(onehot, l2)*(1 - w_b),  ls(o,f) = o*f + (o-1)*((f-1)/(K-1))  (:444-445, fp32) */
+int ee_avmix_labels_f64(double *out, const int64_t *labels, const double *wgt, int64_t B, int64_t K, float lambda1,
+                        float lambda2, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Edge filter CannyFilter_step125_1 (utils/core.py:509-585) + To_compare (core.py:329-358)
+ *   weights27 = HOST pointer to 27 floats: Gaussian 3x3, Sobel-x 3x3, Sobel-y 3x3, row-major; copied into the kernel arguments
+ *   (core.py:524-535; the caller builds them once with get_gaussian_kernel / get_sobel_kernel).
+ * ------------------------------------------------------------------------------------------- */
+
+/* forward: x[B,C,H,W] -> edge[B,1,H,W] in {0,1} (fp32).  mag (nullable) receives the gradient
+ * magnitude before the alpha mask.  Traffic (C+1)*4 B per pixel. */
+int ee_edge125_fwd_f32(const float *x, int B, int C, int H, int W, const float *weights27, float alpha, float high,
+                       float *edge, float *mag, void *stream);
+
+/* backward: u = dL/d(edge) [B,1,H,W] -> g_img[B,1,H,W], the map that EVERY input channel of dL/dx
+ * receives (the adjoint is identical across channels).  Recomputes the forward from x. */
+int ee_edge125_bwd_f32(const float *x, const float *u, int B, int C, int H, int W, const float *weights27,
+                       float alpha, float high, float *g_img, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused EE front end   x_in = clamp(x_hfs + w*edge(x), 0, 1)
+ *   (Tiny_ImageNet/models_tinyimagenet/resnet_EE.py:176-191, resnet_EE_square.py:187-206,
+ *    MNIST/models_mnist/Net2_EE.py:36-49, Net2_EE_square.py:48-63)
+ * ------------------------------------------------------------------------------------------- */
+
+/* forward: reads x, x_hfs [B,C,H,W]; writes x_in [B,C,H,W] and gate [B,C,H,W] (uint8: 1 where
+ * 0 <= x_hfs + w*edge <= 1, i.e. where clamp passes the gradient).  edge (nullable) [B,1,H,W].
+ * 12*C B (+C gate bytes) per pixel. */
+int ee_frontend_fwd_f32(const float *x, const float *x_hfs, int B, int C, int H, int W, const float *weights27,
+                        float alpha, float high, float w, float *x_in, uint8_t *gate, float *edge, void *stream);
+
+/* backward: g_in = dL/dx_in.  Writes g_hfs = g_in*gate [B,C,H,W] (the gradient entering the
+ * low-pass branch) and g_edge [B,1,H,W] (the edge-branch gradient of every channel of x):
+ *     u = w * sum_c g_hfs_c ;  g_edge = edge125_bwd(u).                                        */
+int ee_frontend_bwd_f32(const float *g_in, const uint8_t *gate, const float *x, int B, int C, int H, int W,
+                        const float *weights27, float alpha, float high, float w, float *g_hfs, float *g_edge,
+                        void *stream);
+
+/* last stage of the attack step for EE models, fused: dL/dx = g_lp + g_edge (g_edge broadcast over C),
+ * then the PGD update of ee_pgd_step_f32 on x - the gradient itself never reaches HBM.
+ * g_lp [B,C,H,W] = gradient arriving through the low-pass branch; g_edge [B,1,H,W]. */
+int ee_pgd_step_bcast_f32(float *x, const float *g_lp, const float *g_edge, const float *x0, int B, int C,
+                          int64_t hw, float alpha, float eps, float lo, float hi, int dir, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-row losses on logits [B,K]  (K <= 65536; one 64-lane wavefront per row)
+ *   row_loss: float64[B] per-row values (nullable when only the gradient is wanted)
+ *   ee_reduce_rows_f64 folds them in a fixed order -> bit-reproducible scalars.
+ * ------------------------------------------------------------------------------------------- */
+
+/* F.cross_entropy incl. label smoothing (attacks.py:23 sum, :255 mean, :89-99 LabelSmoothLoss):
+ *     row_loss_b = -sum_k w_bk log_softmax(z_b)_k,  w = smoothing/(K-1) off target, 1-smoothing on it
+ *     dz = gscale * (softmax(z) - w)           gscale = 1 ('sum') or 1/B ('mean')            */
+int ee_ce_f32(const float *logits, const int64_t *labels, int B, int K, float smoothing, float gscale,
+              double *row_loss, float *dlogits, void *stream);
+
+/* nn.KLDivLoss('batchmean')(log_softmax(zq), softmax(zp))  (attacks.py:375, :412, :426):
+ *     row_loss_b = sum_k p(log p - log q);  dzq = gscale*(q - p);  dzp = gscale*p*((log p - log q) - row_loss_b)
+ * dzq / dzp nullable. */
+int ee_kl_f32(const float *zq, const float *zp, int B, int K, float gscale, double *row_loss, float *dzq,
+              float *dzp, void *stream);
+
+/* -sum_k log_softmax(z)_k * t_k with float64 soft targets (attacks.py:462-463;
+ * Tiny_ImageNet/experiments_tinyimagenet.py:292-293): dz (float64, nullable) = gscale*(softmax*sum_k t - t) */
+int ee_softce_f64(const float *z, const double *t, int B, int K, double gscale, double *row_loss, double *dz,
+                  void *stream);
+
+/* F.mse_loss(a, b) pieces (attacks.py:269): partial[nblk] float64 block sums of (a-b)^2 (nullable),
+ * da = gscale*(a - b) (nullable; db = -da).  nblk = ee_mse_num_partials(n). */
+int ee_mse_f32(const float *a, const float *b, int64_t n, float gscale, double *partial, float *da, void *stream);
+int64_t ee_mse_num_partials(int64_t n);
+
+/* out[0] (float64) = scale * (rows[0] + rows[1] + ...) in a fixed order (single workgroup) */
+int ee_reduce_rows_f64(const double *rows, int64_t n, double scale, double *out, void *stream);
+
+/* utils/helper.py:39-55 accuracy / attacks.py:131-132 predict_from_logits:
+ * idx[B,k] = sorted top-k class indices (ties: lower index first), correct[k] (int64, zeroed by the
+ * call) = number of rows whose label is among the first j+1 indices.  labels nullable. */
+int ee_topk_i64(const float *logits, const int64_t *labels, int B, int K, int k, int64_t *idx, int64_t *correct,
+                void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Add_Square (utils/core.py:589-655), element-wise given its random draws
+ *   stripe[B,C,W]  = sign(2*rand-1) of core.py:637 ; sq_sign[nq,C] = sign draws of core.py:648 ;
+ *   sq_pos[nq] (int64, device: the `.long()` draw) and sq_size[nq] (int32, device) = vh and s of core.py:644-645.
+ * ------------------------------------------------------------------------------------------- */
+int ee_add_square_fwd_f32(const float *x, int B, int C, int H, int W, float eps, const float *stripe,
+                          const float *sq_sign, const int64_t *sq_pos, const int32_t *sq_size, int nq, float *out,
+                          void *stream);
+/* backward: g_x = g_out * d(out)/d(x), the derivative autograd assigns (ties of max/min split 1/2) */
+int ee_add_square_bwd_f32(const float *g_out, const float *x, int B, int C, int H, int W, float eps,
+                          const float *stripe, const float *sq_sign, const int64_t *sq_pos, const int32_t *sq_size,
+                          int nq, float *g_x, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optional built-in timing of the last launch of each kernel family (HIP events on `stream`).
+ * Off by default; bench.py switches it on outside graph capture to measure kernel durations live.
+ * ------------------------------------------------------------------------------------------- */
+#define EE_K_PGD_STEP 0
+#define EE_K_FRONTEND_FWD 1
+#define EE_K_FRONTEND_BWD 2
+#define EE_K_EDGE_FWD 3
+#define EE_K_EDGE_BWD 4
+#define EE_K_CE 5
+#define EE_K_PGD_STEP_BCAST 6
+#define EE_K_COUNT 7
+int ee_prof_enable(int on);
+/* synchronises the recorded events and returns accumulated milliseconds / launch count since the last reset */
+int ee_prof_read(int kernel_id, double *total_ms, int64_t *launches);
+int ee_prof_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEADV_H */

@@ -1,0 +1,287 @@
+"""GPU parity: every HIP kernel, called through the C ABI, against the CPU oracle on the same inputs.
+
+Bar (task spec / BASELINE north_star): bit-exact for binary / integer results and for the element-wise
+fp32 updates and stencils (the oracle fixes the operation order); 1e-6 relative (well inside the 1e-4 the
+north star allows) for kernels that call exp/log, whose libm differs between host and device.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ee_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bitexact(got, want, what):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    if got.dtype == np.float32:
+        nan_g, nan_w = np.isnan(got), np.isnan(want)
+        assert np.array_equal(nan_g, nan_w), "%s: NaN pattern differs (%d vs %d)" % (what, nan_g.sum(), nan_w.sum())
+        same = (bits(got) == bits(want)) | nan_g
+        assert same.all(), "%s: %d of %d elements differ, max |d| = %g" % (
+            what, (~same).sum(), same.size, np.nanmax(np.abs(got - want)))
+    else:
+        assert np.array_equal(got, want), what
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from eeadv import ops as _ops
+    return _ops
+
+
+EDGE_CASES = ["rand_tiny", "rand_mnist", "rect_mnist", "rect_rgb", "ramp_thr", "ragged", "two_ch", "one_px", "thin", "big_mag"]
+
+
+@pytest.mark.parametrize("name", EDGE_CASES)
+def test_edge125_fwd_bwd_golden_inputs(ops, golden, name):
+    G = golden("edge125")
+    x, (alpha, high), u = G[name + "__x"], G[name + "__alpha_high"], G[name + "__u"]
+    wts = ops.EdgeWeights(1.0)
+    e, mag = ops.edge125_fwd(dev(x), wts, float(alpha), float(high), want_mag=True)
+    oe, omag, _, _ = O.edge125_fwd(x, alpha, high, want_internals=True)
+    assert_bitexact(e.cpu().numpy(), oe, "edge")
+    assert_bitexact(mag.cpu().numpy(), omag, "mag")
+    # ... and directly against the reference's own output
+    assert np.array_equal(e.cpu().numpy().astype(np.uint8), G[name + "__edge"])
+    g = ops.edge125_bwd(dev(x), dev(u), wts, float(alpha), float(high))
+    assert_bitexact(g.cpu().numpy(), O.edge125_bwd(x, u, alpha, high), "edge bwd")
+    ref = G[name + "__gx"][:, :1]
+    fin = ~np.isnan(ref)
+    assert np.array_equal(np.isnan(g.cpu().numpy()), ~fin)
+    np.testing.assert_allclose(g.cpu().numpy()[fin], ref[fin], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 64, 64), (2, 1, 28, 28), (2, 3, 70, 50), (1, 2, 33, 130), (2, 4, 16, 16), (1, 3, 224, 224)])
+def test_frontend_fwd_bwd_random(ops, shape):
+    rng = np.random.RandomState(sum(shape))
+    x = rng.rand(*shape).astype(np.float32)
+    # low-pass branch output with negative / >1 values and exact 0 / tiny entries so the clamp gate flips
+    xh = (rng.rand(*shape).astype(np.float32) * 1.4 - 0.3)
+    xh.flat[::17] = 0.0
+    xh.flat[5::23] = np.float32(1e-9)
+    xh.flat[7::29] = np.float32(-1e-9)
+    alpha, high, w = 0.0, 76.0 / 255, 1.0
+    wts = ops.EdgeWeights(1.0)
+    x_in, gate, edge = ops.frontend_fwd(dev(x), dev(xh), wts, alpha, high, w, want_edge=True)
+    ox, ogate, oedge = O.frontend_fwd(x, xh, alpha, high, w)
+    assert_bitexact(edge.cpu().numpy(), oedge, "edge")
+    assert_bitexact(x_in.cpu().numpy(), ox, "x_in")
+    assert np.array_equal(gate.cpu().numpy(), ogate)
+    g_in = rng.randn(*shape).astype(np.float32)
+    g_hfs, g_edge = ops.frontend_bwd(dev(g_in), gate, dev(x), wts, alpha, high, w)
+    oh, oe = O.frontend_bwd(g_in, ogate, x, alpha, high, w)
+    assert_bitexact(g_hfs.cpu().numpy(), oh, "g_hfs")
+    assert_bitexact(g_edge.cpu().numpy(), oe, "g_edge")
+
+
+def test_frontend_piecewise_constant_nan_grads(ops, golden):
+    """mag == 0 regions give NaN input gradients, which the PGD step must turn into 'no update'."""
+    x = golden("edge125")["rect_rgb__x"]
+    rng = np.random.RandomState(5)
+    xh = (x * np.float32(0.9)).astype(np.float32)
+    wts = ops.EdgeWeights(1.0)
+    x_in, gate, _ = ops.frontend_fwd(dev(x), dev(xh), wts, 0.0, 76.0 / 255, 1.0)
+    g_in = rng.randn(*x.shape).astype(np.float32)
+    g_hfs, g_edge = ops.frontend_bwd(dev(g_in), gate, dev(x), wts, 0.0, 76.0 / 255, 1.0)
+    oh, oe = O.frontend_bwd(g_in, gate.cpu().numpy(), x, 0.0, 76.0 / 255, 1.0)
+    assert np.isnan(oe).sum() > 100
+    assert_bitexact(g_edge.cpu().numpy(), oe, "g_edge")
+    x0 = x.copy()
+    xd = dev(x.copy())
+    ops.pgd_step_bcast_(xd, g_hfs, g_edge, dev(x0), 2 / 255, 16 / 255)
+    g_full = oh + oe  # broadcast over channels
+    want = O.pgd_step(x, g_full, x0, 2 / 255, 16 / 255)
+    assert_bitexact(xd.cpu().numpy(), want, "pgd_step_bcast")
+    assert np.array_equal(want[np.isnan(g_full)], x[np.isnan(g_full)])
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 1023, 4096 + 7, 100 * 3 * 64 * 64])
+def test_pgd_elementwise(ops, n):
+    rng = np.random.RandomState(n % 1000)
+    x0 = rng.rand(n).astype(np.float32)
+    noise = ((rng.rand(n) - 0.5) * 0.2).astype(np.float32)
+    g = rng.randn(n).astype(np.float32)
+    if n > 8:
+        g[:6] = [np.nan, 0.0, -0.0, np.inf, -np.inf, 1e-40]
+        x0[6:8] = [0.0, 1.0]
+    eps, alpha = 16 / 255, 2 / 255
+    x = ops.pgd_init(dev(x0), dev(noise))
+    assert_bitexact(x.cpu().numpy(), O.pgd_init(x0, noise), "pgd_init")
+    for direction in (1, -1):
+        xc = x.clone()
+        ops.pgd_step_(xc, dev(g), dev(x0), alpha, eps, direction=direction)
+        assert_bitexact(xc.cpu().numpy(), O.pgd_step(x.cpu().numpy(), g, x0, alpha, eps, direction=direction), "pgd_step")
+        f = ops.fgsm_step(x, dev(g), 0.007, direction=direction)
+        assert_bitexact(f.cpu().numpy(), O.fgsm_step(x.cpu().numpy(), g, 0.007, direction=direction), "fgsm")
+    ac = ops.add_clamp(dev(x0), dev(noise))
+    assert_bitexact(ac.cpu().numpy(), O.add_clamp(x0, noise), "add_clamp")
+    d = dev(noise.copy())
+    ops.freeat_update_(d, dev(g), 4 / 255, 4 / 255)
+    assert_bitexact(d.cpu().numpy(), O.freeat_update(noise, g, 4 / 255, 4 / 255), "freeat")
+
+
+def test_pgd_step_unaligned_views(ops):
+    rng = np.random.RandomState(3)
+    n = 4099
+    big = dev(rng.rand(n + 3).astype(np.float32))
+    x0 = dev(rng.rand(n + 3).astype(np.float32))
+    g = dev(rng.randn(n + 3).astype(np.float32))
+    xv, x0v, gv = big[1:n + 1], x0[1:n + 1], g[1:n + 1]
+    want = O.pgd_step(xv.cpu().numpy(), gv.cpu().numpy(), x0v.cpu().numpy(), 0.01, 0.3)
+    guard = big[n + 1:].clone()
+    ops.pgd_step_(xv, gv, x0v, 0.01, 0.3)
+    assert_bitexact(xv.cpu().numpy(), want, "unaligned")
+    assert torch.equal(big[n + 1:], guard)
+
+
+def test_golden_pgd_trajectories(ops, golden):
+    """Replay the reference's own PGD runs step by step: x_k, g_k -> x_{k+1} must match bit for bit."""
+    G = golden("pgd_steps")
+    x0 = G["x0"]
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    x1 = ops.pgd_init(dev(x0), dev(G["pgd_noise"]))
+    assert_bitexact(x1.cpu().numpy(), G["pgd_xs"][0], "random start")
+    for tag, e, a, d in (("pgd", eps, alpha, 1), ("pgdb", 0.3, 0.01, 1), ("tpgd", eps, alpha, -1)):
+        xs, gs, fin = G[tag + "_xs"], G[tag + "_gs"], G[tag + "_final"]
+        for k in range(len(gs)):
+            x = dev(xs[k].copy())
+            ops.pgd_step_(x, dev(gs[k]), dev(x0), a, e, direction=d)
+            want = xs[k + 1] if k + 1 < len(xs) else fin
+            assert_bitexact(x.cpu().numpy(), want, "%s step %d" % (tag, k))
+    for tag, d in (("fgsm_u", 1), ("fgsm_t", -1)):
+        f = ops.fgsm_step(dev(x0), dev(G[tag + "_g"]), 0.007, direction=d)
+        assert_bitexact(f.cpu().numpy(), G[tag + "_final"], tag)
+    x = dev(x0.copy())
+    ops.pgd_step_(x, dev(G["special_g"]), dev(x0), alpha, eps)
+    assert_bitexact(x.cpu().numpy(), G["special_final"], "special values")
+
+
+@pytest.mark.parametrize("B,K", [(4, 10), (100, 200), (37, 1000), (3, 1), (2, 70000 // 2)])
+def test_losses(ops, B, K):
+    rng = np.random.RandomState(B + K)
+    za = (rng.randn(B, K) * 3).astype(np.float32)
+    zb = (rng.randn(B, K) * 3).astype(np.float32)
+    y = rng.randint(0, K, B).astype(np.int64)
+    for mean in (False, True):
+        loss, d = ops.ce(dev(za), dev(y), "mean" if mean else "sum")
+        ol, od = O.ce(za, y, mean=mean)
+        np.testing.assert_allclose(loss.item(), ol, rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(d.cpu().numpy(), od, rtol=1e-5, atol=1e-7)
+    loss, dq, dp = ops.kl_batchmean(dev(zb), dev(za), want_dp=True)
+    ol, odq, odp = O.kl_batchmean(zb, za)
+    np.testing.assert_allclose(loss.item(), ol, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dq.cpu().numpy(), odq, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dp.cpu().numpy(), odp, rtol=1e-4, atol=2e-7)
+    loss, da = ops.mse(dev(za), dev(zb))
+    ol, oda = O.mse(za, zb)
+    np.testing.assert_allclose(loss.item(), ol, rtol=2e-6)
+    np.testing.assert_allclose(da.cpu().numpy(), oda, rtol=1e-6, atol=1e-9)
+    if K > 1:
+        t = rng.rand(B, K)
+        t /= t.sum(1, keepdims=True)
+        loss, dz = ops.softce(dev(za), dev(t), 1.0 / B)
+        ol, odz = O.softce(za, t, 1.0 / B)
+        np.testing.assert_allclose(loss.item(), ol, rtol=2e-6)
+        np.testing.assert_allclose(dz.cpu().numpy(), odz, rtol=1e-5, atol=1e-7)
+    k = min(5, K)
+    idx, correct = ops.topk(dev(za), dev(y), k)
+    oi, oc = O.topk(za, y, k)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(correct.cpu().numpy(), oc)
+
+
+def test_topk_ties_and_golden_losses(ops, golden):
+    z = np.zeros((3, 7), np.float32)
+    z[1, [2, 5]] = 1.0
+    idx, _ = ops.topk(dev(z), None, 3)
+    assert idx.cpu().numpy().tolist() == [[0, 1, 2], [2, 5, 0], [0, 1, 2]]
+    G = golden("losses")
+    for tag in "sti":
+        la, lb, y = G[tag + "_la"], G[tag + "_lb"], G[tag + "_y"]
+        B = la.shape[0]
+        loss, d = ops.ce(dev(la), dev(y), "sum")
+        np.testing.assert_allclose(loss.item(), G[tag + "_ce_sum"], rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(d.cpu().numpy(), G[tag + "_ce_sum_g"], atol=1e-6)
+        loss, d = ops.ce(dev(la), dev(y), "mean")
+        np.testing.assert_allclose(loss.item(), G[tag + "_ce_mean"], atol=1e-4)
+        np.testing.assert_allclose(d.cpu().numpy(), G[tag + "_ce_mean_g"], atol=1e-6)
+        loss, dq, dp = ops.kl_batchmean(dev(lb), dev(la), want_dp=True)
+        np.testing.assert_allclose(loss.item(), G[tag + "_kl"], atol=1e-4)
+        np.testing.assert_allclose(dq.cpu().numpy(), G[tag + "_kl_gq"], atol=1e-6)
+        np.testing.assert_allclose(dp.cpu().numpy(), G[tag + "_kl_gp"], atol=1e-6)
+        loss, _ = ops.mse(dev(la), dev(lb))
+        np.testing.assert_allclose(loss.item(), G[tag + "_mse"], atol=1e-4, rtol=1e-6)
+        loss, d = ops.ce(dev(la), dev(y), "mean", smoothing=0.1)
+        np.testing.assert_allclose(loss.item(), G[tag + "_lsmooth"], atol=1e-4)
+        np.testing.assert_allclose(d.cpu().numpy(), G[tag + "_lsmooth_g"], atol=1e-6)
+        idx, _ = ops.topk(dev(la), None, 1)
+        assert np.array_equal(idx.cpu().numpy()[:, 0], G[tag + "_pred"])
+        K = la.shape[1]
+        soft = dev(G[tag + "_smooth_l2"].astype(np.float64))
+        loss, dz = ops.softce(dev(la), soft, 1.0 / B)
+        np.testing.assert_allclose(loss.item(), G[tag + "_softce_f64"], atol=1e-4)
+        np.testing.assert_allclose(dz.cpu().numpy(), G[tag + "_softce_g"], atol=1e-6)
+        w1 = dev(np.ones(B))
+        lab = ops.avmix_labels(dev(y), w1, K, 1.0, 0.1)
+        np.testing.assert_array_equal(lab.cpu().numpy(), G[tag + "_smooth_l1"].astype(np.float64))
+        lab0 = ops.avmix_labels(dev(y), dev(np.zeros(B)), K, 1.0, 0.1)
+        np.testing.assert_array_equal(lab0.cpu().numpy(), G[tag + "_smooth_l2"].astype(np.float64))
+
+
+def test_avmix_golden(ops, golden):
+    G = golden("avmix_cw")
+    x0, y = G["x0"], G["y"]
+    xs = G["av_xs"]
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    # last PGD iterate: replay the final step, then vertex + mix
+    x = dev(xs[-1].copy())
+    ops.pgd_step_(x, dev(G["av_gs"][-1]), dev(x0), alpha, eps)
+    w = G["av_beta"].reshape(-1)
+    out = ops.avmix(x, dev(x0), dev(w), 2.0)
+    assert_bitexact(out.cpu().numpy(), G["av_x"], "avmix x")
+    assert_bitexact(out.cpu().numpy(), O.avmix(x.cpu().numpy(), x0, w, 2.0), "avmix vs oracle")
+    lab = ops.avmix_labels(dev(y), dev(w), 10, 1.0, 0.1)
+    np.testing.assert_array_equal(lab.cpu().numpy(), G["av_y"])
+
+
+def test_rng_init_statistics(ops):
+    n = 1 << 20
+    x0 = torch.full((n,), 0.5, device=DEV)
+    eps = 16 / 255
+    a = ops.pgd_init_rng(x0, eps, 0, 1234, 0)
+    b = ops.pgd_init_rng(x0, eps, 0, 1234, 0)
+    c = ops.pgd_init_rng(x0, eps, 0, 1234, n // 4)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    d = (a - 0.5).cpu().numpy()
+    assert d.min() >= -eps and d.max() < eps
+    assert abs(d.mean()) < 3e-4 and abs(d.std() - 2 * eps / np.sqrt(12)) < 3e-4
+    z = (ops.pgd_init_rng(x0, 0.001, 1, 99, 0, lo=-np.inf, hi=np.inf) - 0.5).cpu().numpy() / 0.001
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
+
+
+def test_cpu_tensor_is_refused(ops):
+    from eeadv._native import EEError
+    with pytest.raises(EEError):
+        ops.pgd_step_(torch.zeros(4), torch.zeros(4), torch.zeros(4), 0.1, 0.1)
+
+
+def test_bad_shapes_are_refused_before_launch(ops):
+    from eeadv._native import EEError
+    x = torch.zeros(1, 5, 8, 8, device=DEV)
+    with pytest.raises(EEError):
+        ops.edge125_fwd(x, ops.EdgeWeights(1.0), 0.0, 0.3)  # C > 4: EE_ERR_UNSUPPORTED
+    with pytest.raises(ValueError):
+        ops.pgd_step_(torch.zeros(4, device=DEV), torch.zeros(5, device=DEV), torch.zeros(4, device=DEV), 0.1, 0.1)
