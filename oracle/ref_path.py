@@ -1,0 +1,634 @@
+"""Whole-path CPU oracle: a restatement of the reference's attack loops, filters and models in plain,
+modern PyTorch (torch.fft instead of the removed torch.rfft, no hard-coded .cuda()).
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg).  It is what
+"the reference's CPU path" means on the GPU box, where /root/reference does not exist: it is pinned to
+the real reference by tests/golden/*.npz (tests/test_oracle_golden.py) and is the thing timed as
+`cpu_baseline.kind = "port"`.
+
+Every function cites the reference lines it follows.  Randomness is injectable (`noise=`, `draws=`)
+because device and host generators differ; with `None` the same torch CPU calls as the reference are made.
+
+Parity status
+  pinned   : PGD / targeted_PGD / FGSM / CW(targeted) / AVmixup.perturb / losses / CannyFilter_step125_1
+             (fwd + bwd) / Net_2 / resnet18  - fixtures generated from the reference itself.
+  unpinned : HighFreqSuppress (torch.rfft is gone; behaviour on the non-Hermitian +-r row restated from
+             SURVEY.md a13), Add_Square and every *_Linf init with device='cuda' hard-coded (cannot run
+             on CPU in the reference), get_thin_kernels (needs cv2) and therefore CannyFilter /
+             CannyFilter_BPDA (fixtures in canny_full_unpinned.npz use the derived table below).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ee_oracle as O
+
+
+# ======================================================================================================
+# utils/core.py
+# ======================================================================================================
+class HighFreqSuppress(nn.Module):
+    """core.py:15-55.  irfft(rfft(x, 2, onesided=False) * mask, 2, onesided=False) restated as
+    irfft2((fft2(x) * mask)[..., :W//2+1], s=(H, W)) (old C2R reads only the first W//2+1 columns)."""
+
+    def __init__(self, w, h, r):
+        super().__init__()
+        self.w, self.h, self.r = w, h, r
+        self.register_buffer("temp", torch.from_numpy(O.hfs_mask(w, h, r)), persistent=False)
+
+    def forward(self, x):
+        H, W = x.shape[-2:]
+        z = torch.fft.fft2(x) * self.temp.to(x.device)
+        return torch.fft.irfft2(z[..., : W // 2 + 1], s=(H, W))
+
+
+get_gaussian_kernel = O.gaussian_kernel  # core.py:58-72
+get_sobel_kernel = O.sobel_kernel  # core.py:75-84
+
+# k*45 degrees -> (row, col) of the -1 tap (centre +1); DERIVED from core.py:87-112, cv2 unavailable
+THIN_TABLE = {0: (1, 2), 1: (0, 2), 2: (0, 1), 3: (0, 0), 4: (1, 0), 5: (2, 0), 6: (2, 1), 7: (2, 2)}
+
+
+def get_thin_kernels(start=0, end=360, step=45):
+    ks = []
+    for angle in range(start, end, step):
+        k = np.zeros((3, 3))
+        k[1, 1] = 1
+        r, c = THIN_TABLE[(angle // 45) % 8]
+        k[r, c] = -1
+        ks.append(k)
+    return ks
+
+
+def safeSign(t):  # core.py:115-118
+    r = torch.sign(t)
+    r[r == 0] = -1
+    return r
+
+
+class BinaryConnectDeterministic(torch.autograd.Function):  # core.py:121-145
+    @staticmethod
+    def forward(ctx, inp):
+        ctx.save_for_backward(inp)
+        return safeSign(inp)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inp,) = ctx.saved_tensors
+        gi = g.clone()
+        gi[torch.abs(inp) > 1.001] = 0
+        return gi
+
+
+class To_compare(torch.autograd.Function):  # core.py:329-358
+    @staticmethod
+    def forward(ctx, inp, thr):
+        ctx.save_for_backward(inp, thr)
+        out = inp.clone()
+        out[out <= thr] = 0
+        out[out > thr] = 1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        inp, thr = ctx.saved_tensors
+        gi = g.clone()
+        gi[inp <= thr] = 0
+        gi[inp > 1.001] = 0
+        return gi, None
+
+
+class To_eq(torch.autograd.Function):  # core.py:361-382
+    @staticmethod
+    def forward(ctx, inp):
+        ctx.save_for_backward(inp)
+        out = inp.clone()
+        out[inp != 0.5] = 0
+        out[inp == 0.5] = 1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (inp,) = ctx.saved_tensors
+        gi = g.clone()
+        gi[inp != 0.5] = 0
+        return gi
+
+
+class _CannyBase(nn.Module):
+    def __init__(self, k_gaussian=3, mu=0, sigma=1, k_sobel=3, alpha=0.0):
+        super().__init__()
+        g = torch.from_numpy(get_gaussian_kernel(k_gaussian, mu, sigma)).float()[None, None]
+        s = get_sobel_kernel(k_sobel)
+        self.register_buffer("weight_gaussian", g, persistent=False)
+        self.register_buffer("weight_sobel_x", torch.from_numpy(s).float()[None, None], persistent=False)
+        self.register_buffer("weight_sobel_y", torch.from_numpy(s.T.copy()).float()[None, None], persistent=False)
+        self.register_buffer("weight_directional", torch.from_numpy(np.stack(get_thin_kernels())).float()[:, None],
+                             persistent=False)
+        self.register_buffer("weight_hysteresis", torch.full((1, 1, 3, 3), 1.25), persistent=False)
+        self.pad = nn.ReplicationPad2d(1)
+
+    def _grads(self, img):
+        """core.py:233-257 / :436-447 / :560-571: blur per channel, Sobel summed over channels, /C, magnitude."""
+        C = img.shape[1]
+        blurred = torch.cat([F.conv2d(self.pad(img[:, c:c + 1]), self.weight_gaussian) for c in range(C)], 1)
+        pb = self.pad(blurred)
+        gx = F.conv2d(pb, self.weight_sobel_x.repeat(1, C, 1, 1)) / C
+        gy = F.conv2d(pb, self.weight_sobel_y.repeat(1, C, 1, 1)) / C
+        mag = (gx ** 2 + gy ** 2) ** 0.5
+        return gx, gy, mag
+
+
+class CannyFilter_step125_1(_CannyBase):
+    """core.py:509-585: Gaussian -> Sobel -> magnitude -> alpha mask -> To_compare(high)."""
+
+    def __init__(self, k_gaussian=3, mu=0, sigma=1, k_sobel=3, use_cuda=False, alpha=0.0):
+        super().__init__(k_gaussian, mu, sigma, k_sobel, alpha)
+        self.register_buffer("alpha", torch.tensor(alpha), persistent=False)
+
+    def forward(self, img, low_threshold=None, high_threshold=None, hysteresis=False):
+        _, _, mag = self._grads(img)
+        mag = torch.where(mag < self.alpha, torch.zeros_like(mag), mag)
+        high = To_compare.apply(mag.clone(), torch.tensor(high_threshold))
+        return high * 1
+
+
+def _nms(mag, gx, gy, weight_directional, assign):
+    """core.py:258-290 / :448-480: orientation quantisation and non-maximum suppression."""
+    ori = torch.atan(gy / gx) * (360 / np.pi) + 180
+    ori = torch.round(ori / 45) * 45
+    directional = F.conv2d(mag, weight_directional, padding=1)
+    pos = (ori / 45) % 8
+    thin = mag.clone()
+    for i in range(4):
+        oriented = (pos == i) * 1 + (pos == i + 4) * 1
+        is_max = (torch.stack([directional[:, i], directional[:, i + 4]]).min(dim=0)[0] > 0.0).unsqueeze(1)
+        to_remove = (is_max == 0) * 1 * oriented > 0
+        if assign:
+            thin[to_remove] = 0.0  # core.py:290 (in-place, non-differentiable at removed pixels)
+        else:
+            thin = torch.mul(thin, ~to_remove)  # core.py:480
+    return thin
+
+
+class CannyFilter(_CannyBase):
+    """core.py:148-326 (full Canny with STE thresholds and hysteresis).  PARITY UNPINNED (thin kernels)."""
+
+    def __init__(self, k_gaussian=3, mu=0, sigma=1, k_sobel=3, use_cuda=False, alpha=0.0):
+        super().__init__(k_gaussian, mu, sigma, k_sobel, alpha)
+        self.alpha = alpha
+
+    def forward(self, img, low_threshold=None, high_threshold=None, hysteresis=False):
+        gx, gy, mag = self._grads(img)
+        mag_m = torch.where(mag < self.alpha, torch.zeros_like(mag), mag)
+        thin = _nms(mag_m, gx, gy, self.weight_directional, assign=True)
+        if low_threshold is not None:
+            sign = BinaryConnectDeterministic.apply
+            low = (sign(thin - low_threshold) + 1) / 2
+            if high_threshold is not None:
+                high = (sign(thin - high_threshold) + 1) / 2
+                thin = low * 0.5 + high * 0.5
+                if hysteresis:
+                    weak = (thin == 0.5) * 1
+                    weak_is_high = (F.conv2d(thin, self.weight_hysteresis, padding=1) > 1) * weak
+                    thin = high * 1 + weak_is_high * 1
+            else:
+                thin = low * 1
+        return thin
+
+
+class CannyFilter_BPDA(_CannyBase):
+    """core.py:386-505.  PARITY UNPINNED (thin kernels)."""
+
+    def forward(self, img, low_threshold=None, high_threshold=None, hysteresis=False):
+        gx, gy, mag = self._grads(img)
+        thin = _nms(mag, gx, gy, self.weight_directional, assign=False)
+        if low_threshold is not None:
+            low = To_compare.apply(thin, torch.tensor(low_threshold))
+            if high_threshold is not None:
+                high = To_compare.apply(thin, torch.tensor(high_threshold))
+                thin = low * 0.5 + high * 0.5
+                if hysteresis:
+                    weak = To_eq.apply(thin)
+                    weak_1 = To_compare.apply(F.conv2d(thin, self.weight_hysteresis, padding=1), torch.tensor(1.))
+                    thin = high * 1 + weak_1 * weak * 1
+        return thin
+
+
+class Add_Square(nn.Module):
+    """core.py:589-655.  PARITY UNPINNED (the reference hard-codes .cuda()).  `draws` injects the random
+    numbers: dict(stripe [B,C,1,W] in {-1,0,1}, sq_sign [nq,C,1,1], sq_pos [nq] int)."""
+
+    def __init__(self, channels=3, size=224, epsilon=0.05, p_init=0.8, n_queries=5000, rescale_schedule=False):
+        super().__init__()
+        self.c, self.h, self.eps, self.p_init = channels, size, epsilon, p_init
+        self.n_queries, self.rescale_schedule = n_queries, rescale_schedule
+
+    def p_selection(self, it):  # core.py:607-634
+        if self.rescale_schedule:
+            it = int(it / self.n_queries * 10000)
+        for lim, div in ((10, 1), (50, 2), (200, 4), (500, 8), (1000, 16), (2000, 32), (4000, 64), (6000, 128), (8000, 256)):
+            if it <= lim:
+                return self.p_init / div
+        return self.p_init / 512
+
+    def sizes(self):
+        n_features = self.c * self.h * self.h
+        return [max(int(round(math.sqrt(self.p_selection(i) * n_features / self.c))), 1) for i in range(self.n_queries)]
+
+    def draw(self, batch, device="cpu"):
+        d = {"stripe": torch.sign(2 * torch.rand([batch, self.c, 1, self.h], device=device) - 1)}
+        pos, sgn = [], []
+        for s in self.sizes():
+            pos.append((0 + (self.h - s - 0) * torch.rand([1], device=device)).long())
+            sgn.append(torch.sign(2 * torch.rand([self.c, 1, 1], device=device) - 1))
+        d["sq_pos"] = torch.cat(pos) if pos else torch.zeros(0, dtype=torch.long, device=device)
+        d["sq_sign"] = torch.stack(sgn) if sgn else torch.zeros(0, self.c, 1, 1, device=device)
+        return d
+
+    def forward(self, x, draws=None):
+        d = self.draw(x.shape[0], x.device) if draws is None else draws
+        x_best = torch.clamp(x + self.eps * d["stripe"], 0., 1.)
+        for q, s in enumerate(self.sizes()):
+            vh = int(d["sq_pos"][q])
+            new_deltas = torch.zeros([self.c, self.h, self.h], device=x.device)
+            new_deltas[:, vh:vh + s, vh:vh + s] = 2. * self.eps * d["sq_sign"][q]
+            x_best = x_best + new_deltas
+            x_best = torch.min(torch.max(x_best, x - self.eps), x + self.eps)
+            x_best = torch.clamp(x_best, 0., 1.)
+        return x_best
+
+
+# ======================================================================================================
+# utils/attacks.py
+# ======================================================================================================
+def _step(x, grad, x0, step_size, eps, direction=1):
+    """attacks.py:25-27."""
+    x = x.detach() + direction * step_size * torch.sign(grad.detach())
+    x = torch.min(torch.max(x, x0 - eps), x0 + eps)
+    return torch.clamp(x, 0, 1)
+
+
+def PGD(model, args, inputs, targets, num_steps, step_size, noise=None):  # attacks.py:12-29
+    x = inputs.detach()
+    if args.random:
+        nz = torch.zeros_like(x).uniform_(-args.epsilon, args.epsilon) if noise is None else noise
+        x = torch.clamp(x + nz, 0, 1)
+    for _ in range(num_steps):
+        x.requires_grad_()
+        with torch.enable_grad():
+            loss = F.cross_entropy(model(x), targets, reduction='sum')
+        grad = torch.autograd.grad(loss, [x])[0]
+        x = _step(x, grad, inputs, step_size, args.epsilon)
+    return x
+
+
+def targeted_PGD(model, args, inputs, labels, num_steps, step_size, nclass, device, noise=None, label_offset=None):
+    """attacks.py:33-56."""
+    x = inputs.detach()
+    if label_offset is None:
+        label_offset = torch.randint(low=1, high=nclass, size=labels.shape).to(device)
+    target_labels = torch.fmod(labels + label_offset, nclass)
+    if args.random:
+        nz = torch.zeros_like(x).uniform_(-args.epsilon, args.epsilon) if noise is None else noise
+        x = torch.clamp(x + nz, 0.0, 1.0)
+    for _ in range(num_steps):
+        x.requires_grad_()
+        with torch.enable_grad():
+            loss = F.cross_entropy(model(x), target_labels, reduction='sum')
+        grad = torch.autograd.grad(loss, [x])[0]
+        x = _step(x, grad, inputs, step_size, args.epsilon, -1)
+    return x, target_labels
+
+
+def FGSM(model, inputs, target, targeted=False, step_size=0.007):  # attacks.py:110-128
+    x = inputs.detach()
+    x.requires_grad_()
+    with torch.enable_grad():
+        loss = F.cross_entropy(model(x), target, reduction='sum')
+    grad = torch.autograd.grad(loss, [x])[0]
+    x = x.detach() + (-step_size if targeted else step_size) * torch.sign(grad.detach())
+    return torch.clamp(x, 0.0, 1.0)
+
+
+class LabelSmoothLoss(nn.Module):  # attacks.py:89-99
+    def __init__(self, smoothing=0.0):
+        super().__init__()
+        self.smoothing = smoothing
+
+    def forward(self, inp, target):
+        log_prob = F.log_softmax(inp, dim=-1)
+        weight = inp.new_ones(inp.size()) * self.smoothing / (inp.size(-1) - 1.)
+        weight.scatter_(-1, target.unsqueeze(-1), (1. - self.smoothing))
+        return (-weight * log_prob).sum(dim=-1).mean()
+
+
+def l2_norm(x):  # attacks.py:360-366 (mean of squares, not sum)
+    return (x.view(x.shape[0], -1) ** 2).mean(1).sqrt()
+
+
+class Trades:  # attacks.py:369-429
+    def __init__(self, step_size=0.003, epsilon=0.047, perturb_steps=5, beta=1.0):
+        self.step_size, self.epsilon, self.perturb_steps, self.beta = step_size, epsilon, perturb_steps, beta
+        self.criterion_kl = nn.KLDivLoss(reduction="batchmean")
+
+    def reset_steps(self, k):
+        self.perturb_steps = k
+
+    def PGD_Linf(self, model, x_natural, logits, noise=None):  # attacks.py:404-418 (device='cuda' -> x's device)
+        model.eval()
+        nz = torch.randn(x_natural.shape, device=x_natural.device) if noise is None else noise
+        x_adv = x_natural.detach() + 0.001 * nz.detach()
+        prob = F.softmax(logits, dim=-1)
+        for _ in range(self.perturb_steps):
+            x_adv.requires_grad_()
+            with torch.enable_grad():
+                loss_kl = self.criterion_kl(F.log_softmax(model(x_adv), dim=1), prob)
+            grad = torch.autograd.grad(loss_kl, [x_adv])[0].detach()
+            x_adv = _step(x_adv, grad, x_natural, self.step_size, self.epsilon)
+        return x_adv
+
+    def PGD_L2(self, model, x_natural, logits, noise=None):  # attacks.py:381-401
+        model.eval()
+        nz = torch.randn(x_natural.shape, device=x_natural.device) if noise is None else noise
+        x_adv = x_natural.detach() + 0.001 * nz.detach()
+        prob = F.softmax(logits, dim=-1)
+        for _ in range(self.perturb_steps):
+            with torch.enable_grad():
+                x_adv.requires_grad_()
+                loss_kl = self.criterion_kl(F.log_softmax(model(x_adv), dim=1), prob)
+            grad = torch.autograd.grad(loss_kl, [x_adv])[0].detach()
+            grad /= l2_norm(grad).unsqueeze(-1).unsqueeze(-1).unsqueeze(-1) + 1e-8
+            x_adv = x_adv.detach() + self.step_size * grad
+            delta = x_adv - x_natural
+            delta_norm = l2_norm(delta)
+            cond = delta_norm > self.epsilon
+            delta[cond] *= self.epsilon / delta_norm[cond].unsqueeze(-1).unsqueeze(-1).unsqueeze(-1)
+            x_adv = torch.clamp(x_natural + delta, 0.0, 1.0)
+        return x_adv
+
+    def loss(self, model, logits, x_adv, labels, optimizer):  # attacks.py:421-429
+        model.train()
+        optimizer.zero_grad()
+        prob = F.softmax(logits, dim=-1)
+        return F.cross_entropy(logits, labels) + self.beta * self.criterion_kl(F.log_softmax(model(x_adv), dim=1), prob)
+
+
+class ALP:  # attacks.py:236-272
+    def __init__(self, step_size=0.003, epsilon=0.047, perturb_steps=5, beta=1.0):
+        self.step_size, self.epsilon, self.perturb_steps, self.beta = step_size, epsilon, perturb_steps, beta
+
+    def reset_steps(self, k):
+        self.perturb_steps = k
+
+    def PGD_Linf(self, model, x_natural, y, noise=None):
+        model.eval()
+        nz = torch.randn(x_natural.shape, device=x_natural.device) if noise is None else noise
+        x_adv = x_natural.detach() + 0.001 * nz.detach()
+        for _ in range(self.perturb_steps):
+            x_adv.requires_grad_()
+            with torch.enable_grad():
+                loss_c = F.cross_entropy(model(x_adv), y)
+            grad = torch.autograd.grad(loss_c, [x_adv])[0].detach()
+            x_adv = _step(x_adv, grad, x_natural, self.step_size, self.epsilon)
+        return x_adv
+
+    def loss(self, model, logits, logits_adv, y, optimizer):
+        model.train()
+        optimizer.zero_grad()
+        return 0.5 * F.cross_entropy(logits, y) + 0.5 * F.cross_entropy(logits_adv, y) + self.beta * F.mse_loss(logits, logits_adv)
+
+
+class AVmixup:  # attacks.py:433-479
+    def __init__(self, args, gamma, lambda1, lambda2, step_size, num_steps, num_classes=200, device='cpu'):
+        self.args, self.gamma, self.lambda1, self.lambda2 = args, gamma, lambda1, lambda2
+        self.step_size, self.num_steps, self.num_classes, self.device = step_size, num_steps, num_classes, device
+
+    def _label_smoothing(self, one_hot, factor):
+        return one_hot * factor + (one_hot - 1.) * ((factor - 1) / float(self.num_classes - 1))
+
+    def perturb(self, model, inputs, targets, noise=None, beta=None):
+        x = inputs.detach()
+        if self.args.random:
+            nz = torch.zeros_like(x).uniform_(-self.args.epsilon, self.args.epsilon) if noise is None else noise
+            x = torch.clamp(x + nz, 0, 1)
+        for _ in range(self.num_steps):
+            x.requires_grad_()
+            with torch.enable_grad():
+                loss = -torch.sum(F.log_softmax(model(x), dim=1) * targets)
+            grad = torch.autograd.grad(loss, [x])[0]
+            x = _step(x, grad, inputs, self.step_size, self.args.epsilon)
+        vertex = torch.clamp(inputs + (x - inputs) * self.gamma, 0, 1)
+        y_nat = self._label_smoothing(targets, self.lambda1)
+        y_vertex = self._label_smoothing(targets, self.lambda2)
+        x_weight = np.random.beta(1.0, 1.0, [x.shape[0], 1, 1, 1]) if beta is None else beta
+        xw = torch.from_numpy(x_weight).to(self.device)
+        yw = torch.from_numpy(np.reshape(x_weight, [-1, 1])).to(self.device)
+        x = inputs * xw + vertex * (1 - xw)
+        y = y_nat * yw + y_vertex * (1 - yw)
+        return x.to(torch.float), y
+
+
+def CWLinfAttack(x, y, model, magnitude, previous_p, max_eps, max_iters=20, target=None, n_class=10, noise=None):
+    """attacks.py:136-232, targeted form with previous_p=None (the only one that runs).
+    target=None uses the max-other-logit branch (:204) instead of crashing at :152."""
+    model.eval()
+    adv = x.clone()
+    pred = model(x).max(dim=1)[1]
+    if torch.sum(pred == y).item() == 0:
+        return adv, previous_p
+    ind = (pred == y).nonzero().squeeze()
+    x = x[ind]
+    y = y[ind]
+    x = x if len(x.shape) == 4 else x.unsqueeze(0)
+    y = y if len(y.shape) == 1 else y.unsqueeze(0)
+    if target is not None:
+        target = target[ind]
+        target = target if len(target.shape) == 1 else target.unsqueeze(0)
+    one_hot_y = torch.zeros(y.size(0), n_class)
+    one_hot_y[torch.arange(y.size(0)), y] = 1
+    x.requires_grad = True
+    rp = torch.FloatTensor(x.shape).uniform_(-magnitude, magnitude) if noise is None else noise[ind].reshape(x.shape)
+    adv_imgs = x + rp
+    adv_imgs.clamp_(0, 1)
+    max_x, min_x = x + max_eps, x - max_eps
+    with torch.enable_grad():
+        for _ in range(int(max_iters)):
+            outputs = model(adv_imgs)
+            correct_logit = torch.sum(one_hot_y * outputs, dim=1)
+            if target is not None:
+                wl = torch.zeros(target.size(0), n_class)
+                wl[torch.arange(target.size(0)), target] = 1
+                wrong_logit = torch.sum(wl * outputs, dim=1)
+            else:
+                wrong_logit, _ = torch.max((1 - one_hot_y) * outputs - 1e4 * one_hot_y, dim=1)
+            loss = -torch.sum(F.relu(correct_logit - wrong_logit + 50))
+            grads = torch.autograd.grad(loss, adv_imgs)[0]
+            adv_imgs.data += 0.00392 * torch.sign(grads.data)
+            adv_imgs = torch.max(torch.min(adv_imgs, x + magnitude), x - magnitude)
+            adv_imgs.clamp_(0, 1)
+            adv_imgs = torch.max(torch.min(adv_imgs, max_x), min_x)
+    adv_imgs.clamp_(0, 1)
+    now_p = adv_imgs - x
+    adv[ind] = adv_imgs
+    return adv, now_p
+
+
+def accuracy(output, target, topk=(1,)):  # utils/helper.py:39-55
+    maxk = max(topk)
+    _, pred = output.topk(maxk, 1, largest=True, sorted=True)
+    pred = pred.t()
+    if target.shape == output.shape:
+        _, target = target.topk(1, 1, largest=True, sorted=True)
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / target.size(0)) for k in topk]
+
+
+# ======================================================================================================
+# models (MNIST/models_mnist/Net2*.py, Tiny_ImageNet/models_tinyimagenet/resnet*.py)
+# ======================================================================================================
+class Net_2(nn.Module):  # MNIST/models_mnist/Net2.py:6-20
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(1, 32, kernel_size=5)
+        self.conv2 = nn.Conv2d(32, 64, kernel_size=5)
+        self.conv2_drop = nn.Dropout2d()
+        self.fc1 = nn.Linear(4 * 4 * 64, 1024)
+        self.fc2 = nn.Linear(1024, 10)
+
+    def body(self, x):
+        x = F.relu(F.max_pool2d(self.conv1(x), 2))
+        x = F.relu(F.max_pool2d(self.conv2_drop(self.conv2(x)), 2))
+        x = x.view(-1, 4 * 4 * 64)
+        return self.fc2(F.relu(self.fc1(x)))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+class BasicBlock(nn.Module):  # Tiny_ImageNet/models_tinyimagenet/resnet.py:31-60
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out += x if self.downsample is None else self.downsample(x)
+        return self.relu(out)
+
+
+class Bottleneck(nn.Module):  # resnet.py:63-99
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        out += x if self.downsample is None else self.downsample(x)
+        return self.relu(out)
+
+
+class ResNet(nn.Module):
+    """resnet.py:102-162 (Tiny: 200 classes, AdaptiveAvgPool; ImageNet twin: 1000 classes, AvgPool2d(7))."""
+
+    def __init__(self, block, layers, num_classes=200, imagenet_pool=False):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], 2)
+        self.layer3 = self._make_layer(block, 256, layers[2], 2)
+        self.layer4 = self._make_layer(block, 512, layers[3], 2)
+        self.avgpool = nn.AvgPool2d(7, stride=1) if imagenet_pool else nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def body(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.avgpool(x)
+        return self.fc(x.view(x.size(0), -1))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def resnet18(**kw):
+    return ResNet(BasicBlock, [2, 2, 2, 2], **kw)
+
+
+def resnet50(**kw):
+    return ResNet(Bottleneck, [3, 4, 6, 3], **kw)
+
+
+class EEFront(nn.Module):
+    """The six front-end lines of every EE model (resnet_EE.py:176-191, resnet_EE_square.py:187-206,
+    Net2_EE.py:36-49, Net2_EE_square.py:48-63): x_in = clamp(hfs(x or add_square(x)) + w*canny(x), 0, 1)."""
+
+    def __init__(self, size, channels, r, w, low, high, alpha, sigma, type_canny="CannyFilter_step125_1", with_gf=False,
+                 square=False, epsilon=0.05, n_queries=1):
+        super().__init__()
+        self.w, self.with_gf, self.low, self.high = w, with_gf, low / 255, high / 255
+        self.hfs = HighFreqSuppress(size, size, r)
+        self.canny = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1,
+                      "CannyFilter_BPDA": CannyFilter_BPDA}[type_canny](sigma=sigma, alpha=alpha)
+        self.add_square = Add_Square(channels, size, epsilon, n_queries=n_queries) if square else None
+        self.register_buffer("weight_gaussian", torch.from_numpy(get_gaussian_kernel(3, 0., 1.)).float()[None, None],
+                             persistent=False)
+
+    def forward(self, x, draws=None):
+        x_hfs = self.hfs(x if self.add_square is None else self.add_square(x, draws))
+        x_canny = self.canny(x, low_threshold=self.low, high_threshold=self.high, hysteresis=True)
+        if self.with_gf:
+            x_canny = F.conv2d(x_canny.type(torch.float), self.weight_gaussian, padding=1)
+        return torch.clamp(x_hfs + self.w * x_canny, 0.0, 1.0)
+
+
+class EEModel(nn.Module):
+    def __init__(self, front, net):
+        super().__init__()
+        self.front, self.net = front, net
+
+    def forward(self, x, draws=None):
+        return self.net(self.front(x, draws))

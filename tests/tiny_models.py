@@ -1,0 +1,24 @@
+"""Small seeded classifiers shared by the tests (the same construction tests/golden/make_golden.py used)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class TinyNet(nn.Module):
+    """conv3x3(8) -> ReLU -> avgpool2 -> linear; ReLU gives exact-zero gradients so sign(0) = 0 is exercised."""
+
+    def __init__(self, cin, hw, ncls, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w1 = nn.Parameter(torch.randn(8, cin, 3, 3, generator=g) * 0.5)
+        self.w2 = nn.Parameter(torch.randn(ncls, 8 * (hw // 2) * (hw // 2), generator=g) * 0.2)
+
+    def forward(self, x):
+        h = F.relu(F.conv2d(x, self.w1, padding=1))
+        h = F.avg_pool2d(h, 2)
+        return F.linear(h.flatten(1), self.w2)
