@@ -1,0 +1,140 @@
+"""The attack inner loop on the device (the K-step loop of utils/attacks.py:19-27 and its nine copies).
+
+One PGD step = model forward, loss-gradient kernel on the logits, model backward to the input
+(torch.autograd.grad with grad_outputs - the scalar loss itself is never formed inside the loop), then
+ONE in-place update kernel on persistent buffers (x, x0): zero temporaries, where the reference allocates
+six per step.  The K steps may run from a HIP graph captured on the first call for a given (model, shape,
+loss, mode) - the loop body is launch-bound at B = 50..100.
+
+Semantics kept from the reference: the model's train/eval mode is NOT touched here (PGD() runs in whatever
+mode the caller left, BatchNorm statistics and dropout included); callers are entered under
+torch.enable_grad() so an outer no_grad() does not matter; the result is a new detached tensor.
+"""
+import os
+import weakref
+
+import torch
+
+from . import ops
+
+CE_SUM, CE_MEAN, KL, SOFTCE = "ce_sum", "ce_mean", "kl", "softce"
+
+
+class LossSpec:
+    """Which d(loss)/d(logits) the loop needs.  payload: labels (CE), natural logits (KL), float64 soft
+    targets (SOFTCE).  attacks.py:23 (sum CE), :255 (mean CE), :412 (KL batchmean), :462-463 (soft CE)."""
+
+    def __init__(self, kind, payload):
+        self.kind, self.payload = kind, payload
+
+    def dlogits(self, logits):
+        z = logits.detach()
+        if self.kind == CE_SUM:
+            return ops.ce(z, self.payload, "sum", 0.0, False, True)[1]
+        if self.kind == CE_MEAN:
+            return ops.ce(z, self.payload, "mean", 0.0, False, True)[1]
+        if self.kind == KL:
+            return ops.kl_batchmean(z, self.payload, False, True, False)[1]
+        if self.kind == SOFTCE:
+            return ops.softce(z, self.payload, 1.0, False, True)[1].to(torch.float32)
+        raise ValueError(self.kind)
+
+
+def _unwrap(model):
+    """DDP / DataParallel wrappers add nothing to an input-gradient step (no parameter gradients are
+    produced, so there is nothing to all-reduce): run the wrapped module directly."""
+    inner = getattr(model, "module", None)
+    return inner if isinstance(inner, torch.nn.Module) and type(model).__name__ in (
+        "DistributedDataParallel", "DataParallel") else model
+
+
+def input_gradient(model, x, spec):
+    """g = d loss / d x for the current x (x: leaf ROCm tensor)."""
+    x.requires_grad_(True)
+    with torch.enable_grad():
+        logits = model(x)
+    d = spec.dlogits(logits.contiguous())
+    (g,) = torch.autograd.grad(logits, [x], grad_outputs=d)
+    return g
+
+
+class _GraphedStep:
+    """One captured PGD step bound to static buffers."""
+
+    def __init__(self, model, x0, spec, step_size, eps, direction, lo, hi):
+        self.x = torch.empty_like(x0).requires_grad_(True)
+        self.x0 = torch.empty_like(x0)
+        self.payload = torch.empty_like(spec.payload)
+        self.spec = LossSpec(spec.kind, self.payload)
+        self.cfg = (step_size, eps, direction, lo, hi)
+        self.model = weakref.ref(model)
+        self.graph = None
+
+    def _body(self, model):
+        step_size, eps, direction, lo, hi = self.cfg
+        g = input_gradient(model, self.x, self.spec)
+        ops.pgd_step_(self.x.detach(), g.contiguous(), self.x0, step_size, eps, lo, hi, direction)
+
+    def capture(self, model, x_init, x0, payload):
+        self.load(x_init, x0, payload)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up outside capture: MIOpen algorithm search, allocator, autograd
+                self._body(model)
+        torch.cuda.current_stream().wait_stream(side)
+        self.load(x_init, x0, payload)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body(model)
+
+    def load(self, x_init, x0, payload):
+        with torch.no_grad():
+            self.x.detach().copy_(x_init)
+            self.x0.copy_(x0)
+            self.payload.copy_(payload)
+
+
+_GRAPHS = {}
+
+
+def graphs_enabled():
+    return os.environ.get("EEADV_GRAPH", "0") == "1"
+
+
+def clear_graphs():
+    _GRAPHS.clear()
+
+
+def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo=0.0, hi=1.0, use_graph=None):
+    """Runs num_steps updates starting from x_init (a fresh tensor the loop may update in place); returns a
+    detached tensor.  attacks.py:19-27: x = clamp(min(max(x + dir*alpha*sign(g), x0-eps), x0+eps), 0, 1)."""
+    model = _unwrap(model)
+    x0 = x0.detach().contiguous()
+    if use_graph is None:
+        use_graph = graphs_enabled()
+    if use_graph and num_steps > 0:
+        key = (id(model), model.training, tuple(x0.shape), spec.kind, tuple(spec.payload.shape), spec.payload.dtype,
+               float(step_size), float(eps), direction, lo, hi, x0.device.index)
+        gs = _GRAPHS.get(key)
+        if gs is not None and gs.model() is not model:
+            gs = None
+        if gs is None:
+            gs = _GraphedStep(model, x0, spec, step_size, eps, direction, lo, hi)
+            # capturing executes the body (2 warm-up + 1 captured): shield BN statistics from those extra steps
+            saved = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+            gs.capture(model, x_init, x0, spec.payload)
+            if saved:
+                model.load_state_dict(saved, strict=False)
+            _GRAPHS[key] = gs
+        gs.load(x_init, x0, spec.payload)
+        for _ in range(num_steps):
+            gs.graph.replay()
+        return gs.x.detach().clone()
+
+    x = x_init.detach().contiguous()
+    for _ in range(num_steps):
+        g = input_gradient(model, x, spec)
+        x = x.detach()
+        ops.pgd_step_(x, g.contiguous(), x0, step_size, eps, lo, hi, direction)
+    return x.requires_grad_(False)

@@ -1,0 +1,111 @@
+"""torch.autograd bridges onto the HIP kernels (eeadv.ops).  Everything here requires ROCm tensors."""
+import torch
+
+from . import ops
+
+
+class Edge125Fn(torch.autograd.Function):
+    """CannyFilter_step125_1 forward/backward (utils/core.py:549-585, To_compare :329-358)."""
+
+    @staticmethod
+    def forward(ctx, img, wts, alpha, high):
+        img = img.contiguous()
+        ctx.save_for_backward(img)
+        ctx.cfg = (wts, alpha, high)
+        return ops.edge125_fwd(img, wts, alpha, high)
+
+    @staticmethod
+    def backward(ctx, u):
+        (img,) = ctx.saved_tensors
+        wts, alpha, high = ctx.cfg
+        g = ops.edge125_bwd(img, u.contiguous(), wts, alpha, high)
+        return g.expand_as(img), None, None, None
+
+
+class FrontEndFn(torch.autograd.Function):
+    """x_in = clamp(x_hfs + w * edge125(x), 0, 1) in one kernel each way (resnet_EE.py:176-191)."""
+
+    @staticmethod
+    def forward(ctx, x, x_hfs, wts, alpha, high, w):
+        x, x_hfs = x.contiguous(), x_hfs.contiguous()
+        x_in, gate, _ = ops.frontend_fwd(x, x_hfs, wts, alpha, high, w)
+        ctx.save_for_backward(x, gate)
+        ctx.cfg = (wts, alpha, high, w)
+        return x_in
+
+    @staticmethod
+    def backward(ctx, g_in):
+        x, gate = ctx.saved_tensors
+        wts, alpha, high, w = ctx.cfg
+        g_hfs, g_edge = ops.frontend_bwd(g_in.contiguous(), gate, x, wts, alpha, high, w)
+        gx = g_edge.expand_as(x) if ctx.needs_input_grad[0] else None
+        return gx, g_hfs, None, None, None, None
+
+
+class AddSquareFn(torch.autograd.Function):
+    """Add_Square (utils/core.py:636-655) given its random draws."""
+
+    @staticmethod
+    def forward(ctx, x, eps, stripe, sq_sign, sq_pos, sq_size):
+        x = x.contiguous()
+        ctx.save_for_backward(x, stripe, sq_sign, sq_pos, sq_size)
+        ctx.eps = eps
+        return ops.add_square_fwd(x, eps, stripe, sq_sign, sq_pos, sq_size)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stripe, sq_sign, sq_pos, sq_size = ctx.saved_tensors
+        return ops.add_square_bwd(g.contiguous(), x, ctx.eps, stripe, sq_sign, sq_pos, sq_size), None, None, None, None, None
+
+
+class _ScalarLossFn(torch.autograd.Function):
+    """A scalar loss whose gradients were produced by the same kernel launch as its value."""
+
+    @staticmethod
+    def forward(ctx, loss, *pairs):
+        # pairs = (input_0, grad_0, input_1, grad_1, ...): inputs keep the graph, grads are constants
+        ctx.grads = pairs[1::2]
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        out = [None]
+        for g in ctx.grads:
+            out += [None if g is None else (g * go.to(g.dtype)), None]
+        return tuple(out)
+
+
+def _attach(loss, *pairs):
+    if any(t is not None and t.requires_grad for t in pairs[0::2]):
+        flat = []
+        for t, g in zip(pairs[0::2], pairs[1::2]):
+            flat += [t, g]
+        return _ScalarLossFn.apply(loss, *flat)
+    return loss
+
+
+def cross_entropy(logits, labels, reduction="mean", smoothing=0.0):
+    """F.cross_entropy / LabelSmoothLoss (attacks.py:23, :255, :89-99) with the gradient from the same kernel."""
+    loss, d = ops.ce(logits.contiguous(), labels.contiguous(), reduction, smoothing, True, logits.requires_grad)
+    return _attach(loss, logits, d)
+
+
+def kl_div_batchmean(logits_q, logits_p):
+    """nn.KLDivLoss('batchmean')(log_softmax(logits_q), softmax(logits_p)) (attacks.py:375, :412, :426);
+    the gradient flows into BOTH arguments, as in Trades.loss where `logits` is not detached."""
+    loss, dq, dp = ops.kl_batchmean(logits_q.contiguous(), logits_p.contiguous(), True, logits_q.requires_grad,
+                                    logits_p.requires_grad)
+    return _attach(loss, logits_q, dq, logits_p, dp)
+
+
+def mse_loss(a, b):
+    """F.mse_loss (attacks.py:269)."""
+    loss, da = ops.mse(a.contiguous(), b.contiguous(), True, a.requires_grad or b.requires_grad)
+    return _attach(loss, a, da, b, None if da is None else -da)
+
+
+def soft_cross_entropy(logits, soft_targets, scale):
+    """-sum(log_softmax(logits) * soft_targets) * scale with float64 targets -> float64 scalar
+    (attacks.py:462-463; Tiny_ImageNet/experiments_tinyimagenet.py:292-293)."""
+    loss, dz = ops.softce(logits.contiguous(), soft_targets.contiguous(), scale, True, logits.requires_grad)
+    return _attach(loss, logits, None if dz is None else dz.to(torch.float32))

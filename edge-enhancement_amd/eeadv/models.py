@@ -1,0 +1,225 @@
+"""The classifiers the attack loop differentiates, restated for PyTorch-ROCm.
+
+These are the WORKLOAD, not the product: convolutions / BatchNorm / pooling stay on MIOpen and hipBLASLt.
+Parameter names and construction order follow the reference so that (a) the same seed gives the same
+initial weights as the reference's plain models and (b) reference checkpoints load (EE checkpoints carry
+extra `sobel.*` / `u2netp.*` keys of modules the reference constructs but never calls - SURVEY 2.1 #12 -
+load those with strict=False).
+
+  Net_2 / Net2_EE / Net2_EE_square : MNIST/models_mnist/Net2.py:6-20, Net2_EE.py:7-54, Net2_EE_square.py:7-68
+  ResNet / ResNet_EE(_square)      : Tiny_ImageNet/models_tinyimagenet/resnet.py:26-162, resnet_EE.py:107-204,
+                                     resnet_EE_square.py:108-219; ImageNet twins differ in pooling / classes
+                                     (ImageNet/models_imagenet/resnet.py:103,114)
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_step125_1, HighFreqSuppress, ee_front_end,
+                        get_gaussian_kernel)
+
+_CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
+
+
+class _EEFrontMixin:
+    """x_in = clamp(hfs(x | add_square(x)) + w * canny(x), 0, 1): the first lines of every EE forward."""
+
+    def _build_front(self, size, channels, r, w, with_gf, low, high, alpha, sigma, type_canny, square, epsilon, n_queries):
+        self.w = w
+        self.with_gf = with_gf
+        self.hfs = HighFreqSuppress(size, size, r)
+        if type_canny not in _CANNY:
+            raise NotImplementedError
+        self.canny = _CANNY[type_canny](sigma=sigma, use_cuda=True, alpha=alpha)
+        self.add_square = Add_Square(channels=channels, size=size, epsilon=epsilon, n_queries=n_queries) if square else None
+        self.low = low / 255
+        self.high = high / 255
+        g = torch.from_numpy(get_gaussian_kernel(3, 0., 1.)).unsqueeze(0).unsqueeze(0).type(torch.float)
+        self.weight_gaussian = nn.Parameter(data=g, requires_grad=False)
+
+    def front(self, x, draws=None):
+        x_lp = self.hfs(x if self.add_square is None else self.add_square(x, draws))
+        return ee_front_end(x, x_lp, self.canny, self.w, self.low, self.high, self.with_gf, self.weight_gaussian)
+
+
+# ---- MNIST ---------------------------------------------------------------------------------------------------
+class Net_2(nn.Module):
+    def __init__(self):
+        super(Net_2, self).__init__()
+        self.conv1 = nn.Conv2d(1, 32, kernel_size=5)
+        self.conv2 = nn.Conv2d(32, 64, kernel_size=5)
+        self.conv2_drop = nn.Dropout2d()
+        self.fc1 = nn.Linear(4 * 4 * 64, 1024)
+        self.fc2 = nn.Linear(1024, 10)
+
+    def body(self, x):
+        x = F.relu(F.max_pool2d(self.conv1(x), 2))
+        x = F.relu(F.max_pool2d(self.conv2_drop(self.conv2(x)), 2))
+        x = x.view(-1, 4 * 4 * 64)
+        return self.fc2(F.relu(self.fc1(x)))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+class Net2_EE(_EEFrontMixin, Net_2):
+    def __init__(self, r=8, w=1, with_gf=False, low=60.0, high=120.0, alpha=0.0, sigma=1, type_canny='CannyFilter'):
+        nn.Module.__init__(self)
+        self._build_front(28, 1, r, w, with_gf, low, high, alpha, sigma, type_canny, False, 0.05, 1)
+        self.conv1 = nn.Conv2d(1, 32, kernel_size=5)
+        self.conv2 = nn.Conv2d(32, 64, kernel_size=5)
+        self.conv2_drop = nn.Dropout2d()
+        self.fc1 = nn.Linear(4 * 4 * 64, 1024)
+        self.fc2 = nn.Linear(1024, 10)
+
+    def forward(self, x, draws=None):
+        return self.body(self.front(x, draws))
+
+
+class Net2_EE_square(_EEFrontMixin, Net_2):
+    def __init__(self, r=8, w=1, with_gf=False, low=60.0, high=120.0, alpha=0.0, sigma=1, type_canny='CannyFilter',
+                 epsilon=0.05, n_queries=5000):
+        nn.Module.__init__(self)
+        self._build_front(28, 1, r, w, with_gf, low, high, alpha, sigma, type_canny, True, epsilon, n_queries)
+        self.conv1 = nn.Conv2d(1, 32, kernel_size=5)
+        self.conv2 = nn.Conv2d(32, 64, kernel_size=5)
+        self.conv2_drop = nn.Dropout2d()
+        self.fc1 = nn.Linear(4 * 4 * 64, 1024)
+        self.fc2 = nn.Linear(1024, 10)
+
+    def forward(self, x, draws=None):
+        return self.body(self.front(x, draws))
+
+
+# ---- ResNets ---------------------------------------------------------------------------------------------------
+def conv3x3(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super(BasicBlock, self).__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out += x if self.downsample is None else self.downsample(x)
+        return self.relu(out)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super(Bottleneck, self).__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        out += x if self.downsample is None else self.downsample(x)
+        return self.relu(out)
+
+
+class ResNet(nn.Module):
+    """dataset='tiny': 200 classes + AdaptiveAvgPool2d(1); dataset='imagenet': 1000 classes + AvgPool2d(7)."""
+
+    def __init__(self, block, layers, num_classes=200, dataset="tiny"):
+        super(ResNet, self).__init__()
+        self._build_cnn(block, layers, num_classes, dataset)
+        self._init_weights()
+
+    def _build_cnn(self, block, layers, num_classes, dataset):
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AvgPool2d(7, stride=1) if dataset == "imagenet" else nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def body(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.avgpool(x)
+        return self.fc(x.view(x.size(0), -1))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+class ResNet_EE(_EEFrontMixin, ResNet):
+    def __init__(self, block, layers, num_classes=200, cize=224, r=16, w=0.5, with_gf=False, low=60.0, high=120.0, alpha=0.0,
+                 sigma=1, type_canny='CannyFilter', dataset="tiny", square=False, epsilon=0.05, n_queries=5000):
+        nn.Module.__init__(self)
+        self._build_front(cize, 3, r, w, with_gf, low, high, alpha, sigma, type_canny, square, epsilon, n_queries)
+        self._build_cnn(block, layers, num_classes, dataset)
+        self._init_weights()
+
+    def forward(self, x, draws=None):
+        return self.body(self.front(x, draws))
+
+
+_LAYERS = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3]),
+           101: (Bottleneck, [3, 4, 23, 3]), 152: (Bottleneck, [3, 8, 36, 3])}
+
+
+def make_resnet(depth, dataset="tiny", pretrained=False, **kwargs):
+    if pretrained:
+        raise NotImplementedError("pretrained weights are read from ~/.torch/models in the reference; none ship offline")
+    block, layers = _LAYERS[depth]
+    kwargs.setdefault("num_classes", 1000 if dataset == "imagenet" else 200)
+    return ResNet(block, layers, dataset=dataset, **kwargs)
+
+
+def make_resnet_ee(depth, dataset="tiny", square=False, pretrained=False, **kwargs):
+    if pretrained:
+        raise NotImplementedError("pretrained weights are read from ~/.torch/models in the reference; none ship offline")
+    block, layers = _LAYERS[depth]
+    kwargs.setdefault("num_classes", 1000 if dataset == "imagenet" else 200)
+    return ResNet_EE(block, layers, dataset=dataset, square=square, **kwargs)

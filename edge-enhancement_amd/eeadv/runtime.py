@@ -1,0 +1,37 @@
+"""Process-wide switches of the host layer."""
+import torch
+
+_CPU_PLUMBING = False
+
+
+def allow_cpu_plumbing(on=True):
+    """The HIP kernels are the product; CPU tensors are refused unless a driver opts in explicitly
+    (`--no-cuda`, BASELINE config 1: MNIST ST on CPU).  The opt-in path is plain torch ops with the
+    reference's own expressions - it exists for plumbing runs on a GPU-less host, is never taken for a
+    ROCm tensor, and is never what the GPU tests or bench.py measure."""
+    global _CPU_PLUMBING
+    _CPU_PLUMBING = bool(on)
+
+
+def cpu_plumbing_allowed():
+    return _CPU_PLUMBING
+
+
+def require_device(t, what):
+    if t.is_cuda:
+        return True
+    if not _CPU_PLUMBING:
+        raise RuntimeError(
+            "%s received a %s tensor: the eeadv hot path runs on a ROCm device only. Move the data to the GPU, or call "
+            "eeadv.runtime.allow_cpu_plumbing(True) for a torch-op plumbing run on the host (what --no-cuda does)."
+            % (what, t.device))
+    return False
+
+
+def philox_ticket(device, n_elements):
+    """(seed, offset) for a device-side random start, taken from - and advancing - torch's CUDA generator of
+    `device`, so torch.manual_seed / set_seed govern it like they govern uniform_ in the reference."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(off + 4 * ((n_elements + 3) // 4))
+    return seed & 0xFFFFFFFFFFFFFFFF, off // 4

@@ -1,0 +1,365 @@
+"""GPU parity of the whole boundary: utils.attacks / utils.core (HIP path on cuda:0) against the CPU oracle
+(oracle/ref_path.py, pinned to the reference) and against the reference's own golden outputs.
+
+Tolerances (BASELINE north_star): integer predictions bit-exact, fp32 logits / loss within 1e-4.
+Element-wise results that do not pass through a vendor convolution are required bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ee_oracle as O
+from oracle import ref_path as R
+from tiny_models import Args, TinyNet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def A():
+    import utils.attacks as attacks
+    return attacks
+
+
+@pytest.fixture(scope="module")
+def Cm():
+    import utils.core as core
+    return core
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def same_fraction(a, b):
+    return float((a == b).mean())
+
+
+def test_native_library_is_loaded():
+    import eeadv._native as n
+    assert n.abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libeeadv.so" in f.read()
+    assert b"gfx950" in n.lib.ee_device_name()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attacks on a small classifier: the reference's own trajectories
+# ---------------------------------------------------------------------------------------------------------
+def test_pgd_family_vs_reference_golden(A, golden):
+    G = golden("pgd_steps")
+    x0, y = dev(G["x0"]), dev(G["y"])
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    cases = [
+        ("pgd", lambda m: A.PGD(m, Args(random=True, epsilon=eps), x0, y, 6, alpha, noise=dev(G["pgd_noise"])), 31),
+        ("pgdb", lambda m: A.PGD(m, Args(random=False, epsilon=0.3), x0, y, 8, 0.01), 32),
+        ("tpgd", lambda m: A.targeted_PGD(m, Args(random=True, epsilon=eps), x0, y, 6, alpha, 10, DEV, noise=dev(G["tpgd_noise"]),
+                                          label_offset=dev(G["tpgd_offset"]))[0], 33),
+        ("fgsm_u", lambda m: A.FGSM(m, x0, y, targeted=False, step_size=0.007), 34),
+        ("fgsm_t", lambda m: A.FGSM(m, x0, y, targeted=True, step_size=0.007), 34),
+    ]
+    for tag, run, seed in cases:
+        net = TinyNet(2, 8, 10, seed)
+        xa = run(net.to(DEV))
+        assert xa.device.type == "cuda" and not xa.requires_grad and xa.dtype == torch.float32
+        want = G[tag + "_final"]
+        got = xa.cpu().numpy()
+        # the classifier's convolution runs on MIOpen here and on oneDNN there: a gradient within rounding
+        # noise of zero may flip sign, moving that pixel by 2*alpha; everything else is bit-identical
+        assert same_fraction(got, want) > 0.995, tag
+        cpu_net = TinyNet(2, 8, 10, seed)
+        with torch.no_grad():
+            la, lb = cpu_net(torch.from_numpy(got)), cpu_net(torch.from_numpy(want))
+        assert torch.equal(la.argmax(1), lb.argmax(1)), tag
+        np.testing.assert_allclose(la.numpy(), lb.numpy(), atol=1e-4)
+    assert torch.equal(x0, dev(G["x0"]))  # inputs are never mutated
+
+
+def test_targeted_labels_and_side_effects(A):
+    torch.manual_seed(0)
+    net = TinyNet(2, 8, 10, 1).to(DEV)
+    x = torch.rand(5, 2, 8, 8, device=DEV)
+    y = torch.randint(0, 10, (5,), device=DEV)
+    net.train()
+    xa, tl = A.targeted_PGD(net, Args(random=True, epsilon=0.1), x, y, 2, 0.01, 10, DEV)
+    assert net.training and tl.dtype == torch.int64 and bool(((tl != y) & (tl >= 0) & (tl < 10)).all())
+    assert float((xa - x).abs().max()) <= 0.1 + 1e-6 and float(xa.min()) >= 0 and float(xa.max()) <= 1
+    tr = A.Trades(0.01, 0.1, 2, 6.0)
+    logits = net(x)
+    xt = tr.PGD_Linf(net, x, logits)
+    assert not net.training  # eval() side effect (attacks.py:405)
+
+    class Opt:
+        zeroed = False
+
+        def zero_grad(self):
+            self.zeroed = True
+    opt = Opt()
+    loss = tr.loss(net, logits, xt, y, opt)
+    assert net.training and opt.zeroed and loss.requires_grad  # attacks.py:422-423
+    alp = A.ALP(0.01, 0.1, 2, 1.0)
+    xb = alp.PGD_Linf(net, x, y)
+    assert not net.training and xb.shape == x.shape
+    with torch.no_grad():  # callers may sit under no_grad: the loop re-enables grad itself
+        xc = A.PGD(net, Args(random=False, epsilon=0.1), x, y, 2, 0.01)
+    assert float((xc - x).abs().max()) > 0
+
+
+def test_losses_graph_and_values(A, golden):
+    G = golden("losses")
+
+    class Opt:
+        def zero_grad(self):
+            pass
+    for tag in "sti":
+        la = dev(G[tag + "_la"]).requires_grad_(True)
+        lb = dev(G[tag + "_lb"]).requires_grad_(True)
+        y = dev(G[tag + "_y"])
+        K = la.shape[1]
+        alp = A.ALP(beta=0.5).loss(torch.nn.Identity(), la, lb, y, Opt())
+        ga, gb = torch.autograd.grad(alp, [la, lb])
+        np.testing.assert_allclose(alp.item(), G[tag + "_alp"], atol=1e-4)
+        np.testing.assert_allclose(ga.cpu().numpy(), G[tag + "_alp_ga"], atol=1e-6)
+        np.testing.assert_allclose(gb.cpu().numpy(), G[tag + "_alp_gb"], atol=1e-6)
+        lin = torch.nn.Linear(K, K, bias=False).to(DEV)
+        with torch.no_grad():
+            lin.weight.copy_(torch.eye(K))
+        tl = A.Trades(beta=6.0).loss(lin, la, lb.detach(), y, Opt())
+        (gt,) = torch.autograd.grad(tl, la)
+        np.testing.assert_allclose(tl.item(), G[tag + "_trades"], atol=1e-4, rtol=1e-6)
+        np.testing.assert_allclose(gt.cpu().numpy(), G[tag + "_trades_ga"], atol=2e-6)
+        ls = A.LabelSmoothLoss(0.1)(la, y)
+        (gl,) = torch.autograd.grad(ls, la)
+        np.testing.assert_allclose(ls.item(), G[tag + "_lsmooth"], atol=1e-4)
+        np.testing.assert_allclose(gl.cpu().numpy(), G[tag + "_lsmooth_g"], atol=1e-6)
+        np.testing.assert_allclose(A.compute_loss_and_error(la, y, 0.2).item(), G[tag + "_cle"], atol=1e-4)
+        assert np.array_equal(A.predict_from_logits(la).cpu().numpy(), G[tag + "_pred"])
+        av = A.AVmixup(Args(random=False, epsilon=0.1), 2.0, 1.0, 0.1, 0.01, 1, num_classes=K, device=DEV)
+        np.testing.assert_array_equal(av._label_smoothing(torch.eye(K, device=DEV)[y], 0.1).cpu().numpy(), G[tag + "_smooth_l2"])
+        np.testing.assert_allclose(A.l2_norm(la.detach().view(-1, 1, 1, K)).cpu().numpy(), G[tag + "_l2norm"], rtol=1e-6)
+
+
+def test_avmixup_and_cw_vs_reference_golden(A, golden):
+    G = golden("avmix_cw")
+    x0, y = dev(G["x0"]), dev(G["y"])
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    av = A.AVmixup(Args(random=True, epsilon=eps), 2.0, 1.0, 0.1, alpha, 5, num_classes=10, device=DEV)
+    xm, ym = av.perturb(TinyNet(2, 8, 10, 51).to(DEV), x0, torch.eye(10, device=DEV)[y], noise=dev(G["av_noise"]), beta=G["av_beta"])
+    assert xm.dtype == torch.float32 and ym.dtype == torch.float64
+    np.testing.assert_array_equal(ym.cpu().numpy(), G["av_y"])
+    assert same_fraction(xm.cpu().numpy(), G["av_x"]) > 0.99
+    np.testing.assert_allclose(xm.cpu().numpy(), G["av_x"], atol=4 * alpha + 1e-6)
+    net = TinyNet(2, 8, 10, 52)
+    ycl = net(torch.from_numpy(G["x0"])).argmax(1)
+    adv, p = A.CWLinfAttack(x0, ycl.to(DEV), net.to(DEV), eps, None, eps, max_iters=4, target=dev(G["cw_target"]), n_class=10,
+                            cur_device=DEV, noise=dev(G["cw_noise"]))
+    assert same_fraction(adv.cpu().numpy(), G["cw_adv"]) > 0.99
+    np.testing.assert_allclose(p.cpu().numpy(), G["cw_p"], atol=2 * 0.00392 + 1e-6)
+    # untargeted form: the reference crashes; ours must run and stay inside the box
+    adv_u, _ = A.CWLinfAttack(x0, ycl.to(DEV), net, eps, None, eps, max_iters=3, target=None, n_class=10, cur_device=DEV)
+    assert float((adv_u - x0).abs().max()) <= eps + 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's real models: Net_2 PGD-40 and resnet18 PGD-3, eval mode, seeded weights
+# ---------------------------------------------------------------------------------------------------------
+def test_end_to_end_net2_and_resnet18(A, golden):
+    from eeadv.models import Net_2, make_resnet
+    G = golden("e2e")
+    torch.manual_seed(7)
+    net = Net_2().eval()
+    cpu_net = R.Net_2().eval()
+    cpu_net.load_state_dict(net.state_dict())
+    net = net.to(DEV)
+    x, y = dev(G["net2_x"]), dev(G["net2_y"])
+    xa = A.PGD(net, Args(random=True, epsilon=0.3), x, y, 40, 0.01, noise=dev(G["net2_noise"]))
+    with torch.no_grad():
+        logits_gpu = net(xa).cpu().numpy()
+        clean_gpu = net(x).cpu().numpy()
+    assert np.array_equal(logits_gpu.argmax(1), G["net2_logits_adv"].argmax(1))
+    assert np.array_equal(clean_gpu.argmax(1), G["net2_logits_clean"].argmax(1))
+    np.testing.assert_allclose(clean_gpu, G["net2_logits_clean"], atol=1e-4)
+    assert same_fraction(xa.cpu().numpy(), G["net2_xadv"]) > 0.99
+    with torch.no_grad():  # same adversarial inputs through the CPU model: isolates the attack from the final forward
+        np.testing.assert_allclose(cpu_net(xa.cpu()).numpy(), G["net2_logits_adv"], atol=5e-3)
+    torch.manual_seed(8)
+    rn = make_resnet(18, "tiny").eval().to(DEV)
+    x, y = dev(G["rn18_x"]), dev(G["rn18_y"])
+    eps, alpha = 0.062745098039216, 0.007843137254902
+    xa = A.PGD(rn, Args(random=True, epsilon=eps), x, y, 3, alpha, noise=dev(G["rn18_noise"]))
+    with torch.no_grad():
+        clean = rn(x).cpu().numpy()
+        adv = rn(xa).cpu().numpy()
+    np.testing.assert_allclose(clean, G["rn18_logits_clean"], atol=1e-4)
+    assert np.array_equal(clean.argmax(1), G["rn18_logits_clean"].argmax(1))
+    assert np.array_equal(adv.argmax(1), G["rn18_logits_adv"].argmax(1))
+    assert same_fraction(xa.cpu().numpy(), G["rn18_xadv"]) > 0.99
+
+
+# ---------------------------------------------------------------------------------------------------------
+# edge-enhancement modules
+# ---------------------------------------------------------------------------------------------------------
+def test_canny_step125_module_vs_reference_golden(Cm, golden):
+    G = golden("edge125")
+    for name in ["rand_tiny", "rand_mnist", "rect_mnist", "rect_rgb", "ramp_thr", "ragged", "big_mag"]:
+        x = dev(G[name + "__x"]).requires_grad_(True)
+        alpha, high = [float(v) for v in G[name + "__alpha_high"]]
+        filt = Cm.CannyFilter_step125_1(sigma=1, use_cuda=True, alpha=alpha).to(DEV)
+        e = filt(x, low_threshold=high / 2, high_threshold=high, hysteresis=True)
+        assert e.shape == (x.shape[0], 1) + x.shape[2:]
+        assert np.array_equal(e.detach().cpu().numpy().astype(np.uint8), G[name + "__edge"])
+        (e * dev(G[name + "__u"])).sum().backward()
+        ref = G[name + "__gx"]
+        got = x.grad.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), name
+        fin = ~np.isnan(ref)
+        np.testing.assert_allclose(got[fin], ref[fin], atol=1e-6)
+    assert "weight_gaussian" not in filt.state_dict()  # use_cuda=True: plain tensors in the reference
+    assert "weight_gaussian" in Cm.CannyFilter_step125_1(use_cuda=False).state_dict()
+    with pytest.raises(NameError):
+        filt(x.detach())
+
+
+def test_hfs_module_vs_fft_restatement_UNPINNED(Cm):
+    torch.manual_seed(3)
+    for (n, r, c) in [(64, 8, 3), (28, 4, 1)]:
+        x = torch.rand(4, c, n, n)
+        xd = x.to(DEV).requires_grad_(True)
+        y = Cm.HighFreqSuppress(n, n, r)(xd)
+        ref_in = x.clone().requires_grad_(True)
+        ref = R.HighFreqSuppress(n, n, r)(ref_in)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), atol=3e-6)
+        u = torch.randn_like(x)
+        (y * u.to(DEV)).sum().backward()
+        (ref * u).sum().backward()
+        np.testing.assert_allclose(xd.grad.cpu().numpy(), ref_in.grad.numpy(), atol=3e-6)
+
+
+def test_add_square_vs_restatement_UNPINNED(Cm):
+    torch.manual_seed(4)
+    for (B, C, n, nq) in [(3, 3, 64, 1), (2, 1, 28, 1), (2, 3, 16, 12)]:
+        eps = 16 / 255
+        ref_mod = R.Add_Square(C, n, eps, n_queries=nq)
+        mod = Cm.Add_Square(C, n, eps, n_queries=nq)
+        x = torch.rand(B, C, n, n)
+        x[0, 0, 0, :6] = torch.tensor([0.0, 1.0, eps, 1 - eps, eps / 2, 1 - eps / 2])
+        d = ref_mod.draw(B)
+        xr = x.clone().requires_grad_(True)
+        yr = ref_mod(xr, d)
+        u = torch.randn_like(x)
+        (yr * u).sum().backward()
+        xd = x.to(DEV).requires_grad_(True)
+        dd = {"stripe": d["stripe"].to(DEV), "sq_pos": d["sq_pos"].to(DEV), "sq_sign": d["sq_sign"].reshape(nq, C).to(DEV)}
+        yd = mod(xd, dd)
+        (yd * u.to(DEV)).sum().backward()
+        assert np.array_equal(yd.detach().cpu().numpy(), yr.detach().numpy())
+        np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-9)
+        y2 = mod(xd.detach())  # device draws: stays in the eps-box and in [0,1]
+        assert float((y2 - xd.detach()).abs().max()) <= eps + 1e-6 and float(y2.min()) >= 0 and float(y2.max()) <= 1
+
+
+def _ee_pair(square, n=64, c=3, r=8, alpha=0.0, low=38.0, high=76.0, type_canny="CannyFilter_step125_1"):
+    from eeadv.models import Net2_EE_square, Net2_EE, make_resnet_ee
+    torch.manual_seed(11)
+    if c == 3:
+        m = make_resnet_ee(18, "tiny", square, cize=n, r=r, w=1.0, with_gf=False, low=low, high=high, alpha=alpha, sigma=1.0,
+                           type_canny=type_canny, epsilon=16 / 255, n_queries=1)
+        ref_net = R.resnet18()
+    else:
+        kw = dict(r=r, w=1.0, with_gf=False, low=low, high=high, alpha=alpha, sigma=1.0, type_canny=type_canny)
+        m = Net2_EE_square(epsilon=0.3, n_queries=1, **kw) if square else Net2_EE(**kw)
+        ref_net = R.Net_2()
+    ref_net.load_state_dict({k: v for k, v in m.state_dict().items() if k in ref_net.state_dict()})
+    front = R.EEFront(n, c, r, 1.0, low, high, alpha, 1.0, type_canny, False, square, 16 / 255 if c == 3 else 0.3, 1)
+    return m.to(DEV).eval(), R.EEModel(front, ref_net).eval()
+
+
+@pytest.mark.parametrize("square,c,n,r,alpha,low,high", [(True, 3, 64, 8, 0.0, 38.0, 76.0), (False, 3, 64, 8, 0.0, 38.0, 76.0),
+                                                         (True, 1, 28, 4, 0.3, 25.0, 51.0)])
+def test_ee_model_forward_and_input_gradient(square, c, n, r, alpha, low, high):
+    m, ref = _ee_pair(square, n, c, r, alpha, low, high)
+    torch.manual_seed(5)
+    B = 4
+    x = torch.rand(B, c, n, n)
+    x[1, :, 10:20, 5:25] = 0.5  # flat patch: zero magnitude -> NaN gradients
+    draws = ref.front.add_square.draw(B) if square else None
+    ddev = None if draws is None else {"stripe": draws["stripe"].to(DEV), "sq_pos": draws["sq_pos"].to(DEV),
+                                       "sq_sign": draws["sq_sign"].reshape(1, c).to(DEV)}
+    xr = x.clone().requires_grad_(True)
+    xin_ref = ref.front(xr, draws)
+    xd = x.to(DEV).requires_grad_(True)
+    xin = m.front(xd, ddev)
+    d = (xin.detach().cpu() - xin_ref.detach()).abs()
+    assert float((d > 1e-5).float().mean()) == 0.0, "front-end outputs differ (an edge bit flipped?)"
+    y = torch.randint(0, 10 if c == 1 else 200, (B,))
+    logit_ref = ref.net(xin_ref)
+    logit = m.body(xin)
+    np.testing.assert_allclose(logit.detach().cpu().numpy(), logit_ref.detach().numpy(), atol=1e-4)
+    assert torch.equal(logit.argmax(1).cpu(), logit_ref.argmax(1))
+    F.cross_entropy(logit_ref, y, reduction="sum").backward()
+    F.cross_entropy(logit, y.to(DEV), reduction="sum").backward()
+    g, gr = xd.grad.cpu().numpy(), xr.grad.numpy()
+    assert np.isnan(gr).sum() > 0
+    assert np.array_equal(np.isnan(g), np.isnan(gr))
+    fin = ~np.isnan(gr)
+    scale = np.abs(gr[fin]).max()
+    assert np.abs(g[fin] - gr[fin]).max() < 2e-4 * scale + 1e-7
+    agree = (np.sign(g[fin]) == np.sign(gr[fin])).mean()
+    assert agree > 0.999
+
+
+def test_pgd_on_ee_model_matches_oracle(A):
+    m, ref = _ee_pair(False)
+    torch.manual_seed(6)
+    B = 4
+    x = torch.rand(B, 3, 64, 64)
+    x[0, :, 30:50, 30:50] = 0.25
+    y = torch.randint(0, 200, (B,))
+    eps, alpha = 16 / 255, 2 / 255
+    noise = torch.zeros_like(x).uniform_(-eps, eps)
+    xa_ref = R.PGD(ref, Args(random=True, epsilon=eps), x, y, 3, alpha, noise=noise)
+    xa = A.PGD(m, Args(random=True, epsilon=eps), x.to(DEV), y.to(DEV), 3, alpha, noise=noise.to(DEV))
+    assert same_fraction(xa.cpu().numpy(), xa_ref.numpy()) > 0.99
+    with torch.no_grad():
+        la, lb = ref(xa.cpu()), ref(xa_ref)
+    assert torch.equal(la.argmax(1), lb.argmax(1))
+    # without a random start the flat patch has zero edge magnitude: its gradient is NaN in every step
+    # (0 * inf), sign(NaN) = 0, so the patch never moves - on the GPU exactly as in the oracle
+    xb_ref = R.PGD(ref, Args(random=False, epsilon=eps), x, y, 3, alpha)
+    xb = A.PGD(m, Args(random=False, epsilon=eps), x.to(DEV), y.to(DEV), 3, alpha).cpu()
+    assert torch.equal(xb_ref[0, :, 30:50, 30:50], x[0, :, 30:50, 30:50])
+    assert torch.equal(xb[0, :, 30:50, 30:50], x[0, :, 30:50, 30:50])
+    assert same_fraction(xb.numpy(), xb_ref.numpy()) > 0.99 and float((xb - x).abs().max()) > 0
+
+
+def test_hip_graph_replay_equals_eager(A):
+    from eeadv import engine
+    torch.manual_seed(9)
+    net = TinyNet(3, 16, 10, 5).to(DEV).eval()
+    x = torch.rand(8, 3, 16, 16, device=DEV)
+    y = torch.randint(0, 10, (8,), device=DEV)
+    noise = torch.zeros_like(x).uniform_(-0.1, 0.1)
+    args = Args(random=True, epsilon=0.1)
+    eager = A.PGD(net, args, x, y, 5, 0.01, noise=noise)
+    spec = engine.LossSpec(engine.CE_SUM, y)
+    from eeadv import ops
+    xg = engine.pgd_loop(net, x, ops.pgd_init(x, noise), spec, 5, 0.01, 0.1, use_graph=True)
+    xg2 = engine.pgd_loop(net, x, ops.pgd_init(x, noise), spec, 5, 0.01, 0.1, use_graph=True)  # cached graph
+    assert torch.equal(xg, xg2)
+    assert same_fraction(xg.cpu().numpy(), eager.cpu().numpy()) > 0.999
+    engine.clear_graphs()
+
+
+def test_accuracy_helper(golden):
+    from utils.helper import accuracy
+    rng = np.random.RandomState(0)
+    z = rng.randn(100, 200).astype(np.float32)
+    y = rng.randint(0, 200, 100)
+    got = accuracy(dev(z), dev(y), topk=(1, 5))
+    want = R.accuracy(torch.from_numpy(z), torch.from_numpy(y), topk=(1, 5))
+    assert [g.item() for g in got] == [w.item() for w in want]
+    soft = np.eye(200, dtype=np.float32)[y] * 0.9 + 0.0005
+    got = accuracy(dev(z), dev(soft), topk=(1, 5))
+    assert [g.item() for g in got] == [w.item() for w in want]
