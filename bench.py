@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py - adversarial images / second of the hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
+
+Default workload = BASELINE config "Tiny-ImageNet ResNet-18 AT + edge-enhance" (SURVEY.md 8(d) item 4,
+Tiny_ImageNet/configs_tinyimagenet/ee_at_bpda3_square.yml): per-rank batch [100,3,64,64] synthetic U[0,1),
+labels randint(200), model resnet18_EE_square (CannyFilter_step125_1, r=8, w=1, alpha=0, sigma=1,
+high=76/255, Add_Square n_queries=1), train mode.  One "step" = one training step of the reference's
+train() loop (Tiny_ImageNet/experiments_tinyimagenet.py:234-306): PGD-10 attack (eps 16/255, alpha 2/255,
+random start) + forward on the adversarial batch + cross-entropy + backward + SGD(momentum, wd) update
+(+ the gradient all-reduce over RCCL when N > 1).  value = N * B * K / time (weak scaling), fp32 throughout.
+
+Printed JSON also carries
+  roofline     : the dominant hand-written kernel (fused front-end backward), algorithmic bytes per launch
+                 (16*C B/pixel) / its mean duration measured with HIP events on the launch
+                 stream inside the timed region (one PGD iteration per attack runs outside the HIP graph so
+                 that its kernels can be bracketed by events - see DESIGN.md "Measurement").
+  kernels      : the same measurement for every hand-written kernel family.
+  cpu_baseline : the CPU oracle (oracle/ref_path.py, pinned to the reference) running the SAME step with
+                 plain PyTorch CPU ops on the host cores, rank 0 at N = 1 only, bounded sample.
+End-to-end throughput is bounded by the CNN's convolutions (MIOpen, fp32 MFMA), not by these kernels.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "edge-enhancement_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+WORKLOADS = {
+    # name: (arch, method, batch, shape, classes, eps, alpha, K)
+    "tiny_ee_at": dict(arch="resnet18_EE_square", method="EE_BPDA3_AT_square", batch=100, shape=(3, 64, 64), classes=200,
+                       eps=0.062745098039216, alpha=0.007843137254902, steps=10, lr=0.1, momentum=0.9, wd=2e-4),
+    "tiny_at": dict(arch="resnet18", method="AT", batch=100, shape=(3, 64, 64), classes=200,
+                    eps=0.062745098039216, alpha=0.007843137254902, steps=10, lr=0.1, momentum=0.9, wd=2e-4),
+    "tiny_trades": dict(arch="resnet18", method="TRADES", batch=100, shape=(3, 64, 64), classes=200,
+                        eps=0.062745098039216, alpha=0.003921568627451, steps=10, lr=0.1, momentum=0.9, wd=2e-4, beta=6.0),
+    "mnist_ee_at": dict(arch="Net2_EE_square", method="EE_BPDA3_AT_square", batch=50, shape=(1, 28, 28), classes=10,
+                        eps=0.3, alpha=0.01, steps=40, lr=0.1, momentum=0.3, wd=1e-4),
+}
+
+
+class Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def build_model(cfg, oracle=False):
+    if oracle:
+        from oracle import ref_path as R
+        if cfg["arch"] == "resnet18":
+            return R.resnet18()
+        if cfg["arch"] == "resnet18_EE_square":
+            front = R.EEFront(64, 3, 8, 1.0, 38.0, 76.0, 0.0, 1.0, "CannyFilter_step125_1", False, True, cfg["eps"], 1)
+            return R.EEModel(front, R.resnet18())
+        if cfg["arch"] == "Net2_EE_square":
+            front = R.EEFront(28, 1, 4, 1.0, 25.0, 51.0, 0.3, 1.0, "CannyFilter_step125_1", False, True, cfg["eps"], 1)
+            return R.EEModel(front, R.Net_2())
+        raise ValueError(cfg["arch"])
+    from eeadv import models as M
+    if cfg["arch"] == "resnet18":
+        return M.make_resnet(18, "tiny")
+    if cfg["arch"] == "resnet18_EE_square":
+        return M.make_resnet_ee(18, "tiny", True, cize=64, r=8, w=1.0, with_gf=False, low=38.0, high=76.0, alpha=0, sigma=1.0,
+                                type_canny="CannyFilter_step125_1", epsilon=cfg["eps"], n_queries=1)
+    if cfg["arch"] == "Net2_EE_square":
+        return M.Net2_EE_square(r=4, w=1.0, with_gf=False, low=25.0, high=51.0, alpha=0.3, sigma=1.0,
+                                type_canny="CannyFilter_step125_1", epsilon=cfg["eps"], n_queries=1)
+    raise ValueError(cfg["arch"])
+
+
+def train_step(attacks, model, optimizer, criterion, cfg, x, y):
+    """The body of train() in Tiny_ImageNet/experiments_tinyimagenet.py:234-306 for the AT / TRADES branches."""
+    args = Args(random=True, epsilon=cfg["eps"])
+    if cfg["method"] == "TRADES":
+        preds = model(x)
+        data_adv = criterion.PGD_Linf(model, x, preds)
+        output = model(data_adv)
+        loss = criterion.loss(model, preds, data_adv, y, optimizer)
+    else:
+        data_adv = attacks.PGD(model, args, x, y, cfg["steps"], cfg["alpha"])
+        output = model(data_adv)
+        loss = criterion(output, y)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), output.detach()
+
+
+def cpu_baseline(cfg, seconds_target=20.0):
+    """The oracle's step on the host cores (cpu_baseline.kind = 'port')."""
+    import torch.nn.functional as F
+    from oracle import ref_path as R
+    threads = len(os.sched_getaffinity(0))
+    torch.set_num_threads(threads)
+    torch.manual_seed(1)
+    model = build_model(cfg, oracle=True).train()
+    opt = torch.optim.SGD(model.parameters(), lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"])
+    B = cfg["batch"]
+    x = torch.rand(B, *cfg["shape"])
+    y = torch.randint(0, cfg["classes"], (B,))
+    args = Args(random=True, epsilon=cfg["eps"])
+
+    def step():
+        if cfg["method"] == "TRADES":
+            tr = R.Trades(cfg["alpha"], cfg["eps"], cfg["steps"], cfg["beta"])
+            preds = model(x)
+            adv = tr.PGD_Linf(model, x, preds)
+            model(adv)
+            loss = tr.loss(model, preds, adv, y, opt)
+        else:
+            adv = R.PGD(model, args, x, y, cfg["steps"], cfg["alpha"])
+            loss = F.cross_entropy(model(adv), y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    t0 = time.perf_counter()
+    step()  # warm-up (also sizes the sample)
+    warm = time.perf_counter() - t0
+    n = max(1, min(10, int(seconds_target / max(warm, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 2), "unit": "adversarial images/s", "cores": threads, "kind": "port",
+            "sample": "%d training steps of batch %d (after 1 warm-up step), %.1f s, torch CPU ops, %d threads" % (n, B, dt, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="tiny_ee_at", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-rank batch (default: the reference config's)")
+    ap.add_argument("--no-graph", action="store_true", help="run every PGD iteration eagerly (no HIP graph)")
+    ap.add_argument("--probe-iters", type=int, default=1,
+                    help="PGD iterations per attack that run outside the HIP graph so their kernels can be event-timed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels-last", action="store_true")
+    a = ap.parse_args()
+
+    cfg = dict(WORKLOADS[a.workload])
+    if a.batch:
+        cfg["batch"] = a.batch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if a.gpus > 1 and world == 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import utils.attacks as attacks
+    from utils.helper import set_seed
+    from eeadv import engine, ops, _native as N
+
+    os.environ["EEADV_GRAPH"] = "0" if a.no_graph else "1"
+    engine.PROBE_ITERS = 0 if a.no_graph else a.probe_iters
+    set_seed(1 + rank)  # experiments_imagenet.py:61: seed + rank
+    model = build_model(cfg).to(dev).train()
+    if a.channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    optimizer = torch.optim.SGD(model.parameters(), lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"])
+    run_model = model
+    if world > 1:
+        run_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=16,
+                                                              gradient_as_bucket_view=True)
+    if cfg["method"] == "TRADES":
+        criterion = attacks.Trades(cfg["alpha"], cfg["eps"], cfg["steps"], cfg["beta"])
+    else:
+        from eeadv import functional as EF
+        criterion = lambda out, tgt: EF.cross_entropy(out, tgt, "mean")  # nn.CrossEntropyLoss() of the drivers
+    B = cfg["batch"]
+    batches = [(torch.rand(B, *cfg["shape"], device=dev), torch.randint(0, cfg["classes"], (B,), device=dev)) for _ in range(4)]
+
+    def run(n):
+        last = None
+        for i in range(n):
+            x, y = batches[i % len(batches)]
+            last = train_step(attacks, run_model, optimizer, criterion, cfg, x, y)
+        return last
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(a.warmup)
+    fence()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    t0 = time.perf_counter()
+    last = run(a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    ops.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(last[0].item())
+
+    if rank == 0:
+        C, H, W = cfg["shape"]
+        px = B * H * W
+        per_launch = {  # algorithmic bytes per launch, SURVEY.md 8(d)
+            "ee_frontend_bwd": (N.K_FRONTEND_BWD, 16 * C * px), "ee_frontend_fwd": (N.K_FRONTEND_FWD, 12 * C * px),
+            "ee_pgd_step": (N.K_PGD_STEP, 16 * C * px), "ee_ce": (N.K_CE, 3 * B * cfg["classes"] * 4),
+        }
+        kernels = {}
+        for name, (kid, nbytes) in per_launch.items():
+            ms, cnt = ops.prof_read(kid)
+            if cnt:
+                us = 1e3 * ms / cnt
+                kernels[name] = {"launches_timed": cnt, "avg_us": round(us, 3), "bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1)}
+        dom = "ee_frontend_bwd" if "ee_frontend_bwd" in kernels else (max(kernels, key=lambda k: kernels[k]["avg_us"]) if kernels else None)
+        roofline = None
+        if dom:
+            ach = kernels[dom]["GBps"]
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": kernels[dom]["avg_us"]}
+        out = {
+            "metric": "adversarial images/sec (PGD-%d, %s)" % (cfg["steps"], cfg["arch"]),
+            "value": round(world * B * a.steps / dt, 2), "unit": "adversarial images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s %s, per-rank batch %d x %s, PGD-%d eps %.4f alpha %.4f, train step incl. SGD%s" % (
+                a.workload, cfg["arch"], cfg["method"], B, "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"],
+                ", DDP all-reduce (RCCL)" if world > 1 else ""),
+                "global_batch": world * B, "hip_graph": not a.no_graph, "probe_iters": engine.PROBE_ITERS,
+                "device": (N.lib.ee_device_name() or b"?").decode()},
+            "roofline": roofline, "kernels": kernels, "final_loss": round(loss_val, 5),
+            "note": "throughput is bounded by the CNN convolutions (MIOpen fp32), not by the hand-written kernels; "
+                    "reference log (unrecorded GPU): ~143 img/s for this config (BASELINE.md)",
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,14 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// hipGetLastError() is thread-sticky across ALL runtime calls (torch's included): clear it before a launch so
+// that launch_status() reports this launch and not somebody else's stale error.
+#define EE_LAUNCH(...)                    \
+    do {                                  \
+        (void)hipGetLastError();          \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
+    } while (0)
+
 static inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? EE_OK : static_cast<int>(e);

@@ -404,15 +404,15 @@ int launch_fwd(const EdgeParams &p0, const Weights &wt, int B, bool vec, hipStre
     if (l.tw == 64) {
         const size_t lds = sizeof(float) * 2 * p.C * Frame<16, 64, 2>::kPlane;
         if (vec)
-            hipLaunchKernelGGL((edge_fwd_kernel<16, 64, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
+            EE_LAUNCH((edge_fwd_kernel<16, 64, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
         else
-            hipLaunchKernelGGL((edge_fwd_kernel<16, 64, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
+            EE_LAUNCH((edge_fwd_kernel<16, 64, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
     } else {
         const size_t lds = sizeof(float) * 2 * p.C * Frame<32, 32, 2>::kPlane;
         if (vec)
-            hipLaunchKernelGGL((edge_fwd_kernel<32, 32, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
+            EE_LAUNCH((edge_fwd_kernel<32, 32, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
         else
-            hipLaunchKernelGGL((edge_fwd_kernel<32, 32, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
+            EE_LAUNCH((edge_fwd_kernel<32, 32, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
     }
     return launch_status();
 }
@@ -428,15 +428,15 @@ int launch_bwd(const EdgeParams &p0, const Weights &wt, int B, bool vec, hipStre
     if (l.tw == 64) {
         const size_t lds = sizeof(float) * planes * Frame<16, 64, 4>::kPlane;
         if (vec)
-            hipLaunchKernelGGL((edge_bwd_kernel<16, 64, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
+            EE_LAUNCH((edge_bwd_kernel<16, 64, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
         else
-            hipLaunchKernelGGL((edge_bwd_kernel<16, 64, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
+            EE_LAUNCH((edge_bwd_kernel<16, 64, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
     } else {
         const size_t lds = sizeof(float) * planes * Frame<32, 32, 4>::kPlane;
         if (vec)
-            hipLaunchKernelGGL((edge_bwd_kernel<32, 32, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
+            EE_LAUNCH((edge_bwd_kernel<32, 32, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
         else
-            hipLaunchKernelGGL((edge_bwd_kernel<32, 32, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
+            EE_LAUNCH((edge_bwd_kernel<32, 32, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
     }
     return launch_status();
 }

@@ -55,9 +55,9 @@ int launch_map3(float *out, const float *a, const float *b, const float *c, int6
     int64_t blocks = (work + kBlock - 1) / kBlock;
     if (blocks > kMaxGrid) blocks = kMaxGrid;
     if (vec)
-        hipLaunchKernelGGL((map3_kernel<4, Op>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, out, a, b, c, n, op);
+        EE_LAUNCH((map3_kernel<4, Op>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, out, a, b, c, n, op);
     else
-        hipLaunchKernelGGL((map3_kernel<1, Op>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, out, a, b, c, n, op);
+        EE_LAUNCH((map3_kernel<1, Op>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, out, a, b, c, n, op);
     return launch_status();
 }
 
@@ -194,9 +194,9 @@ EE_API int ee_pgd_init_rng_f32(float *x, const float *x0, int64_t n, float scale
     if (!x || !x0) return EE_ERR_NULL;
     const int g = grid_for((n + 3) / 4);
     if (dist == 0)
-        hipLaunchKernelGGL(init_rng_kernel<0>, dim3(g), dim3(kBlock), 0, as_stream(stream), x, x0, n, scale, seed, offset, lo, hi);
+        EE_LAUNCH(init_rng_kernel<0>, dim3(g), dim3(kBlock), 0, as_stream(stream), x, x0, n, scale, seed, offset, lo, hi);
     else
-        hipLaunchKernelGGL(init_rng_kernel<1>, dim3(g), dim3(kBlock), 0, as_stream(stream), x, x0, n, scale, seed, offset, lo, hi);
+        EE_LAUNCH(init_rng_kernel<1>, dim3(g), dim3(kBlock), 0, as_stream(stream), x, x0, n, scale, seed, offset, lo, hi);
     return launch_status();
 }
 
@@ -246,10 +246,10 @@ EE_API int ee_pgd_step_bcast_f32(float *x, const float *g_lp, const float *g_edg
     const bool vec = (hw % 4 == 0) && aligned16(x) && aligned16(g_lp) && aligned16(g_edge) && aligned16(x0);
     ProfScope prof(EE_K_PGD_STEP_BCAST, as_stream(stream));
     if (vec)
-        hipLaunchKernelGGL(pgd_step_bcast_kernel<4>, dim3(grid_for(n / 4)), dim3(kBlock), 0, as_stream(stream), x, g_lp,
+        EE_LAUNCH(pgd_step_bcast_kernel<4>, dim3(grid_for(n / 4)), dim3(kBlock), 0, as_stream(stream), x, g_lp,
                            g_edge, x0, C, hw, n, op);
     else
-        hipLaunchKernelGGL(pgd_step_bcast_kernel<1>, dim3(grid_for(n)), dim3(kBlock), 0, as_stream(stream), x, g_lp,
+        EE_LAUNCH(pgd_step_bcast_kernel<1>, dim3(grid_for(n)), dim3(kBlock), 0, as_stream(stream), x, g_lp,
                            g_edge, x0, C, hw, n, op);
     return launch_status();
 }
@@ -260,7 +260,7 @@ EE_API int ee_avmix_f32(float *out, const float *x, const float *x0, const doubl
     if (B < 0 || per_sample < 1) return EE_ERR_SHAPE;
     const int64_t n = B * per_sample;
     if (n == 0) return EE_OK;
-    hipLaunchKernelGGL(avmix_kernel, dim3(grid_for(n)), dim3(kBlock), 0, as_stream(stream), out, x, x0, wgt, per_sample, n, gamma);
+    EE_LAUNCH(avmix_kernel, dim3(grid_for(n)), dim3(kBlock), 0, as_stream(stream), out, x, x0, wgt, per_sample, n, gamma);
     return launch_status();
 }
 
@@ -269,7 +269,7 @@ EE_API int ee_avmix_labels_f64(double *out, const int64_t *labels, const double 
     if (!out || !labels || !wgt) return EE_ERR_NULL;
     if (B < 0 || K < 2) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
-    hipLaunchKernelGGL(avmix_labels_kernel, dim3(grid_for(B * K)), dim3(kBlock), 0, as_stream(stream), out, labels, wgt, B, K,
+    EE_LAUNCH(avmix_labels_kernel, dim3(grid_for(B * K)), dim3(kBlock), 0, as_stream(stream), out, labels, wgt, B, K,
                        lambda1, lambda2);
     return launch_status();
 }

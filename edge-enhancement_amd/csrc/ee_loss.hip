@@ -223,7 +223,7 @@ EE_API int ee_ce_f32(const float *logits, const int64_t *labels, int B, int K, f
     if (B < 0 || K < 1 || K > 65536 || (smoothing != 0.0f && K < 2)) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
     ProfScope prof(EE_K_CE, as_stream(stream));
-    hipLaunchKernelGGL(ce_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), logits, labels, B, K, smoothing, gscale,
+    EE_LAUNCH(ce_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), logits, labels, B, K, smoothing, gscale,
                        row_loss, dlogits);
     return launch_status();
 }
@@ -233,7 +233,7 @@ EE_API int ee_kl_f32(const float *zq, const float *zp, int B, int K, float gscal
     if (!zq || !zp) return EE_ERR_NULL;
     if (B < 0 || K < 1 || K > 65536) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
-    hipLaunchKernelGGL(kl_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), zq, zp, B, K, gscale, row_loss, dzq, dzp);
+    EE_LAUNCH(kl_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), zq, zp, B, K, gscale, row_loss, dzq, dzp);
     return launch_status();
 }
 
@@ -242,7 +242,7 @@ EE_API int ee_softce_f64(const float *z, const double *t, int B, int K, double g
     if (!z || !t) return EE_ERR_NULL;
     if (B < 0 || K < 1 || K > 65536) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
-    hipLaunchKernelGGL(softce_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), z, t, B, K, gscale, row_loss, dz);
+    EE_LAUNCH(softce_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), z, t, B, K, gscale, row_loss, dz);
     return launch_status();
 }
 
@@ -252,7 +252,7 @@ EE_API int ee_mse_f32(const float *a, const float *b, int64_t n, float gscale, d
     if (!a || !b) return EE_ERR_NULL;
     if (n < 0 || ee_mse_num_partials(n) > 0x7fffffffLL) return EE_ERR_SHAPE;
     if (n == 0) return EE_OK;
-    hipLaunchKernelGGL(mse_kernel, dim3(static_cast<unsigned>(ee_mse_num_partials(n))), dim3(kBlock), 0, as_stream(stream), a, b, n,
+    EE_LAUNCH(mse_kernel, dim3(static_cast<unsigned>(ee_mse_num_partials(n))), dim3(kBlock), 0, as_stream(stream), a, b, n,
                        gscale, partial, da);
     return launch_status();
 }
@@ -260,7 +260,7 @@ EE_API int ee_mse_f32(const float *a, const float *b, int64_t n, float gscale, d
 EE_API int ee_reduce_rows_f64(const double *rows, int64_t n, double scale, double *out, void *stream) {
     if (!rows || !out) return EE_ERR_NULL;
     if (n < 0) return EE_ERR_SHAPE;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), rows, n, scale, out);
+    EE_LAUNCH(reduce_rows_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), rows, n, scale, out);
     return launch_status();
 }
 
@@ -273,7 +273,7 @@ EE_API int ee_topk_i64(const float *logits, const int64_t *labels, int B, int K,
         if (e != hipSuccess) return static_cast<int>(e);
     }
     if (B == 0) return EE_OK;
-    hipLaunchKernelGGL(topk_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), logits, labels, B, K, k, idx,
+    EE_LAUNCH(topk_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), logits, labels, B, K, k, idx,
                        reinterpret_cast<unsigned long long *>(correct));
     return launch_status();
 }

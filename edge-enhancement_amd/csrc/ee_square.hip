@@ -84,9 +84,9 @@ int launch(bool bwd, const float *x, const float *g_out, float *out, int B, int 
     int64_t blocks = ((n + 3) / 4 + kBlock - 1) / kBlock;
     if (blocks > kMaxGrid) blocks = kMaxGrid;
     if (bwd)
-        hipLaunchKernelGGL(square_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, x, g_out, out, n, a);
+        EE_LAUNCH(square_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, x, g_out, out, n, a);
     else
-        hipLaunchKernelGGL(square_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, x, g_out, out, n, a);
+        EE_LAUNCH(square_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, x, g_out, out, n, a);
     return launch_status();
 }
 

@@ -7,6 +7,13 @@ include/eeadv.h, importing this module raises - a GPU run can never silently use
 import ctypes
 import os
 
+# PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  libeeadv.so must share THAT
+# runtime instance - device pointers and streams come from torch - so torch is imported first: the dynamic
+# loader then resolves libeeadv's NEEDED libamdhip64.so.7 to the copy already in the process.  Loading
+# libeeadv first would pull /opt/rocm's copy in as a second, separate runtime (launches fail with
+# hipErrorNoDevice).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libeeadv.so")
 

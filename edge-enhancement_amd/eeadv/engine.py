@@ -96,6 +96,9 @@ class _GraphedStep:
 
 
 _GRAPHS = {}
+# PGD iterations per attack that run OUTSIDE the captured graph even in graph mode, so that the library's
+# HIP-event hooks (ee_prof_*) can time their kernels live; bench.py sets it (DESIGN.md "Measurement").
+PROBE_ITERS = 0
 
 
 def graphs_enabled():
@@ -127,8 +130,14 @@ def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo
             if saved:
                 model.load_state_dict(saved, strict=False)
             _GRAPHS[key] = gs
-        gs.load(x_init, x0, spec.payload)
-        for _ in range(num_steps):
+        x = x_init.detach().contiguous()
+        probe = min(PROBE_ITERS, num_steps)
+        for _ in range(probe):
+            g = input_gradient(model, x, spec)
+            x = x.detach()
+            ops.pgd_step_(x, g.contiguous(), x0, step_size, eps, lo, hi, direction)
+        gs.load(x, x0, spec.payload)
+        for _ in range(num_steps - probe):
             gs.graph.replay()
         return gs.x.detach().clone()
 
