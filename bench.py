@@ -148,6 +148,7 @@ def main():
                     help="PGD iterations per attack that run outside the HIP graph so their kernels can be event-timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen find)")
     a = ap.parse_args()
 
     cfg = dict(WORKLOADS[a.workload])
@@ -162,6 +163,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    torch.backends.cudnn.benchmark = bool(a.miopen_benchmark)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1,0 +1,126 @@
+"""The per-batch body of the reference drivers' train() / validate() loops, shared by the drivers and bench.py.
+
+train_batch follows Tiny_ImageNet/experiments_tinyimagenet.py:245-306 (MNIST twin: MNIST/experiments_mnist.py:
+215-251): `method_name` selects the attack that builds data_adv and the loss on top of it, then
+zero_grad / backward / optimizer.step.  Everything stays on the device; nothing calls .item() here (the
+reference syncs every batch at :299 - the drivers sync only when they print).
+"""
+import torch
+import torch.nn as nn
+
+from utils import attacks as A
+from utils.helper import accuracy
+
+
+class Criterion:
+    """nn.CrossEntropyLoss() of the drivers (experiments_tinyimagenet.py:127) on the HIP loss kernel for ROCm logits."""
+
+    def __init__(self):
+        self._host = nn.CrossEntropyLoss()
+
+    def __call__(self, output, target):
+        if output.is_cuda:
+            from eeadv import functional as EF
+            return EF.cross_entropy(output, target, "mean")
+        return self._host(output, target)
+
+
+def make_criterion(args):
+    """experiments_tinyimagenet.py:120-127."""
+    n_class = getattr(args, "num_classes", 200)
+    if args.method_name == 'ALP':
+        return A.ALP(args.step_size_1, args.epsilon, args.num_steps_1, args.beta)
+    if args.method_name == 'tarALP':
+        return A.targeted_ALP(args.step_size_1, args.epsilon, args.num_steps_1, args.beta, n_class)
+    if args.method_name == 'TRADES':
+        return A.Trades(args.step_size_1, args.epsilon, args.num_steps_1, args.beta)
+    return Criterion()
+
+
+def attack_for_training(model, criterion, args, input, target, device, avmixup=None):
+    """experiments_tinyimagenet.py:245-282: returns (data_adv, preds_or_None, new_target_or_None)."""
+    m = args.method_name
+    n_class = getattr(args, "num_classes", 200)
+    if m == 'ST':
+        return input, None, None
+    if m == 'ALP':
+        preds = model(input)
+        return criterion.PGD_Linf(model, input, target), preds, None
+    if m == 'tarALP':
+        preds = model(input)
+        return criterion.tarPGD_Linf(model, input, target, device), preds, None
+    if m == 'TRADES':
+        preds = model(input)
+        return criterion.PGD_Linf(model, input, preds), preds, None
+    if m in ('AVmixup', 'tarAVmixup'):
+        onehot = torch.eye(n_class, device=input.device)[target]
+        fn = avmixup.perturb if m == 'AVmixup' else avmixup.tar_perturb
+        data_adv, new_target = fn(model, input, onehot)
+        return data_adv, None, new_target
+    if m.startswith('tar'):  # tarAT, tarEE, tarEE_BPDA3_AT_square
+        data_adv, _ = A.targeted_PGD(model, args, input, target, args.num_steps_1, args.step_size_1, n_class, device)
+        return data_adv, None, None
+    return A.PGD(model, args, input, target, args.num_steps_1, args.step_size_1), None, None  # AT and every EE_* method
+
+
+def train_batch(model, criterion, optimizer, args, input, target, device, avmixup=None):
+    """One optimisation step; returns (loss, output) detached, both still on the device."""
+    data_adv, preds, new_target = attack_for_training(model, criterion, args, input, target, device, avmixup)
+    output = model(data_adv)
+    m = args.method_name
+    if m in ('ALP', 'tarALP'):
+        loss = criterion.loss(model, preds, output, target, optimizer)
+    elif m == 'TRADES':
+        loss = criterion.loss(model, preds, data_adv, target, optimizer)
+    elif m in ('AVmixup', 'tarAVmixup'):
+        if output.is_cuda:
+            from eeadv import functional as EF
+            loss = EF.soft_cross_entropy(output, new_target.contiguous(), 1.0 / input.shape[0])
+        else:
+            loss = -torch.sum(nn.functional.log_softmax(output, dim=1) * new_target) / input.shape[0]
+    else:
+        loss = criterion(output, target)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), output.detach()
+
+
+def attack_for_validation(model, args, input, target, device, num_steps, step_size, n_class):
+    """experiments_tinyimagenet.py:354-374."""
+    targeted = "tar" in args.method_name
+    if args.attack_method == 'PGD':
+        if targeted:
+            return A.targeted_PGD(model, args, input, target, num_steps, step_size, n_class, device)[0]
+        return A.PGD(model, args, input, target, num_steps, step_size)
+    if args.attack_method == 'FGSM':
+        if targeted:
+            off = torch.randint(low=1, high=n_class, size=target.shape).to(device)
+            return A.FGSM(model, input, torch.fmod(target + off, n_class), targeted=True, step_size=step_size)
+        return A.FGSM(model, input, target, targeted=False, step_size=step_size)
+    if args.attack_method == 'CW':
+        tl = None
+        if targeted:
+            off = torch.randint(low=1, high=n_class, size=target.shape).to(device)
+            tl = torch.fmod(target + off, n_class)
+        return A.CWLinfAttack(x=input, y=target, model=model, magnitude=args.epsilon, previous_p=None, max_eps=args.epsilon,
+                              max_iters=20, target=tl, n_class=n_class, cur_device=device)[0]
+    raise NotImplementedError
+
+
+def validate_batch(model, criterion, args, input, target, device, num_steps, step_size, n_class):
+    """experiments_tinyimagenet.py:354-397: attack, then clean and adversarial forward under no_grad.
+    Returns device tensors (loss_clean, loss_adv, prec1_cle, prec5_cle, prec1_adv, prec5_adv)."""
+    data_adv = attack_for_validation(model, args, input, target, device, num_steps, step_size, n_class)
+    with torch.no_grad():
+        output_clean = model(input)
+        output_adv = model(data_adv)
+        if "ALP" in args.method_name or "TRADES" in args.method_name:
+            loss_clean = torch.zeros((), device=input.device)
+            loss_adv = torch.zeros((), device=input.device)
+        else:
+            loss_clean = criterion(output_clean, target)
+            loss_adv = criterion(output_adv, target)
+        p1c, p5c = accuracy(output_clean.data, target, topk=(1, min(5, n_class)))
+        p1a, p5a = accuracy(output_adv.data, target, topk=(1, min(5, n_class)))
+    return loss_clean, loss_adv, p1c, p5c, p1a, p5a

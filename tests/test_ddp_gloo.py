@@ -1,0 +1,105 @@
+"""CPU, world_size 2 over gloo: the N > 1 path (batch sharding + gradient all-reduce, no collective inside
+the attack loop).  Kernels cannot run here, so the attack goes through the opt-in torch plumbing path; what
+is under test is the partitioning, seeding and gradient-averaging logic of eeadv.ddp / eeadv.trainer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tiny_models import Args, TinyNet
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg():
+    return Args(method_name="AT", random=False, epsilon=0.1, num_steps_1=3, step_size_1=0.02, num_classes=10, attack_method="PGD")
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "edge-enhancement_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    from eeadv import ddp, runtime, trainer
+    runtime.allow_cpu_plumbing(True)
+    ddp.setup(device="cpu")
+    assert ddp.world() == 2 and ddp.rank() == rank and ddp.rank_seed(5) == 5 + rank and ddp.per_rank_batch(8) == 4
+    torch.manual_seed(0)  # same weights on every rank
+    model = ddp.wrap(TinyNet(2, 8, 10, 7), device="cpu")
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(123)
+    X, Y = torch.rand(8, 2, 8, 8, generator=g), torch.randint(0, 10, (8,), generator=g)
+    idx = ddp.shard_indices(8)
+    x, y = X[idx], Y[idx]
+    args = _cfg()
+    crit = trainer.make_criterion(args)
+    data_adv, _, _ = trainer.attack_for_training(model, crit, args, x, y, "cpu")
+    loss, out = trainer.train_batch(model, crit, opt, args, x, y, "cpu")
+    m1, m2 = ddp.gather_mean(float(loss), float(rank))
+    tmax = ddp.max_over_ranks(1.0 + rank)
+    torch.save({"idx": idx, "adv": data_adv, "params": [p.detach().clone() for p in model.parameters()], "loss": float(loss),
+                "mean_loss": m1, "mean_rank": m2, "tmax": tmax}, os.path.join(out_dir, "r%d.pt" % rank))
+    ddp.teardown()
+
+
+def test_two_rank_gloo_training_step(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(str(tmp_path / "r0.pt"), weights_only=False)
+    r1 = torch.load(str(tmp_path / "r1.pt"), weights_only=False)
+    assert r0["idx"] == [0, 2, 4, 6] and r1["idx"] == [1, 3, 5, 7]
+    # parameters are identical on both ranks after the all-reduced step
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    assert abs(r0["mean_loss"] - 0.5 * (r0["loss"] + r1["loss"])) < 1e-12 and r0["mean_rank"] == 0.5 and r0["tmax"] == 2.0
+    # single-process emulation: same shards, gradients averaged by hand
+    from eeadv import runtime, trainer
+    import torch.nn.functional as F
+    runtime.allow_cpu_plumbing(True)
+    try:
+        torch.manual_seed(0)
+        net = TinyNet(2, 8, 10, 7)
+        opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        g = torch.Generator().manual_seed(123)
+        X, Y = torch.rand(8, 2, 8, 8, generator=g), torch.randint(0, 10, (8,), generator=g)
+        args = _cfg()
+        crit = trainer.make_criterion(args)
+        grads = []
+        for r, res in ((0, r0), (1, r1)):
+            x, y = X[res["idx"]], Y[res["idx"]]
+            adv, _, _ = trainer.attack_for_training(net, crit, args, x, y, "cpu")
+            assert torch.equal(adv, res["adv"])  # no collective inside the attack: a rank's shard is attacked independently
+            net.zero_grad()
+            F.cross_entropy(net(adv), y).backward()
+            grads.append([p.grad.clone() for p in net.parameters()])
+        for p, g0, g1 in zip(net.parameters(), *grads):
+            p.grad = (g0 + g1) / 2
+        opt.step()
+        for p, q in zip(net.parameters(), r0["params"]):
+            np.testing.assert_allclose(p.detach().numpy(), q.numpy(), rtol=1e-6, atol=1e-7)
+    finally:
+        runtime.allow_cpu_plumbing(False)
+
+
+def test_shard_indices_and_padding():
+    from eeadv import ddp
+    assert ddp.shard_indices(10, 0, 4) == [0, 4, 8] and ddp.shard_indices(10, 3, 4) == [3, 7, 1]
+    assert sorted(sum((ddp.shard_indices(12, r, 4) for r in range(4)), [])) == list(range(12))
+    with pytest.raises(ValueError):
+        os.environ["WORLD_SIZE"] = "3"
+        try:
+            ddp.per_rank_batch(100)
+        finally:
+            os.environ.pop("WORLD_SIZE")
