@@ -78,29 +78,30 @@ def build_model(cfg, oracle=False):
     raise ValueError(cfg["arch"])
 
 
-def train_step(attacks, model, optimizer, criterion, cfg, x, y):
-    """The body of train() in Tiny_ImageNet/experiments_tinyimagenet.py:234-306 for the AT / TRADES branches."""
-    args = Args(random=True, epsilon=cfg["eps"])
-    if cfg["method"] == "TRADES":
-        preds = model(x)
-        data_adv = criterion.PGD_Linf(model, x, preds)
-        output = model(data_adv)
-        loss = criterion.loss(model, preds, data_adv, y, optimizer)
-    else:
-        data_adv = attacks.PGD(model, args, x, y, cfg["steps"], cfg["alpha"])
-        output = model(data_adv)
-        loss = criterion(output, y)
-    optimizer.zero_grad()
-    loss.backward()
-    optimizer.step()
-    return loss.detach(), output.detach()
+def driver_args(cfg):
+    """The EasyDict the reference drivers build from YAML + CLI, reduced to what the step reads."""
+    return Args(method_name=cfg["method"], random=True, epsilon=cfg["eps"], num_steps_1=cfg["steps"], step_size_1=cfg["alpha"],
+                beta=cfg.get("beta", 1.0), num_classes=cfg["classes"], attack_method="PGD")
 
 
-def cpu_baseline(cfg, seconds_target=20.0):
+def host_cores():
+    """Cores this process may actually use: the cgroup CPU quota when there is one (the GPU box shows 256
+    CPUs but grants 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(cfg, seconds_target=25.0):
     """The oracle's step on the host cores (cpu_baseline.kind = 'port')."""
     import torch.nn.functional as F
     from oracle import ref_path as R
-    threads = len(os.sched_getaffinity(0))
+    threads = host_cores()
     torch.set_num_threads(threads)
     torch.manual_seed(1)
     model = build_model(cfg, oracle=True).train()
@@ -127,7 +128,7 @@ def cpu_baseline(cfg, seconds_target=20.0):
     t0 = time.perf_counter()
     step()  # warm-up (also sizes the sample)
     warm = time.perf_counter() - t0
-    n = max(1, min(10, int(seconds_target / max(warm, 1e-3))))
+    n = max(1, min(40, int(seconds_target / max(warm, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(n):
         step()
@@ -148,7 +149,8 @@ def main():
                     help="PGD iterations per attack that run outside the HIP graph so their kernels can be event-timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
-    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen find)")
+    ap.add_argument("--no-miopen-benchmark", action="store_true",
+                    help="leave torch.backends.cudnn.benchmark off (default: on, MIOpen searches its solvers once per shape)")
     a = ap.parse_args()
 
     cfg = dict(WORKLOADS[a.workload])
@@ -163,15 +165,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    torch.backends.cudnn.benchmark = bool(a.miopen_benchmark)
+    torch.backends.cudnn.benchmark = not a.no_miopen_benchmark
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    import utils.attacks as attacks
     from utils.helper import set_seed
-    from eeadv import engine, ops, _native as N
+    from eeadv import engine, ops, trainer, _native as N
 
     os.environ["EEADV_GRAPH"] = "0" if a.no_graph else "1"
     engine.PROBE_ITERS = 0 if a.no_graph else a.probe_iters
@@ -184,11 +185,8 @@ def main():
     if world > 1:
         run_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=16,
                                                               gradient_as_bucket_view=True)
-    if cfg["method"] == "TRADES":
-        criterion = attacks.Trades(cfg["alpha"], cfg["eps"], cfg["steps"], cfg["beta"])
-    else:
-        from eeadv import functional as EF
-        criterion = lambda out, tgt: EF.cross_entropy(out, tgt, "mean")  # nn.CrossEntropyLoss() of the drivers
+    dargs = driver_args(cfg)
+    criterion = trainer.make_criterion(dargs)
     B = cfg["batch"]
     batches = [(torch.rand(B, *cfg["shape"], device=dev), torch.randint(0, cfg["classes"], (B,), device=dev)) for _ in range(4)]
 
@@ -196,7 +194,7 @@ def main():
         last = None
         for i in range(n):
             x, y = batches[i % len(batches)]
-            last = train_step(attacks, run_model, optimizer, criterion, cfg, x, y)
+            last = trainer.train_batch(run_model, criterion, optimizer, dargs, x, y, dev)
         return last
 
     def fence():
