@@ -1,16 +1,19 @@
 // ee_edge.hip - CannyFilter_step125_1 (utils/core.py:509-585) forward / backward and the fused EE front
-// end, as LDS-tiled stencil kernels for gfx950.
+// end, as LDS-tiled, register-blocked stencil kernels for gfx950.
 //
-// Tiling.  One 256-thread workgroup owns a TH x TW tile of one image (16x64 when W > 32, else 32x32);
-// grid = B * tilesY * tilesX workgroups, so a batch of 100 64x64 images launches 400 workgroups over
-// the 256 CUs.  Every stage works in ONE local frame of (TH+2*HALO) x (TW+2*HALO) positions whose
-// origin is image pixel (i0-HALO, j0-HALO); replicate padding is expressed by clamping coordinates,
-// never by materialising a padded tensor.  Each lane produces 4 consecutive pixels of a row, so global
-// stores (and the x_hfs / g_in loads) are 16 B per lane, 1 KiB per wave-instruction.
+// Tiling.  One 256-thread workgroup (4 waves) owns a TH x TW tile of one image (16x64 when W > 32, else
+// 32x32); grid = B * tilesY * tilesX, e.g. 400 workgroups for a batch of 100 64x64 images.  The only data
+// staged in LDS are the clamped input frame (tile + halo, filled with 16-B global loads / 16-B LDS
+// stores; replicate padding = clamped coordinates, never a padded tensor) and, in the backward, the
+// per-pixel magnitude gradients.  Each lane owns 4 consecutive pixels of a row: it pulls a 5x8 window per
+// channel out of LDS (ds_read_b64), keeps the 3x6 blurred neighbourhood of all channels in registers and
+// runs the Sobel / magnitude / threshold chain there, so the forward needs ONE barrier and the backward
+// three.  All global traffic is 16 B per lane (1 KiB per wave-instruction) and is issued before the first
+// barrier, so its latency hides under the stencil arithmetic.
 //
-// Arithmetic: identical, operation for operation, to oracle/ee_oracle.c (fmaf chains: blur row-major
-// over taps, Sobel over (kh, kw, c) with c innermost; IEEE divide / sqrt; -ffp-contract=off), so edge
-// bits, gate bits and gradients (NaNs included) are bit-exact against the oracle.
+// Arithmetic is identical, operation for operation, to oracle/ee_oracle.c (fmaf chains: blur row-major over
+// taps, Sobel over (kh, kw, c) with c innermost; IEEE divide / sqrt; -ffp-contract=off): edge bits, gate
+// bits and gradients (NaNs included) are bit-exact against the oracle.
 #include <math.h>
 
 #include "ee_common.hpp"
@@ -29,25 +32,23 @@ struct EdgeParams {
     const float *u;      // [B,1,H,W] (plain backward)
     const float *g_in;   // [B,C,H,W] (fused backward)
     const uint8_t *gate_in;
-    float *edge;   // [B,1,H,W]
-    float *mag;    // [B,1,H,W]
-    float *x_in;   // [B,C,H,W]
-    uint8_t *gate; // [B,C,H,W]
-    float *g_hfs;  // [B,C,H,W]
-    float *g_img;  // [B,1,H,W]
-    int C, H, W, tiles_x, tiles_y;
+    float *edge;    // [B,1,H,W]
+    float *mag;     // [B,1,H,W]
+    float *x_in;    // [B,C,H,W]
+    uint8_t *gate;  // [B,C,H,W]
+    float *g_hfs;   // [B,C,H,W]
+    float *g_img;   // [B,1,H,W]
+    int H, W, tiles_x, tiles_y;
+    int vec;  // W % 4 == 0 and every pointer 16-B aligned: 16-B global accesses are legal
     float alpha, high, w;
 };
 
-template <int TH, int TW, int HALO>
-struct Frame {
-    static constexpr int FH = TH + 2 * HALO, FW = TW + 2 * HALO;
-    static constexpr int kPlane = FH * FW;
-};
+constexpr int kColHalo = 4;  // frame columns start at j0 - 4 so that every row of the frame is 16-B aligned
 
 // edge decision for one pixel from the channel-summed Sobel responses (core.py:570-583, To_compare.forward)
-__device__ __forceinline__ void edge_from_sums(float ax, float ay, int C, float alpha, float high, float &gx1, float &gy1,
-                                               float &s2, float &mag, float &mag_a, float &e) {
+template <int C>
+__device__ __forceinline__ void edge_from_sums(float ax, float ay, float alpha, float high, float &gx1, float &gy1, float &s2,
+                                               float &mag, float &mag_a, float &e) {
     gx1 = ax / static_cast<float>(C);
     gy1 = ay / static_cast<float>(C);
     s2 = gx1 * gx1 + gy1 * gy1;
@@ -56,115 +57,157 @@ __device__ __forceinline__ void edge_from_sums(float ax, float ay, int C, float 
     e = (mag_a > high) ? 1.0f : ((mag_a <= high) ? 0.0f : mag_a);
 }
 
-// ---- stage helpers on the shared local frame ------------------------------------------------------
-// xs[c][r][s] = x(n, c, clamp(i0-HALO+r), clamp(j0-HALO+s))
-template <int CT, int FH, int FW>
-__device__ __forceinline__ void load_x_frame(float *xs, const float *__restrict__ xn, int C, int H, int W, int i0, int j0,
-                                             int halo) {
-    const int total = C * FH * FW;
+// frame[c][r][s] = src(c, clamp(i0 - hr + r), clamp(j0 - 4 + s)),  r < FH, s < FW (FW % 4 == 0); planes of `src`
+// are H*W apart.  16-B loads wherever a whole float4 lies inside the image.
+template <int FH, int FW>
+__device__ __forceinline__ void load_frame(float *frame, const float *__restrict__ src, int planes, int H, int W, int i0, int j0,
+                                           int hr, bool vec) {
+    constexpr int F4 = FW / 4;
+    const int total = planes * FH * F4;
     for (int idx = threadIdx.x; idx < total; idx += kBlock) {
-        const int c = idx / (FH * FW), rem = idx - c * (FH * FW);
-        const int r = rem / FW, s = rem - r * FW;
-        const int gi = clampi(i0 - halo + r, 0, H - 1), gj = clampi(j0 - halo + s, 0, W - 1);
-        xs[idx] = xn[(static_cast<size_t>(c) * H + gi) * W + gj];
+        const int c = idx / (FH * F4), rem = idx - c * (FH * F4);
+        const int r = rem / F4, f = rem - r * F4;
+        const int gi = clampi(i0 - hr + r, 0, H - 1), gj = j0 - kColHalo + 4 * f;
+        const float *row = src + (static_cast<size_t>(c) * H + gi) * W;
+        float4 v;
+        if (vec && gj >= 0 && gj + 3 < W) {
+            v = *reinterpret_cast<const float4 *>(row + gj);
+        } else {
+            v.x = row[clampi(gj, 0, W - 1)];
+            v.y = row[clampi(gj + 1, 0, W - 1)];
+            v.z = row[clampi(gj + 2, 0, W - 1)];
+            v.w = row[clampi(gj + 3, 0, W - 1)];
+        }
+        *reinterpret_cast<float4 *>(frame + (c * FH + r) * FW + 4 * f) = v;
     }
 }
 
-// bs[c][r][s] = blur(c, clamp(i0-HALO+r), clamp(j0-HALO+s)) for r in [1, FH-1), s in [1, FW-1)
-// (core.py:560-563: replicate-pad 1 then 3x3 cross-correlation, fmaf chain row-major from 0)
-template <int FH, int FW>
-__device__ __forceinline__ void blur_frame(float *bs, const float *xs, const Weights &wt, int C, int H, int W, int i0, int j0,
-                                           int halo) {
-    constexpr int IH = FH - 2, IW = FW - 2;
-    const int total = IH * IW;
-    for (int idx = threadIdx.x; idx < total; idx += kBlock) {
-        const int r = 1 + idx / IW, s = 1 + idx % IW;
-        const int ci = clampi(i0 - halo + r, 0, H - 1), cj = clampi(j0 - halo + s, 0, W - 1);
-        int rr[3], ss[3];
+// Blurred 3x6 neighbourhood (rows i-1..i+1, cols jb-1..jb+4) of a 4-pixel group whose pixels are (i, jb..jb+3),
+// for all C channels, from the clamped frame.  (row0, col0) = frame coordinates of image pixel (i-2, jb-2);
+// col0 must be even.  core.py:560-563: replicate-pad 1, 3x3 cross-correlation, fmaf chain row-major from 0.
+// Positions outside the image take the value of the clamped position (replicate padding of the BLURRED
+// plane, core.py:565), which is why the border fix-up copies registers instead of re-blurring.
+template <int C, int FH, int FW>
+__device__ __forceinline__ void blur_group(const float *frame, const Weights &wt, int row0, int col0, int i, int jb, int H, int W,
+                                           float (&b)[C][3][6]) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            rr[d] = clampi(ci + d - 1, 0, H - 1) - (i0 - halo);
-            ss[d] = clampi(cj + d - 1, 0, W - 1) - (j0 - halo);
+    for (int c = 0; c < C; ++c) {
+        float xv[5][8];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const float *p = frame + (c * FH + row0 + r) * FW + col0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float2 t = *reinterpret_cast<const float2 *>(p + 2 * q);
+                xv[r][2 * q] = t.x;
+                xv[r][2 * q + 1] = t.y;
+            }
         }
-        for (int c = 0; c < C; ++c) {
-            const float *xc = xs + c * (FH * FW);
-            float acc = 0.0f;
 #pragma unroll
-            for (int di = 0; di < 3; ++di)
+        for (int rb = 0; rb < 3; ++rb)
 #pragma unroll
-                for (int dj = 0; dj < 3; ++dj) acc = fmaf(wt.g[di * 3 + dj], xc[rr[di] * FW + ss[dj]], acc);
-            bs[c * (FH * FW) + r * FW + s] = acc;
+            for (int k = 0; k < 6; ++k) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int di = 0; di < 3; ++di)
+#pragma unroll
+                    for (int dj = 0; dj < 3; ++dj) acc = fmaf(wt.g[di * 3 + dj], xv[rb + di][k + dj], acc);
+                b[c][rb][k] = acc;
+            }
+        // replicate padding of the blurred plane at the image border
+        if (i - 1 < 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) b[c][0][k] = b[c][1][k];
+        }
+        if (i + 1 > H - 1) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) b[c][2][k] = b[c][1][k];
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+#pragma unroll
+            for (int k = 4; k >= 0; --k)  // columns left of the image take column 0 (groups may start at jb = -2)
+                if (jb - 1 + k < 0) b[c][rb][k] = b[c][rb][k + 1];
+#pragma unroll
+            for (int k = 1; k < 6; ++k)  // columns right of the image take column W-1
+                if (jb - 1 + k > W - 1) b[c][rb][k] = b[c][rb][k - 1];
         }
     }
 }
 
-// channel-summed Sobel responses at IMAGE pixel (i, j) from the blurred frame (core.py:565-567)
-template <int FH, int FW>
-__device__ __forceinline__ void sobel_at(const float *bs, const Weights &wt, int C, int H, int W, int i0, int j0, int halo,
-                                         int i, int j, float &ax, float &ay) {
-    int rr[3], ss[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        rr[d] = clampi(i + d - 1, 0, H - 1) - (i0 - halo);
-        ss[d] = clampi(j + d - 1, 0, W - 1) - (j0 - halo);
-    }
+// channel-summed Sobel responses of pixel k (0..3) of the group (core.py:565-567): fmaf chain over (kh, kw, c)
+template <int C>
+__device__ __forceinline__ void sobel_px(const float (&b)[C][3][6], const Weights &wt, int k, float &ax, float &ay) {
     ax = 0.0f;
     ay = 0.0f;
 #pragma unroll
     for (int di = 0; di < 3; ++di)
 #pragma unroll
         for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
             for (int c = 0; c < C; ++c) {
-                const float bv = bs[c * (FH * FW) + rr[di] * FW + ss[dj]];
+                const float bv = b[c][di][k + dj];
                 ax = fmaf(wt.sx[di * 3 + dj], bv, ax);
                 ay = fmaf(wt.sy[di * 3 + dj], bv, ay);
             }
 }
 
+__device__ __forceinline__ void tile_origin(const EdgeParams &p, int TH, int TW, int &n, int &i0, int &j0) {
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    n = t / p.tiles_y;
+    i0 = ty * TH;
+    j0 = tx * TW;
+}
+
 // =====================================================================================================
 // forward:  edge map, optionally fused with  x_in = clamp(x_hfs + w*edge, 0, 1)  and the clamp gate
 // =====================================================================================================
-template <int TH, int TW, bool FUSED, bool VEC>
+template <int C, int TH, int TW, bool FUSED>
 __global__ __launch_bounds__(kBlock) void edge_fwd_kernel(EdgeParams p, Weights wt) {
-    constexpr int HALO = 2;
-    using F = Frame<TH, TW, HALO>;
-    extern __shared__ __align__(16) float lds[];
-    const int C = p.C, H = p.H, W = p.W;
-    float *xs = lds;                 // [C][FH][FW]
-    float *bs = lds + C * F::kPlane; // [C][FH][FW]
-
-    int t = blockIdx.x;
-    const int tx_ = t % p.tiles_x;
-    t /= p.tiles_x;
-    const int ty_ = t % p.tiles_y;
-    const int n = t / p.tiles_y;
-    const int i0 = ty_ * TH, j0 = tx_ * TW;
-    const float *xn = p.x + static_cast<size_t>(n) * C * H * W;
-
-    load_x_frame<0, F::FH, F::FW>(xs, xn, C, H, W, i0, j0, HALO);
-    __syncthreads();
-    blur_frame<F::FH, F::FW>(bs, xs, wt, C, H, W, i0, j0, HALO);
-    __syncthreads();
-
-    constexpr int LANES_X = TW / 4;
-    const int lx = threadIdx.x % LANES_X, ly = threadIdx.x / LANES_X;
+    constexpr int FH = TH + 4, FW = TW + 2 * kColHalo, LX = TW / 4;
+    __shared__ __align__(16) float xs[C * FH * FW];
+    const int H = p.H, W = p.W;
+    int n, i0, j0;
+    tile_origin(p, TH, TW, n, i0, j0);
+    const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
     const int i = i0 + ly, jb = j0 + 4 * lx;
-    if (i >= H || jb >= W) return;
+    const bool live = (i < H) && (jb < W);
+    const bool vec = p.vec != 0;
 
+    // low-pass branch values for this lane's pixels: issued before the barrier so the latency overlaps the stencil
+    float4 xh[C];
+    if (FUSED && live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float *src = p.x_hfs + ((static_cast<size_t>(n) * C + c) * H + i) * W + jb;
+            if (vec) {
+                xh[c] = *reinterpret_cast<const float4 *>(src);
+            } else {
+                xh[c].x = src[0];
+                xh[c].y = (jb + 1 < W) ? src[1] : 0.0f;
+                xh[c].z = (jb + 2 < W) ? src[2] : 0.0f;
+                xh[c].w = (jb + 3 < W) ? src[3] : 0.0f;
+            }
+        }
+    }
+    load_frame<FH, FW>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, 2, vec);
+    __syncthreads();
+    if (!live) return;
+
+    float b[C][3][6];
+    blur_group<C, FH, FW>(xs, wt, ly, 4 * lx + kColHalo - 2, i, jb, H, W, b);
     float e[4], m[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int j = jb + k;
-        e[k] = 0.0f;
-        m[k] = 0.0f;
-        if (j < W) {
-            float ax, ay, gx1, gy1, s2, mag_a;
-            sobel_at<F::FH, F::FW>(bs, wt, C, H, W, i0, j0, HALO, i, j, ax, ay);
-            edge_from_sums(ax, ay, C, p.alpha, p.high, gx1, gy1, s2, m[k], mag_a, e[k]);
-        }
+        float ax, ay, gx1, gy1, s2, mag_a;
+        sobel_px<C>(b, wt, k, ax, ay);
+        edge_from_sums<C>(ax, ay, p.alpha, p.high, gx1, gy1, s2, m[k], mag_a, e[k]);
     }
     const size_t pix = (static_cast<size_t>(n) * H + i) * W + jb;
-    if (VEC) {
+    if (vec) {
         if (p.edge) *reinterpret_cast<float4 *>(p.edge + pix) = make_float4(e[0], e[1], e[2], e[3]);
         if (p.mag) *reinterpret_cast<float4 *>(p.mag + pix) = make_float4(m[0], m[1], m[2], m[3]);
     } else {
@@ -174,11 +217,12 @@ __global__ __launch_bounds__(kBlock) void edge_fwd_kernel(EdgeParams p, Weights 
         }
     }
     if (FUSED) {
+#pragma unroll
         for (int c = 0; c < C; ++c) {
             const size_t o = ((static_cast<size_t>(n) * C + c) * H + i) * W + jb;
-            if (VEC) {
-                const float4 xh = *reinterpret_cast<const float4 *>(p.x_hfs + o);
-                const float s0 = xh.x + p.w * e[0], s1 = xh.y + p.w * e[1], s2_ = xh.z + p.w * e[2], s3 = xh.w + p.w * e[3];
+            const float s0 = xh[c].x + p.w * e[0], s1 = xh[c].y + p.w * e[1], s2_ = xh[c].z + p.w * e[2], s3 = xh[c].w + p.w * e[3];
+            const float sv[4] = {s0, s1, s2_, s3};
+            if (vec) {
                 *reinterpret_cast<float4 *>(p.x_in + o) =
                     make_float4(tclamp(s0, 0.0f, 1.0f), tclamp(s1, 0.0f, 1.0f), tclamp(s2_, 0.0f, 1.0f), tclamp(s3, 0.0f, 1.0f));
                 if (p.gate) {
@@ -191,9 +235,8 @@ __global__ __launch_bounds__(kBlock) void edge_fwd_kernel(EdgeParams p, Weights 
                 }
             } else {
                 for (int k = 0; k < 4 && jb + k < W; ++k) {
-                    const float s = p.x_hfs[o + k] + p.w * e[k];
-                    p.x_in[o + k] = tclamp(s, 0.0f, 1.0f);
-                    if (p.gate) p.gate[o + k] = (s >= 0.0f && s <= 1.0f);
+                    p.x_in[o + k] = tclamp(sv[k], 0.0f, 1.0f);
+                    if (p.gate) p.gate[o + k] = (sv[k] >= 0.0f && sv[k] <= 1.0f);
                 }
             }
         }
@@ -201,156 +244,230 @@ __global__ __launch_bounds__(kBlock) void edge_fwd_kernel(EdgeParams p, Weights 
 }
 
 // =====================================================================================================
-// backward:  g_img = adjoint of the edge filter applied to u (NaN-faithful); fused variant also forms
-//            g_hfs = g_in*gate and u = w * sum_c g_hfs_c itself.
-// All stages share one (TH+8) x (TW+8) frame; a stage writes 0 wherever its quantity is outside the
-// image or not needed, so later stages may read any in-frame neighbour unconditionally.
+// backward:  g_img = adjoint of the edge filter applied to u (NaN-faithful); the fused variant forms
+//            g_hfs = g_in * gate and u = w * sum_c g_hfs_c itself.
+//
+// Frame = (TH+8) x (TW+8) positions with origin at image pixel (i0-4, j0-4).
+//   stage 1 (global -> LDS/regs): clamped x frame; u on the frame; this lane's g_in / gate values
+//   stage 2: gg = d(loss)/d(gx1, gy1) per pixel, rows/cols [i0-2, i0+TH+2) x [j0-2, j0+TW+2), 0 outside the image
+//   stage 3: gb = ReplicationPad^T( Sx^T ggx + Sy^T ggy ), rows/cols [i0-1, i0+TH+1) x [j0-1, j0+TW+1)
+//   stage 4: out = ReplicationPad^T( G^T gb ) on the tile
+// Transposed correlations visit taps in row-major order as one fmaf chain and DO multiply zero-weight
+// taps (0 * NaN = NaN, like a GEMM-based dgrad); the pad adjoint adds its cells in raster order.
 // =====================================================================================================
-template <int TH, int TW, bool FUSED, bool VEC>
+template <int C, int TH, int TW, bool FUSED>
 __global__ __launch_bounds__(kBlock) void edge_bwd_kernel(EdgeParams p, Weights wt) {
-    constexpr int HALO = 4;
-    using F = Frame<TH, TW, HALO>;
-    constexpr int FH = F::FH, FW = F::FW, PL = F::kPlane;
-    extern __shared__ __align__(16) float lds[];
-    const int C = p.C, H = p.H, W = p.W;
-    const int nA = C > 2 ? C : 2;
-    float *poolA = lds;             // xs[C]  -> later ggx, ggy
-    float *poolB = lds + nA * PL;   // bs[C]  -> later gbp, gb, dxp   (max(C,3) planes)
+    constexpr int FH = TH + 8, FW = TW + 2 * kColHalo, PL = FH * FW, LX = TW / 4;
+    constexpr int GG_GX = (TW + 4 + 3) / 4, GG_ROWS = TH + 4;  // 4-pixel groups of the gg region
+    constexpr int GB_GX = (TW + 4 + 3) / 4, GB_ROWS = TH + 2;  // 4-pixel groups of the gb region (cols from j0-2: 8-B aligned windows)
+    __shared__ __align__(16) float lds[(C + 4) * PL];
+    float *xs = lds;           // [C] planes: clamped input frame
+    float *us = lds + C * PL;  // upstream gradient u on the frame
+    float *ggx = us + PL, *ggy = ggx + PL, *gb = ggy + PL;  // zero wherever nothing is written (see stage 1)
+    const int H = p.H, W = p.W;
+    int n, i0, j0;
+    tile_origin(p, TH, TW, n, i0, j0);
+    const int oi = i0 - 4, oj = j0 - kColHalo;  // image coordinates of frame (0, 0)
+    const bool vec = p.vec != 0;
+    const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+    const int ti = i0 + ly, tjb = j0 + 4 * lx;
+    const bool live = (ly < TH) && (ti < H) && (tjb < W);
 
-    int t = blockIdx.x;
-    const int tx_ = t % p.tiles_x;
-    t /= p.tiles_x;
-    const int ty_ = t % p.tiles_y;
-    const int n = t / p.tiles_y;
-    const int i0 = ty_ * TH, j0 = tx_ * TW;
-    const int oi = i0 - HALO, oj = j0 - HALO;  // image coordinates of local (0,0)
-    const float *xn = p.x + static_cast<size_t>(n) * C * H * W;
-
-    // ---- A, B: x frame and blurred frame (rows/cols [1, F-1)) ------------------------------------
-    load_x_frame<0, FH, FW>(poolA, xn, C, H, W, i0, j0, HALO);
-    __syncthreads();
-    blur_frame<FH, FW>(poolB, poolA, wt, C, H, W, i0, j0, HALO);
-    __syncthreads();
-
-    // ---- C: per-pixel gradient of the magnitude stage, local rows/cols [2, F-2), 0 elsewhere ----------
-    // ggx/ggy overwrite the x planes, which are dead once the blurred frame exists
-    float *ggx = poolA, *ggy = poolA + PL;
-    for (int idx = threadIdx.x; idx < PL; idx += kBlock) {
-        const int r = idx / FW, s = idx - r * FW;
-        const int i = oi + r, j = oj + s;
-        float vx = 0.0f, vy = 0.0f;
-        if (r >= 2 && r < FH - 2 && s >= 2 && s < FW - 2 && i >= 0 && i < H && j >= 0 && j < W) {
-            float uu;
-            if (FUSED) {
-                float acc = 0.0f;
-                for (int c = 0; c < C; ++c) {
-                    const size_t o = ((static_cast<size_t>(n) * C + c) * H + i) * W + j;
-                    const float v = p.gate_in[o] ? p.g_in[o] : 0.0f;
-                    acc = (c == 0) ? v : acc + v;
-                }
-                uu = acc * p.w;
+    // ---- stage 1 -------------------------------------------------------------------------------------
+    float4 gin[FUSED ? C : 1];
+    uchar4 gtv[FUSED ? C : 1];
+    if (FUSED && live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const size_t o = ((static_cast<size_t>(n) * C + c) * H + ti) * W + tjb;
+            if (vec) {
+                gin[c] = *reinterpret_cast<const float4 *>(p.g_in + o);
+                gtv[c] = *reinterpret_cast<const uchar4 *>(p.gate_in + o);
             } else {
-                uu = p.u[(static_cast<size_t>(n) * H + i) * W + j];
+                float gv[4] = {0, 0, 0, 0};
+                unsigned char tv[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 4 && tjb + k < W; ++k) {
+                    gv[k] = p.g_in[o + k];
+                    tv[k] = p.gate_in[o + k];
+                }
+                gin[c] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                gtv[c] = make_uchar4(tv[0], tv[1], tv[2], tv[3]);
             }
-            float ax, ay, gx1, gy1, s2, mag, mag_a, e;
-            sobel_at<FH, FW>(poolB, wt, C, H, W, i0, j0, HALO, i, j, ax, ay);
-            edge_from_sums(ax, ay, C, p.alpha, p.high, gx1, gy1, s2, mag, mag_a, e);
-            float gm = uu;
-            if (mag_a <= p.high) gm = 0.0f;     // To_compare.backward core.py:356
-            if (mag_a > 1.001f) gm = 0.0f;      // core.py:357
-            if (mag < p.alpha) gm = 0.0f;       // where() backward core.py:575
-            const float rs = 1.0f / sqrtf(s2);  // pow(s2, -0.5): 0 -> inf
-            const float gs = gm * (0.5f * rs);  // 0*inf = NaN kept
-            vx = (gs * (2.0f * gx1)) / static_cast<float>(C);
-            vy = (gs * (2.0f * gy1)) / static_cast<float>(C);
         }
-        ggx[idx] = vx;
-        ggy[idx] = vy;
     }
-    __syncthreads();  // gg complete; the blurred planes (poolB) are dead from here on
-
-    // From here on a local (r, s) of a PADDED-domain array denotes padded position (oi + r + 1, oj + s + 1),
-    // i.e. the padded cell that sits on top of image pixel (oi + r, oj + s); pad row 0 <-> image row -1.
-    float *gbp = poolB, *gb = poolB + PL, *dxp = poolB + 2 * PL;
-
-    // transposed 3x3 correlation into the padded domain:  out(P,Q) = sum_{di,dj} w[di][dj] * src(P-di, Q-dj)
-    // (src at image coordinates, zero outside the image; zero-weight taps still multiply: 0*NaN = NaN)
-    auto corrT = [&](const float *src0, const float *w0, const float *src1, const float *w1, float *dst, int lo, int hiR,
-                     int hiS) {
-        for (int idx = threadIdx.x; idx < PL; idx += kBlock) {
-            const int r = idx / FW, s = idx - r * FW;
-            float acc = 0.0f;
-            if (r >= lo && r < hiR && s >= lo && s < hiS) {
-                const int P = oi + r + 1, Q = oj + s + 1;  // padded coordinates
-                if (P >= 0 && P <= H + 1 && Q >= 0 && Q <= W + 1) {
-                    for (int pass = 0; pass < 2; ++pass) {
-                        const float *src = pass ? src1 : src0;
-                        const float *wv = pass ? w1 : w0;
-                        if (!src) break;
+    load_frame<FH, FW>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, 4, vec);
+    if (FUSED) {
+        // u = w * (g_hfs_0 + g_hfs_1 + ...) on the frame (clamped coordinates; out-of-image cells are never used)
+        constexpr int F4 = FW / 4;
+        for (int idx = threadIdx.x; idx < FH * F4; idx += kBlock) {
+            const int r = idx / F4, f = idx - r * F4;
+            const int gi = clampi(oi + r, 0, H - 1), gj = oj + 4 * f;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                        for (int di = 0; di < 3; ++di)
+            for (int c = 0; c < C; ++c) {
+                const size_t o = ((static_cast<size_t>(n) * C + c) * H + gi) * W;
+                float v[4];
+                if (vec && gj >= 0 && gj + 3 < W) {
+                    const float4 g4 = *reinterpret_cast<const float4 *>(p.g_in + o + gj);
+                    const uchar4 t4 = *reinterpret_cast<const uchar4 *>(p.gate_in + o + gj);
+                    v[0] = t4.x ? g4.x : 0.0f;
+                    v[1] = t4.y ? g4.y : 0.0f;
+                    v[2] = t4.z ? g4.z : 0.0f;
+                    v[3] = t4.w ? g4.w : 0.0f;
+                } else {
 #pragma unroll
-                            for (int dj = 0; dj < 3; ++dj) {
-                                const int i = P - di, j = Q - dj;  // image coords of the contributing output
-                                if (i < 0 || i >= H || j < 0 || j >= W) continue;
-                                acc = fmaf(wv[di * 3 + dj], src[(i - oi) * FW + (j - oj)], acc);
-                            }
+                    for (int k = 0; k < 4; ++k) {
+                        const int cj = clampi(gj + k, 0, W - 1);
+                        v[k] = p.gate_in[o + cj] ? p.g_in[o + cj] : 0.0f;
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = (c == 0) ? v[k] : acc[k] + v[k];
             }
-            dst[idx] = acc;
+            *reinterpret_cast<float4 *>(us + r * FW + 4 * f) = make_float4(acc[0] * p.w, acc[1] * p.w, acc[2] * p.w, acc[3] * p.w);
+        }
+    } else {
+        load_frame<FH, FW>(us, p.u + static_cast<size_t>(n) * H * W, 1, H, W, i0, j0, 4, vec);
+    }
+    // gg / gb planes start as zeros: a cell outside the image, or outside the range a stage fills, then reads as
+    // "contributes nothing" and the transposed correlations below need no per-tap bounds test
+    for (int idx = threadIdx.x; idx < 3 * PL / 4; idx += kBlock) reinterpret_cast<float4 *>(ggx)[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
+
+    // ---- stage 2: magnitude-stage gradient on 4-pixel groups ---------------------------------------------
+    for (int gidx = threadIdx.x; gidx < GG_ROWS * GG_GX; gidx += kBlock) {
+        const int r = gidx / GG_GX, g = gidx - r * GG_GX;
+        const int fr = r + 2, fc = 2 + 4 * g;  // frame coordinates of the group's first pixel
+        const int i = oi + fr, jb = oj + fc;
+        if (i >= 0 && i < H && jb < W && jb + 3 >= 0) {
+            float b[C][3][6];
+            blur_group<C, FH, FW>(xs, wt, fr - 2, fc - 2, i, jb, H, W, b);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = jb + k;
+                if (j >= 0 && j < W && fc + k < FW) {
+                    float ax, ay, gx1, gy1, s2, mag, mag_a, e;
+                    sobel_px<C>(b, wt, k, ax, ay);
+                    edge_from_sums<C>(ax, ay, p.alpha, p.high, gx1, gy1, s2, mag, mag_a, e);
+                    float gm = us[fr * FW + fc + k];
+                    if (mag_a <= p.high) gm = 0.0f;     // To_compare.backward core.py:356
+                    if (mag_a > 1.001f) gm = 0.0f;      // core.py:357
+                    if (mag < p.alpha) gm = 0.0f;       // where() backward core.py:575
+                    const float rs = 1.0f / sqrtf(s2);  // pow(s2, -0.5): 0 -> inf
+                    const float gs = gm * (0.5f * rs);  // 0*inf = NaN kept
+                    ggx[fr * FW + fc + k] = (gs * (2.0f * gx1)) / static_cast<float>(C);
+                    ggy[fr * FW + fc + k] = (gs * (2.0f * gy1)) / static_cast<float>(C);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // Transposed 3x3 correlation, register-blocked.  cells[a][q] = padded cell (P0 + a, Q0 + q), a < 3, q < 6:
+    //     cell(P, Q) = fmaf-chain over (di, dj) row-major of w[di][dj] * src(P - di, Q - dj)
+    // where src(i, j) is the plane value at IMAGE pixel (i, j) (zero outside the image).  `first` chains continue
+    // an accumulator (Sx pass then Sy pass of the same cell).  Rows a = 0 / 2 are only needed next to the top /
+    // bottom image border (the pad adjoint folds them onto row 1) and are computed under a wave-level branch.
+    auto cells_row = [&](const float *src, const float *w9, int P, int Q0, float (&cell)[6]) {
+        // window: image rows P-2..P, image cols Q0-2 .. Q0+5  ->  frame rows/cols offset by (oi, oj)
+        float win[3][8];
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const float *q = src + (P - di - oi) * FW + (Q0 - 2 - oj);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float2 v = *reinterpret_cast<const float2 *>(q + 2 * t);
+                win[di][2 * t] = v.x;
+                win[di][2 * t + 1] = v.y;
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < 6; ++qq) {
+            float acc = cell[qq];
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) acc = fmaf(w9[di * 3 + dj], win[di][qq + 2 - dj], acc);
+            cell[qq] = acc;
         }
     };
-    // adjoint of ReplicationPad2d(1): image pixel (i,j) gathers its padded cells in raster order
-    auto fold = [&](const float *srcp, int i, int j) -> float {
-        const int P0 = (i == 0) ? 0 : i + 1, P1 = (i == H - 1) ? H + 1 : i + 1;
-        const int Q0 = (j == 0) ? 0 : j + 1, Q1 = (j == W - 1) ? W + 1 : j + 1;
-        float acc = 0.0f;
-        for (int P = P0; P <= P1; ++P)
-            for (int Q = Q0; Q <= Q1; ++Q) acc = acc + srcp[(P - 1 - oi) * FW + (Q - 1 - oj)];
-        return acc;
+    // pad adjoint for the 4 pixels (i, jb..jb+3): cells[a][q] holds padded cell (i + a, jb + q); raster-order sum of
+    // the cells that replicate padding maps onto each pixel (core.py ReplicationPad2d backward)
+    auto fold4 = [&](const float (&cells)[3][6], int i, int jb, float (&out)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = jb + k;
+            float acc = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const bool row_in = (a == 1) || (a == 0 && i == 0) || (a == 2 && i == H - 1);
+#pragma unroll
+                for (int qd = 0; qd < 3; ++qd) {
+                    const bool col_in = (qd == 1) || (qd == 0 && j == 0) || (qd == 2 && j == W - 1);
+                    if (row_in && col_in) acc = acc + cells[a][k + qd];
+                }
+            }
+            out[k] = acc;
+        }
     };
 
-    // ---- D: gbp = Sx^T ggx + Sy^T ggy on padded cells, local [2, F-1) ------------------------------
-    corrT(ggx, wt.sx, ggy, wt.sy, gbp, 2, FH - 1, FW - 1);
-    __syncthreads();
-    // ---- E: gb = fold(gbp) on image pixels, local [3, F-3) ------------------------------------------
-    for (int idx = threadIdx.x; idx < PL; idx += kBlock) {
-        const int r = idx / FW, s = idx - r * FW;
-        const int i = oi + r, j = oj + s;
-        float v = 0.0f;
-        if (r >= 3 && r < FH - 3 && s >= 3 && s < FW - 3 && i >= 0 && i < H && j >= 0 && j < W) v = fold(gbp, i, j);
-        gb[idx] = v;
+    // ---- stage 3: gb = pad^T( Sx^T ggx + Sy^T ggy ) on [i0-1, i0+TH+1) x [j0-2, j0+TW+2) -------------------
+    // (column j0-2 is computed from an incomplete window and is only ever read into a cell the fold discards)
+    for (int gidx = threadIdx.x; gidx < GB_ROWS * GB_GX; gidx += kBlock) {
+        const int r = gidx / GB_GX, g = gidx - r * GB_GX;
+        const int i = i0 - 1 + r, jb = j0 - 2 + 4 * g;
+        if (i >= 0 && i < H && jb < W && jb + 3 >= 0) {
+            float cells[3][6];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const bool need = (a == 1) || (a == 0 && i == 0) || (a == 2 && i == H - 1);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) cells[a][q] = 0.0f;
+                if (need) {
+                    cells_row(ggx, wt.sx, i + a, jb, cells[a]);
+                    cells_row(ggy, wt.sy, i + a, jb, cells[a]);
+                }
+            }
+            float o[4];
+            fold4(cells, i, jb, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (jb + k >= 0 && jb + k < W) gb[(i - oi) * FW + (jb + k - oj)] = o[k];
+        }
     }
-    __syncthreads();
-    // ---- F: dxp = G^T gb on padded cells, local [3, F-2) ---------------------------------------------
-    corrT(gb, wt.g, nullptr, nullptr, dxp, 3, FH - 2, FW - 2);
     __syncthreads();
 
-    // ---- G: fold onto the tile's own pixels and store; fused: also g_hfs = g_in * gate --------------
-    constexpr int LANES_X = TW / 4;
-    const int lx = threadIdx.x % LANES_X, ly = threadIdx.x / LANES_X;
-    const int i = i0 + ly, jb = j0 + 4 * lx;
-    if (i >= H || jb >= W) return;
+    // ---- stage 4: out = pad^T( G^T gb ) on this lane's 4 pixels; fused: g_hfs = g_in * gate ------------------
+    if (!live) return;
     float o4[4];
+    {
+        float cells[3][6];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o4[k] = (jb + k < W) ? fold(dxp, i, jb + k) : 0.0f;
-    const size_t pix = (static_cast<size_t>(n) * H + i) * W + jb;
-    if (VEC) {
+        for (int a = 0; a < 3; ++a) {
+            const bool need = (a == 1) || (a == 0 && ti == 0) || (a == 2 && ti == H - 1);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) cells[a][q] = 0.0f;
+            if (need) cells_row(gb, wt.g, ti + a, tjb, cells[a]);
+        }
+        fold4(cells, ti, tjb, o4);
+    }
+    const size_t pix = (static_cast<size_t>(n) * H + ti) * W + tjb;
+    if (vec) {
         *reinterpret_cast<float4 *>(p.g_img + pix) = make_float4(o4[0], o4[1], o4[2], o4[3]);
     } else {
-        for (int k = 0; k < 4 && jb + k < W; ++k) p.g_img[pix + k] = o4[k];
+        for (int k = 0; k < 4 && tjb + k < W; ++k) p.g_img[pix + k] = o4[k];
     }
     if (FUSED) {
+#pragma unroll
         for (int c = 0; c < C; ++c) {
-            const size_t o = ((static_cast<size_t>(n) * C + c) * H + i) * W + jb;
-            if (VEC) {
-                const float4 g = *reinterpret_cast<const float4 *>(p.g_in + o);
-                const uchar4 gt = *reinterpret_cast<const uchar4 *>(p.gate_in + o);
-                *reinterpret_cast<float4 *>(p.g_hfs + o) =
-                    make_float4(gt.x ? g.x : 0.0f, gt.y ? g.y : 0.0f, gt.z ? g.z : 0.0f, gt.w ? g.w : 0.0f);
+            const size_t o = ((static_cast<size_t>(n) * C + c) * H + ti) * W + tjb;
+            const float4 g = gin[c];
+            const uchar4 gt = gtv[c];
+            const float r4[4] = {gt.x ? g.x : 0.0f, gt.y ? g.y : 0.0f, gt.z ? g.z : 0.0f, gt.w ? g.w : 0.0f};
+            if (vec) {
+                *reinterpret_cast<float4 *>(p.g_hfs + o) = make_float4(r4[0], r4[1], r4[2], r4[3]);
             } else {
-                for (int k = 0; k < 4 && jb + k < W; ++k) p.g_hfs[o + k] = p.gate_in[o + k] ? p.g_in[o + k] : 0.0f;
+                for (int k = 0; k < 4 && tjb + k < W; ++k) p.g_hfs[o + k] = r4[k];
             }
         }
     }
@@ -362,17 +479,20 @@ struct Launch {
     unsigned grid;
 };
 
-Launch plan(int B, int H, int W) {
+// forward: 16x64 / 32x32 tiles = exactly 256 four-pixel groups.  backward: 11x64 / 24x32, because its heaviest
+// stage works on the (TH+4) x (TW+4) halo region: 15 x 17 = 255 (resp. 28 x 9 = 252) groups = one round of 256 lanes.
+constexpr int kFwdTH64 = 16, kFwdTH32 = 32, kBwdTH64 = 11, kBwdTH32 = 24;
+
+Launch plan(int B, int H, int W, bool bwd) {
     Launch l;
-    if (W > 32) {
-        l.th = 16;
-        l.tw = 64;
-    } else {
-        l.th = 32;
-        l.tw = 32;
-    }
+    int th = (W > 32) ? (bwd ? kBwdTH64 : kFwdTH64) : (bwd ? kBwdTH32 : kFwdTH32);
+    l.tw = (W > 32) ? 64 : 32;
+    // plenty of workgroups (> 4 per CU): total work, not the critical path of one workgroup, sets the time, and the
+    // 16-row tile recomputes less halo (two rounds of stage 2, but 20/16 instead of 15/11 rows per output row)
+    if (bwd && W > 32 && static_cast<int64_t>(B) * ((H + kFwdTH64 - 1) / kFwdTH64) * ((W + 63) / 64) >= 1024) th = kFwdTH64;
+    l.th = th;
     l.tiles_x = (W + l.tw - 1) / l.tw;
-    l.tiles_y = (H + l.th - 1) / l.th;
+    l.tiles_y = (H + th - 1) / th;
     l.grid = static_cast<unsigned>(static_cast<int64_t>(B) * l.tiles_x * l.tiles_y);
     return l;
 }
@@ -380,7 +500,7 @@ Launch plan(int B, int H, int W) {
 int check_dims(int B, int C, int H, int W) {
     if (B < 0 || C < 1 || H < 1 || W < 1) return EE_ERR_SHAPE;
     if (C > 4) return EE_ERR_UNSUPPORTED;
-    if (static_cast<int64_t>(B) * ((H + 15) / 16) * ((W + 31) / 32) > 0x7fffffffLL) return EE_ERR_SHAPE;
+    if (static_cast<int64_t>(B) * ((H + 10) / 11) * ((W + 31) / 32) > 0x7fffffffLL) return EE_ERR_SHAPE;
     return EE_OK;
 }
 
@@ -394,118 +514,110 @@ Weights load_weights(const float *w27) {
     return wt;
 }
 
-template <bool FUSED>
-int launch_fwd(const EdgeParams &p0, const Weights &wt, int B, bool vec, hipStream_t s) {
+template <int C, bool FUSED>
+void launch_fwd_c(const EdgeParams &p, const Weights &wt, const Launch &l, hipStream_t s) {
+    if (l.tw == 64)
+        EE_LAUNCH((edge_fwd_kernel<C, kFwdTH64, 64, FUSED>), dim3(l.grid), dim3(kBlock), 0, s, p, wt);
+    else
+        EE_LAUNCH((edge_fwd_kernel<C, kFwdTH32, 32, FUSED>), dim3(l.grid), dim3(kBlock), 0, s, p, wt);
+}
+
+template <int C, bool FUSED>
+void launch_bwd_c(const EdgeParams &p, const Weights &wt, const Launch &l, hipStream_t s) {
+    if (l.tw == 64 && l.th == kBwdTH64)
+        EE_LAUNCH((edge_bwd_kernel<C, kBwdTH64, 64, FUSED>), dim3(l.grid), dim3(kBlock), 0, s, p, wt);
+    else if (l.tw == 64)
+        EE_LAUNCH((edge_bwd_kernel<C, kFwdTH64, 64, FUSED>), dim3(l.grid), dim3(kBlock), 0, s, p, wt);
+    else
+        EE_LAUNCH((edge_bwd_kernel<C, kBwdTH32, 32, FUSED>), dim3(l.grid), dim3(kBlock), 0, s, p, wt);
+}
+
+template <bool FUSED, bool BWD>
+int launch(const EdgeParams &p0, const Weights &wt, int B, int C, hipStream_t s) {
     EdgeParams p = p0;
-    const Launch l = plan(B, p.H, p.W);
+    const Launch l = plan(B, p.H, p.W, BWD);
     p.tiles_x = l.tiles_x;
     p.tiles_y = l.tiles_y;
     if (l.grid == 0) return EE_OK;
-    if (l.tw == 64) {
-        const size_t lds = sizeof(float) * 2 * p.C * Frame<16, 64, 2>::kPlane;
-        if (vec)
-            EE_LAUNCH((edge_fwd_kernel<16, 64, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
-        else
-            EE_LAUNCH((edge_fwd_kernel<16, 64, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
-    } else {
-        const size_t lds = sizeof(float) * 2 * p.C * Frame<32, 32, 2>::kPlane;
-        if (vec)
-            EE_LAUNCH((edge_fwd_kernel<32, 32, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
-        else
-            EE_LAUNCH((edge_fwd_kernel<32, 32, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
+    switch (C) {
+        case 1: BWD ? launch_bwd_c<1, FUSED>(p, wt, l, s) : launch_fwd_c<1, FUSED>(p, wt, l, s); break;
+        case 2: BWD ? launch_bwd_c<2, FUSED>(p, wt, l, s) : launch_fwd_c<2, FUSED>(p, wt, l, s); break;
+        case 3: BWD ? launch_bwd_c<3, FUSED>(p, wt, l, s) : launch_fwd_c<3, FUSED>(p, wt, l, s); break;
+        default: BWD ? launch_bwd_c<4, FUSED>(p, wt, l, s) : launch_fwd_c<4, FUSED>(p, wt, l, s); break;
     }
     return launch_status();
 }
 
-template <bool FUSED>
-int launch_bwd(const EdgeParams &p0, const Weights &wt, int B, bool vec, hipStream_t s) {
-    EdgeParams p = p0;
-    const Launch l = plan(B, p.H, p.W);
-    p.tiles_x = l.tiles_x;
-    p.tiles_y = l.tiles_y;
-    if (l.grid == 0) return EE_OK;
-    const int planes = (p.C > 2 ? p.C : 2) + (p.C > 3 ? p.C : 3);
-    if (l.tw == 64) {
-        const size_t lds = sizeof(float) * planes * Frame<16, 64, 4>::kPlane;
-        if (vec)
-            EE_LAUNCH((edge_bwd_kernel<16, 64, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
-        else
-            EE_LAUNCH((edge_bwd_kernel<16, 64, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
-    } else {
-        const size_t lds = sizeof(float) * planes * Frame<32, 32, 4>::kPlane;
-        if (vec)
-            EE_LAUNCH((edge_bwd_kernel<32, 32, FUSED, true>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
-        else
-            EE_LAUNCH((edge_bwd_kernel<32, 32, FUSED, false>), dim3(l.grid), dim3(kBlock), lds, s, p, wt);
-    }
-    return launch_status();
-}
+inline bool al16(const void *q) { return !q || aligned16(q); }
+inline bool al4(const void *q) { return !q || (reinterpret_cast<uintptr_t>(q) & 3u) == 0; }
 
 }  // namespace
 
 EE_API int ee_edge125_fwd_f32(const float *x, int B, int C, int H, int W, const float *weights27, float alpha, float high,
                               float *edge, float *mag, void *stream) {
-    if (!x || !weights27 || !edge) return EE_ERR_NULL;
     if (int rc = check_dims(B, C, H, W)) return rc;
+    if (B == 0) return EE_OK;
+    if (!x || !weights27 || !edge) return EE_ERR_NULL;
     EdgeParams p{};
     p.x = x;
     p.edge = edge;
     p.mag = mag;
-    p.C = C; p.H = H; p.W = W;
+    p.H = H; p.W = W;
     p.alpha = alpha; p.high = high; p.w = 0.0f;
-    const bool vec = (W % 4 == 0) && aligned16(edge) && (!mag || aligned16(mag));
+    p.vec = (W % 4 == 0) && al16(x) && al16(edge) && al16(mag);
     ProfScope prof(EE_K_EDGE_FWD, as_stream(stream));
-    return launch_fwd<false>(p, load_weights(weights27), B, vec, as_stream(stream));
+    return launch<false, false>(p, load_weights(weights27), B, C, as_stream(stream));
 }
 
 EE_API int ee_edge125_bwd_f32(const float *x, const float *u, int B, int C, int H, int W, const float *weights27, float alpha,
                               float high, float *g_img, void *stream) {
-    if (!x || !u || !weights27 || !g_img) return EE_ERR_NULL;
     if (int rc = check_dims(B, C, H, W)) return rc;
+    if (B == 0) return EE_OK;
+    if (!x || !u || !weights27 || !g_img) return EE_ERR_NULL;
     EdgeParams p{};
     p.x = x;
     p.u = u;
     p.g_img = g_img;
-    p.C = C; p.H = H; p.W = W;
+    p.H = H; p.W = W;
     p.alpha = alpha; p.high = high; p.w = 0.0f;
-    const bool vec = (W % 4 == 0) && aligned16(g_img);
+    p.vec = (W % 4 == 0) && al16(x) && al16(u) && al16(g_img);
     ProfScope prof(EE_K_EDGE_BWD, as_stream(stream));
-    return launch_bwd<false>(p, load_weights(weights27), B, vec, as_stream(stream));
+    return launch<false, true>(p, load_weights(weights27), B, C, as_stream(stream));
 }
 
 EE_API int ee_frontend_fwd_f32(const float *x, const float *x_hfs, int B, int C, int H, int W, const float *weights27,
                                float alpha, float high, float w, float *x_in, uint8_t *gate, float *edge, void *stream) {
-    if (!x || !x_hfs || !weights27 || !x_in) return EE_ERR_NULL;
     if (int rc = check_dims(B, C, H, W)) return rc;
+    if (B == 0) return EE_OK;
+    if (!x || !x_hfs || !weights27 || !x_in) return EE_ERR_NULL;
     EdgeParams p{};
     p.x = x;
     p.x_hfs = x_hfs;
     p.x_in = x_in;
     p.gate = gate;
     p.edge = edge;
-    p.C = C; p.H = H; p.W = W;
+    p.H = H; p.W = W;
     p.alpha = alpha; p.high = high; p.w = w;
-    const bool vec = (W % 4 == 0) && aligned16(x_hfs) && aligned16(x_in) && (!edge || aligned16(edge)) &&
-                     (!gate || (reinterpret_cast<uintptr_t>(gate) & 3u) == 0);
+    p.vec = (W % 4 == 0) && al16(x) && al16(x_hfs) && al16(x_in) && al16(edge) && al4(gate);
     ProfScope prof(EE_K_FRONTEND_FWD, as_stream(stream));
-    return launch_fwd<true>(p, load_weights(weights27), B, vec, as_stream(stream));
+    return launch<true, false>(p, load_weights(weights27), B, C, as_stream(stream));
 }
 
 EE_API int ee_frontend_bwd_f32(const float *g_in, const uint8_t *gate, const float *x, int B, int C, int H, int W,
                                const float *weights27, float alpha, float high, float w, float *g_hfs, float *g_edge,
                                void *stream) {
-    if (!g_in || !gate || !x || !weights27 || !g_hfs || !g_edge) return EE_ERR_NULL;
     if (int rc = check_dims(B, C, H, W)) return rc;
+    if (B == 0) return EE_OK;
+    if (!g_in || !gate || !x || !weights27 || !g_hfs || !g_edge) return EE_ERR_NULL;
     EdgeParams p{};
     p.x = x;
     p.g_in = g_in;
     p.gate_in = gate;
     p.g_hfs = g_hfs;
     p.g_img = g_edge;
-    p.C = C; p.H = H; p.W = W;
+    p.H = H; p.W = W;
     p.alpha = alpha; p.high = high; p.w = w;
-    const bool vec = (W % 4 == 0) && aligned16(g_in) && aligned16(g_hfs) && aligned16(g_edge) &&
-                     (reinterpret_cast<uintptr_t>(gate) & 3u) == 0;
+    p.vec = (W % 4 == 0) && al16(x) && al16(g_in) && al16(g_hfs) && al16(g_edge) && al4(gate);
     ProfScope prof(EE_K_FRONTEND_BWD, as_stream(stream));
-    return launch_bwd<true>(p, load_weights(weights27), B, vec, as_stream(stream));
+    return launch<true, true>(p, load_weights(weights27), B, C, as_stream(stream));
 }
