@@ -104,6 +104,11 @@ EE_API int ee_prof_enable(int on) {
     return EE_OK;
 }
 
+EE_API int ee_prof_mark_empty(void *stream) {
+    ee::ProfScope scope(EE_K_EMPTY, ee::as_stream(stream));
+    return EE_OK;
+}
+
 EE_API int ee_prof_read(int kernel_id, double *total_ms, int64_t *launches) {
     if (kernel_id < 0 || kernel_id >= EE_K_COUNT) return EE_ERR_SHAPE;
     if (!total_ms || !launches) return EE_ERR_NULL;

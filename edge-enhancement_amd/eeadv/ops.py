@@ -302,6 +302,10 @@ def prof_enable(on=True):
     N.check(N.lib.ee_prof_enable(1 if on else 0), "ee_prof_enable")
 
 
+def prof_mark_empty():
+    N.check(N.lib.ee_prof_mark_empty(_stream()), "ee_prof_mark_empty")
+
+
 def prof_reset():
     N.check(N.lib.ee_prof_reset(), "ee_prof_reset")
 

@@ -188,8 +188,12 @@ int ee_add_square_bwd_f32(const float *g_out, const float *x, int B, int C, int 
 #define EE_K_EDGE_BWD 4
 #define EE_K_CE 5
 #define EE_K_PGD_STEP_BCAST 6
-#define EE_K_COUNT 7
+#define EE_K_EMPTY 7 /* an event pair with nothing in between: the bracket's own cost, see ee_prof_mark_empty */
+#define EE_K_COUNT 8
 int ee_prof_enable(int on);
+/* records one empty start/stop bracket on `stream` (family EE_K_EMPTY): callers subtract its mean from the other
+ * families' means, because a HIP event pair costs ~4-5 us on gfx950 - comparable to the kernels being timed */
+int ee_prof_mark_empty(void *stream);
 /* synchronises the recorded events and returns accumulated milliseconds / launch count since the last reset */
 int ee_prof_read(int kernel_id, double *total_ms, int64_t *launches);
 int ee_prof_reset(void);
