@@ -6,54 +6,39 @@
 // element forward (read x, write out) and 12 B backward (read g_out and x, write g_x), whatever nq is.
 // The draws stay on the device (stripe / sq_sign / sq_pos are device arrays), so nothing synchronises.
 #include "ee_common.hpp"
+#include "ee_square.hpp"
 
 namespace {
 
 using namespace ee;
-
-struct SquareArgs {
-    const float *stripe;     // [B,C,W]  sign(2*rand-1), core.py:637
-    const float *sq_sign;    // [nq,C]   sign draws, core.py:648
-    const int64_t *sq_pos;   // [nq]     vh, core.py:645
-    const int32_t *sq_size;  // [nq]     s, core.py:644
-    int nq, C, H, W;
-    float eps, two_eps;
-};
-
-// value and d(out)/d(x) for one element, following core.py:637-653 and autograd's rules:
-// clamp passes the gradient on the closed interval; max/min split a tie 1/2 : 1/2 (both operands
-// depend on x with slope 1, except the clamped stripe start whose slope is `d`).
-template <bool WANT_D>
-__device__ __forceinline__ float square_elem(const SquareArgs &a, float x, int b, int c, int h, int w, float &d) {
-    const float t0 = x + a.eps * a.stripe[(static_cast<size_t>(b) * a.C + c) * a.W + w];
-    float y = tclamp(t0, 0.0f, 1.0f);
-    if (WANT_D) d = (t0 >= 0.0f && t0 <= 1.0f) ? 1.0f : 0.0f;
-    const float lb = x - a.eps, ub = x + a.eps;
-    for (int q = 0; q < a.nq; ++q) {
-        const int vh = static_cast<int>(a.sq_pos[q]), s = a.sq_size[q];
-        const bool inside = (h >= vh && h < vh + s && w >= vh && w < vh + s);
-        const float delta = inside ? a.two_eps * a.sq_sign[q * a.C + c] : 0.0f;
-        const float y1 = y + delta;
-        const float m = tmax(y1, lb);
-        const float y2 = tmin(m, ub);
-        if (WANT_D) {
-            const float dm = (y1 > lb) ? d : ((y1 < lb) ? 1.0f : 0.5f * d + 0.5f);
-            const float d2 = (m < ub) ? dm : ((m > ub) ? 1.0f : 0.5f * dm + 0.5f);
-            d = (y2 >= 0.0f && y2 <= 1.0f) ? d2 : 0.0f;
-        }
-        y = tclamp(y2, 0.0f, 1.0f);
-    }
-    return y;
-}
 
 template <bool BWD>
 __global__ __launch_bounds__(kBlock) void square_kernel(const float *__restrict__ x, const float *__restrict__ g_out,
                                                         float *__restrict__ out, int64_t n, SquareArgs a) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     const int64_t hw = static_cast<int64_t>(a.H) * a.W;
+    const bool vec = ((a.W & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) &&
+                     (!BWD || (reinterpret_cast<uintptr_t>(g_out) & 15u) == 0);
     for (int64_t v = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; v < (n + 3) / 4; v += stride) {
         const int64_t e0 = v * 4;
-        float r[4];
+        // W % 4 == 0: the four elements share (b, c, h); otherwise decode each element
+        const int64_t plane0 = e0 / hw;
+        const int b0 = static_cast<int>(plane0 / a.C), c0 = static_cast<int>(plane0 - static_cast<int64_t>(b0) * a.C);
+        const SquarePlane pl0 = square_plane(a, c0);
+        float xv[4] = {0, 0, 0, 0}, gv[4] = {0, 0, 0, 0}, r[4];
+        if (vec) {
+            const float4 t = *reinterpret_cast<const float4 *>(x + e0);
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            if (BWD) {
+                const float4 g4 = *reinterpret_cast<const float4 *>(g_out + e0);
+                gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+            }
+        } else {
+            for (int k = 0; k < 4 && e0 + k < n; ++k) {
+                xv[k] = x[e0 + k];
+                if (BWD) gv[k] = g_out[e0 + k];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t e = e0 + k;
@@ -62,14 +47,18 @@ __global__ __launch_bounds__(kBlock) void square_kernel(const float *__restrict_
                 const int64_t plane = e / hw, pix = e - plane * hw;
                 const int b = static_cast<int>(plane / a.C), c = static_cast<int>(plane - static_cast<int64_t>(b) * a.C);
                 const int h = static_cast<int>(pix / a.W), w = static_cast<int>(pix - static_cast<int64_t>(h) * a.W);
+                const float sv = a.stripe[(static_cast<size_t>(b) * a.C + c) * a.W + w];
                 float d = 0.0f;
-                const float y = square_elem<BWD>(a, x[e], b, c, h, w, d);
-                r[k] = BWD ? g_out[e] * d : y;
+                const float y = (c == c0 && b == b0) ? square_elem<BWD>(a, pl0, xv[k], sv, c, h, w, d)
+                                                     : square_elem<BWD>(a, square_plane(a, c), xv[k], sv, c, h, w, d);
+                r[k] = BWD ? gv[k] * d : y;
             }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (e0 + k < n) out[e0 + k] = r[k];
+        if (vec) {
+            *reinterpret_cast<float4 *>(out + e0) = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+            for (int k = 0; k < 4 && e0 + k < n; ++k) out[e0 + k] = r[k];
+        }
     }
 }
 

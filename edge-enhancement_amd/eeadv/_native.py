@@ -47,6 +47,8 @@ SIGNATURES = {
     "ee_topk_i64": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "ee_add_square_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "ee_add_square_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    "ee_hfs_table_floats": [c_i, c_i, c_i, c_i],
+    "ee_hfs_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_f, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],
     "ee_prof_enable": [c_i],
     "ee_prof_mark_empty": [c_p],
     "ee_prof_read": [c_i, c_p, c_p],
@@ -55,7 +57,7 @@ SIGNATURES = {
 _RESTYPE = {"ee_strerror": ctypes.c_char_p, "ee_device_name": ctypes.c_char_p, "ee_mse_num_partials": c_l}
 
 # kernel-family ids of include/eeadv.h (ee_prof_*)
-K_PGD_STEP, K_FRONTEND_FWD, K_FRONTEND_BWD, K_EDGE_FWD, K_EDGE_BWD, K_CE, K_PGD_STEP_BCAST, K_EMPTY = range(8)
+K_PGD_STEP, K_FRONTEND_FWD, K_FRONTEND_BWD, K_EDGE_FWD, K_EDGE_BWD, K_CE, K_PGD_STEP_BCAST, K_EMPTY, K_HFS = range(9)
 
 
 class EEError(RuntimeError):

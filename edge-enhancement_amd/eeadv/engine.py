@@ -49,13 +49,33 @@ def _unwrap(model):
 
 
 def input_gradient(model, x, spec):
-    """g = d loss / d x for the current x (x: leaf ROCm tensor)."""
+    """g = d loss / d x for the current x (x: leaf ROCm tensor), through autograd end to end."""
     x.requires_grad_(True)
     with torch.enable_grad():
         logits = model(x)
     d = spec.dlogits(logits.contiguous())
     (g,) = torch.autograd.grad(logits, [x], grad_outputs=d)
     return g
+
+
+def attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi):
+    """One PGD iteration in place on x (attacks.py:20-27).  Edge-enhanced models that expose their front end
+    (eeadv.models._EEFrontMixin) run it as explicit kernel calls around an autograd pass over the CNN body only:
+    the input gradient then never exists as one tensor - the update kernel adds its two parts in registers."""
+    if getattr(model, "manual_ok", None) is not None and model.manual_ok(x):
+        with torch.no_grad():
+            x_in, ctx = model.front_manual(x.detach())
+        x_in.requires_grad_(True)
+        with torch.enable_grad():
+            logits = model.body(x_in)
+        d = spec.dlogits(logits.contiguous())
+        (g_in,) = torch.autograd.grad(logits, [x_in], grad_outputs=d)
+        with torch.no_grad():
+            g_lp, g_edge = model.front_manual_backward(g_in.contiguous(), ctx)
+            ops.pgd_step_bcast_(x.detach(), g_lp, g_edge, x0, step_size, eps, lo, hi, direction)
+        return
+    g = input_gradient(model, x, spec)
+    ops.pgd_step_(x.detach(), g.contiguous(), x0, step_size, eps, lo, hi, direction)
 
 
 class _GraphedStep:
@@ -72,8 +92,7 @@ class _GraphedStep:
 
     def _body(self, model):
         step_size, eps, direction, lo, hi = self.cfg
-        g = input_gradient(model, self.x, self.spec)
-        ops.pgd_step_(self.x.detach(), g.contiguous(), self.x0, step_size, eps, lo, hi, direction)
+        attack_step_(model, self.x, self.x0, self.spec, step_size, eps, direction, lo, hi)
 
     def capture(self, model, x_init, x0, payload):
         self.load(x_init, x0, payload)
@@ -133,9 +152,8 @@ def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo
         x = x_init.detach().contiguous()
         probe = min(PROBE_ITERS, num_steps)
         for _ in range(probe):
-            g = input_gradient(model, x, spec)
+            attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi)
             x = x.detach()
-            ops.pgd_step_(x, g.contiguous(), x0, step_size, eps, lo, hi, direction)
         gs.load(x, x0, spec.payload)
         for _ in range(num_steps - probe):
             gs.graph.replay()
@@ -143,7 +161,6 @@ def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo
 
     x = x_init.detach().contiguous()
     for _ in range(num_steps):
-        g = input_gradient(model, x, spec)
+        attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi)
         x = x.detach()
-        ops.pgd_step_(x, g.contiguous(), x0, step_size, eps, lo, hi, direction)
     return x.requires_grad_(False)

@@ -51,11 +51,41 @@ def hfs_matrices(H, W, r):
     return Ar, Ai, B1, B2
 
 
+def lowrank_tables(H, W, r):
+    """The device table of ee_hfs_f32 (layout documented in include/eeadv.h): cos / sin factors of the operator's
+    exact low-rank form  y = U Cw^T + V Sw^T  (csrc/ee_hfs.hip).  Returns (float32 array, NU, NV)."""
+    us = np.array([u if u < H / 2 else u - H for u in keep_set(H, r)], dtype=np.float64)
+    vs = np.array([v for v in keep_set(W, r) if v <= W // 2], dtype=np.float64)
+    kap = np.array([1.0 if (v == 0 or (W % 2 == 0 and v == W // 2)) else 2.0 for v in vs])
+    NU, NV = len(us), len(vs)
+    up, vp, Hp, Wp = (NU + 3) & ~3, (NV + 3) & ~3, (H + 3) & ~3, (W + 3) & ~3
+    hs = Hp + 4
+    h, w = np.arange(H)[:, None], np.arange(W)[:, None]
+    Ch, Sh = np.cos(2 * np.pi * h * us[None, :] / H), np.sin(2 * np.pi * h * us[None, :] / H)  # [H, NU]
+    Cw, Sw = np.cos(2 * np.pi * w * vs[None, :] / W), np.sin(2 * np.pi * w * vs[None, :] / W)  # [W, NV]
+    cwT, swT = np.zeros((vp, Wp)), np.zeros((vp, Wp))
+    cwT[:NV, :W], swT[:NV, :W] = Cw.T, Sw.T
+    chT, shT = np.zeros((up, hs)), np.zeros((up, hs))
+    chT[:NU, :H], shT[:NU, :H] = Ch.T, Sh.T
+    chN, shN = np.zeros((H, up)), np.zeros((H, up))
+    chN[:, :NU], shN[:, :NU] = Ch, Sh
+    dv = np.zeros(vp)
+    dv[:NV] = kap / W
+    flat = np.concatenate([a.reshape(-1) for a in (cwT, swT, chT, shT, chN, shN, dv)]).astype(np.float32)
+    return flat, NU, NV
+
+
 class HFSOperator:
-    """Device-resident factors of the operator and of its adjoint."""
+    """Device-resident factors of the operator (which equals its own adjoint).  ROCm planes up to 64x64 go through the
+    single-launch LDS kernel ee_hfs_f32; larger planes (ImageNet 224x224) and the CPU plumbing path use the dense form."""
 
     def __init__(self, H, W, r, device):
         Ar, Ai, B1, B2 = hfs_matrices(H, W, r)
+        self.kernel = None
+        if torch.device(device).type == "cuda":
+            flat, NU, NV = lowrank_tables(H, W, r)
+            if H <= 64 and W <= 64 and NU <= 16 and NV <= 8:
+                self.kernel = (torch.from_numpy(flat).to(device), NU, NV)
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=torch.float32)
         self.H, self.W = H, W
         self.Bcat = f(np.concatenate([B1, B2], axis=1))      # [W, 2W]   x @ Bcat = [x B1 | x B2]
@@ -75,10 +105,28 @@ class HFSOperator:
         return y.view(B, C, H, W)
 
     def forward(self, x):
+        if self.kernel is not None and x.is_cuda:
+            from . import ops
+            return ops.hfs(x.contiguous(), *self.kernel)
         return self._apply(x, self.Bcat, self.Ar, self.Ai)
 
     def adjoint(self, g):
+        if self.kernel is not None and g.is_cuda:
+            from . import ops
+            return ops.hfs(g.contiguous(), *self.kernel)  # self-adjoint
         return self._apply(g, self.BcatT, self.ArT, self.AiT)
+
+    def forward_square(self, x, eps, draws):
+        """F(add_square(x)) in one launch (ROCm, small planes)."""
+        from . import ops
+        t, NU, NV = self.kernel
+        return ops.hfs(x.contiguous(), t, NU, NV, 1, None, eps, draws["stripe"], draws["sq_sign"], draws["sq_pos"], draws["sq_size"])
+
+    def backward_square(self, g, x, eps, draws):
+        """F(g) * d add_square/dx (x): the backward of forward_square, one launch."""
+        from . import ops
+        t, NU, NV = self.kernel
+        return ops.hfs(g.contiguous(), t, NU, NV, 2, x, eps, draws["stripe"], draws["sq_sign"], draws["sq_pos"], draws["sq_size"])
 
 
 class _HFSFn(torch.autograd.Function):
@@ -94,3 +142,25 @@ class _HFSFn(torch.autograd.Function):
 
 def hfs_apply(x, op):
     return _HFSFn.apply(x, op)
+
+
+class _SquareHFSFn(torch.autograd.Function):
+    """hfs(add_square(x)) with the Add_Square arithmetic fused into the low-pass kernel's load / store stages."""
+
+    @staticmethod
+    def forward(ctx, x, op, eps, stripe, sq_sign, sq_pos, sq_size):
+        x = x.contiguous()
+        draws = {"stripe": stripe, "sq_sign": sq_sign, "sq_pos": sq_pos, "sq_size": sq_size}
+        ctx.save_for_backward(x, stripe, sq_sign, sq_pos, sq_size)
+        ctx.op, ctx.eps = op, eps
+        return op.forward_square(x, eps, draws)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stripe, sq_sign, sq_pos, sq_size = ctx.saved_tensors
+        draws = {"stripe": stripe, "sq_sign": sq_sign, "sq_pos": sq_pos, "sq_size": sq_size}
+        return ctx.op.backward_square(g.contiguous(), x, ctx.eps, draws), None, None, None, None, None, None
+
+
+def square_hfs_apply(x, op, eps, draws):
+    return _SquareHFSFn.apply(x, op, float(eps), draws["stripe"], draws["sq_sign"], draws["sq_pos"], draws["sq_size"])

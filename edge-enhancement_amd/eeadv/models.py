@@ -20,7 +20,33 @@ import torch.nn.functional as F
 from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_step125_1, HighFreqSuppress, ee_front_end,
                         get_gaussian_kernel)
 
+from . import hfs as _hfs, ops
+
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d whose `num_batches_tracked += 1` is NOT launched per layer: stock PyTorch issues one int64 add
+    kernel per BatchNorm per training forward (20 launches per ResNet-18 forward, ~5 us each on MI355X, 3 % of a
+    PGD-10 step).  The owning model bumps all counters with ONE multi-tensor add after its forward (`_bump_bn_counters`);
+    state_dict keys, running statistics (momentum is never None here) and numerics are unchanged."""
+
+    def forward(self, input):
+        if self.training and self.track_running_stats:
+            return F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
+        return F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, not self.track_running_stats,
+                            0.0 if self.momentum is None else self.momentum, self.eps)
+
+
+def _bump_bn_counters(model):
+    if not model.training:
+        return
+    counters = getattr(model, "_bn_counters", None)
+    if counters is None or (counters and counters[0].device != next(model.parameters()).device):
+        counters = [m.num_batches_tracked for m in model.modules() if isinstance(m, BatchNorm2d) and m.num_batches_tracked is not None]
+        model._bn_counters = counters
+    if counters:
+        torch._foreach_add_(counters, 1)
 
 
 class _EEFrontMixin:
@@ -40,8 +66,48 @@ class _EEFrontMixin:
         self.weight_gaussian = nn.Parameter(data=g, requires_grad=False)
 
     def front(self, x, draws=None):
-        x_lp = self.hfs(x if self.add_square is None else self.add_square(x, draws))
+        """Autograd-capable front end (used by every ordinary forward)."""
+        if self.add_square is None:
+            x_lp = self.hfs(x)
+        else:
+            op = self.hfs.operator(x.device) if x.is_cuda else None
+            if op is not None and op.kernel is not None:  # Add_Square fused into the low-pass kernel's load / store
+                x_lp = _hfs.square_hfs_apply(x, op, self.add_square.eps, self.add_square.prepare(x, draws))
+            else:
+                x_lp = self.hfs(self.add_square(x, draws))
         return ee_front_end(x, x_lp, self.canny, self.w, self.low, self.high, self.with_gf, self.weight_gaussian)
+
+    # ---- the same front end without autograd, for the attack loop (eeadv.engine): two launches forward, two backward,
+    # and the input gradient stays split into (low-pass part [B,C,H,W], edge part [B,1,H,W]) so that the PGD update
+    # kernel can add them in registers --------------------------------------------------------------------------------
+    def manual_ok(self, x):
+        return x.is_cuda and isinstance(self.canny, CannyFilter_step125_1) and not self.with_gf
+
+    def front_manual(self, x, draws=None):
+        op = self.hfs.operator(x.device)
+        d = None
+        if self.add_square is not None:
+            d = self.add_square.prepare(x, draws)
+            if op.kernel is not None:
+                x_lp = op.forward_square(x, self.add_square.eps, d)
+            else:
+                x_lp = op.forward(ops.add_square_fwd(x, float(self.add_square.eps), d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"]))
+        else:
+            x_lp = op.forward(x)
+        x_in, gate, _ = ops.frontend_fwd(x, x_lp, self.canny.edge_weights, float(self.canny.alpha), float(self.high), float(self.w))
+        return x_in, (x, gate, d)
+
+    def front_manual_backward(self, g_in, ctx):
+        x, gate, d = ctx
+        op = self.hfs.operator(x.device)
+        g_hfs, g_edge = ops.frontend_bwd(g_in, gate, x, self.canny.edge_weights, float(self.canny.alpha), float(self.high), float(self.w))
+        if d is None:
+            g_lp = op.adjoint(g_hfs)
+        elif op.kernel is not None:
+            g_lp = op.backward_square(g_hfs, x, self.add_square.eps, d)
+        else:
+            g_lp = ops.add_square_bwd(op.adjoint(g_hfs), x, float(self.add_square.eps), d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"])
+        return g_lp, g_edge
 
 
 # ---- MNIST ---------------------------------------------------------------------------------------------------
@@ -104,10 +170,10 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super(BasicBlock, self).__init__()
         self.conv1 = conv3x3(inplanes, planes, stride)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = conv3x3(planes, planes)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.downsample = downsample
         self.stride = stride
 
@@ -124,11 +190,11 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super(Bottleneck, self).__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
@@ -152,7 +218,7 @@ class ResNet(nn.Module):
     def _build_cnn(self, block, layers, num_classes, dataset):
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
@@ -176,7 +242,7 @@ class ResNet(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(
                 nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                nn.BatchNorm2d(planes * block.expansion))
+                BatchNorm2d(planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
@@ -187,6 +253,7 @@ class ResNet(nn.Module):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = self.avgpool(x)
+        _bump_bn_counters(self)
         return self.fc(x.view(x.size(0), -1))
 
     def forward(self, x):

@@ -297,6 +297,29 @@ def add_square_bwd(g_out, x, eps, stripe, sq_sign, sq_pos, sq_size):
     return g_x
 
 
+# ---- HighFreqSuppress -----------------------------------------------------------------------------------------------
+def hfs(x, tables, NU, NV, sq_mode=0, sq_x=None, eps=0.0, stripe=None, sq_sign=None, sq_pos=None, sq_size=None):
+    """y = F(x) (sq_mode 0), F(add_square(x)) (1) or F(x) * d add_square/dx at sq_x (2); F = the low-pass operator."""
+    B, C, H, W = x.shape
+    px = _chk(x, torch.float32, "x")
+    need = N.lib.ee_hfs_table_floats(H, W, NU, NV)
+    pt = _chk(tables, torch.float32, "tables", (need,))
+    out = torch.empty_like(x)
+    nq = 0
+    ps = pg = pp = pz = pxo = None
+    if sq_mode:
+        nq = int(sq_size.numel())
+        ps = _chk(stripe, torch.float32, "stripe", (B, C, 1, W))
+        pg = _chk(sq_sign, torch.float32, "sq_sign", (nq, C))
+        pp = _chk(sq_pos, torch.int64, "sq_pos", (nq,))
+        pz = _chk(sq_size, torch.int32, "sq_size", (nq,))
+        if sq_mode == 2:
+            pxo = _chk(sq_x, torch.float32, "sq_x", x.shape)
+    N.check(N.lib.ee_hfs_f32(px, _chk(out, torch.float32, "out"), B, C, H, W, pt, NU, NV, 1.0 / H, sq_mode, pxo, eps, ps, pg, pp, pz, nq,
+                             _stream()), "ee_hfs_f32")
+    return out
+
+
 # ---- timing hooks ------------------------------------------------------------------------------------------------------
 def prof_enable(on=True):
     N.check(N.lib.ee_prof_enable(1 if on else 0), "ee_prof_enable")

@@ -346,14 +346,21 @@ class Add_Square(nn.Module):
         sq_sign = self.random_choice([nq, self.c], device)
         return {"stripe": stripe, "sq_pos": sq_pos, "sq_sign": sq_sign, "sq_size": sizes_dev}
 
+    def prepare(self, x, draws=None):
+        """Draws in the layout the kernels take: stripe [B,C,1,W] fp32, sq_sign [nq,C] fp32, sq_pos [nq] int64,
+        sq_size [nq] int32, all on x's device (fresh device-side draws when `draws` is None)."""
+        d = self.draw(x.shape[0], x.device) if draws is None else draws
+        return {"stripe": d["stripe"].to(x.device, torch.float32).contiguous(),
+                "sq_sign": d["sq_sign"].reshape(-1, self.c).to(x.device, torch.float32).contiguous(),
+                "sq_pos": d["sq_pos"].to(x.device, torch.int64).contiguous(),
+                "sq_size": d["sq_size"].to(x.device) if "sq_size" in d else self.square_sizes(x.device)[1]}
+
     def forward(self, x, draws=None):
         runtime.require_device(x, "Add_Square")
-        d = self.draw(x.shape[0], x.device) if draws is None else draws
         if x.is_cuda:
-            sq_sign = d["sq_sign"].reshape(-1, self.c).to(torch.float32).contiguous()
-            size = d.get("sq_size", self.square_sizes(x.device)[1])
-            return EF.AddSquareFn.apply(x, float(self.eps), d["stripe"].contiguous(), sq_sign,
-                                        d["sq_pos"].to(torch.int64).contiguous(), size)
+            d = self.prepare(x, draws)
+            return EF.AddSquareFn.apply(x, float(self.eps), d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"])
+        d = self.draw(x.shape[0], x.device) if draws is None else draws
         x_best = torch.clamp(x + self.eps * d["stripe"], 0., 1.)
         for q, s in enumerate(self.square_sizes(x.device)[0]):
             vh = int(d["sq_pos"][q])

@@ -178,6 +178,23 @@ int ee_add_square_bwd_f32(const float *g_out, const float *x, int B, int C, int 
                           int nq, float *g_x, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * HighFreqSuppress (utils/core.py:15-55) as a fixed real, self-adjoint linear operator, one workgroup per plane
+ *   in / out [B,C,H,W], H, W <= 64 (EE_ERR_UNSUPPORTED beyond: callers use the dense two-contraction form there).
+ *   tables: DEVICE buffer of ee_hfs_table_floats(H, W, NU, NV) floats built by the host (eeadv/hfs.py):
+ *       CwT[NVp][Wp], SwT[NVp][Wp]   cos / sin(2 pi v w / W) for the NV kept half-spectrum column frequencies
+ *       ChT[NUp][Hp+4], ShT[NUp][Hp+4], ChN[H][NUp], ShN[H][NUp]   cos / sin(2 pi u h / H) for the NU kept row frequencies
+ *       dv[NVp] = kappa_v / W          (NUp, NVp, Hp, Wp: rounded up to multiples of 4, zero padded)
+ *   inv_h = 1/H.  The operator equals its own adjoint, so the same call is the backward.
+ *   sq_mode 0: y = F(in).  1: y = F(add_square(in))  (core.py:636-655 fused into the load).
+ *   2: y = F(in) * d add_square / dx evaluated at sq_x  (the backward of mode 1).  Add_Square draws as in
+ *   ee_add_square_fwd_f32.  8 B of HBM traffic per element.
+ * ------------------------------------------------------------------------------------------- */
+int ee_hfs_table_floats(int H, int W, int NU, int NV);
+int ee_hfs_f32(const float *in, float *out, int B, int C, int H, int W, const float *tables, int NU, int NV, float inv_h,
+               int sq_mode, const float *sq_x, float eps, const float *stripe, const float *sq_sign, const int64_t *sq_pos,
+               const int32_t *sq_size, int nq, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optional built-in timing of the last launch of each kernel family (HIP events on `stream`).
  * Off by default; bench.py switches it on outside graph capture to measure kernel durations live.
  * ------------------------------------------------------------------------------------------- */
@@ -189,7 +206,8 @@ int ee_add_square_bwd_f32(const float *g_out, const float *x, int B, int C, int 
 #define EE_K_CE 5
 #define EE_K_PGD_STEP_BCAST 6
 #define EE_K_EMPTY 7 /* an event pair with nothing in between: the bracket's own cost, see ee_prof_mark_empty */
-#define EE_K_COUNT 8
+#define EE_K_HFS 8
+#define EE_K_COUNT 9
 int ee_prof_enable(int on);
 /* records one empty start/stop bracket on `stream` (family EE_K_EMPTY): callers subtract its mean from the other
  * families' means, because a HIP event pair costs ~4-5 us on gfx950 - comparable to the kernels being timed */

@@ -7,6 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "edge-enhancement_amd"))
+sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from eeadv import ops  # noqa: E402
@@ -44,7 +45,22 @@ def main():
         gl, ge = ops.frontend_bwd(g, gate, x, wts, 0.0, 76 / 255, 1.0)
         y = torch.randint(0, 200, (B,), device=dev)
         z = torch.randn(B, 200, device=dev)
-        rows = [
+        from eeadv import hfs as HF
+        import utils.core as core
+        hfs_rows = []
+        if H <= 64 and W <= 64 and H == W:
+            r = 8 if H == 64 else 4
+            op = HF.HFSOperator(H, W, r, dev)
+            sq = core.Add_Square(C, H, 16 / 255, n_queries=1)
+            d = sq.prepare(x)
+            hfs_rows = [
+                ("hfs", lambda: op.forward(x), 8 * C * px),
+                ("hfs+square", lambda: op.forward_square(x, 16 / 255, d), 8 * C * px),
+                ("hfs*dsquare", lambda: op.backward_square(g, x, 16 / 255, d), 12 * C * px),
+                ("add_square_fwd", lambda: ops.add_square_fwd(x, 16 / 255, d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"]), 8 * C * px),
+                ("hfs dense(rocBLAS)", lambda: op._apply(x, op.Bcat, op.Ar, op.Ai), 8 * C * px),
+            ]
+        rows = hfs_rows + [
             ("pgd_step", lambda: ops.pgd_step_(x, g, x0, 2 / 255, 16 / 255), 16 * C * px),
             ("pgd_step_bcast", lambda: ops.pgd_step_bcast_(x, gl, ge, x0, 2 / 255, 16 / 255), (16 * C + 4) * px),
             ("frontend_fwd", lambda: ops.frontend_fwd(x, xh, wts, 0.0, 76 / 255, 1.0), 12 * C * px),

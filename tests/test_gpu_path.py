@@ -363,3 +363,71 @@ def test_accuracy_helper(golden):
     soft = np.eye(200, dtype=np.float32)[y] * 0.9 + 0.0005
     got = accuracy(dev(z), dev(soft), topk=(1, 5))
     assert [g.item() for g in got] == [w.item() for w in want]
+
+
+@pytest.mark.parametrize("H,W,r,C", [(64, 64, 8, 3), (28, 28, 4, 1), (7, 9, 2, 2), (9, 7, 2, 1), (32, 32, 4, 3), (64, 48, 8, 2)])
+def test_hfs_kernel_vs_fft_restatement_UNPINNED(H, W, r, C):
+    """ee_hfs_f32 (low-rank LDS kernel) against the float32 FFT restatement and against the dense operator."""
+    from eeadv import hfs as HF
+    torch.manual_seed(H * W + r)
+    x = torch.rand(5, C, H, W)
+    op = HF.HFSOperator(H, W, r, DEV)
+    assert op.kernel is not None
+    y = op.forward(x.to(DEV)).cpu()
+    ref = R.HighFreqSuppress(H, W, r)(x)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=3e-6)
+    dense = op._apply(x.to(DEV), op.Bcat, op.Ar, op.Ai).cpu()
+    np.testing.assert_allclose(y.numpy(), dense.numpy(), atol=3e-6)
+    u = torch.randn_like(x)
+    np.testing.assert_allclose(op.adjoint(u.to(DEV)).cpu().numpy(), op._apply(u.to(DEV), op.BcatT, op.ArT, op.AiT).cpu().numpy(), atol=1e-5)
+
+
+def test_fused_square_hfs_equals_unfused():
+    from eeadv import hfs as HF
+    import utils.core as C
+    torch.manual_seed(12)
+    for (B, Cn, n, r, nq) in [(4, 3, 64, 8, 1), (3, 1, 28, 4, 2)]:
+        eps = 16 / 255
+        sq = C.Add_Square(Cn, n, eps, n_queries=nq)
+        x = torch.rand(B, Cn, n, n, device=DEV)
+        x[0, 0, 0, :4] = torch.tensor([0.0, 1.0, eps, 1 - eps])
+        d = sq.prepare(x)
+        op = HF.HFSOperator(n, n, r, DEV)
+        x1 = x.clone().requires_grad_(True)
+        y1 = HF.square_hfs_apply(x1, op, eps, d)
+        x2 = x.clone().requires_grad_(True)
+        y2 = HF.hfs_apply(sq(x2, d), op)
+        assert torch.equal(y1, y2)  # same kernel, Add_Square arithmetic identical element for element
+        u = torch.randn_like(x)
+        (y1 * u).sum().backward()
+        (y2 * u).sum().backward()
+        assert torch.equal(x1.grad, x2.grad)
+
+
+def test_manual_front_end_chain_equals_autograd():
+    """The attack loop's explicit kernel chain (engine.attack_step_) gives the same update as autograd end to end."""
+    from eeadv import engine, ops
+    m, _ = _ee_pair(True)
+    torch.manual_seed(13)
+    B = 4
+    x = torch.rand(B, 3, 64, 64, device=DEV)
+    x[2, :, 5:25, 30:60] = 0.75
+    y = torch.randint(0, 200, (B,), device=DEV)
+    draws = m.add_square.prepare(x)
+    xa = x.clone().requires_grad_(True)
+    logits = m(xa, draws)
+    d = engine.LossSpec(engine.CE_SUM, y).dlogits(logits.contiguous())
+    (g,) = torch.autograd.grad(logits, [xa], grad_outputs=d)
+    want = x.clone()
+    ops.pgd_step_(want, g.contiguous(), x, 2 / 255, 16 / 255)
+    x_in, ctx = m.front_manual(x, draws)
+    x_in.requires_grad_(True)
+    logits2 = m.body(x_in)
+    (g_in,) = torch.autograd.grad(logits2, [x_in], grad_outputs=engine.LossSpec(engine.CE_SUM, y).dlogits(logits2.contiguous()))
+    g_lp, g_edge = m.front_manual_backward(g_in.contiguous(), ctx)
+    got = x.clone()
+    ops.pgd_step_bcast_(got, g_lp, g_edge, x, 2 / 255, 16 / 255)
+    # two forwards of the same CNN are not bit-reproducible: MIOpen's split-K igemm solvers accumulate with atomics
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), logits2.detach().cpu().numpy(), atol=1e-5)
+    assert int(torch.isnan(g).sum()) > 0
+    assert same_fraction(got.cpu().numpy(), want.cpu().numpy()) > 0.999
