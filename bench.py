@@ -238,10 +238,16 @@ def main():
                                  "GBps": round(nbytes / us / 1e3, 1)}
         dom = "ee_frontend_bwd" if "ee_frontend_bwd" in kernels else (max(kernels, key=lambda k: kernels[k]["avg_us"]) if kernels else None)
         roofline = None
+        traffic = None
+        try:  # HBM bytes per launch from the TCC counters, measured with rocprofv3 --pmc at this exact shape (profiles/)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = pmc.get("%dx%dx%dx%d" % (B, C, H, W), {}).get(dom)
+        except (OSError, ValueError):
+            pass
         if dom:
             ach = kernels[dom]["GBps"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": kernels[dom]["avg_us"],
                         "event_pair_overhead_us": round(overhead_us, 3)}
         out = {

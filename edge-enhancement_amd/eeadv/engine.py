@@ -143,11 +143,17 @@ def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo
             gs = None
         if gs is None:
             gs = _GraphedStep(model, x0, spec, step_size, eps, direction, lo, hi)
-            # capturing executes the body (2 warm-up + 1 captured): shield BN statistics from those extra steps
-            saved = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+            # the two warm-up executions before capture are extra train-mode forwards: shield the BatchNorm statistics
+            # from them.  Restored through .data so that autograd graphs the caller still holds (TRADES / ALP keep
+            # `preds = model(x)` alive across the attack) do not see a version bump on the saved running statistics.
+            saved = {}
+            if model.training:
+                saved = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
             gs.capture(model, x_init, x0, spec.payload)
             if saved:
-                model.load_state_dict(saved, strict=False)
+                live = model.state_dict()
+                for k, v in saved.items():
+                    live[k].data.copy_(v)
             _GRAPHS[key] = gs
         x = x_init.detach().contiguous()
         probe = min(PROBE_ITERS, num_steps)

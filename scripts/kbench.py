@@ -13,7 +13,7 @@ import torch  # noqa: E402
 from eeadv import ops  # noqa: E402
 
 
-def timeit(fn, iters=200, warm=20):
+def timeit(fn, iters=200, warm=5):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -29,6 +29,7 @@ def timeit(fn, iters=200, warm=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="100x3x64x64,400x3x64x64,1600x3x64x64,50x1x28x28,32x3x224x224")
+    ap.add_argument("--iters", type=int, default=200)
     a = ap.parse_args()
     dev = "cuda:0"
     wts = ops.EdgeWeights(1.0)
@@ -70,7 +71,7 @@ def main():
             ("ce_grad", lambda: ops.ce(z, y, "sum", 0.0, False, True), 2 * B * 200 * 4),
         ]
         for name, fn, nbytes in rows:
-            us = timeit(fn)
+            us = timeit(fn, a.iters)
             print("%-18s %-16s %9.2f %9.1f" % (name, shp, us, nbytes / us / 1e3))
 
 

@@ -431,3 +431,32 @@ def test_manual_front_end_chain_equals_autograd():
     np.testing.assert_allclose(logits.detach().cpu().numpy(), logits2.detach().cpu().numpy(), atol=1e-5)
     assert int(torch.isnan(g).sum()) > 0
     assert same_fraction(got.cpu().numpy(), want.cpu().numpy()) > 0.999
+
+
+def test_trades_and_alp_training_step_under_hip_graphs(monkeypatch):
+    """TRADES / ALP keep `preds = model(x)` (train mode) alive across the attack; capturing the attack graph must not
+    disturb that autograd graph (BatchNorm statistics are restored without a version bump) and must leave the
+    statistics exactly as an eager run does."""
+    from eeadv import engine, trainer
+    from eeadv.models import make_resnet
+    monkeypatch.setenv("EEADV_GRAPH", "1")
+    engine.clear_graphs()
+    try:
+        for method in ("TRADES", "ALP", "AT"):
+            torch.manual_seed(3)
+            net = make_resnet(18, "tiny").to(DEV).train()
+            opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+            args = Args(method_name=method, random=True, epsilon=16 / 255, num_steps_1=2, step_size_1=2 / 255, beta=6.0, num_classes=200)
+            crit = trainer.make_criterion(args)
+            x = torch.rand(8, 3, 64, 64, device=DEV)
+            y = torch.randint(0, 200, (8,), device=DEV)
+            n0 = int(net.bn1.num_batches_tracked)
+            for _ in range(2):
+                loss, out = trainer.train_batch(net, crit, opt, args, x, y, DEV)
+            assert torch.isfinite(loss) and out.shape == (8, 200)
+            # forwards in train mode per step: TRADES preds + loss (attack and output forward run in eval mode) = 2;
+            # ALP preds (attack + output in eval) = 1; AT: K attack iterations + output = 3
+            per_step = {"TRADES": 2, "ALP": 1, "AT": 3}[method]
+            assert int(net.bn1.num_batches_tracked) - n0 == 2 * per_step, method
+    finally:
+        engine.clear_graphs()
