@@ -81,12 +81,8 @@ def main(argv=None):
                 loss = criterion(output, target)
                 optimizer.zero_grad()
                 loss.backward()
-                # d in1 / d delta is 1 where the clamp is inactive and 0 where it clips: Variable(noise).grad in the
-                # reference is in1.grad masked by the clamp; sign() only needs the mask applied to exact zeros
-                g = in1.grad
-                s = input + delta
-                g = torch.where((s >= 0) & (s <= 1), g, torch.zeros_like(g))
-                ops.freeat_update_(noise, g.contiguous(), args.fgsm_step, args.clip_eps)
+                # Variable(noise).grad of the reference = in1.grad masked by the in-place clamp; the kernel applies the mask
+                ops.freeat_update_masked_(noise, in1.grad.contiguous(), input.contiguous(), args.fgsm_step, args.clip_eps)
                 optimizer.step()
             batch_time.update(time.time() - end)
             end = time.time()

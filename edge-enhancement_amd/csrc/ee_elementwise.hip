@@ -76,6 +76,15 @@ struct FreeAtOp {  // a = delta, b = g
     }
 };
 
+struct FreeAtMaskedOp {  // a = delta, b = d loss / d clamp(x + delta), c = x
+    float alpha, eps;
+    __device__ __forceinline__ float operator()(float d, float g, float x) const {
+        const float s = x + d;  // AT_free_imagenet_ddp.py:289-290: in1 = (x + delta).clamp_(0, 1); clamp passes the gradient on [0, 1]
+        const float gd = (s >= 0.0f && s <= 1.0f) ? g : 0.0f;
+        return tclamp(d + alpha * sgn(gd), -eps, eps);
+    }
+};
+
 // ---- random start drawn on the device -----------------------------------------------------------
 template <int DIST>
 __global__ __launch_bounds__(kBlock) void init_rng_kernel(float *__restrict__ x, const float *__restrict__ x0,
@@ -233,6 +242,14 @@ EE_API int ee_freeat_update_f32(float *delta, const float *g, int64_t n, float a
     if (!delta || !g) return EE_ERR_NULL;
     if (!aligned4(delta) || !aligned4(g)) return EE_ERR_ALIGN;
     return launch_map3(delta, delta, g, nullptr, n, FreeAtOp{alpha, eps}, as_stream(stream));
+}
+
+EE_API int ee_freeat_update_masked_f32(float *delta, const float *g_in1, const float *x, int64_t n, float alpha, float eps, void *stream) {
+    if (n < 0) return EE_ERR_SHAPE;
+    if (n == 0) return EE_OK;
+    if (!delta || !g_in1 || !x) return EE_ERR_NULL;
+    if (!aligned4(delta) || !aligned4(g_in1) || !aligned4(x)) return EE_ERR_ALIGN;
+    return launch_map3(delta, delta, g_in1, x, n, FreeAtMaskedOp{alpha, eps}, as_stream(stream));
 }
 
 EE_API int ee_pgd_step_bcast_f32(float *x, const float *g_lp, const float *g_edge, const float *x0, int B, int C,

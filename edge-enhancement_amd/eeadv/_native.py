@@ -31,6 +31,7 @@ SIGNATURES = {
     "ee_fgsm_step_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_i, c_p],
     "ee_add_clamp_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_p],
     "ee_freeat_update_f32": [c_p, c_p, c_l, c_f, c_f, c_p],
+    "ee_freeat_update_masked_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_p],
     "ee_avmix_f32": [c_p, c_p, c_p, c_p, c_l, c_l, c_f, c_p],
     "ee_avmix_labels_f64": [c_p, c_p, c_p, c_l, c_l, c_f, c_f, c_p],
     "ee_edge125_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_p, c_p, c_p],

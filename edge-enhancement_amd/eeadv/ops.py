@@ -134,6 +134,17 @@ def freeat_update_(delta, g, alpha, eps):
     return delta
 
 
+def freeat_update_masked_(delta, g_in1, x, alpha, eps):
+    """delta[:n] += alpha*sign(g_in1 * 1[0 <= x + delta <= 1]); clamp(+-eps); n = x.numel()."""
+    pd = _chk(delta, torch.float32, "delta")
+    pg = _chk(g_in1, torch.float32, "g_in1", x.shape)
+    px = _chk(x, torch.float32, "x")
+    if x.numel() > delta.numel():
+        raise ValueError("batch has more elements than the noise buffer")
+    N.check(N.lib.ee_freeat_update_masked_f32(pd, pg, px, x.numel(), alpha, eps, _stream()), "ee_freeat_update_masked_f32")
+    return delta
+
+
 def avmix(x, x0, wgt, gamma):
     B = x.shape[0]
     px = _chk(x, torch.float32, "x")

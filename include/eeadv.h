@@ -76,6 +76,10 @@ int ee_add_clamp_f32(float *out, const float *x, const float *delta, int64_t n, 
  * inside the box, so touching only the n live elements gives the same buffer. */
 int ee_freeat_update_f32(float *delta, const float *g, int64_t n, float alpha, float eps, void *stream);
 
+/* the same update when the caller holds g_in1 = dL/d(in1), in1 = clamp(x + delta, 0, 1) (AT_free_imagenet_ddp.py:289-290):
+ * the clamp's gradient mask (0 <= x + delta <= 1) is applied in the kernel, dL/d(delta) never exists as a tensor. */
+int ee_freeat_update_masked_f32(float *delta, const float *g_in1, const float *x, int64_t n, float alpha, float eps, void *stream);
+
 /* attacks.py:469-479 AVmixup vertex + per-sample mix.  wgt = float64[B] (numpy Beta(1,1) weights):
  *     v = clamp(x0 + (x - x0)*gamma, 0, 1);   out = float(double(x0)*w_b + double(v)*(1 - w_b)) */
 int ee_avmix_f32(float *out, const float *x, const float *x0, const double *wgt, int64_t B, int64_t per_sample,

@@ -285,3 +285,34 @@ def test_bad_shapes_are_refused_before_launch(ops):
         ops.edge125_fwd(x, ops.EdgeWeights(1.0), 0.0, 0.3)  # C > 4: EE_ERR_UNSUPPORTED
     with pytest.raises(ValueError):
         ops.pgd_step_(torch.zeros(4, device=DEV), torch.zeros(5, device=DEV), torch.zeros(4, device=DEV), 0.1, 0.1)
+
+
+def test_freeat_masked_update_equals_reference_lines(ops):
+    """AT_free_imagenet_ddp.py:287-307 on torch CPU ops vs the fused kernel (bit-exact)."""
+    torch.manual_seed(2)
+    B, full = 6, 10
+    x = torch.rand(B, 3, 8, 8)
+    x[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 0.001, 0.999])
+    noise = (torch.rand(full, 3, 8, 8) - 0.5) * (8 / 255)
+    w = torch.randn(3 * 8 * 8, 5)
+    y = torch.randint(0, 5, (B,))
+    step, eps = 4 / 255, 4 / 255
+    # reference lines
+    ref_noise = noise.clone()
+    nb = ref_noise[0:B].clone().requires_grad_(True)
+    in1 = x + nb
+    in1.clamp_(0, 1.0)
+    torch.nn.functional.cross_entropy(in1.flatten(1) @ w, y).backward()
+    ref_noise[0:B] += step * torch.sign(nb.grad)
+    ref_noise.clamp_(-eps, eps)
+    # kernel path: gradient w.r.t. the clamped input, mask applied in the kernel
+    xd, nd = dev(x.numpy()), dev(noise.numpy())
+    in1d = ops.add_clamp(xd, nd[0:B].contiguous()).requires_grad_(True)
+    assert np.array_equal(in1d.detach().cpu().numpy(), in1.detach().numpy())
+    g_in1 = torch.autograd.grad(torch.nn.functional.cross_entropy(in1d.flatten(1) @ w.to(DEV), y.to(DEV)), in1d)[0]
+    ops.freeat_update_masked_(nd, g_in1.contiguous(), xd, step, eps)
+    got = nd.cpu().numpy()
+    assert np.array_equal(got[B:], noise.numpy()[B:])  # rows beyond the batch are untouched
+    same = (got[:B] == ref_noise.numpy()[:B]).mean()
+    assert same > 0.995  # GEMM rounding may flip the sign of a ~0 gradient; everything else is bit-identical
+    assert np.abs(got).max() <= eps + 1e-9
