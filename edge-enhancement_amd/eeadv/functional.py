@@ -42,6 +42,43 @@ class FrontEndFn(torch.autograd.Function):
         return gx, g_hfs, None, None, None, None
 
 
+class CannyFn(torch.autograd.Function):
+    """Full CannyFilter forward/backward (utils/core.py:222-326; thresholds given, hysteresis=True)."""
+
+    @staticmethod
+    def forward(ctx, img, wts, alpha, low, high):
+        img = img.contiguous()
+        ctx.save_for_backward(img)
+        ctx.cfg = (wts, alpha, low, high)
+        return ops.canny_fwd(img, wts, alpha, low, high)
+
+    @staticmethod
+    def backward(ctx, u):
+        (img,) = ctx.saved_tensors
+        wts, alpha, low, high = ctx.cfg
+        return ops.canny_bwd(img, u.contiguous(), wts, alpha, low, high).expand_as(img), None, None, None, None
+
+
+class CannyFrontEndFn(torch.autograd.Function):
+    """x_in = clamp(x_hfs + w * CannyFilter(x), 0, 1) in one kernel each way (Net2_EE.py:36-49, resnet_EE.py:176-191)."""
+
+    @staticmethod
+    def forward(ctx, x, x_hfs, wts, alpha, low, high, w):
+        x, x_hfs = x.contiguous(), x_hfs.contiguous()
+        x_in, gate, _ = ops.canny_frontend_fwd(x, x_hfs, wts, alpha, low, high, w)
+        ctx.save_for_backward(x, gate)
+        ctx.cfg = (wts, alpha, low, high, w)
+        return x_in
+
+    @staticmethod
+    def backward(ctx, g_in):
+        x, gate = ctx.saved_tensors
+        wts, alpha, low, high, w = ctx.cfg
+        g_hfs, g_edge = ops.canny_frontend_bwd(g_in.contiguous(), gate, x, wts, alpha, low, high, w)
+        gx = g_edge.expand_as(x) if ctx.needs_input_grad[0] else None
+        return gx, g_hfs, None, None, None, None, None
+
+
 class AddSquareFn(torch.autograd.Function):
     """Add_Square (utils/core.py:636-655) given its random draws."""
 

@@ -57,10 +57,17 @@ def sobel_kernel_np(k=3):
     return x / den
 
 
+# k*45 degrees -> (drow, dcol) of the -1 tap of the directional kernel relative to its centre (core.py:87-112).
+# DERIVED (the reference rotates [0,0,1,-1,-1] with cv2, which is unavailable): parity unpinned.
+CANNY_DIRS = np.array([(0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1), (1, 0), (1, 1)], dtype=np.int32)
+
+
 class EdgeWeights:
-    """The 27 host floats every edge kernel takes (Gaussian, Sobel-x, Sobel-y)."""
+    """The 27 host floats every edge kernel takes (Gaussian, Sobel-x, Sobel-y) + the full filter's direction table."""
 
     def __init__(self, sigma=1.0, mu=0.0):
+        self.dirs = np.ascontiguousarray(CANNY_DIRS.reshape(-1), dtype=np.int32)
+        self.dirs_ptr = self.dirs.ctypes.data_as(ctypes.c_void_p)
         g = gaussian_kernel_np(3, mu, sigma).astype(np.float32).reshape(9)
         s = sobel_kernel_np(3)
         self.host = np.concatenate([g, s.astype(np.float32).reshape(9), s.T.astype(np.float32).reshape(9)])
@@ -209,6 +216,44 @@ def frontend_bwd(g_in, gate, x, wts, alpha, high, w):
     g_edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
     N.check(N.lib.ee_frontend_bwd_f32(pg, pt, px, B, C, H, W, wts.ptr, alpha, high, w, _chk(g_hfs, torch.float32, "g_hfs"),
                                       _chk(g_edge, torch.float32, "g_edge"), _stream()), "ee_frontend_bwd_f32")
+    return g_hfs, g_edge
+
+
+def canny_fwd(x, wts, alpha, low, high):
+    B, C, H, W = x.shape
+    edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_canny_fwd_f32(_chk(x, torch.float32, "x"), None, B, C, H, W, wts.ptr, wts.dirs_ptr, alpha, low, high, 0.0,
+                                   _chk(edge, torch.float32, "edge"), None, None, _stream()), "ee_canny_fwd_f32")
+    return edge
+
+
+def canny_bwd(x, u, wts, alpha, low, high):
+    B, C, H, W = x.shape
+    g = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_canny_bwd_f32(_chk(x, torch.float32, "x"), _chk(u, torch.float32, "u", (B, 1, H, W)), None, None, B, C, H, W, wts.ptr,
+                                   wts.dirs_ptr, alpha, low, high, 0.0, _chk(g, torch.float32, "g"), None, _stream()), "ee_canny_bwd_f32")
+    return g
+
+
+def canny_frontend_fwd(x, x_hfs, wts, alpha, low, high, w, want_edge=False):
+    B, C, H, W = x.shape
+    x_in = torch.empty_like(x)
+    gate = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device) if want_edge else None
+    N.check(N.lib.ee_canny_fwd_f32(_chk(x, torch.float32, "x"), _chk(x_hfs, torch.float32, "x_hfs", x.shape), B, C, H, W, wts.ptr,
+                                   wts.dirs_ptr, alpha, low, high, w, _opt(edge, torch.float32, "edge"), _chk(x_in, torch.float32, "x_in"),
+                                   _chk(gate, torch.uint8, "gate"), _stream()), "ee_canny_fwd_f32")
+    return x_in, gate, edge
+
+
+def canny_frontend_bwd(g_in, gate, x, wts, alpha, low, high, w):
+    B, C, H, W = x.shape
+    g_hfs = torch.empty_like(x)
+    g_edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_canny_bwd_f32(_chk(x, torch.float32, "x"), None, _chk(g_in, torch.float32, "g_in", x.shape),
+                                   _chk(gate, torch.uint8, "gate", x.shape), B, C, H, W, wts.ptr, wts.dirs_ptr, alpha, low, high, w,
+                                   _chk(g_edge, torch.float32, "g_edge"), _chk(g_hfs, torch.float32, "g_hfs"), _stream()),
+            "ee_canny_bwd_f32")
     return g_hfs, g_edge
 
 

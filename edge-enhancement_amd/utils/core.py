@@ -191,8 +191,9 @@ def _nms(mag, gx, gy, weight_directional, assign):
 
 
 class CannyFilter(_CannyWeights):
-    """core.py:148-326: full Canny (NMS, STE double threshold, hysteresis).  Runs in device torch ops for now
-    (next row for a hand-written kernel); thin kernels derived -> parity unpinned."""
+    """core.py:148-326: full Canny (NMS, STE double threshold, hysteresis).  The path every model takes (both thresholds
+    given, hysteresis=True) is ONE HIP kernel each way on ROCm tensors; other argument combinations and the opt-in CPU
+    plumbing path run the same expressions in torch ops.  Thin kernels derived (cv2 unavailable) -> parity unpinned."""
 
     def __init__(self, k_gaussian=3, mu=0, sigma=1, k_sobel=3, use_cuda=False, alpha=0.0):
         super(CannyFilter, self).__init__(k_gaussian, mu, sigma, k_sobel, registered=True)
@@ -201,7 +202,8 @@ class CannyFilter(_CannyWeights):
         print('CannyFilter; sigma:{}, alpha:{}'.format(sigma, alpha))
 
     def forward(self, img, low_threshold=None, high_threshold=None, hysteresis=False):
-        runtime.require_device(img, "CannyFilter")
+        if runtime.require_device(img, "CannyFilter") and low_threshold is not None and high_threshold is not None and hysteresis:
+            return EF.CannyFn.apply(img, self.edge_weights, float(self.alpha), float(low_threshold), float(high_threshold))
         grad_x, grad_y, mag = self._grads(img)
         mag = torch.where(mag < self.alpha, torch.zeros_like(mag), mag)
         thin_edges = _nms(mag, grad_x, grad_y, self.weight_directional, assign=True)
@@ -274,6 +276,8 @@ def ee_front_end(x, x_hfs, canny, w, low, high, with_gf=False, weight_gaussian=N
     Fused into one kernel each way for the primary filter; other filters compose."""
     if isinstance(canny, CannyFilter_step125_1) and not with_gf and x.is_cuda:
         return EF.FrontEndFn.apply(x, x_hfs, canny.edge_weights, float(canny.alpha), float(high), float(w))
+    if isinstance(canny, CannyFilter) and not with_gf and x.is_cuda:
+        return EF.CannyFrontEndFn.apply(x, x_hfs, canny.edge_weights, float(canny.alpha), float(low), float(high), float(w))
     x_canny = canny(x, low_threshold=low, high_threshold=high, hysteresis=True)
     if with_gf:
         x_canny = F.conv2d(x_canny.type(torch.float), weight_gaussian, padding=1)

@@ -125,6 +125,24 @@ int ee_frontend_bwd_f32(const float *g_in, const uint8_t *gate, const float *x, 
                         const float *weights27, float alpha, float high, float w, float *g_hfs, float *g_edge,
                         void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Full CannyFilter (utils/core.py:148-326): blur, Sobel, magnitude, alpha mask, orientation-quantised non-maximum
+ * suppression, straight-through double threshold, hysteresis - the path every model takes (low and high thresholds
+ * given, hysteresis=True).  dirs16 = HOST int[16]: (drow, dcol) of the -1 tap of the 8 directional kernels
+ * (core.py:87-112; the reference builds them with cv2, the caller passes the derived table -> parity unpinned).
+ * ------------------------------------------------------------------------------------------- */
+
+/* forward.  x_in == NULL: edge[B,1,H,W] only.  x_in != NULL: fused front end, x_in = clamp(x_hfs + w*edge, 0, 1) and
+ * gate (nullable) as in ee_frontend_fwd_f32; edge then optional. */
+int ee_canny_fwd_f32(const float *x, const float *x_hfs, int B, int C, int H, int W, const float *weights27, const int *dirs16,
+                     float alpha, float low, float high, float w, float *edge, float *x_in, uint8_t *gate, void *stream);
+
+/* backward.  g_in == NULL: u = dL/d(edge) [B,1,H,W] -> g_img[B,1,H,W].  g_in != NULL (fused front end): u is formed from
+ * g_in * gate as in ee_frontend_bwd_f32 and g_hfs = g_in * gate is written too. */
+int ee_canny_bwd_f32(const float *x, const float *u, const float *g_in, const uint8_t *gate, int B, int C, int H, int W,
+                     const float *weights27, const int *dirs16, float alpha, float low, float high, float w, float *g_img,
+                     float *g_hfs, void *stream);
+
 /* last stage of the attack step for EE models, fused: dL/dx = g_lp + g_edge (g_edge broadcast over C),
  * then the PGD update of ee_pgd_step_f32 on x - the gradient itself never reaches HBM.
  * g_lp [B,C,H,W] = gradient arriving through the low-pass branch; g_edge [B,1,H,W]. */

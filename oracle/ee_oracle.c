@@ -376,3 +376,108 @@ EXPORT void orc_topk_i64(const float *logits, const int64_t *y, int B, int K, in
                 for (int jj = j; jj < k; ++jj) correct_at_k[jj] += 1;
     }
 }
+
+/* ---------------------------------------------------------------------------
+ * CannyFilter (full: NMS + STE double threshold + hysteresis)  utils/core.py:148-326
+ *   dirs[16] = (drow, dcol) of the -1 tap of the 8 directional kernels (core.py:87-112).  The reference builds them
+ *   with cv2 (absent here); the table passed in is DERIVED -> every result of these two functions is PARITY UNPINNED
+ *   with respect to that table, and pinned to the reference's own forward/backward code given the table
+ *   (tests/golden/canny_full_unpinned.npz).  Only the path every model takes is restated: low_threshold and
+ *   high_threshold given, hysteresis=True.
+ * ------------------------------------------------------------------------- */
+static float magA_at(const float *magA, int H, int W, int i, int j) {
+    return (i < 0 || i >= H || j < 0 || j >= W) ? 0.0f : magA[(size_t)i * W + j]; /* conv2d(padding=1): zero padding, core.py:268 */
+}
+
+/* per-image intermediate maps shared by forward and backward */
+static void canny_maps(const float *x, int C, int H, int W, const float *g9, const float *sx9, const float *sy9, float alpha,
+                       float high, const int *dirs, float *mag, float *gx1, float *gy1, float *magA, unsigned char *removed) {
+    size_t HW = (size_t)H * W;
+    orc_edge125_fwd_f32(x, 1, C, H, W, g9, sx9, sy9, alpha, high, NULL, mag, gx1, gy1);
+    for (size_t k = 0; k < HW; ++k) magA[k] = (mag[k] < alpha) ? 0.0f : mag[k]; /* core.py:263-264 */
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            size_t p = (size_t)i * W + j;
+            /* core.py:258-260, 270: orientation -> degrees -> multiples of 45 -> index mod 8 (all fp32) */
+            float ori = atanf(gy1[p] / gx1[p]) * (float)(360.0 / 3.141592653589793) + 180.0f;
+            float ori2 = rintf(ori / 45.0f) * 45.0f;
+            float q = ori2 / 45.0f;
+            float pidx = q - 8.0f * floorf(q / 8.0f); /* torch remainder */
+            unsigned char rem = 0;
+            if (pidx == pidx) { /* NaN orientation (gx = gy = 0) matches no direction: never suppressed */
+                int kk = ((int)pidx) % 4;
+                float d1 = magA[p] - magA_at(magA, H, W, i + dirs[2 * kk], j + dirs[2 * kk + 1]);
+                float d2 = magA[p] - magA_at(magA, H, W, i + dirs[2 * (kk + 4)], j + dirs[2 * (kk + 4) + 1]);
+                float mn = (d1 != d1 || d2 != d2) ? (d1 + d2) : (d1 < d2 ? d1 : d2);
+                rem = !(mn > 0.0f); /* core.py:285-290 */
+            }
+            removed[p] = rem;
+        }
+}
+
+EXPORT void orc_canny_fwd_f32(const float *x, int B, int C, int H, int W, const float *g9, const float *sx9, const float *sy9,
+                              float alpha, float low, float high, const int *dirs, float *out) {
+    size_t HW = (size_t)H * W;
+    float *mag = malloc(sizeof(float) * HW), *gx1 = malloc(sizeof(float) * HW), *gy1 = malloc(sizeof(float) * HW);
+    float *magA = malloc(sizeof(float) * HW), *t2 = malloc(sizeof(float) * HW), *hb = malloc(sizeof(float) * HW);
+    unsigned char *rem = malloc(HW);
+    for (int n = 0; n < B; ++n) {
+        canny_maps(x + (size_t)n * C * HW, C, H, W, g9, sx9, sy9, alpha, high, dirs, mag, gx1, gy1, magA, rem);
+        for (size_t k = 0; k < HW; ++k) {
+            float t = rem[k] ? 0.0f : magA[k];
+            /* safeSign(t - thr): 0 -> -1, NaN -> sign 0 -> -1   (core.py:115-118, 299-310) */
+            float lowb = ((t - low) > 0.0f) ? 1.0f : 0.0f, highb = ((t - high) > 0.0f) ? 1.0f : 0.0f;
+            hb[k] = highb;
+            t2[k] = lowb * 0.5f + highb * 0.5f; /* core.py:315 */
+        }
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                float acc = 0.0f;
+                for (int di = -1; di <= 1; ++di)
+                    for (int dj = -1; dj <= 1; ++dj) {
+                        int r = i + di, s = j + dj;
+                        float v = (r < 0 || r >= H || s < 0 || s >= W) ? 0.0f : t2[(size_t)r * W + s];
+                        acc = fmaf(1.25f, v, acc);
+                    }
+                size_t p = (size_t)i * W + j;
+                float weak_is_high = (acc > 1.0f && t2[p] == 0.5f) ? 1.0f : 0.0f; /* core.py:319-320 */
+                out[(size_t)n * HW + p] = hb[p] + weak_is_high;                  /* core.py:321 */
+            }
+    }
+    free(mag); free(gx1); free(gy1); free(magA); free(t2); free(hb); free(rem);
+}
+
+/* backward of the above.  Only `high` carries gradient (low and the hysteresis terms enter through comparisons):
+ *   g_t = (u / 2) where |t - high| <= 1.001 (BinaryConnectDeterministic.backward core.py:138-145), 0 at suppressed
+ *   pixels (in-place assignment core.py:290), then the alpha mask and the magnitude / Sobel / blur adjoints as in
+ *   orc_edge125_bwd_f32 (0 * inf = NaN at mag == 0 kept). */
+EXPORT void orc_canny_bwd_f32(const float *x, const float *u, int B, int C, int H, int W, const float *g9, const float *sx9,
+                              const float *sy9, float alpha, float low, float high, const int *dirs, float *gx_img) {
+    (void)low;
+    size_t HW = (size_t)H * W, PW = (size_t)(H + 2) * (W + 2);
+    float *mag = malloc(sizeof(float) * HW), *gx1 = malloc(sizeof(float) * HW), *gy1 = malloc(sizeof(float) * HW);
+    float *magA = malloc(sizeof(float) * HW), *ggx = malloc(sizeof(float) * HW), *ggy = malloc(sizeof(float) * HW);
+    float *gp = malloc(sizeof(float) * PW), *gb = malloc(sizeof(float) * HW);
+    unsigned char *rem = malloc(HW);
+    for (int n = 0; n < B; ++n) {
+        canny_maps(x + (size_t)n * C * HW, C, H, W, g9, sx9, sy9, alpha, high, dirs, mag, gx1, gy1, magA, rem);
+        for (size_t k = 0; k < HW; ++k) {
+            float t = rem[k] ? 0.0f : magA[k];
+            float gm = u[(size_t)n * HW + k] / 2.0f;
+            if (fabsf(t - high) > 1.001f) gm = 0.0f;
+            if (rem[k]) gm = 0.0f;
+            if (mag[k] < alpha) gm = 0.0f;
+            float s2 = gx1[k] * gx1[k] + gy1[k] * gy1[k];
+            float r = 1.0f / sqrtf(s2);
+            float gs = gm * (0.5f * r);
+            ggx[k] = (gs * (2.0f * gx1[k])) / (float)C;
+            ggy[k] = (gs * (2.0f * gy1[k])) / (float)C;
+        }
+        corr3_transpose_acc(ggx, H, W, sx9, gp, 1);
+        corr3_transpose_acc(ggy, H, W, sy9, gp, 0);
+        reppad1_adjoint(gp, H, W, gb);
+        corr3_transpose_acc(gb, H, W, g9, gp, 1);
+        reppad1_adjoint(gp, H, W, gx_img + (size_t)n * HW);
+    }
+    free(mag); free(gx1); free(gy1); free(magA); free(ggx); free(ggy); free(gp); free(gb); free(rem);
+}

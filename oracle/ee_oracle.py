@@ -233,3 +233,30 @@ def hfs_mask(w, h, r):
     temp = np.roll(temp, -cw, axis=0)
     temp = np.roll(temp, -ch, axis=1)
     return temp
+
+
+# ---- full CannyFilter (PARITY UNPINNED: derived thin-kernel table) -----------------------------------------
+# k*45 degrees -> (drow, dcol) of the -1 neighbour relative to the centre (core.py:87-112, derived; see ref_path.THIN_TABLE)
+CANNY_DIRS = np.array([(0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1), (1, 0), (1, 1)], dtype=np.int32)
+
+
+def canny_fwd(x, alpha, low, high, sigma=1.0):
+    x = _f32(x)
+    B, C, H, W = x.shape
+    g9, sx9, sy9 = edge_weights(sigma)
+    out = np.empty((B, 1, H, W), np.float32)
+    dirs = np.ascontiguousarray(CANNY_DIRS.reshape(-1))
+    lib().orc_canny_fwd_f32(_p(x), c_i(B), c_i(C), c_i(H), c_i(W), _p(g9), _p(sx9), _p(sy9), c_f(alpha), c_f(low), c_f(high),
+                            _p(dirs), _p(out))
+    return out
+
+
+def canny_bwd(x, u, alpha, low, high, sigma=1.0):
+    x, u = _f32(x), _f32(u)
+    B, C, H, W = x.shape
+    g9, sx9, sy9 = edge_weights(sigma)
+    out = np.empty((B, 1, H, W), np.float32)
+    dirs = np.ascontiguousarray(CANNY_DIRS.reshape(-1))
+    lib().orc_canny_bwd_f32(_p(x), _p(u), c_i(B), c_i(C), c_i(H), c_i(W), _p(g9), _p(sx9), _p(sy9), c_f(alpha), c_f(low),
+                            c_f(high), _p(dirs), _p(out))
+    return out

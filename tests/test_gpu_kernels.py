@@ -316,3 +316,52 @@ def test_freeat_masked_update_equals_reference_lines(ops):
     same = (got[:B] == ref_noise.numpy()[:B]).mean()
     assert same > 0.995  # GEMM rounding may flip the sign of a ~0 gradient; everything else is bit-identical
     assert np.abs(got).max() <= eps + 1e-9
+
+
+# ---- full CannyFilter (PARITY UNPINNED: derived thin-kernel table on both sides) ---------------------------------------
+@pytest.mark.parametrize("shape,alpha,low,high", [((3, 3, 64, 64), 0.0, 38 / 255, 76 / 255), ((2, 1, 28, 28), 0.3, 25 / 255, 51 / 255),
+                                                  ((2, 3, 70, 50), 0.0, 38 / 255, 76 / 255), ((2, 2, 17, 130), 0.05, 0.1, 0.2),
+                                                  ((2, 4, 9, 9), 0.0, 0.05, 0.1), ((1, 3, 224, 224), 0.0, 38 / 255, 76 / 255)])
+def test_canny_full_fwd_bwd_vs_oracle_UNPINNED(ops, shape, alpha, low, high):
+    rng = np.random.RandomState(sum(shape))
+    x = rng.rand(*shape).astype(np.float32)
+    x[0, :, 2:8, 3:9] = 0.5  # flat patch: NaN orientation, zero magnitude
+    wts = ops.EdgeWeights(1.0)
+    e = ops.canny_fwd(dev(x), wts, alpha, low, high)
+    oe = O.canny_fwd(x, alpha, low, high)
+    # orientation uses atanf (device libm != host libm): a pixel exactly on a 22.5-degree boundary could differ; none may here
+    assert_bitexact(e.cpu().numpy(), oe, "canny edge")
+    u = rng.randn(shape[0], 1, shape[2], shape[3]).astype(np.float32)
+    g = ops.canny_bwd(dev(x), dev(u), wts, alpha, low, high)
+    assert_bitexact(g.cpu().numpy(), O.canny_bwd(x, u, alpha, low, high), "canny bwd")
+    # fused front end
+    xh = (rng.rand(*shape).astype(np.float32) * 1.4 - 0.3)
+    x_in, gate, edge = ops.canny_frontend_fwd(dev(x), dev(xh), wts, alpha, low, high, 1.0, want_edge=True)
+    assert_bitexact(edge.cpu().numpy(), oe, "fused edge")
+    s = xh + np.float32(1.0) * oe
+    assert_bitexact(x_in.cpu().numpy(), np.clip(s, 0, 1).astype(np.float32), "fused x_in")
+    assert np.array_equal(gate.cpu().numpy(), ((s >= 0) & (s <= 1)).astype(np.uint8))
+    g_in = rng.randn(*shape).astype(np.float32)
+    g_hfs, g_edge = ops.canny_frontend_bwd(dev(g_in), gate, dev(x), wts, alpha, low, high, 1.0)
+    gh = np.where(gate.cpu().numpy() > 0, g_in, np.float32(0))
+    uu = gh[:, 0:1].copy()
+    for c in range(1, shape[1]):
+        uu = uu + gh[:, c:c + 1]
+    assert_bitexact(g_hfs.cpu().numpy(), gh, "fused g_hfs")
+    assert_bitexact(g_edge.cpu().numpy(), O.canny_bwd(x, uu * np.float32(1.0), alpha, low, high), "fused g_edge")
+
+
+def test_canny_full_vs_reference_golden_UNPINNED(ops, golden):
+    """Against the reference's own CannyFilter forward / backward run with the derived table (make_golden.py)."""
+    G = golden("canny_full_unpinned")
+    wts = ops.EdgeWeights(1.0)
+    for name in ["rand_rgb", "rand_mnist", "rect_rgb"]:
+        x, u = G[name + "__x"], G[name + "__u"]
+        alpha, low, high = [float(v) for v in G[name + "__alpha_low_high"]]
+        e = ops.canny_fwd(dev(x), wts, alpha, low, high)
+        assert np.array_equal(e.cpu().numpy(), G[name + "__CannyFilter__edge"])
+        g = ops.canny_bwd(dev(x), dev(u), wts, alpha, low, high).cpu().numpy()
+        ref = G[name + "__CannyFilter__gx"][:, :1]
+        assert np.array_equal(np.isnan(g), np.isnan(ref))
+        fin = ~np.isnan(ref)
+        np.testing.assert_allclose(g[fin], ref[fin], atol=1e-6)

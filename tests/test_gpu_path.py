@@ -460,3 +460,34 @@ def test_trades_and_alp_training_step_under_hip_graphs(monkeypatch):
             assert int(net.bn1.num_batches_tracked) - n0 == 2 * per_step, method
     finally:
         engine.clear_graphs()
+
+
+def test_full_canny_module_and_ee_at_model_UNPINNED(Cm, golden):
+    """utils.core.CannyFilter (HIP) vs the torch restatement, and an EE_AT model (Net2_EE with the full filter) end to end."""
+    G = golden("canny_full_unpinned")
+    x = dev(G["rand_rgb__x"]).requires_grad_(True)
+    alpha, low, high = [float(v) for v in G["rand_rgb__alpha_low_high"]]
+    filt = Cm.CannyFilter(sigma=1, use_cuda=True, alpha=alpha).to(DEV)
+    e = filt(x, low_threshold=low, high_threshold=high, hysteresis=True)
+    assert np.array_equal(e.detach().cpu().numpy(), G["rand_rgb__CannyFilter__edge"])
+    (e * dev(G["rand_rgb__u"])).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), G["rand_rgb__CannyFilter__gx"], atol=1e-6)
+    e2 = filt(x.detach(), low_threshold=low, high_threshold=high, hysteresis=False)  # other modes: torch ops on the device
+    assert set(np.unique(e2.cpu().numpy()).tolist()) <= {0.0, 0.5, 1.0}
+    assert sorted(filt.state_dict()) == ["weight_directional", "weight_gaussian", "weight_hysteresis", "weight_sobel_x", "weight_sobel_y"]
+    m, ref = _ee_pair(False, 28, 1, 4, 0.3, 25.0, 51.0, type_canny="CannyFilter")
+    torch.manual_seed(21)
+    xb = torch.rand(6, 1, 28, 28)
+    xb[1, :, 8:20, 8:20] = 0.9
+    yb = torch.randint(0, 10, (6,))
+    xr = xb.clone().requires_grad_(True)
+    lr = ref(xr)
+    xd = xb.to(DEV).requires_grad_(True)
+    ld = m(xd)
+    np.testing.assert_allclose(ld.detach().cpu().numpy(), lr.detach().numpy(), atol=1e-4)
+    F.cross_entropy(lr, yb, reduction="sum").backward()
+    F.cross_entropy(ld, yb.to(DEV), reduction="sum").backward()
+    g, gr = xd.grad.cpu().numpy(), xr.grad.numpy()
+    assert np.array_equal(np.isnan(g), np.isnan(gr))
+    fin = ~np.isnan(gr)
+    assert np.abs(g[fin] - gr[fin]).max() < 2e-4 * np.abs(gr[fin]).max() + 1e-7
