@@ -1,0 +1,435 @@
+// ee_bn.hip - BatchNorm2d fused with the residual add and the ReLU that follow it in every ResNet block
+// (Tiny_ImageNet/models_tinyimagenet/resnet.py:44-59: out = relu(bn(conv(x)) [+ residual])).
+//
+// Why it exists: at the reference batch size (100 x 64x64 images) one PGD iteration of ResNet-18 is ~170 kernel
+// launches averaging ~12 us, so the attack loop is launch-bound; BatchNorm -> (+ residual) -> ReLU are three (forward)
+// and two (backward) launches per layer of pure HBM-bound element-wise work.  Fused: one launch each way, the
+// normalised tensor is written once, and the ReLU mask is taken from the output instead of a saved copy.
+//
+// One workgroup per channel.  Training mode: pass 1 mean, pass 2 centred variance (two-pass, fp32, fixed-order wave /
+// workgroup reductions -> bit-reproducible), pass 3 normalise + add + ReLU; the channel's slice (<= 410 KB) stays in the
+// XCD's L2 between passes.  Running statistics are updated in the kernel exactly as nn.BatchNorm2d does (momentum,
+// unbiased variance).  NCHW fp32; 16-B accesses when H*W % 4 == 0 (every ResNet stage: 1024, 256, 64, 16, 4).
+//
+// This is CNN-body glue, not one of SURVEY.md section 8's rows: parity is "logits within 1e-4" through the model tests.
+#include "ee_common.hpp"
+
+namespace {
+
+using namespace ee;
+
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float *scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // scratch may still be read from a previous call
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += scratch[w];
+    return t;
+}
+
+struct BnShape {
+    int B, C, HW;
+};
+
+// element e (0 .. B*HW) of channel c lives at ((b*C + c)*HW + p), b = e / HW, p = e % HW; VEC = 4 walks float4s (HW % 4 == 0)
+template <int NT, int VEC, class F>
+__device__ __forceinline__ void for_channel(const BnShape s, int c, F f) {
+    const int per = s.HW / VEC;
+    const int total = s.B * per;
+    for (int e = threadIdx.x; e < total; e += NT) {
+        const int b = e / per, q = e - b * per;
+        f((static_cast<size_t>(b) * s.C + c) * s.HW + static_cast<size_t>(q) * VEC);
+    }
+}
+
+template <int NT, int VEC, bool RELU, bool RES>
+__global__ __launch_bounds__(NT) void bn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, float *running_mean, float *running_var, float momentum,
+                                                    float eps, int training, float *__restrict__ y, float *__restrict__ save_mean,
+                                                    float *__restrict__ save_invstd, BnShape s) {
+    __shared__ float scratch[NT / 64];
+    const int c = blockIdx.x;
+    const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
+    float mean, invstd;
+    if (training) {
+        float acc = 0.0f;
+        for_channel<NT, VEC>(s, c, [&](size_t o) {
+            if (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + o);
+                acc += (v.x + v.y) + (v.z + v.w);
+            } else {
+                acc += x[o];
+            }
+        });
+        mean = block_sum<NT>(acc, scratch) / n;
+        float var = 0.0f;
+        for_channel<NT, VEC>(s, c, [&](size_t o) {
+            if (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + o);
+                const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+                var += (a * a + b * b) + (cc * cc + d * d);
+            } else {
+                const float a = x[o] - mean;
+                var += a * a;
+            }
+        });
+        var = block_sum<NT>(var, scratch) / n;
+        invstd = 1.0f / sqrtf(var + eps);
+        if (threadIdx.x == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = invstd;
+            if (running_mean) {
+                const float unbiased = (n > 1.0f) ? var * (n / (n - 1.0f)) : var;
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
+    for_channel<NT, VEC>(s, c, [&](size_t o) {
+        if (VEC == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + o);
+            float4 r = make_float4((v.x - mean) * a + b0, (v.y - mean) * a + b0, (v.z - mean) * a + b0, (v.w - mean) * a + b0);
+            if (RES) {
+                const float4 q = *reinterpret_cast<const float4 *>(res + o);
+                r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+            }
+            if (RELU) {
+                r.x = r.x > 0.0f ? r.x : (r.x != r.x ? r.x : 0.0f);
+                r.y = r.y > 0.0f ? r.y : (r.y != r.y ? r.y : 0.0f);
+                r.z = r.z > 0.0f ? r.z : (r.z != r.z ? r.z : 0.0f);
+                r.w = r.w > 0.0f ? r.w : (r.w != r.w ? r.w : 0.0f);
+            }
+            *reinterpret_cast<float4 *>(y + o) = r;
+        } else {
+            float r = (x[o] - mean) * a + b0;
+            if (RES) r += res[o];
+            if (RELU) r = r > 0.0f ? r : (r != r ? r : 0.0f);
+            y[o] = r;
+        }
+    });
+}
+
+// backward.  dz = RELU ? dy * (y > 0) : dy  (threshold_backward); dres = dz (the residual branch's gradient);
+// training: dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat));  eval: dx = gamma*invstd_running * dz.
+template <int NT, int VEC, bool RELU>
+__global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
+                                                    const float *__restrict__ gamma, const float *__restrict__ save_mean,
+                                                    const float *__restrict__ save_invstd, const float *__restrict__ running_mean,
+                                                    const float *__restrict__ running_var, float eps, int training, float *__restrict__ dx,
+                                                    float *__restrict__ dres, float *__restrict__ dgamma, float *__restrict__ dbeta, BnShape s) {
+    __shared__ float scratch[NT / 64];
+    const int c = blockIdx.x;
+    const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
+    const float mean = training ? save_mean[c] : running_mean[c];
+    const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
+    float sdz = 0.0f, sdzx = 0.0f;
+    for_channel<NT, VEC>(s, c, [&](size_t o) {
+        if (VEC == 4) {
+            float4 g = *reinterpret_cast<const float4 *>(dy + o);
+            if (RELU) {
+                const float4 yy = *reinterpret_cast<const float4 *>(y + o);
+                g.x = yy.x > 0.0f ? g.x : 0.0f;
+                g.y = yy.y > 0.0f ? g.y : 0.0f;
+                g.z = yy.z > 0.0f ? g.z : 0.0f;
+                g.w = yy.w > 0.0f ? g.w : 0.0f;
+            }
+            const float4 v = *reinterpret_cast<const float4 *>(x + o);
+            sdz += (g.x + g.y) + (g.z + g.w);
+            sdzx += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) + (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
+        } else {
+            float g = dy[o];
+            if (RELU) g = y[o] > 0.0f ? g : 0.0f;
+            sdz += g;
+            sdzx += g * ((x[o] - mean) * invstd);
+        }
+    });
+    sdz = block_sum<NT>(sdz, scratch);
+    sdzx = block_sum<NT>(sdzx, scratch);
+    if (threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = sdzx;
+        if (dbeta) dbeta[c] = sdz;
+    }
+    const float w = (gamma ? gamma[c] : 1.0f) * invstd;
+    const float m1 = training ? sdz / n : 0.0f, m2 = training ? sdzx / n : 0.0f;
+    for_channel<NT, VEC>(s, c, [&](size_t o) {
+        if (VEC == 4) {
+            float4 g = *reinterpret_cast<const float4 *>(dy + o);
+            if (RELU) {
+                const float4 yy = *reinterpret_cast<const float4 *>(y + o);
+                g.x = yy.x > 0.0f ? g.x : 0.0f;
+                g.y = yy.y > 0.0f ? g.y : 0.0f;
+                g.z = yy.z > 0.0f ? g.z : 0.0f;
+                g.w = yy.w > 0.0f ? g.w : 0.0f;
+            }
+            if (dres) *reinterpret_cast<float4 *>(dres + o) = g;
+            if (dx) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + o);
+                float4 r;
+                r.x = w * ((g.x - m1) - ((v.x - mean) * invstd) * m2);
+                r.y = w * ((g.y - m1) - ((v.y - mean) * invstd) * m2);
+                r.z = w * ((g.z - m1) - ((v.z - mean) * invstd) * m2);
+                r.w = w * ((g.w - m1) - ((v.w - mean) * invstd) * m2);
+                *reinterpret_cast<float4 *>(dx + o) = r;
+            }
+        } else {
+            float g = dy[o];
+            if (RELU) g = y[o] > 0.0f ? g : 0.0f;
+            if (dres) dres[o] = g;
+            if (dx) dx[o] = w * ((g - m1) - ((x[o] - mean) * invstd) * m2);
+        }
+    });
+}
+
+
+// ---- register-cached variants: a channel that fits MAXV float4s per lane is read from memory ONCE (the two-pass
+// statistics and the normalisation run on registers), which removes two of the three dependent L2 round trips -------------
+__device__ __forceinline__ float relu_nan(float r) { return r > 0.0f ? r : (r != r ? r : 0.0f); }
+
+template <int NT, int MAXV, bool RELU, bool RES>
+__global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           float *running_mean, float *running_var, float momentum, float eps, int training,
+                                                           float *__restrict__ y, float *__restrict__ save_mean,
+                                                           float *__restrict__ save_invstd, BnShape s) {
+    __shared__ float scratch[NT / 64];
+    const int c = blockIdx.x;
+    const int per = s.HW / 4, total = s.B * per;
+    const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    float4 xv[MAXV];
+    unsigned off[MAXV];
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int e = threadIdx.x + j * NT;
+        xv[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        off[j] = 0;
+        if (e < total) {
+            const int b = e / per, q = e - b * per;
+            off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
+            xv[j] = x4[off[j]];
+            acc += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+        }
+    }
+    float mean, invstd;
+    if (training) {
+        mean = block_sum<NT>(acc, scratch) / n;
+        float var = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j)
+            if (static_cast<int>(threadIdx.x) + j * NT < total) {
+                const float a = xv[j].x - mean, b = xv[j].y - mean, cc = xv[j].z - mean, d = xv[j].w - mean;
+                var += (a * a + b * b) + (cc * cc + d * d);
+            }
+        var = block_sum<NT>(var, scratch) / n;
+        invstd = 1.0f / sqrtf(var + eps);
+        if (threadIdx.x == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = invstd;
+            if (running_mean) {
+                const float unbiased = (n > 1.0f) ? var * (n / (n - 1.0f)) : var;
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
+    float4 *y4 = reinterpret_cast<float4 *>(y);
+    const float4 *r4 = reinterpret_cast<const float4 *>(res);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+        if (static_cast<int>(threadIdx.x) + j * NT < total) {
+            const float4 v = xv[j];
+            float4 r = make_float4((v.x - mean) * a + b0, (v.y - mean) * a + b0, (v.z - mean) * a + b0, (v.w - mean) * a + b0);
+            if (RES) {
+                const float4 q = r4[off[j]];
+                r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+            }
+            if (RELU) {
+                r.x = relu_nan(r.x); r.y = relu_nan(r.y); r.z = relu_nan(r.z); r.w = relu_nan(r.w);
+            }
+            y4[off[j]] = r;
+        }
+}
+
+template <int NT, int MAXV, bool RELU>
+__global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
+                                                           const float *__restrict__ gamma, const float *__restrict__ save_mean,
+                                                           const float *__restrict__ save_invstd, const float *__restrict__ running_mean,
+                                                           const float *__restrict__ running_var, float eps, int training,
+                                                           float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ dgamma,
+                                                           float *__restrict__ dbeta, BnShape s) {
+    __shared__ float scratch[NT / 64];
+    const int c = blockIdx.x;
+    const int per = s.HW / 4, total = s.B * per;
+    const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
+    const float mean = training ? save_mean[c] : running_mean[c];
+    const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
+    const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
+    float4 gv[MAXV], hv[MAXV];  // masked gradient dz and xhat
+    unsigned off[MAXV];
+    float sdz = 0.0f, sdzx = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int e = threadIdx.x + j * NT;
+        off[j] = 0;
+        gv[j] = hv[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (e < total) {
+            const int b = e / per, q = e - b * per;
+            off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
+            float4 g = dy4[off[j]];
+            if (RELU) {
+                const float4 yy = y4[off[j]];
+                g.x = yy.x > 0.0f ? g.x : 0.0f;
+                g.y = yy.y > 0.0f ? g.y : 0.0f;
+                g.z = yy.z > 0.0f ? g.z : 0.0f;
+                g.w = yy.w > 0.0f ? g.w : 0.0f;
+            }
+            const float4 v = x4[off[j]];
+            const float4 h = make_float4((v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd);
+            sdz += (g.x + g.y) + (g.z + g.w);
+            sdzx += (g.x * h.x + g.y * h.y) + (g.z * h.z + g.w * h.w);
+            gv[j] = g;
+            hv[j] = h;
+        }
+    }
+    sdz = block_sum<NT>(sdz, scratch);
+    sdzx = block_sum<NT>(sdzx, scratch);
+    if (threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = sdzx;
+        if (dbeta) dbeta[c] = sdz;
+    }
+    const float w = (gamma ? gamma[c] : 1.0f) * invstd;
+    const float m1 = training ? sdz / n : 0.0f, m2 = training ? sdzx / n : 0.0f;
+    float4 *dx4 = reinterpret_cast<float4 *>(dx), *dr4 = reinterpret_cast<float4 *>(dres);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+        if (static_cast<int>(threadIdx.x) + j * NT < total) {
+            const float4 g = gv[j], h = hv[j];
+            if (dres) dr4[off[j]] = g;
+            if (dx) dx4[off[j]] = make_float4(w * ((g.x - m1) - h.x * m2), w * ((g.y - m1) - h.y * m2), w * ((g.z - m1) - h.z * m2),
+                                              w * ((g.w - m1) - h.w * m2));
+        }
+}
+
+template <int NT, int MAXV>
+void launch_fwd_cached(bool relu, bool has_res, hipStream_t st, const float *x, const float *res, const float *gamma, const float *beta, float *rm,
+                       float *rv, float momentum, float eps, int training, float *y, float *sm, float *si, BnShape s) {
+    const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
+    if (relu && has_res)
+        EE_LAUNCH((bn_fwd_cached_kernel<NT, MAXV, true, true>), grid, block, 0, st, x, res, gamma, beta, rm, rv, momentum, eps, training, y, sm, si, s);
+    else if (relu)
+        EE_LAUNCH((bn_fwd_cached_kernel<NT, MAXV, true, false>), grid, block, 0, st, x, res, gamma, beta, rm, rv, momentum, eps, training, y, sm, si, s);
+    else if (has_res)
+        EE_LAUNCH((bn_fwd_cached_kernel<NT, MAXV, false, true>), grid, block, 0, st, x, res, gamma, beta, rm, rv, momentum, eps, training, y, sm, si, s);
+    else
+        EE_LAUNCH((bn_fwd_cached_kernel<NT, MAXV, false, false>), grid, block, 0, st, x, res, gamma, beta, rm, rv, momentum, eps, training, y, sm, si, s);
+}
+
+template <int NT, int MAXV>
+void launch_bwd_cached(bool relu, hipStream_t st, const float *dy, const float *y, const float *x, const float *gamma, const float *sm,
+                       const float *si, const float *rm, const float *rv, float eps, int training, float *dx, float *dres, float *dgamma,
+                       float *dbeta, BnShape s) {
+    const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
+    if (relu)
+        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, true>), grid, block, 0, st, dy, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+    else
+        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, false>), grid, block, 0, st, dy, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+}
+
+// which cached variant holds a channel of `quads` float4s: 0 = none
+inline int cached_variant(int64_t quads, int64_t numel) {
+    if (numel / 4 > 0xffffffffLL) return 0;  // 32-bit float4 offsets
+    if (quads <= 2 * 256) return 1;          // <256, 2>
+    if (quads <= 7 * 256) return 2;          // <256, 7>
+    if (quads <= 7 * 1024) return 3;         // <1024, 7>
+    return 0;
+}
+
+template <int NT, int VEC>
+void launch_fwd(bool relu, bool has_res, hipStream_t st, const float *x, const float *res, const float *gamma, const float *beta, float *rm,
+                float *rv, float momentum, float eps, int training, float *y, float *sm, float *si, BnShape s) {
+    const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
+    if (relu && has_res)
+        EE_LAUNCH((bn_fwd_kernel<NT, VEC, true, true>), grid, block, 0, st, x, res, gamma, beta, rm, rv, momentum, eps, training, y, sm, si, s);
+    else if (relu)
+        EE_LAUNCH((bn_fwd_kernel<NT, VEC, true, false>), grid, block, 0, st, x, res, gamma, beta, rm, rv, momentum, eps, training, y, sm, si, s);
+    else if (has_res)
+        EE_LAUNCH((bn_fwd_kernel<NT, VEC, false, true>), grid, block, 0, st, x, res, gamma, beta, rm, rv, momentum, eps, training, y, sm, si, s);
+    else
+        EE_LAUNCH((bn_fwd_kernel<NT, VEC, false, false>), grid, block, 0, st, x, res, gamma, beta, rm, rv, momentum, eps, training, y, sm, si, s);
+}
+
+template <int NT, int VEC>
+void launch_bwd(bool relu, hipStream_t st, const float *dy, const float *y, const float *x, const float *gamma, const float *sm, const float *si,
+                const float *rm, const float *rv, float eps, int training, float *dx, float *dres, float *dgamma, float *dbeta, BnShape s) {
+    const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
+    if (relu)
+        EE_LAUNCH((bn_bwd_kernel<NT, VEC, true>), grid, block, 0, st, dy, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+    else
+        EE_LAUNCH((bn_bwd_kernel<NT, VEC, false>), grid, block, 0, st, dy, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+}
+
+inline bool al16(const void *q) { return !q || aligned16(q); }
+
+}  // namespace
+
+EE_API int ee_bn_act_fwd_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
+                             float *running_var, float momentum, float eps, int training, int relu, float *y, float *save_mean,
+                             float *save_invstd, int B, int C, int HW, void *stream) {
+    if (B < 0 || C < 1 || HW < 1) return EE_ERR_SHAPE;
+    if (static_cast<int64_t>(B) * HW > 0x7fffffffLL) return EE_ERR_SHAPE;
+    if (B == 0) return EE_OK;
+    if (!x || !y) return EE_ERR_NULL;
+    if (training && (!save_mean || !save_invstd)) return EE_ERR_NULL;
+    if (!training && (!running_mean || !running_var)) return EE_ERR_NULL;
+    const BnShape s{B, C, HW};
+    const bool vec = (HW % 4 == 0) && al16(x) && al16(y) && al16(residual);
+    const bool big = static_cast<int64_t>(B) * HW >= 16384;
+    hipStream_t st = as_stream(stream);
+    const int cv = vec ? cached_variant(static_cast<int64_t>(B) * (HW / 4), static_cast<int64_t>(B) * C * HW) : 0;
+    if (cv == 1) launch_fwd_cached<256, 2>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
+    else if (cv == 2) launch_fwd_cached<256, 7>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
+    else if (cv == 3) launch_fwd_cached<1024, 7>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
+    else if (vec && big) launch_fwd<1024, 4>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
+    else if (vec) launch_fwd<256, 4>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
+    else if (big) launch_fwd<1024, 1>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
+    else launch_fwd<256, 1>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
+    return launch_status();
+}
+
+EE_API int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
+                             const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training, int relu,
+                             float *dx, float *dresidual, float *dgamma, float *dbeta, int B, int C, int HW, void *stream) {
+    if (B < 0 || C < 1 || HW < 1) return EE_ERR_SHAPE;
+    if (static_cast<int64_t>(B) * HW > 0x7fffffffLL) return EE_ERR_SHAPE;
+    if (B == 0) return EE_OK;
+    if (!dy || !x || (relu && !y)) return EE_ERR_NULL;
+    if (training && (!save_mean || !save_invstd)) return EE_ERR_NULL;
+    if (!training && (!running_mean || !running_var)) return EE_ERR_NULL;
+    const BnShape s{B, C, HW};
+    const bool vec = (HW % 4 == 0) && al16(dy) && al16(y) && al16(x) && al16(dx) && al16(dresidual);
+    const bool big = static_cast<int64_t>(B) * HW >= 16384;
+    hipStream_t st = as_stream(stream);
+    const int cv = vec ? cached_variant(static_cast<int64_t>(B) * (HW / 4), static_cast<int64_t>(B) * C * HW) : 0;
+    if (cv == 1) launch_bwd_cached<256, 2>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (cv == 2) launch_bwd_cached<256, 7>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (cv == 3) launch_bwd_cached<1024, 7>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (vec && big) launch_bwd<1024, 4>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (vec) launch_bwd<256, 4>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (big) launch_bwd<1024, 1>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else launch_bwd<256, 1>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    return launch_status();
+}

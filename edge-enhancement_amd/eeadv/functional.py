@@ -95,6 +95,70 @@ class AddSquareFn(torch.autograd.Function):
         return ops.add_square_bwd(g.contiguous(), x, ctx.eps, stripe, sq_sign, sq_pos, sq_size), None, None, None, None, None
 
 
+class BnActFn(torch.autograd.Function):
+    """[relu]( batch_norm(x) [+ residual] ) in one launch each way (resnet.py:44-59 / :90-110; ee_bn.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+        y, sm, si = ops.bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu)
+        ctx.save_for_backward(x, y if relu else None, gamma, sm, si, None if training else running_mean, None if training else running_var)
+        ctx.cfg = (eps, training, relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, sm, si, rm, rv = ctx.saved_tensors
+        eps, training, relu, has_res = ctx.cfg
+        want = ctx.needs_input_grad
+        dy = dy.contiguous()
+        if not relu and not want[0] and not want[2] and not want[3]:
+            return None, (dy if has_res and want[1] else None), None, None, None, None, None, None, None, None
+        want_dres = has_res and want[1] and relu  # without the ReLU the residual's gradient IS dy: no copy needed
+        dx, dres, dg, db = ops.bn_act_bwd(dy, y, x, gamma, sm, si, rm, rv, eps, training, relu, want[0], want_dres,
+                                          want[2] or want[3])
+        if has_res and want[1] and not relu:
+            dres = dy
+        return dx, dres, (dg if want[2] else None), (db if want[3] else None), None, None, None, None, None, None
+
+
+class MaxPool3s2Fn(torch.autograd.Function):
+    """MaxPool2d(3, stride 2, padding 1) with a one-byte argmax code (resnet.py:117; ee_pool.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, code = ops.maxpool3s2_fwd(x)
+        ctx.save_for_backward(code)
+        ctx.hw = (x.shape[2], x.shape[3])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (code,) = ctx.saved_tensors
+        return ops.maxpool3s2_bwd(dy.contiguous(), code, *ctx.hw)
+
+
+class PoolLinearFn(torch.autograd.Function):
+    """fc(global_avgpool(feat).view(B, -1)) in one launch each way (resnet.py:157-160; ee_head.hip).  The weight and
+    bias gradients (once per training step) are two BLAS calls on the saved pooled features."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias):
+        logits, pooled = ops.pool_linear_fwd(feat, weight, bias)
+        ctx.save_for_backward(pooled, weight)
+        ctx.feat_shape = tuple(feat.shape)
+        ctx.has_bias = bias is not None
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        pooled, weight = ctx.saved_tensors
+        dl = dl.contiguous()
+        dfeat = ops.pool_linear_bwd(dl, weight, ctx.feat_shape) if ctx.needs_input_grad[0] else None
+        dw = dl.t().mm(pooled) if ctx.needs_input_grad[1] else None
+        db = dl.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dfeat, dw, db
+
+
 class _ScalarLossFn(torch.autograd.Function):
     """A scalar loss whose gradients were produced by the same kernel launch as its value."""
 

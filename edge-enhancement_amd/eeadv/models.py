@@ -12,6 +12,7 @@ load those with strict=False).
                                      (ImageNet/models_imagenet/resnet.py:103,114)
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -21,6 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops
+from .functional import BnActFn, MaxPool3s2Fn, PoolLinearFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -36,6 +38,49 @@ class BatchNorm2d(nn.BatchNorm2d):
             return F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
         return F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, not self.track_running_stats,
                             0.0 if self.momentum is None else self.momentum, self.eps)
+
+
+def bn_act(bn, x, residual=None, relu=True):
+    """[relu]( bn(x) [+ residual] ): ONE HIP launch each way (ee_bn.hip) for our BatchNorm2d on dense NCHW fp32 ROCm
+    tensors; the stock three-op sequence for anything else (SyncBatchNorm after convert_sync_batchnorm, channels_last,
+    CPU plumbing in the host tests)."""
+    if ("bn" not in _STOCK and type(bn) is BatchNorm2d and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and bn.affine
+            and bn.track_running_stats and (residual is None or (residual.is_contiguous() and residual.dtype == torch.float32))):
+        return BnActFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                             0.0 if bn.momentum is None else bn.momentum, bn.eps, bn.training, relu)
+    out = bn(x)
+    if residual is not None:
+        out = out + residual
+    return F.relu(out) if relu else out
+
+
+# EEADV_STOCK_GLUE=bn,pool,head (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
+# ee_bn.hip / ee_pool.hip / ee_head.hip: an A/B switch for measurements, never needed for correctness.
+_STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") if t)
+
+
+def _dense_f32(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+
+
+def stem_pool(pool, x):
+    """The stem's MaxPool2d(3, 2, 1) through ee_pool.hip (bit-identical to ATen's, one-byte argmax); anything else stock."""
+    if ("pool" not in _STOCK and type(pool) is nn.MaxPool2d and _dense_f32(x) and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1
+            and pool.dilation == 1 and not pool.ceil_mode and not pool.return_indices):
+        return MaxPool3s2Fn.apply(x)
+    return pool(x)
+
+
+def head(avgpool, fc, x):
+    """x = avgpool(x); x = x.view(B, -1); x = fc(x) (resnet.py:157-160): ONE launch each way (ee_head.hip) when the pool
+    is global (AdaptiveAvgPool2d(1), or AvgPool2d(7) on a 7x7 map) and the tensors are dense fp32 ROCm."""
+    is_global = (isinstance(avgpool, nn.AdaptiveAvgPool2d) and avgpool.output_size in (1, (1, 1))) or (
+        isinstance(avgpool, nn.AvgPool2d) and avgpool.kernel_size in (x.shape[2], (x.shape[2], x.shape[3])) and x.shape[2] == x.shape[3]
+        and avgpool.padding == 0)
+    if "head" not in _STOCK and is_global and type(fc) is nn.Linear and _dense_f32(x) and x.shape[1] <= 4096 and fc.out_features <= 8192 and fc.weight.is_cuda:
+        return PoolLinearFn.apply(x, fc.weight, fc.bias)
+    x = avgpool(x)
+    return fc(x.view(x.size(0), -1))
 
 
 def _bump_bn_counters(model):
@@ -178,10 +223,8 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        out += x if self.downsample is None else self.downsample(x)
-        return self.relu(out)
+        out = bn_act(self.bn1, self.conv1(x))
+        return bn_act(self.bn2, self.conv2(out), x if self.downsample is None else self.downsample(x))
 
 
 class Bottleneck(nn.Module):
@@ -200,11 +243,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        out += x if self.downsample is None else self.downsample(x)
-        return self.relu(out)
+        out = bn_act(self.bn1, self.conv1(x))
+        out = bn_act(self.bn2, self.conv2(out))
+        return bn_act(self.bn3, self.conv3(out), x if self.downsample is None else self.downsample(x))
 
 
 class ResNet(nn.Module):
@@ -250,11 +291,10 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def body(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = stem_pool(self.maxpool, bn_act(self.bn1, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        x = self.avgpool(x)
         _bump_bn_counters(self)
-        return self.fc(x.view(x.size(0), -1))
+        return head(self.avgpool, self.fc, x)
 
     def forward(self, x):
         return self.body(x)

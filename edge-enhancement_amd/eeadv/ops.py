@@ -376,6 +376,97 @@ def hfs(x, tables, NU, NV, sq_mode=0, sq_x=None, eps=0.0, stripe=None, sq_sign=N
     return out
 
 
+# ---- BatchNorm2d (+ residual) (+ ReLU) ----------------------------------------------------------------------------------
+def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+    """y = [relu]( bn(x) [+ residual] ), one launch; returns (y, save_mean, save_invstd) (the saves are None in eval mode).
+    Updates running_mean / running_var in place in training mode, as nn.BatchNorm2d does (resnet.py:44-59)."""
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel() if B else 1
+    px = _chk(x, torch.float32, "x")
+    pr = None if residual is None else _chk(residual, torch.float32, "residual", x.shape)
+    pg = None if gamma is None else _chk(gamma, torch.float32, "gamma", (C,))
+    pb = None if beta is None else _chk(beta, torch.float32, "beta", (C,))
+    prm = None if running_mean is None else _chk(running_mean, torch.float32, "running_mean", (C,))
+    prv = None if running_var is None else _chk(running_var, torch.float32, "running_var", (C,))
+    y = torch.empty_like(x)
+    sm = si = psm = psi = None
+    if training:
+        sm = torch.empty(C, dtype=torch.float32, device=x.device)
+        si = torch.empty(C, dtype=torch.float32, device=x.device)
+        psm, psi = sm.data_ptr(), si.data_ptr()
+    N.check(N.lib.ee_bn_act_fwd_f32(px, pr, pg, pb, prm, prv, float(momentum), float(eps), 1 if training else 0, 1 if relu else 0,
+                                    _chk(y, torch.float32, "y"), psm, psi, B, C, HW, _stream()), "ee_bn_act_fwd_f32")
+    return y, sm, si
+
+
+def bn_act_bwd(dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, relu, want_dx=True,
+               want_dres=False, want_dparams=True):
+    """Backward of bn_act_fwd: returns (dx, dresidual, dgamma, dbeta), None where not wanted."""
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel() if B else 1
+    pdy = _chk(dy, torch.float32, "dy", x.shape)
+    py = None if y is None else _chk(y, torch.float32, "y", x.shape)
+    px = _chk(x, torch.float32, "x")
+    pg = None if gamma is None else _chk(gamma, torch.float32, "gamma", (C,))
+    dx = torch.empty_like(x) if want_dx else None
+    dres = torch.empty_like(x) if want_dres else None
+    dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
+    db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
+    ptr = lambda t: None if t is None else t.data_ptr()
+    N.check(N.lib.ee_bn_act_bwd_f32(pdy, py, px, pg, ptr(save_mean), ptr(save_invstd), ptr(running_mean), ptr(running_var), float(eps),
+                                    1 if training else 0, 1 if relu else 0, ptr(dx), ptr(dres), ptr(dg), ptr(db), B, C, HW, _stream()),
+            "ee_bn_act_bwd_f32")
+    return dx, dres, dg, db
+
+
+# ---- stem max-pool and classifier head -----------------------------------------------------------------------------------
+def maxpool3s2_fwd(x):
+    """MaxPool2d(3, 2, 1) of x [B,C,H,W] -> (y, code uint8) (resnet.py:117)."""
+    B, C, H, W = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+    code = torch.empty((B, C, OH, OW), dtype=torch.uint8, device=x.device)
+    N.check(N.lib.ee_maxpool3s2_fwd_f32(_chk(x, torch.float32, "x"), _chk(y, torch.float32, "y"), _chk(code, torch.uint8, "code"), B * C, H, W,
+                                        _stream()), "ee_maxpool3s2_fwd_f32")
+    return y, code
+
+
+def maxpool3s2_bwd(dy, code, H, W):
+    B, C, OH, OW = dy.shape
+    if (OH, OW) != ((H - 1) // 2 + 1, (W - 1) // 2 + 1):
+        raise ValueError("maxpool3s2_bwd: dy %s does not belong to a %dx%d input" % (tuple(dy.shape), H, W))
+    dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+    N.check(N.lib.ee_maxpool3s2_bwd_f32(_chk(dy, torch.float32, "dy"), _chk(code, torch.uint8, "code", dy.shape), _chk(dx, torch.float32, "dx"),
+                                        B * C, H, W, _stream()), "ee_maxpool3s2_bwd_f32")
+    return dx
+
+
+def pool_linear_fwd(feat, weight, bias):
+    """logits = fc(global_avgpool(feat)) (resnet.py:157-160) -> (logits [B,K], pooled [B,C])."""
+    B, C = feat.shape[0], feat.shape[1]
+    HW = feat[0, 0].numel() if B else 1
+    K = weight.shape[0]
+    pooled = torch.empty((B, C), dtype=torch.float32, device=feat.device)
+    logits = torch.empty((B, K), dtype=torch.float32, device=feat.device)
+    pb = None if bias is None else _chk(bias, torch.float32, "bias", (K,))
+    N.check(N.lib.ee_pool_linear_fwd_f32(_chk(feat, torch.float32, "feat"), _chk(weight, torch.float32, "weight", (K, C)), pb,
+                                         _chk(pooled, torch.float32, "pooled"), _chk(logits, torch.float32, "logits"), B, C, HW, K, _stream()),
+            "ee_pool_linear_fwd_f32")
+    return logits, pooled
+
+
+def pool_linear_bwd(dlogits, weight, feat_shape):
+    B, C = feat_shape[0], feat_shape[1]
+    HW = 1
+    for d in feat_shape[2:]:
+        HW *= d
+    K = weight.shape[0]
+    dfeat = torch.empty(feat_shape, dtype=torch.float32, device=dlogits.device)
+    N.check(N.lib.ee_pool_linear_bwd_f32(_chk(dlogits, torch.float32, "dlogits", (B, K)), _chk(weight, torch.float32, "weight", (K, C)),
+                                         _chk(dfeat, torch.float32, "dfeat"), B, C, HW, K, _stream()), "ee_pool_linear_bwd_f32")
+    return dfeat
+
+
 # ---- timing hooks ------------------------------------------------------------------------------------------------------
 def prof_enable(on=True):
     N.check(N.lib.ee_prof_enable(1 if on else 0), "ee_prof_enable")

@@ -217,6 +217,42 @@ int ee_hfs_f32(const float *in, float *out, int B, int C, int H, int W, const fl
                const int32_t *sq_size, int nq, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d fused with the residual add and the ReLU that follow it in the reference's ResNet blocks
+ * (Tiny_ImageNet/models_tinyimagenet/resnet.py:44-59, :90-110: out = relu(bn(conv(x)) [+ identity])).
+ *   x, residual (nullable), y: [B,C,HW] fp32 (NCHW, HW = H*W); gamma / beta (nullable = 1 / 0), running_*: [C].
+ *   training != 0: batch statistics (two-pass, biased variance for the output, unbiased for running_var), saved to
+ *     save_mean / save_invstd [C]; running_* (nullable) updated with `momentum` as nn.BatchNorm2d does.
+ *   training == 0: running statistics.      relu != 0: y = max(., 0) (NaN propagates).
+ * backward: dz = relu ? dy * (y > 0) : dy ; dresidual (nullable) = dz ; dgamma / dbeta (nullable) = sum dz*xhat / sum dz ;
+ *   dx (nullable) = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) in training mode, gamma*invstd*dz otherwise.
+ * One workgroup per channel, fixed-order reductions: results are bit-reproducible run to run.
+ * ------------------------------------------------------------------------------------------- */
+int ee_bn_act_fwd_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
+                      float *running_var, float momentum, float eps, int training, int relu, float *y, float *save_mean,
+                      float *save_invstd, int B, int C, int HW, void *stream);
+int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
+                      const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training,
+                      int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, int B, int C, int HW, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The stem's MaxPool2d(3, stride 2, padding 1) (Tiny_ImageNet/models_tinyimagenet/resnet.py:117), bit-identical to ATen's
+ * (first maximum wins, NaN always wins).  x [planes,H,W] -> y, code [planes,OH,OW], OH = (H-1)/2+1; code = 3*kh+kw of the
+ * argmax inside its window (one byte).  Backward gathers: dx [planes,H,W] from dy, code.
+ * ------------------------------------------------------------------------------------------- */
+int ee_maxpool3s2_fwd_f32(const float *x, float *y, uint8_t *code, int planes, int H, int W, void *stream);
+int ee_maxpool3s2_bwd_f32(const float *dy, const uint8_t *code, float *dx, int planes, int H, int W, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Classifier head: logits = fc(avgpool(feat).view(B,-1)) for a global average pool
+ * (Tiny_ImageNet/models_tinyimagenet/resnet.py:157-160).  feat [B,C,HW], weight [K,C], bias [K] (nullable);
+ * pooled [B,C] (kept for the weight gradient), logits [B,K].  C <= 4096, K <= 8192 (EE_ERR_UNSUPPORTED beyond).
+ * Backward w.r.t. feat: dfeat[b,c,:] = (dlogits[b,:] . weight[:,c]) / HW.
+ * ------------------------------------------------------------------------------------------- */
+int ee_pool_linear_fwd_f32(const float *feat, const float *weight, const float *bias, float *pooled, float *logits, int B,
+                           int C, int HW, int K, void *stream);
+int ee_pool_linear_bwd_f32(const float *dlogits, const float *weight, float *dfeat, int B, int C, int HW, int K, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optional built-in timing of the last launch of each kernel family (HIP events on `stream`).
  * Off by default; bench.py switches it on outside graph capture to measure kernel durations live.
  * ------------------------------------------------------------------------------------------- */

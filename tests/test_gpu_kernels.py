@@ -365,3 +365,102 @@ def test_canny_full_vs_reference_golden_UNPINNED(ops, golden):
         assert np.array_equal(np.isnan(g), np.isnan(ref))
         fin = ~np.isnan(ref)
         np.testing.assert_allclose(g[fin], ref[fin], atol=1e-6)
+
+
+# ---- fused BatchNorm2d (+ residual) (+ ReLU): CNN-body glue, checked against torch's own fp32 ops (tolerance 1e-5) ----
+@pytest.mark.parametrize("shape", [(100, 64, 32, 32), (100, 128, 8, 8), (7, 5, 3, 3), (2, 512, 2, 2), (3, 4, 1, 1), (100, 512, 1, 1)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_matches_torch(ops, shape, relu, res, training):
+    import torch.nn.functional as F
+    from eeadv.functional import BnActFn
+    g = torch.Generator(device="cpu").manual_seed(sum(shape) + 2 * relu + res)
+    B, C = shape[:2]
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).to(DEV).requires_grad_(True)
+    r = torch.randn(shape, generator=g).to(DEV).requires_grad_(True) if res else None
+    w = (torch.rand(C, generator=g) + 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+    rm0, rv0 = torch.randn(C, generator=g).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    dy = torch.randn(shape, generator=g).to(DEV)
+
+    rm_a, rv_a = rm0.clone(), rv0.clone()
+    ref = F.batch_norm(x, rm_a, rv_a, w, b, training, 0.1, 1e-5)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    ins = [x, w, b] + ([r] if res else [])
+    g_ref = torch.autograd.grad(ref, ins, dy)
+
+    rm_b, rv_b = rm0.clone(), rv0.clone()
+    got = BnActFn.apply(x, r, w, b, rm_b, rv_b, 0.1, 1e-5, training, relu)
+    g_got = torch.autograd.grad(got, ins, dy)
+
+    n = B * shape[2] * shape[3]
+    if training and n == 1:
+        return  # torch refuses one value per channel in training mode; nothing to compare
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(rm_b, rm_a, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv_b, rv_a, rtol=1e-5, atol=1e-6)
+    scale = max(1.0, float(n) ** 0.5)
+    for a, e, nm in zip(g_got, g_ref, ["dx", "dgamma", "dbeta", "dres"]):
+        # ReLU ties (y == 0 exactly) cannot occur with these random inputs; sums over n elements get an n^(1/2)-scaled tolerance
+        tol = 2e-5 * (scale if nm in ("dgamma", "dbeta") else 1.0)
+        torch.testing.assert_close(a, e, rtol=2e-5, atol=tol, msg=lambda m: nm + ": " + m)
+
+
+def test_bn_act_only_input_grad_and_reproducible(ops):
+    """The attack loop differentiates w.r.t. the input only (attacks.py:24): no parameter gradients are produced, and two
+    runs give the same bits (fixed-order reductions)."""
+    from eeadv.functional import BnActFn
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(16, 8, 4, 4, generator=g).to(DEV).requires_grad_(True)
+    w, b = torch.ones(8, device=DEV, requires_grad=True), torch.zeros(8, device=DEV, requires_grad=True)
+    outs = []
+    for _ in range(2):
+        rm, rv = torch.zeros(8, device=DEV), torch.ones(8, device=DEV)
+        y = BnActFn.apply(x, None, w, b, rm, rv, 0.1, 1e-5, True, True)
+        (gx,) = torch.autograd.grad(y.square().sum(), x)
+        outs.append((y.detach().clone(), gx.clone(), rm, rv))
+    for a, e in zip(outs[0], outs[1]):
+        assert torch.equal(a, e)
+    assert w.grad is None and b.grad is None
+
+
+@pytest.mark.parametrize("shape", [(100, 64, 32, 32), (2, 3, 7, 9), (3, 2, 1, 1), (2, 2, 2, 5), (1, 1, 112, 112)])
+def test_maxpool3s2_bit_identical_to_aten(ops, shape):
+    """Stem MaxPool2d(3,2,1) (resnet.py:117): values, and the gradient routing (first maximum wins), equal ATen's bit for bit,
+    ties and NaNs included."""
+    import torch.nn.functional as F
+    from eeadv.functional import MaxPool3s2Fn
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    x = torch.where(torch.rand(shape, generator=g) < 0.3, torch.zeros(()), x)  # many exact ties (post-ReLU zeros)
+    if x.numel() > 50:
+        x.view(-1)[7] = float("nan")
+    x = x.to(DEV).requires_grad_(True)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    got = MaxPool3s2Fn.apply(x)
+    dy = torch.randn(ref.shape, generator=g).to(DEV)
+    (g_ref,) = torch.autograd.grad(ref, x, dy)
+    (g_got,) = torch.autograd.grad(got, x, dy)
+    assert_bitexact(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), "maxpool fwd")
+    assert_bitexact(g_got.cpu().numpy(), g_ref.cpu().numpy(), "maxpool bwd")
+
+
+@pytest.mark.parametrize("B,C,HW,K", [(100, 512, (2, 2), 200), (3, 2048, (7, 7), 1000), (5, 7, (1, 1), 3), (2, 64, (3, 5), 10)])
+def test_pool_linear_head_matches_torch(ops, B, C, HW, K):
+    import torch.nn.functional as F
+    from eeadv.functional import PoolLinearFn
+    g = torch.Generator(device="cpu").manual_seed(B + C + K)
+    feat = torch.randn(B, C, *HW, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(K, C, generator=g) / C ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(K, generator=g).to(DEV).requires_grad_(True)
+    dl = torch.randn(B, K, generator=g).to(DEV)
+    ref = F.linear(F.adaptive_avg_pool2d(feat, 1).view(B, -1), w, b)
+    got = PoolLinearFn.apply(feat, w, b)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    for a, e in zip(torch.autograd.grad(got, [feat, w, b], dl), torch.autograd.grad(ref, [feat, w, b], dl, retain_graph=True)):
+        torch.testing.assert_close(a, e, rtol=1e-5, atol=1e-5)
+    (gx,) = torch.autograd.grad(PoolLinearFn.apply(feat, w, None), feat, dl)  # no bias; input gradient only
+    torch.testing.assert_close(gx, torch.autograd.grad(ref, feat, dl)[0], rtol=1e-5, atol=1e-5)
