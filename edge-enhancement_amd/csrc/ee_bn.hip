@@ -358,6 +358,197 @@ inline int cached_variant(int64_t quads, int64_t numel) {
     return 0;
 }
 
+
+// ---- split variants: a channel too large for one workgroup's registers (the ResNet stem: 102 400 values per channel at the
+// reference batch, only 64 channels) is cut into S slices, one workgroup each, in two launches: partial statistics into a
+// small workspace, then every workgroup recombines the S partials in the same fixed order (Chan's parallel variance
+// update, so the two-pass accuracy is kept) and handles its slice.  One workgroup per channel left 3/4 of the chip idle
+// and ran at the per-CU L2 bandwidth (35 us forward / 50 us backward for the stem, rocprofv3). --------------------------
+constexpr int SPLIT_NT = 256;
+constexpr int SPLIT_MAX = 64;
+
+inline int split_slices(int64_t quads) {
+    const int64_t s = (quads + 2047) / 2048;
+    return static_cast<int>(s < 1 ? 1 : (s > SPLIT_MAX ? SPLIT_MAX : s));
+}
+
+struct Slice {
+    int begin, end;  // float4 index range inside the channel
+};
+__device__ __forceinline__ Slice my_slice(int total, int S, int s) {
+    const int chunk = (total + S - 1) / S;
+    const int b = s * chunk, e = b + chunk;
+    return {b < total ? b : total, e < total ? e : total};
+}
+
+template <class F>
+__device__ __forceinline__ void for_slice(const BnShape s, int c, Slice sl, F f) {
+    const int per = s.HW / 4;
+    for (int e = sl.begin + threadIdx.x; e < sl.end; e += SPLIT_NT) {
+        const int b = e / per, q = e - b * per;
+        f((static_cast<size_t>(b) * s.C + c) * per + q);
+    }
+}
+
+// ws[(c*S + s)*2 + {0,1}] = (sum, M2 about the slice's own mean)
+__global__ __launch_bounds__(SPLIT_NT) void bn_split_stats_kernel(const float *__restrict__ x, float *__restrict__ ws, BnShape s, int S) {
+    __shared__ float scratch[SPLIT_NT / 64];
+    const int c = blockIdx.x, sl_i = blockIdx.y;
+    const Slice sl = my_slice(s.B * (s.HW / 4), S, sl_i);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    float acc = 0.0f;
+    for_slice(s, c, sl, [&](size_t o) {
+        const float4 v = x4[o];
+        acc += (v.x + v.y) + (v.z + v.w);
+    });
+    const float sum = block_sum<SPLIT_NT>(acc, scratch);
+    const float cnt = 4.0f * static_cast<float>(sl.end - sl.begin);
+    const float mean = cnt > 0.0f ? sum / cnt : 0.0f;
+    float m2 = 0.0f;
+    for_slice(s, c, sl, [&](size_t o) {
+        const float4 v = x4[o];
+        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+        m2 += (a * a + b * b) + (cc * cc + d * d);
+    });
+    m2 = block_sum<SPLIT_NT>(m2, scratch);
+    if (threadIdx.x == 0) {
+        ws[(static_cast<size_t>(c) * S + sl_i) * 2 + 0] = sum;
+        ws[(static_cast<size_t>(c) * S + sl_i) * 2 + 1] = m2;
+    }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(SPLIT_NT) void bn_split_apply_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                  float *running_mean, float *running_var, float momentum, float eps,
+                                                                  int training, float *__restrict__ y, float *__restrict__ save_mean,
+                                                                  float *__restrict__ save_invstd, const float *__restrict__ ws, BnShape s, int S) {
+    const int c = blockIdx.x, sl_i = blockIdx.y;
+    const int total = s.B * (s.HW / 4);
+    const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
+    float mean, invstd;
+    if (training) {  // every lane recombines the S partials itself, in slice order: no LDS, identical in all workgroups
+        float sum = 0.0f;
+        for (int i = 0; i < S; ++i) sum += ws[(static_cast<size_t>(c) * S + i) * 2];
+        mean = sum / n;
+        float m2 = 0.0f;
+        for (int i = 0; i < S; ++i) {
+            const Slice sl = my_slice(total, S, i);
+            const float cnt = 4.0f * static_cast<float>(sl.end - sl.begin);
+            if (cnt > 0.0f) {
+                const float d = ws[(static_cast<size_t>(c) * S + i) * 2] / cnt - mean;
+                m2 += ws[(static_cast<size_t>(c) * S + i) * 2 + 1] + cnt * (d * d);
+            }
+        }
+        const float var = m2 / n;
+        invstd = 1.0f / sqrtf(var + eps);
+        if (sl_i == 0 && threadIdx.x == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = invstd;
+            if (running_mean) {
+                const float unbiased = (n > 1.0f) ? var * (n / (n - 1.0f)) : var;
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *r4 = reinterpret_cast<const float4 *>(res);
+    float4 *y4 = reinterpret_cast<float4 *>(y);
+    for_slice(s, c, my_slice(total, S, sl_i), [&](size_t o) {
+        const float4 v = x4[o];
+        float4 r = make_float4((v.x - mean) * a + b0, (v.y - mean) * a + b0, (v.z - mean) * a + b0, (v.w - mean) * a + b0);
+        if (RES) {
+            const float4 q = r4[o];
+            r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+        }
+        if (RELU) {
+            r.x = relu_nan(r.x); r.y = relu_nan(r.y); r.z = relu_nan(r.z); r.w = relu_nan(r.w);
+        }
+        y4[o] = r;
+    });
+}
+
+__device__ __forceinline__ float4 masked_dz(const float4 *dy4, const float4 *y4, size_t o, bool relu) {
+    float4 g = dy4[o];
+    if (relu) {
+        const float4 yy = y4[o];
+        g.x = yy.x > 0.0f ? g.x : 0.0f;
+        g.y = yy.y > 0.0f ? g.y : 0.0f;
+        g.z = yy.z > 0.0f ? g.z : 0.0f;
+        g.w = yy.w > 0.0f ? g.w : 0.0f;
+    }
+    return g;
+}
+
+// ws[(c*S + s)*2 + {0,1}] = (sum dz, sum dz*xhat) of the slice
+template <bool RELU>
+__global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                                        const float *__restrict__ x, const float *__restrict__ save_mean,
+                                                                        const float *__restrict__ save_invstd,
+                                                                        const float *__restrict__ running_mean,
+                                                                        const float *__restrict__ running_var, float eps, int training,
+                                                                        float *__restrict__ ws, BnShape s, int S) {
+    __shared__ float scratch[SPLIT_NT / 64];
+    const int c = blockIdx.x, sl_i = blockIdx.y;
+    const float mean = training ? save_mean[c] : running_mean[c];
+    const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
+    const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
+    float sdz = 0.0f, sdzx = 0.0f;
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) {
+        const float4 g = masked_dz(dy4, y4, o, RELU);
+        const float4 v = x4[o];
+        sdz += (g.x + g.y) + (g.z + g.w);
+        sdzx += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) + (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
+    });
+    sdz = block_sum<SPLIT_NT>(sdz, scratch);
+    sdzx = block_sum<SPLIT_NT>(sdzx, scratch);
+    if (threadIdx.x == 0) {
+        ws[(static_cast<size_t>(c) * S + sl_i) * 2 + 0] = sdz;
+        ws[(static_cast<size_t>(c) * S + sl_i) * 2 + 1] = sdzx;
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                                      const float *__restrict__ x, const float *__restrict__ gamma,
+                                                                      const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+                                                                      const float *__restrict__ running_mean,
+                                                                      const float *__restrict__ running_var, float eps, int training,
+                                                                      float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ dgamma,
+                                                                      float *__restrict__ dbeta, const float *__restrict__ ws, BnShape s, int S) {
+    const int c = blockIdx.x, sl_i = blockIdx.y;
+    const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
+    const float mean = training ? save_mean[c] : running_mean[c];
+    const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
+    float sdz = 0.0f, sdzx = 0.0f;
+    for (int i = 0; i < S; ++i) {
+        sdz += ws[(static_cast<size_t>(c) * S + i) * 2];
+        sdzx += ws[(static_cast<size_t>(c) * S + i) * 2 + 1];
+    }
+    if (sl_i == 0 && threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = sdzx;
+        if (dbeta) dbeta[c] = sdz;
+    }
+    if (!dx && !dres) return;
+    const float w = (gamma ? gamma[c] : 1.0f) * invstd;
+    const float m1 = training ? sdz / n : 0.0f, m2 = training ? sdzx / n : 0.0f;
+    const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *dx4 = reinterpret_cast<float4 *>(dx), *dr4 = reinterpret_cast<float4 *>(dres);
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) {
+        const float4 g = masked_dz(dy4, y4, o, RELU);
+        if (dres) dr4[o] = g;
+        if (dx) {
+            const float4 v = x4[o];
+            dx4[o] = make_float4(w * ((g.x - m1) - ((v.x - mean) * invstd) * m2), w * ((g.y - m1) - ((v.y - mean) * invstd) * m2),
+                                 w * ((g.z - m1) - ((v.z - mean) * invstd) * m2), w * ((g.w - m1) - ((v.w - mean) * invstd) * m2));
+        }
+    });
+}
+
 template <int NT, int VEC>
 void launch_fwd(bool relu, bool has_res, hipStream_t st, const float *x, const float *res, const float *gamma, const float *beta, float *rm,
                 float *rv, float momentum, float eps, int training, float *y, float *sm, float *si, BnShape s) {
@@ -386,9 +577,17 @@ inline bool al16(const void *q) { return !q || aligned16(q); }
 
 }  // namespace
 
+// floats of workspace the split path wants for this shape; 0 = the shape runs in one workgroup per channel
+EE_API int ee_bn_workspace_floats(int B, int C, int HW) {
+    if (B < 1 || C < 1 || HW < 1 || HW % 4) return 0;
+    const int64_t quads = static_cast<int64_t>(B) * (HW / 4);
+    if (cached_variant(quads, static_cast<int64_t>(B) * C * HW) || static_cast<int64_t>(B) * C * HW / 4 > 0x7fffffffLL) return 0;
+    return C * split_slices(quads) * 2;
+}
+
 EE_API int ee_bn_act_fwd_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
                              float *running_var, float momentum, float eps, int training, int relu, float *y, float *save_mean,
-                             float *save_invstd, int B, int C, int HW, void *stream) {
+                             float *save_invstd, float *workspace, int B, int C, int HW, void *stream) {
     if (B < 0 || C < 1 || HW < 1) return EE_ERR_SHAPE;
     if (static_cast<int64_t>(B) * HW > 0x7fffffffLL) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
@@ -403,7 +602,19 @@ EE_API int ee_bn_act_fwd_f32(const float *x, const float *residual, const float 
     if (cv == 1) launch_fwd_cached<256, 2>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
     else if (cv == 2) launch_fwd_cached<256, 7>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
     else if (cv == 3) launch_fwd_cached<1024, 7>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
-    else if (vec && big) launch_fwd<1024, 4>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
+    else if (vec && workspace && static_cast<int64_t>(B) * C * HW / 4 <= 0x7fffffffLL) {
+        const int S = split_slices(static_cast<int64_t>(B) * (HW / 4));
+        const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(S)), block(SPLIT_NT);
+        if (training) EE_LAUNCH(bn_split_stats_kernel, grid, block, 0, st, x, workspace, s, S);
+        if (relu && residual)
+            EE_LAUNCH((bn_split_apply_kernel<true, true>), grid, block, 0, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, workspace, s, S);
+        else if (relu)
+            EE_LAUNCH((bn_split_apply_kernel<true, false>), grid, block, 0, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, workspace, s, S);
+        else if (residual)
+            EE_LAUNCH((bn_split_apply_kernel<false, true>), grid, block, 0, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, workspace, s, S);
+        else
+            EE_LAUNCH((bn_split_apply_kernel<false, false>), grid, block, 0, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, workspace, s, S);
+    } else if (vec && big) launch_fwd<1024, 4>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
     else if (vec) launch_fwd<256, 4>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
     else if (big) launch_fwd<1024, 1>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
     else launch_fwd<256, 1>(relu != 0, residual != nullptr, st, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, y, save_mean, save_invstd, s);
@@ -412,7 +623,7 @@ EE_API int ee_bn_act_fwd_f32(const float *x, const float *residual, const float 
 
 EE_API int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
                              const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training, int relu,
-                             float *dx, float *dresidual, float *dgamma, float *dbeta, int B, int C, int HW, void *stream) {
+                             float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW, void *stream) {
     if (B < 0 || C < 1 || HW < 1) return EE_ERR_SHAPE;
     if (static_cast<int64_t>(B) * HW > 0x7fffffffLL) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
@@ -427,7 +638,17 @@ EE_API int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, co
     if (cv == 1) launch_bwd_cached<256, 2>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     else if (cv == 2) launch_bwd_cached<256, 7>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     else if (cv == 3) launch_bwd_cached<1024, 7>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else if (vec && big) launch_bwd<1024, 4>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (vec && workspace && static_cast<int64_t>(B) * C * HW / 4 <= 0x7fffffffLL) {
+        const int S = split_slices(static_cast<int64_t>(B) * (HW / 4));
+        const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(S)), block(SPLIT_NT);
+        if (relu) {
+            EE_LAUNCH((bn_split_bwd_partial_kernel<true>), grid, block, 0, st, dy, y, x, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_apply_kernel<true>), grid, block, 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
+        } else {
+            EE_LAUNCH((bn_split_bwd_partial_kernel<false>), grid, block, 0, st, dy, y, x, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_apply_kernel<false>), grid, block, 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
+        }
+    } else if (vec && big) launch_bwd<1024, 4>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     else if (vec) launch_bwd<256, 4>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     else if (big) launch_bwd<1024, 1>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     else launch_bwd<256, 1>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);

@@ -52,8 +52,9 @@ SIGNATURES = {
     "ee_add_square_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "ee_hfs_table_floats": [c_i, c_i, c_i, c_i],
     "ee_hfs_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_f, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],
-    "ee_bn_act_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
-    "ee_bn_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "ee_bn_workspace_floats": [c_i, c_i, c_i],
+    "ee_bn_act_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "ee_bn_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_maxpool3s2_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_maxpool3s2_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_pool_linear_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],

@@ -377,6 +377,11 @@ def hfs(x, tables, NU, NV, sq_mode=0, sq_x=None, eps=0.0, stripe=None, sq_sign=N
 
 
 # ---- BatchNorm2d (+ residual) (+ ReLU) ----------------------------------------------------------------------------------
+def _bn_workspace(x, B, C, HW):
+    n = N.lib.ee_bn_workspace_floats(B, C, HW)
+    return torch.empty(n, dtype=torch.float32, device=x.device).data_ptr() if n else None
+
+
 def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
     """y = [relu]( bn(x) [+ residual] ), one launch; returns (y, save_mean, save_invstd) (the saves are None in eval mode).
     Updates running_mean / running_var in place in training mode, as nn.BatchNorm2d does (resnet.py:44-59)."""
@@ -395,7 +400,8 @@ def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, ep
         si = torch.empty(C, dtype=torch.float32, device=x.device)
         psm, psi = sm.data_ptr(), si.data_ptr()
     N.check(N.lib.ee_bn_act_fwd_f32(px, pr, pg, pb, prm, prv, float(momentum), float(eps), 1 if training else 0, 1 if relu else 0,
-                                    _chk(y, torch.float32, "y"), psm, psi, B, C, HW, _stream()), "ee_bn_act_fwd_f32")
+                                    _chk(y, torch.float32, "y"), psm, psi, _bn_workspace(x, B, C, HW), B, C, HW, _stream()),
+            "ee_bn_act_fwd_f32")
     return y, sm, si
 
 
@@ -414,7 +420,8 @@ def bn_act_bwd(dy, y, x, gamma, save_mean, save_invstd, running_mean, running_va
     db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
     ptr = lambda t: None if t is None else t.data_ptr()
     N.check(N.lib.ee_bn_act_bwd_f32(pdy, py, px, pg, ptr(save_mean), ptr(save_invstd), ptr(running_mean), ptr(running_var), float(eps),
-                                    1 if training else 0, 1 if relu else 0, ptr(dx), ptr(dres), ptr(dg), ptr(db), B, C, HW, _stream()),
+                                    1 if training else 0, 1 if relu else 0, ptr(dx), ptr(dres), ptr(dg), ptr(db),
+                                    _bn_workspace(x, B, C, HW), B, C, HW, _stream()),
             "ee_bn_act_bwd_f32")
     return dx, dres, dg, db
 

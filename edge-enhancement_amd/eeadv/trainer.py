@@ -5,6 +5,8 @@ train_batch follows Tiny_ImageNet/experiments_tinyimagenet.py:245-306 (MNIST twi
 zero_grad / backward / optimizer.step.  Everything stays on the device; nothing calls .item() here (the
 reference syncs every batch at :299 - the drivers sync only when they print).
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -63,9 +65,80 @@ def attack_for_training(model, criterion, args, input, target, device, avmixup=N
     return A.PGD(model, args, input, target, args.num_steps_1, args.step_size_1), None, None  # AT and every EE_* method
 
 
+# ---- the parameter update as ONE HIP graph ---------------------------------------------------------------------------------
+# forward on data_adv, cross-entropy, zero_grad, backward and the SGD update are ~600 launches issued eagerly from Python;
+# behind a captured attack loop that is where the GPU waits for the host.  With EEADV_GRAPH=1 the plain-criterion update
+# (ST / AT / every EE_* and tar* method: experiments_tinyimagenet.py:283-306) of a single-process model with a torch SGD
+# optimiser is captured once per (model, optimiser hyper-parameters, batch shape) and replayed; the first two updates of a
+# configuration run eagerly (they create the momentum buffers and let MIOpen pick its algorithms).  A changed learning rate
+# (adjust_learning_rate, once per epoch) is a new configuration: the old graph is dropped.
+_UPDATES = {}
+EAGER_UPDATES_BEFORE_CAPTURE = 2
+
+
+def clear_update_graphs():
+    _UPDATES.clear()
+
+
+def _sgd_signature(optimizer):
+    return tuple((float(g['lr']), float(g['momentum']), float(g['dampening']), float(g['weight_decay']), bool(g['nesterov']),
+                  bool(g.get('maximize', False))) for g in optimizer.param_groups)
+
+
+class _GraphedUpdate:
+    def __init__(self, model, criterion, optimizer, data_adv, target):
+        self.model, self.criterion, self.optimizer = weakref.ref(model), criterion, weakref.ref(optimizer)
+        self.x = torch.empty_like(data_adv)
+        self.y = torch.empty_like(target)
+        self.graph = None
+        self.eager_left = EAGER_UPDATES_BEFORE_CAPTURE
+
+    def _body(self):
+        model, optimizer = self.model(), self.optimizer()
+        output = model(self.x)
+        loss = self.criterion(output, self.y)
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        optimizer.step()
+        return loss.detach(), output.detach()
+
+    def __call__(self, data_adv, target):
+        self.x.copy_(data_adv)
+        self.y.copy_(target)
+        if self.eager_left > 0:
+            self.eager_left -= 1
+            return self._body()
+        if self.graph is None:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss, self.output = self._body()
+        self.graph.replay()
+        return self.loss.clone(), self.output.clone()
+
+
+def _graphable_update(model, criterion, optimizer, args, data_adv):
+    from eeadv import engine
+    return (engine.graphs_enabled() and data_adv.is_cuda and isinstance(criterion, Criterion) and type(optimizer) is torch.optim.SGD
+            and not isinstance(model, (nn.parallel.DistributedDataParallel, nn.DataParallel)) and model.training
+            and args.method_name not in ('ALP', 'tarALP', 'TRADES', 'AVmixup', 'tarAVmixup'))
+
+
 def train_batch(model, criterion, optimizer, args, input, target, device, avmixup=None):
     """One optimisation step; returns (loss, output) detached, both still on the device."""
     data_adv, preds, new_target = attack_for_training(model, criterion, args, input, target, device, avmixup)
+    if _graphable_update(model, criterion, optimizer, args, data_adv):
+        owner = (id(model), id(optimizer))
+        sig = _sgd_signature(optimizer)
+        slot = _UPDATES.get(owner)
+        if slot is None or slot[0] != sig or slot[1]() is not model or slot[2]() is not optimizer:
+            slot = (sig, weakref.ref(model), weakref.ref(optimizer), {})  # hyper-parameters changed: drop the old graphs
+            _UPDATES[owner] = slot
+        key = (tuple(data_adv.shape), tuple(target.shape), target.dtype, data_adv.device.index)
+        update = slot[3].get(key)
+        if update is None:
+            update = slot[3][key] = _GraphedUpdate(model, criterion, optimizer, data_adv, target)
+        return update(data_adv.detach(), target)
     output = model(data_adv)
     m = args.method_name
     if m in ('ALP', 'tarALP'):

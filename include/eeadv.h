@@ -225,14 +225,18 @@ int ee_hfs_f32(const float *in, float *out, int B, int C, int H, int W, const fl
  *   training == 0: running statistics.      relu != 0: y = max(., 0) (NaN propagates).
  * backward: dz = relu ? dy * (y > 0) : dy ; dresidual (nullable) = dz ; dgamma / dbeta (nullable) = sum dz*xhat / sum dz ;
  *   dx (nullable) = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) in training mode, gamma*invstd*dz otherwise.
- * One workgroup per channel, fixed-order reductions: results are bit-reproducible run to run.
+ * Fixed-order reductions: results are bit-reproducible run to run.  One workgroup per channel; a channel too large for one
+ * workgroup's registers (B*HW > 28672 values) is split across workgroups in two launches when `workspace` (nullable, DEVICE,
+ * ee_bn_workspace_floats(B, C, HW) floats, contents undefined on entry and exit) is given.
  * ------------------------------------------------------------------------------------------- */
+int ee_bn_workspace_floats(int B, int C, int HW);
 int ee_bn_act_fwd_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
                       float *running_var, float momentum, float eps, int training, int relu, float *y, float *save_mean,
-                      float *save_invstd, int B, int C, int HW, void *stream);
+                      float *save_invstd, float *workspace, int B, int C, int HW, void *stream);
 int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
                       const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training,
-                      int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, int B, int C, int HW, void *stream);
+                      int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW,
+                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The stem's MaxPool2d(3, stride 2, padding 1) (Tiny_ImageNet/models_tinyimagenet/resnet.py:117), bit-identical to ATen's

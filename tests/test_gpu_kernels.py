@@ -368,7 +368,7 @@ def test_canny_full_vs_reference_golden_UNPINNED(ops, golden):
 
 
 # ---- fused BatchNorm2d (+ residual) (+ ReLU): CNN-body glue, checked against torch's own fp32 ops (tolerance 1e-5) ----
-@pytest.mark.parametrize("shape", [(100, 64, 32, 32), (100, 128, 8, 8), (7, 5, 3, 3), (2, 512, 2, 2), (3, 4, 1, 1), (100, 512, 1, 1)])
+@pytest.mark.parametrize("shape", [(100, 64, 32, 32), (40, 3, 36, 36), (100, 128, 8, 8), (7, 5, 3, 3), (2, 512, 2, 2), (3, 4, 1, 1), (100, 512, 1, 1)])
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_act_matches_torch(ops, shape, relu, res, training):

@@ -462,6 +462,48 @@ def test_trades_and_alp_training_step_under_hip_graphs(monkeypatch):
         engine.clear_graphs()
 
 
+def test_parameter_update_graph_equals_eager(monkeypatch):
+    """trainer.train_batch captures forward + loss + backward + SGD into one HIP graph after two eager updates
+    (experiments_tinyimagenet.py:283-306); the trajectory must match the eager one, and a changed learning rate must
+    take effect (new capture)."""
+    from eeadv import engine, trainer
+    from eeadv.models import make_resnet
+    x = torch.rand(8, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 200, (8,), device=DEV)
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EEADV_GRAPH", mode)
+        engine.clear_graphs()
+        trainer.clear_update_graphs()
+        torch.manual_seed(11)
+        net = make_resnet(18, "tiny").to(DEV).train()
+        opt = torch.optim.SGD(net.parameters(), lr=0.002, momentum=0.9, weight_decay=2e-4)  # small: a smooth trajectory
+        args = Args(method_name="ST", random=True, epsilon=16 / 255, num_steps_1=2, step_size_1=2 / 255, num_classes=200)
+        crit = trainer.make_criterion(args)
+        losses = []
+        for step in range(7):
+            if step == 5:
+                for g in opt.param_groups:
+                    g["lr"] = 0.0  # adjust_learning_rate: the next updates must leave the weights alone
+                w_before = net.fc.weight.detach().clone()
+                m_before = opt.state[net.fc.weight]["momentum_buffer"].clone()
+            loss, out = trainer.train_batch(net, crit, opt, args, x, y, DEV)
+            losses.append(float(loss))
+        if mode == "1":
+            slot = trainer._UPDATES[(id(net), id(opt))]
+            assert len(slot[3]) == 1  # the first learning rate's graph was dropped with its signature
+        # lr = 0: weights unchanged by updates 5 and 6 (the momentum buffer keeps integrating)
+        assert torch.equal(net.fc.weight.detach(), w_before)
+        assert not torch.equal(opt.state[net.fc.weight]["momentum_buffer"], m_before)
+        runs[mode] = (losses, net.fc.weight.detach().clone(), int(net.bn1.num_batches_tracked), net.bn1.running_mean.clone())
+    trainer.clear_update_graphs()
+    # not bit-equal: MIOpen's split-K solvers accumulate with atomics, and every update feeds the difference forward
+    np.testing.assert_allclose(runs["1"][0], runs["0"][0], rtol=1e-2)
+    assert runs["1"][2] == runs["0"][2] == 7
+    torch.testing.assert_close(runs["1"][3], runs["0"][3], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(runs["1"][1], runs["0"][1], rtol=1e-2, atol=2e-4)
+
+
 def test_full_canny_module_and_ee_at_model_UNPINNED(Cm, golden):
     """utils.core.CannyFilter (HIP) vs the torch restatement, and an EE_AT model (Net2_EE with the full filter) end to end."""
     G = golden("canny_full_unpinned")
