@@ -26,6 +26,10 @@ struct CannyDirs {
 struct CannyParams {
     EdgeParams e;  // pointers / sizes exactly as in ee_edge.hip
     float low;
+    // CannyFilter_BPDA (core.py:386-505): the forward also stores the thinned magnitude and the {0, .5, 1} threshold map;
+    // the backward then receives d loss / d thin (bpda_threshold_bwd_kernel) instead of d loss / d edge
+    float *thin_out, *t2_out;
+    int thin_grad;
 };
 
 // quantised orientation index of core.py:258-260, 270 (fp32 throughout): NaN (gx = gy = 0) -> -1
@@ -138,7 +142,13 @@ __global__ __launch_bounds__(kBlock) void canny_fwd_kernel(CannyParams cp, Weigh
                 const int fr = i - oi, fc = j - oj;
                 const float t = nms_removed<FW>(magAs, kdirs, dirs, fr, fc) ? 0.0f : magAs[fr * FW + fc];
                 const float lowb = ((t - cp.low) > 0.0f) ? 1.0f : 0.0f, highb = ((t - p.high) > 0.0f) ? 1.0f : 0.0f;
-                t2s[fr * FW + fc] = lowb * 0.5f + highb * 0.5f;
+                const float t2 = lowb * 0.5f + highb * 0.5f;
+                t2s[fr * FW + fc] = t2;
+                if (cp.thin_out && r >= 1 && r <= TH && s >= 1 && s <= TW) {  // this tile's own pixels
+                    const size_t o = (static_cast<size_t>(n) * H + i) * W + j;
+                    cp.thin_out[o] = t;
+                    cp.t2_out[o] = t2;
+                }
             }
         }
     }
@@ -287,10 +297,16 @@ __global__ __launch_bounds__(kBlock) void canny_bwd_kernel(CannyParams cp, Weigh
                 const float s2 = gx1 * gx1 + gy1 * gy1;
                 const float mag = sqrtf(s2);
                 const float t = removed ? 0.0f : magAs[o];
-                float gm = us[o] / 2.0f;                          // (sign + 1) / 2
-                if (fabsf(t - p.high) > 1.001f) gm = 0.0f;        // BinaryConnectDeterministic.backward core.py:138-145
-                if (removed) gm = 0.0f;                           // thin_edges[to_remove] = 0.0, core.py:290
-                if (mag < p.alpha) gm = 0.0f;                     // where() backward core.py:264
+                float gm;
+                if (cp.thin_grad) {                                   // CannyFilter_BPDA: us already holds d loss / d thin
+                    gm = us[o];
+                    if (removed) gm = gm * 0.0f;                      // thin * ~to_remove, core.py:480 (keeps the sign of zero)
+                } else {
+                    gm = us[o] / 2.0f;                                // (sign + 1) / 2
+                    if (fabsf(t - p.high) > 1.001f) gm = 0.0f;        // BinaryConnectDeterministic.backward core.py:138-145
+                    if (removed) gm = 0.0f;                           // thin_edges[to_remove] = 0.0, core.py:290
+                    if (mag < p.alpha) gm = 0.0f;                     // where() backward core.py:264
+                }
                 const float rs = 1.0f / sqrtf(s2);
                 const float gs = gm * (0.5f * rs);
                 ggx[o] = (gs * (2.0f * gx1)) / static_cast<float>(C);
@@ -380,6 +396,56 @@ int launch(CannyParams cp, const float *w27, const int *dirs16, int B, int C, hi
     return launch_status();
 }
 
+// CannyFilter_BPDA backward, threshold / hysteresis part (core.py:482-504): d loss / d thin from u = d loss / d edge,
+// the stored thin and t2 planes.  out = high + To_compare(conv(t2), 1) * To_eq(t2);  t2 = .5 low + .5 high;
+// low / high = To_compare(thin, thr).  To_compare passes the gradient where thr < x <= 1.001, To_eq where x == 0.5.
+__global__ __launch_bounds__(256) void bpda_threshold_bwd_kernel(const float *__restrict__ u, const float *__restrict__ thin,
+                                                                 const float *__restrict__ t2, float *__restrict__ g_thin, int H, int W,
+                                                                 float low, float high, int64_t total) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = static_cast<int>(idx % W);
+    const int64_t r = idx / W;
+    const int i = static_cast<int>(r % H);
+    const float *t2p = t2 + (r / H) * H * W, *up = u + (r / H) * H * W;
+    // weak_0 and its To_compare(., 1) gradient mask at (a, b); the hysteresis weights are all 1.25 (core.py:422)
+    auto weak0 = [&](int a, int b) {
+        float acc = 0.0f;
+        for (int di = -1; di <= 1; ++di)
+            for (int dj = -1; dj <= 1; ++dj) {
+                const int rr = a + di, ss = b + dj;
+                acc = fmaf(1.25f, (rr < 0 || rr >= H || ss < 0 || ss >= W) ? 0.0f : t2p[rr * W + ss], acc);
+            }
+        return acc;
+    };
+    const float w0 = weak0(i, j);
+    const float t2c = t2p[i * W + j], uc = up[i * W + j];
+    const float weak1 = (w0 <= 1.0f) ? 0.0f : ((w0 > 1.0f) ? 1.0f : w0);
+    float g_eq = uc * weak1;            // To_eq.backward
+    if (t2c != 0.5f) g_eq = 0.0f;
+    float g_cv = 0.0f;                  // transposed hysteresis convolution of the To_compare(., 1) gradient
+    for (int di = -1; di <= 1; ++di)
+        for (int dj = -1; dj <= 1; ++dj) {
+            const int rr = i - di, ss = j - dj;
+            float v = 0.0f;
+            if (rr >= 0 && rr < H && ss >= 0 && ss < W) {
+                const float wq = weak0(rr, ss);
+                v = up[rr * W + ss] * ((t2p[rr * W + ss] == 0.5f) ? 1.0f : 0.0f);
+                if (wq <= 1.0f) v = 0.0f;
+                if (wq > 1.001f) v = 0.0f;
+            }
+            g_cv = fmaf(1.25f, v, g_cv);
+        }
+    const float g_t2 = g_eq + g_cv;
+    const float th = thin[idx];
+    float g_low = g_t2 * 0.5f, g_high = uc * 1.0f + g_t2 * 0.5f;
+    if (th <= low) g_low = 0.0f;
+    if (th > 1.001f) g_low = 0.0f;
+    if (th <= high) g_high = 0.0f;
+    if (th > 1.001f) g_high = 0.0f;
+    g_thin[idx] = g_low + g_high;
+}
+
 inline bool al16(const void *q) { return !q || aligned16(q); }
 inline bool al4(const void *q) { return !q || (reinterpret_cast<uintptr_t>(q) & 3u) == 0; }
 
@@ -425,4 +491,46 @@ EE_API int ee_canny_bwd_f32(const float *x, const float *u, const float *g_in, c
     cp.e.vec = (W % 4 == 0) && al16(x) && al16(u) && al16(g_in) && al16(g_img) && al16(g_hfs) && al4(gate);
     return fused ? launch<true, true>(cp, weights27, dirs16, B, C, as_stream(stream))
                  : launch<false, true>(cp, weights27, dirs16, B, C, as_stream(stream));
+}
+
+// CannyFilter_BPDA (utils/core.py:386-505): the forward is the CannyFilter pipeline without the alpha mask; thin / t2 are kept
+// for the backward.  NaN pixels (NaN input only) are not reproduced: To_compare keeps them, the sign-based forward does not.
+EE_API int ee_canny_bpda_fwd_f32(const float *x, int B, int C, int H, int W, const float *weights27, const int *dirs16, float low, float high,
+                                 float *edge, float *thin, float *t2, void *stream) {
+    if (int rc = check_dims(B, C, H, W)) return rc;
+    if (B == 0) return EE_OK;
+    if (!x || !weights27 || !dirs16 || !edge || !thin || !t2) return EE_ERR_NULL;
+    CannyParams cp{};
+    cp.e.x = x;
+    cp.e.edge = edge;
+    cp.e.H = H; cp.e.W = W;
+    cp.e.alpha = 0.0f; cp.e.high = high; cp.e.w = 0.0f;
+    cp.low = low;
+    cp.thin_out = thin;
+    cp.t2_out = t2;
+    cp.e.vec = (W % 4 == 0) && al16(x) && al16(edge);
+    return launch<false, false>(cp, weights27, dirs16, B, C, as_stream(stream));
+}
+
+EE_API int ee_canny_bpda_bwd_f32(const float *x, const float *u, const float *thin, const float *t2, int B, int C, int H, int W,
+                                 const float *weights27, const int *dirs16, float low, float high, float *g_thin, float *g_img,
+                                 void *stream) {
+    if (int rc = check_dims(B, C, H, W)) return rc;
+    if (B == 0) return EE_OK;
+    if (!x || !u || !thin || !t2 || !weights27 || !dirs16 || !g_thin || !g_img) return EE_ERR_NULL;
+    const int64_t total = static_cast<int64_t>(B) * H * W;
+    if ((total + 255) / 256 > 0x7fffffffLL) return EE_ERR_SHAPE;
+    EE_LAUNCH(bpda_threshold_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, as_stream(stream), u, thin, t2, g_thin, H,
+              W, low, high, total);
+    if (int rc = launch_status()) return rc;
+    CannyParams cp{};
+    cp.e.x = x;
+    cp.e.u = g_thin;
+    cp.e.g_img = g_img;
+    cp.e.H = H; cp.e.W = W;
+    cp.e.alpha = 0.0f; cp.e.high = high; cp.e.w = 0.0f;
+    cp.low = low;
+    cp.thin_grad = 1;
+    cp.e.vec = (W % 4 == 0) && al16(x) && al16(g_thin) && al16(g_img);
+    return launch<false, true>(cp, weights27, dirs16, B, C, as_stream(stream));
 }

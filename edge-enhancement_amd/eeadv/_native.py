@@ -40,6 +40,8 @@ SIGNATURES = {
     "ee_frontend_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_p, c_p, c_p],
     "ee_canny_fwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
     "ee_canny_bwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_p, c_p, c_p],
+    "ee_canny_bpda_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p],
+    "ee_canny_bpda_bwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p],
     "ee_pgd_step_bcast_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_f, c_f, c_f, c_f, c_i, c_p],
     "ee_ce_f32": [c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p],
     "ee_kl_f32": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],

@@ -59,6 +59,24 @@ class CannyFn(torch.autograd.Function):
         return ops.canny_bwd(img, u.contiguous(), wts, alpha, low, high).expand_as(img), None, None, None, None
 
 
+class CannyBPDAFn(torch.autograd.Function):
+    """CannyFilter_BPDA forward/backward (utils/core.py:386-505; thresholds given, hysteresis=True)."""
+
+    @staticmethod
+    def forward(ctx, img, wts, low, high):
+        img = img.contiguous()
+        edge, thin, t2 = ops.canny_bpda_fwd(img, wts, low, high)
+        ctx.save_for_backward(img, thin, t2)
+        ctx.cfg = (wts, low, high)
+        return edge
+
+    @staticmethod
+    def backward(ctx, u):
+        img, thin, t2 = ctx.saved_tensors
+        wts, low, high = ctx.cfg
+        return ops.canny_bpda_bwd(img, u.contiguous(), thin, t2, wts, low, high).expand_as(img), None, None, None
+
+
 class CannyFrontEndFn(torch.autograd.Function):
     """x_in = clamp(x_hfs + w * CannyFilter(x), 0, 1) in one kernel each way (Net2_EE.py:36-49, resnet_EE.py:176-191)."""
 

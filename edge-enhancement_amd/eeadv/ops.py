@@ -235,6 +235,26 @@ def canny_bwd(x, u, wts, alpha, low, high):
     return g
 
 
+def canny_bpda_fwd(x, wts, low, high):
+    """CannyFilter_BPDA forward (core.py:426-505) -> (edge, thin, t2); thin / t2 are the backward's saved state."""
+    B, C, H, W = x.shape
+    edge, thin, t2 = (torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device) for _ in range(3))
+    N.check(N.lib.ee_canny_bpda_fwd_f32(_chk(x, torch.float32, "x"), B, C, H, W, wts.ptr, wts.dirs_ptr, low, high, edge.data_ptr(),
+                                        thin.data_ptr(), t2.data_ptr(), _stream()), "ee_canny_bpda_fwd_f32")
+    return edge, thin, t2
+
+
+def canny_bpda_bwd(x, u, thin, t2, wts, low, high):
+    B, C, H, W = x.shape
+    g = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_canny_bpda_bwd_f32(_chk(x, torch.float32, "x"), _chk(u, torch.float32, "u", (B, 1, H, W)),
+                                        _chk(thin, torch.float32, "thin", (B, 1, H, W)), _chk(t2, torch.float32, "t2", (B, 1, H, W)), B, C, H,
+                                        W, wts.ptr, wts.dirs_ptr, low, high, scratch.data_ptr(), g.data_ptr(), _stream()),
+            "ee_canny_bpda_bwd_f32")
+    return g
+
+
 def canny_frontend_fwd(x, x_hfs, wts, alpha, low, high, w, want_edge=False):
     B, C, H, W = x.shape
     x_in = torch.empty_like(x)

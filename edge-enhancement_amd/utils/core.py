@@ -223,7 +223,10 @@ class CannyFilter(_CannyWeights):
 
 
 class CannyFilter_BPDA(_CannyWeights):
-    """core.py:386-505 (AWP configs only).  Device torch ops; parity unpinned (thin kernels)."""
+    """core.py:386-505 (AWP configs only): no alpha mask, NMS by multiplication, thresholds through To_compare, hysteresis
+    through To_eq.  The path the models take (both thresholds given, hysteresis=True) runs on the HIP kernels of
+    ee_canny.hip (one launch forward, two backward); other argument combinations and the opt-in CPU plumbing path run the
+    same expressions in torch ops.  Thin kernels derived (cv2 unavailable) -> parity unpinned."""
 
     def __init__(self, k_gaussian=3, mu=0, sigma=1, k_sobel=3, use_cuda=False, alpha=0.0):
         super(CannyFilter_BPDA, self).__init__(k_gaussian, mu, sigma, k_sobel, registered=not use_cuda)
@@ -232,7 +235,8 @@ class CannyFilter_BPDA(_CannyWeights):
         print('CannyFilter; sigma:{}, alpha:{}'.format(sigma, alpha))
 
     def forward(self, img, low_threshold=None, high_threshold=None, hysteresis=False):
-        runtime.require_device(img, "CannyFilter_BPDA")
+        if runtime.require_device(img, "CannyFilter_BPDA") and low_threshold is not None and high_threshold is not None and hysteresis:
+            return EF.CannyBPDAFn.apply(img, self.edge_weights, float(low_threshold), float(high_threshold))
         grad_x, grad_y, mag = self._grads(img)
         thin_edges = _nms(mag, grad_x, grad_y, self.weight_directional, assign=False)
         if low_threshold is not None:

@@ -186,6 +186,17 @@ int ee_reduce_rows_f64(const double *rows, int64_t n, double scale, double *out,
 int ee_topk_i64(const float *logits, const int64_t *labels, int B, int K, int k, int64_t *idx, int64_t *correct,
                 void *stream);
 
+/* CannyFilter_BPDA (utils/core.py:386-505; AWP configs): no alpha mask, NMS by multiplication, thresholds through
+ * To_compare (core.py:329-358), hysteresis through To_eq (core.py:361-382).  thresholds given, hysteresis=True.
+ *   forward: edge, thin (the thinned magnitude), t2 (the {0, .5, 1} threshold map) [B,1,H,W]; thin / t2 feed the backward.
+ *   backward: u = dL/d(edge) -> g_img [B,1,H,W] (the map every input channel receives); g_thin [B,1,H,W] is scratch.
+ *   NaN pixels (NaN / inf input only) are not reproduced.  dirs16 as for ee_canny_fwd_f32 (HOST). */
+int ee_canny_bpda_fwd_f32(const float *x, int B, int C, int H, int W, const float *weights27, const int *dirs16, float low,
+                          float high, float *edge, float *thin, float *t2, void *stream);
+int ee_canny_bpda_bwd_f32(const float *x, const float *u, const float *thin, const float *t2, int B, int C, int H, int W,
+                          const float *weights27, const int *dirs16, float low, float high, float *g_thin, float *g_img,
+                          void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Add_Square (utils/core.py:589-655), element-wise given its random draws
  *   stripe[B,C,W]  = sign(2*rand-1) of core.py:637 ; sq_sign[nq,C] = sign draws of core.py:648 ;

@@ -481,3 +481,110 @@ EXPORT void orc_canny_bwd_f32(const float *x, const float *u, int B, int C, int 
     }
     free(mag); free(gx1); free(gy1); free(magA); free(ggx); free(ggy); free(gp); free(gb); free(rem);
 }
+
+/* ---------------------------------------------------------------------------
+ * CannyFilter_BPDA  utils/core.py:386-505 (AWP configs only), low/high thresholds given, hysteresis=True.
+ *   Differences from CannyFilter: no alpha mask; NMS multiplies by the keep mask (core.py:480) instead of assigning 0;
+ *   thresholds through To_compare (core.py:329-358: x <= thr -> 0, x > thr -> 1, NaN kept; backward passes where
+ *   thr < x <= 1.001), hysteresis through To_eq (core.py:361-382) and To_compare(conv, 1).  Same DERIVED direction
+ *   table -> PARITY UNPINNED w.r.t. that table, pinned to the reference's own code given the table
+ *   (tests/golden/canny_full_unpinned.npz, CannyFilter_BPDA entries).
+ * ------------------------------------------------------------------------- */
+static float to_compare(float v, float thr) { return (v <= thr) ? 0.0f : ((v > thr) ? 1.0f : v); }
+
+static void bpda_maps(const float *mag, const unsigned char *rem, int H, int W, float low, float high, float *thin, float *hb,
+                      float *t2, float *w0) {
+    size_t HW = (size_t)H * W;
+    for (size_t k = 0; k < HW; ++k) {
+        thin[k] = rem[k] ? mag[k] * 0.0f : mag[k]; /* core.py:480 */
+        hb[k] = to_compare(thin[k], high);
+        t2[k] = to_compare(thin[k], low) * 0.5f + hb[k] * 0.5f; /* core.py:493 */
+    }
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            float acc = 0.0f;
+            for (int di = -1; di <= 1; ++di)
+                for (int dj = -1; dj <= 1; ++dj) {
+                    int r = i + di, s = j + dj;
+                    float v = (r < 0 || r >= H || s < 0 || s >= W) ? 0.0f : t2[(size_t)r * W + s];
+                    acc = fmaf(1.25f, v, acc);
+                }
+            w0[(size_t)i * W + j] = acc; /* core.py:500 */
+        }
+}
+
+EXPORT void orc_canny_bpda_fwd_f32(const float *x, int B, int C, int H, int W, const float *g9, const float *sx9, const float *sy9,
+                                   float low, float high, const int *dirs, float *out) {
+    size_t HW = (size_t)H * W;
+    float *mag = malloc(sizeof(float) * HW), *gx1 = malloc(sizeof(float) * HW), *gy1 = malloc(sizeof(float) * HW);
+    float *magA = malloc(sizeof(float) * HW), *thin = malloc(sizeof(float) * HW), *hb = malloc(sizeof(float) * HW);
+    float *t2 = malloc(sizeof(float) * HW), *w0 = malloc(sizeof(float) * HW);
+    unsigned char *rem = malloc(HW);
+    for (int n = 0; n < B; ++n) {
+        canny_maps(x + (size_t)n * C * HW, C, H, W, g9, sx9, sy9, 0.0f, high, dirs, mag, gx1, gy1, magA, rem);
+        bpda_maps(mag, rem, H, W, low, high, thin, hb, t2, w0);
+        for (size_t k = 0; k < HW; ++k) {
+            float weak = (t2[k] == 0.5f) ? 1.0f : 0.0f;                           /* To_eq, core.py:498 */
+            out[(size_t)n * HW + k] = hb[k] * 1.0f + (to_compare(w0[k], 1.0f) * weak) * 1.0f; /* core.py:501-504 */
+        }
+    }
+    free(mag); free(gx1); free(gy1); free(magA); free(thin); free(hb); free(t2); free(w0); free(rem);
+}
+
+EXPORT void orc_canny_bpda_bwd_f32(const float *x, const float *u, int B, int C, int H, int W, const float *g9, const float *sx9,
+                                   const float *sy9, float low, float high, const int *dirs, float *gx_img) {
+    size_t HW = (size_t)H * W, PW = (size_t)(H + 2) * (W + 2);
+    float *mag = malloc(sizeof(float) * HW), *gx1 = malloc(sizeof(float) * HW), *gy1 = malloc(sizeof(float) * HW);
+    float *magA = malloc(sizeof(float) * HW), *thin = malloc(sizeof(float) * HW), *hb = malloc(sizeof(float) * HW);
+    float *t2 = malloc(sizeof(float) * HW), *w0 = malloc(sizeof(float) * HW), *gw0 = malloc(sizeof(float) * HW);
+    float *ggx = malloc(sizeof(float) * HW), *ggy = malloc(sizeof(float) * HW);
+    float *gp = malloc(sizeof(float) * PW), *gb = malloc(sizeof(float) * HW);
+    unsigned char *rem = malloc(HW);
+    for (int n = 0; n < B; ++n) {
+        const float *un = u + (size_t)n * HW;
+        canny_maps(x + (size_t)n * C * HW, C, H, W, g9, sx9, sy9, 0.0f, high, dirs, mag, gx1, gy1, magA, rem);
+        bpda_maps(mag, rem, H, W, low, high, thin, hb, t2, w0);
+        /* out = high + weak_1 * weak.  d/d weak_0 through To_compare(., 1): passes only where 1 < weak_0 <= 1.001 */
+        for (size_t k = 0; k < HW; ++k) {
+            float weak = (t2[k] == 0.5f) ? 1.0f : 0.0f;
+            float g = un[k] * weak;
+            if (w0[k] <= 1.0f) g = 0.0f;
+            if (w0[k] > 1.001f) g = 0.0f;
+            gw0[k] = g;
+        }
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                size_t k = (size_t)i * W + j;
+                /* d/d t2: To_eq.backward (core.py:373-382) + the transposed hysteresis convolution */
+                float g_eq = un[k] * to_compare(w0[k], 1.0f);
+                if (t2[k] != 0.5f) g_eq = 0.0f;
+                float g_cv = 0.0f;
+                for (int di = -1; di <= 1; ++di)
+                    for (int dj = -1; dj <= 1; ++dj) {
+                        int r = i - di, s = j - dj;
+                        float v = (r < 0 || r >= H || s < 0 || s >= W) ? 0.0f : gw0[(size_t)r * W + s];
+                        g_cv = fmaf(1.25f, v, g_cv);
+                    }
+                float g_t2 = g_eq + g_cv;
+                float g_low = g_t2 * 0.5f, g_high = un[k] * 1.0f + g_t2 * 0.5f;
+                if (thin[k] <= low) g_low = 0.0f;
+                if (thin[k] > 1.001f) g_low = 0.0f;
+                if (thin[k] <= high) g_high = 0.0f;
+                if (thin[k] > 1.001f) g_high = 0.0f;
+                float gm = g_low + g_high;
+                if (rem[k]) gm = gm * 0.0f; /* mul by the keep mask, core.py:480 */
+                float s2 = gx1[k] * gx1[k] + gy1[k] * gy1[k];
+                float r = 1.0f / sqrtf(s2);
+                float gs = gm * (0.5f * r);
+                ggx[k] = (gs * (2.0f * gx1[k])) / (float)C;
+                ggy[k] = (gs * (2.0f * gy1[k])) / (float)C;
+            }
+        corr3_transpose_acc(ggx, H, W, sx9, gp, 1);
+        corr3_transpose_acc(ggy, H, W, sy9, gp, 0);
+        reppad1_adjoint(gp, H, W, gb);
+        corr3_transpose_acc(gb, H, W, g9, gp, 1);
+        reppad1_adjoint(gp, H, W, gx_img + (size_t)n * HW);
+    }
+    free(mag); free(gx1); free(gy1); free(magA); free(thin); free(hb); free(t2); free(w0); free(gw0);
+    free(ggx); free(ggy); free(gp); free(gb); free(rem);
+}

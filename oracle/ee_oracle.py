@@ -260,3 +260,25 @@ def canny_bwd(x, u, alpha, low, high, sigma=1.0):
     lib().orc_canny_bwd_f32(_p(x), _p(u), c_i(B), c_i(C), c_i(H), c_i(W), _p(g9), _p(sx9), _p(sy9), c_f(alpha), c_f(low),
                             c_f(high), _p(dirs), _p(out))
     return out
+
+
+def canny_bpda_fwd(x, low, high, sigma=1.0):
+    """CannyFilter_BPDA forward (core.py:426-505; thresholds given, hysteresis=True)."""
+    x = _f32(x)
+    B, C, H, W = x.shape
+    g9, sx9, sy9 = edge_weights(sigma)
+    out = np.empty((B, 1, H, W), np.float32)
+    dirs = np.ascontiguousarray(CANNY_DIRS.reshape(-1))
+    lib().orc_canny_bpda_fwd_f32(_p(x), c_i(B), c_i(C), c_i(H), c_i(W), _p(g9), _p(sx9), _p(sy9), c_f(low), c_f(high), _p(dirs), _p(out))
+    return out
+
+
+def canny_bpda_bwd(x, u, low, high, sigma=1.0):
+    x, u = _f32(x), _f32(u)
+    B, C, H, W = x.shape
+    g9, sx9, sy9 = edge_weights(sigma)
+    out = np.empty((B, 1, H, W), np.float32)
+    dirs = np.ascontiguousarray(CANNY_DIRS.reshape(-1))
+    lib().orc_canny_bpda_bwd_f32(_p(x), _p(u), c_i(B), c_i(C), c_i(H), c_i(W), _p(g9), _p(sx9), _p(sy9), c_f(low), c_f(high), _p(dirs),
+                                 _p(out))
+    return out

@@ -367,6 +367,38 @@ def test_canny_full_vs_reference_golden_UNPINNED(ops, golden):
         np.testing.assert_allclose(g[fin], ref[fin], atol=1e-6)
 
 
+@pytest.mark.parametrize("shape,low,high", [((2, 3, 64, 64), 0.05, 0.2), ((3, 1, 28, 28), 0.1, 0.3), ((2, 3, 17, 23), 0.02, 0.1),
+                                            ((2, 2, 5, 4), 0.05, 0.2), ((1, 3, 80, 72), 0.2, 0.45)])
+def test_canny_bpda_fwd_bwd_vs_oracle_UNPINNED(ops, shape, low, high):
+    """CannyFilter_BPDA (core.py:386-505) on the HIP kernels vs the C restatement: bit-exact, NaN gradients included."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.random(shape, dtype=np.float32)
+    x[0, :, : shape[2] // 2, : shape[3] // 2] = 0.25  # a flat patch: zero magnitude -> 0 * inf = NaN in the gradient
+    u = rng.standard_normal((shape[0], 1) + shape[2:]).astype(np.float32)
+    wts = ops.EdgeWeights(1.0)
+    e, thin, t2 = ops.canny_bpda_fwd(dev(x), wts, low, high)
+    assert_bitexact(e.cpu().numpy(), O.canny_bpda_fwd(x, low, high), "bpda fwd")
+    g = ops.canny_bpda_bwd(dev(x), dev(u), thin, t2, wts, low, high)
+    assert_bitexact(g.cpu().numpy(), O.canny_bpda_bwd(x, u, low, high), "bpda bwd")
+
+
+def test_canny_bpda_module_vs_reference_golden_UNPINNED(golden):
+    """utils.core.CannyFilter_BPDA (HIP path) against the fixtures generated by the reference's class (derived thin table)."""
+    import utils.core as Cm
+    G = golden("canny_full_unpinned")
+    for name in ("rand_rgb", "rand_mnist", "rect_rgb"):
+        x = dev(G[name + "__x"]).requires_grad_(True)
+        _, low, high = [float(v) for v in G[name + "__alpha_low_high"]]
+        filt = Cm.CannyFilter_BPDA(sigma=1, use_cuda=True)
+        e = filt(x, low_threshold=low, high_threshold=high, hysteresis=True)
+        (e * dev(G[name + "__u"])).sum().backward()
+        assert np.array_equal(e.detach().cpu().numpy(), G[name + "__CannyFilter_BPDA__edge"]), name
+        ref, got = G[name + "__CannyFilter_BPDA__gx"], x.grad.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), name
+        fin = ~np.isnan(ref)
+        np.testing.assert_allclose(got[fin], ref[fin], atol=1e-6)
+
+
 # ---- fused BatchNorm2d (+ residual) (+ ReLU): CNN-body glue, checked against torch's own fp32 ops (tolerance 1e-5) ----
 @pytest.mark.parametrize("shape", [(100, 64, 32, 32), (40, 3, 36, 36), (100, 128, 8, 8), (7, 5, 3, 3), (2, 512, 2, 2), (3, 4, 1, 1), (100, 512, 1, 1)])
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])

@@ -206,6 +206,26 @@ def test_full_canny_restatement_UNPINNED(golden, name, cls):
     np.testing.assert_allclose(x.grad.numpy()[fin], ref[fin], atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["rand_rgb", "rand_mnist", "rect_rgb"])
+@pytest.mark.parametrize("cls", ["CannyFilter", "CannyFilter_BPDA"])
+def test_full_canny_c_oracle_UNPINNED(golden, name, cls):
+    """The C restatement (the GPU tests' checker) against the same fixtures: edge maps exactly, input gradients with the
+    NaN pattern exact and the finite values to 1e-6 (torch's CPU convolutions order their sums differently from N = 1 up)."""
+    G = golden("canny_full_unpinned")
+    x, u = G[name + "__x"], G[name + "__u"]
+    alpha, low, high = [float(v) for v in G[name + "__alpha_low_high"]]
+    if cls == "CannyFilter":
+        e, g = O.canny_fwd(x, alpha, low, high), O.canny_bwd(x, u, alpha, low, high)
+    else:
+        e, g = O.canny_bpda_fwd(x, low, high), O.canny_bpda_bwd(x, u, low, high)
+    assert np.array_equal(e, G[name + "__" + cls + "__edge"])
+    ref = G[name + "__" + cls + "__gx"]
+    g = np.broadcast_to(g, ref.shape)
+    assert np.array_equal(np.isnan(g), np.isnan(ref))
+    fin = ~np.isnan(ref)
+    np.testing.assert_allclose(g[fin], ref[fin], atol=1e-6)
+
+
 def test_hfs_restatement_properties_UNPINNED():
     """PARITY UNPINNED (torch.rfft no longer exists): linear, idempotent on its pass band, keeps DC."""
     torch.manual_seed(0)
