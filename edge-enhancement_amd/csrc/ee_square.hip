@@ -79,7 +79,53 @@ int launch(bool bwd, const float *x, const float *g_out, float *out, int B, int 
     return launch_status();
 }
 
+// ---- the random draws of one Add_Square forward (core.py:637, :645, :648) in ONE launch ----------------------------------
+// The reference spells them as ~15 tiny torch ops (rand, 2*t-1, sign, rand, (h-s)*u, .long(), rand, ...), i.e. ~15 launches per
+// model forward inside a launch-bound attack loop.  Here a single workgroup draws everything from Philox4x32-10 keyed by a
+// (seed, offset) pair that lives in DEVICE memory and is advanced by the kernel itself, so a captured HIP graph draws fresh
+// numbers at every replay.  Same expressions as the reference on the uniforms: sign(2u - 1) and long(0 + (h - s) * u).
+constexpr int DRAW_NT = 1024;
+
+__global__ __launch_bounds__(DRAW_NT) void square_draw_kernel(float *__restrict__ stripe, int64_t n_stripe, int64_t *__restrict__ sq_pos,
+                                                              float *__restrict__ sq_sign, const int32_t *__restrict__ sq_size, int nq, int C,
+                                                              int h, unsigned long long *state) {
+    const unsigned long long seed = state[0], base = state[1];
+    __syncthreads();  // everybody has read the state before lane 0 advances it
+    const Philox rng(seed);
+    const int64_t total = n_stripe + static_cast<int64_t>(nq) * (1 + C);
+    const int64_t nv = (total + 3) >> 2;
+    for (int64_t v = threadIdx.x; v < nv; v += DRAW_NT) {
+        const uint4 r = rng(base + static_cast<unsigned long long>(v));
+        const float uu[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t e = (v << 2) + k;
+            if (e >= total) break;
+            if (e < n_stripe) {
+                stripe[e] = sgn(2.0f * uu[k] - 1.0f);
+            } else if (e < n_stripe + nq) {
+                const int64_t q = e - n_stripe;
+                const float span = static_cast<float>(h) - static_cast<float>(sq_size[q]);
+                sq_pos[q] = static_cast<int64_t>(0.0f + (span - 0.0f) * uu[k]);
+            } else {
+                sq_sign[e - n_stripe - nq] = sgn(2.0f * uu[k] - 1.0f);
+            }
+        }
+    }
+    if (threadIdx.x == 0) state[1] = base + static_cast<unsigned long long>(nv);
+}
+
 }  // namespace
+
+EE_API int ee_square_draw_f32(float *stripe, int64_t n_stripe, int64_t *sq_pos, float *sq_sign, const int32_t *sq_size, int nq, int C, int h,
+                              uint64_t *state, void *stream) {
+    if (n_stripe < 0 || nq < 0 || C < 1 || h < 1) return EE_ERR_SHAPE;
+    if (!state) return EE_ERR_NULL;
+    if ((n_stripe && !stripe) || (nq && (!sq_pos || !sq_sign || !sq_size))) return EE_ERR_NULL;
+    EE_LAUNCH(square_draw_kernel, dim3(1), dim3(DRAW_NT), 0, as_stream(stream), stripe, n_stripe, sq_pos, sq_sign, sq_size, nq, C, h,
+              reinterpret_cast<unsigned long long *>(state));
+    return launch_status();
+}
 
 EE_API int ee_add_square_fwd_f32(const float *x, int B, int C, int H, int W, float eps, const float *stripe, const float *sq_sign,
                                  const int64_t *sq_pos, const int32_t *sq_size, int nq, float *out, void *stream) {

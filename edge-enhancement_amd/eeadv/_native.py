@@ -52,6 +52,7 @@ SIGNATURES = {
     "ee_topk_i64": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "ee_add_square_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "ee_add_square_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    "ee_square_draw_f32": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "ee_hfs_table_floats": [c_i, c_i, c_i, c_i],
     "ee_hfs_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_f, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],
     "ee_bn_workspace_floats": [c_i, c_i, c_i],

@@ -374,6 +374,20 @@ def add_square_bwd(g_out, x, eps, stripe, sq_sign, sq_pos, sq_size):
 
 
 # ---- HighFreqSuppress -----------------------------------------------------------------------------------------------
+def square_draw(batch, C, h, sq_size, state):
+    """The random draws of one Add_Square forward in one launch (core.py:637, :645, :648): returns stripe [B,C,1,h] fp32,
+    sq_pos [nq] int64, sq_sign [nq,C] fp32.  state: int64[2] device tensor {seed, offset}, advanced by the kernel."""
+    dev = sq_size.device
+    nq = int(sq_size.numel())
+    stripe = torch.empty((batch, C, 1, h), dtype=torch.float32, device=dev)
+    sq_pos = torch.empty((nq,), dtype=torch.int64, device=dev)
+    sq_sign = torch.empty((nq, C), dtype=torch.float32, device=dev)
+    N.check(N.lib.ee_square_draw_f32(stripe.data_ptr(), stripe.numel(), sq_pos.data_ptr(), sq_sign.data_ptr(),
+                                     _chk(sq_size, torch.int32, "sq_size"), nq, C, h, _chk(state, torch.int64, "state", (2,)), _stream()),
+            "ee_square_draw_f32")
+    return stripe, sq_pos, sq_sign
+
+
 def hfs(x, tables, NU, NV, sq_mode=0, sq_x=None, eps=0.0, stripe=None, sq_sign=None, sq_pos=None, sq_size=None):
     """y = F(x) (sq_mode 0), F(add_square(x)) (1) or F(x) * d add_square/dx at sq_x (2); F = the low-pass operator."""
     B, C, H, W = x.shape

@@ -346,6 +346,9 @@ class Add_Square(nn.Module):
     def draw(self, batch, device):
         """The random numbers of one forward (core.py:637, :645, :648), all left on `device` - no host sync."""
         sizes, sizes_dev = self.square_sizes(device)
+        if torch.device(device).type == "cuda":  # one launch instead of ~15 (ee_square.hip), graph-replay safe
+            stripe, sq_pos, sq_sign = ops.square_draw(batch, self.c, self.h, sizes_dev, runtime.draw_state(torch.device(device)))
+            return {"stripe": stripe, "sq_pos": sq_pos, "sq_sign": sq_sign, "sq_size": sizes_dev}
         stripe = self.random_choice([batch, self.c, 1, self.h], device)
         nq = len(sizes)
         u = torch.rand([nq], device=device)

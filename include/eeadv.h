@@ -205,6 +205,11 @@ int ee_canny_bpda_bwd_f32(const float *x, const float *u, const float *thin, con
 int ee_add_square_fwd_f32(const float *x, int B, int C, int H, int W, float eps, const float *stripe,
                           const float *sq_sign, const int64_t *sq_pos, const int32_t *sq_size, int nq, float *out,
                           void *stream);
+/* the draws themselves, one launch: stripe[n_stripe] = sign(2u-1) (core.py:637), sq_pos[q] = long((h - sq_size[q]) * u)
+ * (core.py:645), sq_sign[nq*C] = sign(2u-1) (core.py:648), u ~ U[0,1) from Philox4x32-10.  state = DEVICE uint64[2]
+ * {seed, offset}; the kernel advances the offset itself, so replays of a captured graph draw fresh numbers. */
+int ee_square_draw_f32(float *stripe, int64_t n_stripe, int64_t *sq_pos, float *sq_sign, const int32_t *sq_size, int nq,
+                       int C, int h, uint64_t *state, void *stream);
 /* backward: g_x = g_out * d(out)/d(x), the derivative autograd assigns (ties of max/min split 1/2) */
 int ee_add_square_bwd_f32(const float *g_out, const float *x, int B, int C, int H, int W, float eps,
                           const float *stripe, const float *sq_sign, const int64_t *sq_pos, const int32_t *sq_size,

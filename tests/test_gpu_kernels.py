@@ -496,3 +496,37 @@ def test_pool_linear_head_matches_torch(ops, B, C, HW, K):
         torch.testing.assert_close(a, e, rtol=1e-5, atol=1e-5)
     (gx,) = torch.autograd.grad(PoolLinearFn.apply(feat, w, None), feat, dl)  # no bias; input gradient only
     torch.testing.assert_close(gx, torch.autograd.grad(ref, feat, dl)[0], rtol=1e-5, atol=1e-5)
+
+
+def test_square_draw_one_launch_statistics_and_graph_replay(ops):
+    """Add_Square's draws (core.py:637, :645, :648) from the device-side Philox state: right supports and frequencies,
+    reproducible from the state, and a replayed HIP graph draws NEW numbers (the kernel advances the state itself)."""
+    h, C, B = 64, 3, 100
+    sizes = torch.tensor([41, 29, 1, 64, 7], dtype=torch.int32, device=DEV)
+    state = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    stripe, pos, sign = ops.square_draw(B, C, h, sizes, state)
+    assert stripe.shape == (B, C, 1, h) and pos.shape == (5,) and sign.shape == (5, C) and pos.dtype == torch.int64
+    assert set(np.unique(stripe.cpu().numpy())) <= {-1.0, 0.0, 1.0}
+    assert abs(float(stripe.mean())) < 0.03 and float((stripe == 0).float().mean()) < 1e-3
+    assert bool(((pos >= 0) & (pos <= (h - sizes).clamp(min=0))).all()) and int(pos[3]) == 0
+    n_used = (B * C * h + 5 * (1 + C) + 3) // 4
+    assert state.tolist() == [1234, n_used]
+    state2 = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    again = ops.square_draw(B, C, h, sizes, state2)
+    assert torch.equal(again[0], stripe) and torch.equal(again[1], pos) and torch.equal(again[2], sign)
+    nxt = ops.square_draw(B, C, h, sizes, state2)
+    assert not torch.equal(nxt[0], stripe)
+    # positions are uniform over [0, h - s]: many draws of one size
+    many = torch.full((4000,), 24, dtype=torch.int32, device=DEV)
+    _, p2, s2 = ops.square_draw(1, C, h, many, state2)
+    cnt = torch.bincount(p2, minlength=41).float()
+    assert int(p2.max()) <= 40 and float(cnt[:40].min()) > 50 and abs(float(s2.mean())) < 0.05
+    # graph replay
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.square_draw(B, C, h, sizes, state2)
+    g.replay()
+    a = out[0].clone()
+    g.replay()
+    assert not torch.equal(out[0], a)
