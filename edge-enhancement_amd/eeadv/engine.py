@@ -16,6 +16,7 @@ import weakref
 import torch
 
 from . import ops
+from .functional import input_grad_only
 
 CE_SUM, CE_MEAN, KL, SOFTCE = "ce_sum", "ce_mean", "kl", "softce"
 
@@ -54,7 +55,8 @@ def input_gradient(model, x, spec):
     with torch.enable_grad():
         logits = model(x)
     d = spec.dlogits(logits.contiguous())
-    (g,) = torch.autograd.grad(logits, [x], grad_outputs=d)
+    with input_grad_only():
+        (g,) = torch.autograd.grad(logits, [x], grad_outputs=d)
     return g
 
 
@@ -69,7 +71,8 @@ def attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi):
         with torch.enable_grad():
             logits = model.body(x_in)
         d = spec.dlogits(logits.contiguous())
-        (g_in,) = torch.autograd.grad(logits, [x_in], grad_outputs=d)
+        with input_grad_only():
+            (g_in,) = torch.autograd.grad(logits, [x_in], grad_outputs=d)
         with torch.no_grad():
             g_lp, g_edge = model.front_manual_backward(g_in.contiguous(), ctx)
             ops.pgd_step_bcast_(x.detach(), g_lp, g_edge, x0, step_size, eps, lo, hi, direction)

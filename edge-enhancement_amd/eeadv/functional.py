@@ -4,6 +4,24 @@ import torch
 from . import ops
 
 
+# ctx.needs_input_grad says whether an input REQUIRES grad, not whether this particular backward pass wants its gradient:
+# a PGD iteration (torch.autograd.grad w.r.t. the input only, attacks.py:24) would still make the Functions below produce
+# weight / bias gradients (a GEMM and a reduction per iteration for the classifier head).  The attack loop brackets its
+# backward pass with input_grad_only(); the flag is a plain module global because autograd runs Function.backward on its own
+# device thread while the calling thread blocks inside torch.autograd.grad.
+_INPUT_GRAD_ONLY = False
+
+
+class input_grad_only:
+    def __enter__(self):
+        global _INPUT_GRAD_ONLY
+        self._prev, _INPUT_GRAD_ONLY = _INPUT_GRAD_ONLY, True
+
+    def __exit__(self, *exc):
+        global _INPUT_GRAD_ONLY
+        _INPUT_GRAD_ONLY = self._prev
+
+
 class Edge125Fn(torch.autograd.Function):
     """CannyFilter_step125_1 forward/backward (utils/core.py:549-585, To_compare :329-358)."""
 
@@ -127,7 +145,9 @@ class BnActFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, gamma, sm, si, rm, rv = ctx.saved_tensors
         eps, training, relu, has_res = ctx.cfg
-        want = ctx.needs_input_grad
+        want = list(ctx.needs_input_grad)
+        if _INPUT_GRAD_ONLY:
+            want[2] = want[3] = False
         dy = dy.contiguous()
         if not relu and not want[0] and not want[2] and not want[3]:
             return None, (dy if has_res and want[1] else None), None, None, None, None, None, None, None, None
@@ -172,8 +192,8 @@ class PoolLinearFn(torch.autograd.Function):
         pooled, weight = ctx.saved_tensors
         dl = dl.contiguous()
         dfeat = ops.pool_linear_bwd(dl, weight, ctx.feat_shape) if ctx.needs_input_grad[0] else None
-        dw = dl.t().mm(pooled) if ctx.needs_input_grad[1] else None
-        db = dl.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dw = dl.t().mm(pooled) if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY else None
+        db = dl.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] and not _INPUT_GRAD_ONLY else None
         return dfeat, dw, db
 
 
