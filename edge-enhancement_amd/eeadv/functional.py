@@ -175,6 +175,26 @@ class MaxPool3s2Fn(torch.autograd.Function):
         return ops.maxpool3s2_bwd(dy.contiguous(), code, *ctx.hw)
 
 
+class Conv1x1S2Fn(torch.autograd.Function):
+    """The shortcut Conv2d(Cin, Cout, 1, stride=2, bias=False) (resnet.py:137-142) on ee_conv.hip; the weight gradient
+    (once per training step) comes from ATen's convolution_backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return ops.conv1x1s2_fwd(x, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.conv1x1s2_bwd(dy, weight, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw
+
+
 class PoolLinearFn(torch.autograd.Function):
     """fc(global_avgpool(feat).view(B, -1)) in one launch each way (resnet.py:157-160; ee_head.hip).  The weight and
     bias gradients (once per training step) are two BLAS calls on the saved pooled features."""

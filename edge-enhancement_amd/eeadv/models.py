@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops
-from .functional import BnActFn, MaxPool3s2Fn, PoolLinearFn
+from .functional import BnActFn, Conv1x1S2Fn, MaxPool3s2Fn, PoolLinearFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -54,8 +54,8 @@ def bn_act(bn, x, residual=None, relu=True):
     return F.relu(out) if relu else out
 
 
-# EEADV_STOCK_GLUE=bn,pool,head (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
-# ee_bn.hip / ee_pool.hip / ee_head.hip: an A/B switch for measurements, never needed for correctness.
+# EEADV_STOCK_GLUE=bn,pool,head,conv (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
+# ee_bn.hip / ee_pool.hip / ee_head.hip / ee_conv.hip: an A/B switch for measurements, never needed for correctness.
 _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") if t)
 
 
@@ -81,6 +81,21 @@ def head(avgpool, fc, x):
         return PoolLinearFn.apply(x, fc.weight, fc.bias)
     x = avgpool(x)
     return fc(x.view(x.size(0), -1))
+
+
+def shortcut(block, x):
+    """identity, or downsample(x) = BatchNorm(Conv2d(1x1, stride 2)) (resnet.py:137-142) with the convolution on ee_conv.hip
+    and the BatchNorm on ee_bn.hip when the shapes allow; the stock modules otherwise."""
+    ds = block.downsample
+    if ds is None:
+        return x
+    if ("conv" not in _STOCK and isinstance(ds, nn.Sequential) and len(ds) == 2 and type(ds[0]) is nn.Conv2d and _dense_f32(x)):
+        cv = ds[0]
+        if (cv.kernel_size == (1, 1) and cv.stride == (2, 2) and cv.padding == (0, 0) and cv.bias is None and cv.groups == 1
+                and cv.in_channels % 2 == 0 and cv.out_channels % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                and cv.weight.is_contiguous()):
+            return bn_act(ds[1], Conv1x1S2Fn.apply(x, cv.weight), relu=False)
+    return ds(x)
 
 
 def _bump_bn_counters(model):
@@ -224,7 +239,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         out = bn_act(self.bn1, self.conv1(x))
-        return bn_act(self.bn2, self.conv2(out), x if self.downsample is None else self.downsample(x))
+        return bn_act(self.bn2, self.conv2(out), shortcut(self, x))
 
 
 class Bottleneck(nn.Module):
@@ -245,7 +260,7 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         out = bn_act(self.bn1, self.conv1(x))
         out = bn_act(self.bn2, self.conv2(out))
-        return bn_act(self.bn3, self.conv3(out), x if self.downsample is None else self.downsample(x))
+        return bn_act(self.bn3, self.conv3(out), shortcut(self, x))
 
 
 class ResNet(nn.Module):

@@ -482,6 +482,26 @@ def maxpool3s2_bwd(dy, code, H, W):
     return dx
 
 
+def conv1x1s2_fwd(x, weight):
+    """Conv2d(Cin, Cout, 1, stride=2, bias=False) (resnet.py:137-142): x [B,Cin,H,W], weight [Cout,Cin,1,1]."""
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    y = torch.empty((B, Cout, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_conv1x1s2_fwd_f32(_chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight", (Cout, Cin, 1, 1)), y.data_ptr(), B,
+                                       Cin, Cout, H, W, _stream()), "ee_conv1x1s2_fwd_f32")
+    return y
+
+
+def conv1x1s2_bwd(dy, weight, H, W):
+    B, Cout = dy.shape[0], dy.shape[1]
+    Cin = weight.shape[1]
+    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
+    N.check(N.lib.ee_conv1x1s2_bwd_f32(_chk(dy, torch.float32, "dy", (B, Cout, H // 2, W // 2)),
+                                       _chk(weight, torch.float32, "weight", (Cout, Cin, 1, 1)), dx.data_ptr(), B, Cin, Cout, H, W, _stream()),
+            "ee_conv1x1s2_bwd_f32")
+    return dx
+
+
 def pool_linear_fwd(feat, weight, bias):
     """logits = fc(global_avgpool(feat)) (resnet.py:157-160) -> (logits [B,K], pooled [B,C])."""
     B, C = feat.shape[0], feat.shape[1]

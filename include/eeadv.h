@@ -263,6 +263,16 @@ int ee_maxpool3s2_fwd_f32(const float *x, float *y, uint8_t *code, int planes, i
 int ee_maxpool3s2_bwd_f32(const float *dy, const uint8_t *code, float *dx, int planes, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The shortcut convolution Conv2d(Cin, Cout, kernel_size=1, stride=2, bias=False) of the ResNet blocks
+ * (Tiny_ImageNet/models_tinyimagenet/resnet.py:137-142) on the exact-f32 matrix cores.
+ *   forward : x [B,Cin,H,W], weight [Cout,Cin] -> y [B,Cout,H/2,W/2]
+ *   backward: dy [B,Cout,H/2,W/2] -> dx [B,Cin,H,W] (all of it is written: three of every four pixels are zero)
+ *   Cin, Cout, H, W even (EE_ERR_UNSUPPORTED otherwise).  The weight gradient is not provided.
+ * ------------------------------------------------------------------------------------------- */
+int ee_conv1x1s2_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream);
+int ee_conv1x1s2_bwd_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Classifier head: logits = fc(avgpool(feat).view(B,-1)) for a global average pool
  * (Tiny_ImageNet/models_tinyimagenet/resnet.py:157-160).  feat [B,C,HW], weight [K,C], bias [K] (nullable);
  * pooled [B,C] (kept for the weight gradient), logits [B,K].  C <= 4096, K <= 8192 (EE_ERR_UNSUPPORTED beyond).

@@ -530,3 +530,23 @@ def test_square_draw_one_launch_statistics_and_graph_replay(ops):
     a = out[0].clone()
     g.replay()
     assert not torch.equal(out[0], a)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(100, 64, 128, 16, 16), (100, 128, 256, 8, 8), (100, 256, 512, 4, 4), (3, 6, 34, 10, 6),
+                                            (2, 130, 200, 4, 4), (1, 2, 2, 2, 2), (5, 64, 256, 56, 56)])
+def test_conv1x1s2_matches_aten(ops, B, Cin, Cout, H, W):
+    """The shortcut convolution (resnet.py:137-142) on the f32 matrix cores vs ATen's conv2d: forward, input gradient and
+    (through ATen) weight gradient."""
+    import torch.nn.functional as F
+    from eeadv.functional import Conv1x1S2Fn
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).to(DEV).requires_grad_(True)
+    ref = F.conv2d(x, w, None, 2, 0)
+    got = Conv1x1S2Fn.apply(x, w)
+    dy = torch.randn(ref.shape, generator=g).to(DEV)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
+    torch.testing.assert_close(gx, ex, rtol=1e-5, atol=2e-5)
+    # both weight gradients come from MIOpen (sums over B*OH*OW terms, possibly through different solvers)
+    torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)

@@ -500,7 +500,7 @@ def test_parameter_update_graph_equals_eager(monkeypatch):
     # not bit-equal: MIOpen's split-K solvers accumulate with atomics, and every update feeds the difference forward
     np.testing.assert_allclose(runs["1"][0], runs["0"][0], rtol=1e-2)
     assert runs["1"][2] == runs["0"][2] == 7
-    torch.testing.assert_close(runs["1"][3], runs["0"][3], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(runs["1"][3], runs["0"][3], rtol=1e-2, atol=2e-3)  # running mean of unit-scale activations
     torch.testing.assert_close(runs["1"][1], runs["0"][1], rtol=1e-2, atol=2e-4)
 
 
