@@ -158,3 +158,100 @@ EE_API int ee_conv1x1s2_bwd_f32(const float *dy, const float *weight, float *dx,
     if (reinterpret_cast<uintptr_t>(dx) & 7u) return EE_ERR_ALIGN;
     return conv_launch<false>(dy, weight, dx, ConvDims{B, Cin, Cout, H, W, H / 2, W / 2}, as_stream(stream));
 }
+
+// =====================================================================================================================
+// Backward-data of the stem convolution Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+// (Tiny_ImageNet/models_tinyimagenet/resnet.py:112-113): the last step of every PGD iteration's backward pass, the gradient
+// with respect to the IMAGE.  With three output channels the generic solvers have nothing to tile over (MIOpen: 110 us
+// for [100,64,32,32] -> [100,3,64,64] plus a zero fill, rocprofv3; 172 us with torch events).
+//
+// dx[n,c,2a+ph,2b+pw] = sum_k sum_{u,v} dy[n,k,a-1+u,b-1+v] * W[k,c,r(ph,u),s(pw,v)],  r(0,u) = 5-2u (u < 3), r(1,u) = 6-2u (u < 4)
+// i.e. a 4x4-window correlation on the dy grid producing the 2x2x3 = 12 values of one input cell: one lane per cell, 12
+// accumulators, the 16 window values from LDS, and the 147 weights of one k as wave-uniform scalar operands (the loop index
+// is the only variable part of their address, so they are scalar loads, not vector traffic): 147 FMAs per 16 LDS reads.
+// =====================================================================================================================
+namespace {
+
+constexpr int ST_TA = 8, ST_TB = 32, ST_KC = 16;  // dy-grid tile (rows x cols) and channels staged per round
+constexpr int ST_FH = ST_TA + 3, ST_FW = ST_TB + 4;  // frame: rows a-1 .. a+TA+1, cols b-1 .. b+TB+1 (+1 pad)
+
+__global__ __launch_bounds__(ST_TA *ST_TB) void stem_bwd_data_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                                      float *__restrict__ dx, int K, int OH, int OW, int tiles_a, int tiles_b) {
+    __shared__ float fr[ST_KC][ST_FH][ST_FW];
+    const int tb = threadIdx.x % ST_TB, ta = threadIdx.x / ST_TB;
+    int bid = blockIdx.x;
+    const int tjb = bid % tiles_b;
+    bid /= tiles_b;
+    const int tia = bid % tiles_a;
+    const int n = bid / tiles_a;
+    const int a0 = tia * ST_TA, b0 = tjb * ST_TB;
+    const int a = a0 + ta, b = b0 + tb;
+    float acc[2][2][3];
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[ph][pw][c] = 0.0f;
+    const float *dyn = dy + static_cast<size_t>(n) * K * OH * OW;
+    for (int kc = 0; kc < K; kc += ST_KC) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < ST_KC * ST_FH * ST_FW; idx += ST_TA * ST_TB) {
+            const int fc = idx % ST_FW, t = idx / ST_FW;
+            const int frow = t % ST_FH, k = t / ST_FH;
+            const int i = a0 - 1 + frow, j = b0 - 1 + fc;
+            float v = 0.0f;
+            if (kc + k < K && i >= 0 && i < OH && j >= 0 && j < OW) v = dyn[(static_cast<size_t>(kc + k) * OH + i) * OW + j];
+            fr[k][frow][fc] = v;
+        }
+        __syncthreads();
+        const int kn = (K - kc) < ST_KC ? (K - kc) : ST_KC;
+        for (int k = 0; k < kn; ++k) {
+            const float *wk = w + static_cast<size_t>(kc + k) * 147;  // W[k][c][r][s], wave-uniform
+            float win[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) win[u][v] = fr[k][ta + u][tb + v];
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int u = 0; u < 3 + ph; ++u) {
+                    const int r = 5 + ph - 2 * u;
+#pragma unroll
+                    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                        for (int v = 0; v < 3 + pw; ++v) {
+                            const int s = 5 + pw - 2 * v;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) acc[ph][pw][c] = fmaf(win[u][v], wk[c * 49 + r * 7 + s], acc[ph][pw][c]);
+                        }
+                }
+        }
+    }
+    if (a >= OH || b >= OW) return;
+    const int H = 2 * OH, W = 2 * OW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+            *reinterpret_cast<float2 *>(dx + ((static_cast<size_t>(n) * 3 + c) * H + 2 * a + ph) * W + 2 * b) =
+                make_float2(acc[ph][0][c], acc[ph][1][c]);
+}
+
+}  // namespace
+
+EE_API int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int K, int H, int W, void *stream) {
+    if (B < 0 || K < 1 || H < 2 || W < 2) return EE_ERR_SHAPE;
+    if ((H & 1) || (W & 1)) return EE_ERR_UNSUPPORTED;
+    if (B == 0) return EE_OK;
+    if (!dy || !weight || !dx) return EE_ERR_NULL;
+    if (reinterpret_cast<uintptr_t>(dx) & 7u) return EE_ERR_ALIGN;
+    const int OH = H / 2, OW = W / 2;
+    const int tiles_a = (OH + ST_TA - 1) / ST_TA, tiles_b = (OW + ST_TB - 1) / ST_TB;
+    const int64_t grid = static_cast<int64_t>(B) * tiles_a * tiles_b;
+    if (grid > 0x7fffffffLL) return EE_ERR_SHAPE;
+    EE_LAUNCH(stem_bwd_data_kernel, dim3(static_cast<unsigned>(grid)), dim3(ST_TA * ST_TB), 0, as_stream(stream), dy, weight, dx, K, OH, OW, tiles_a,
+              tiles_b);
+    return launch_status();
+}

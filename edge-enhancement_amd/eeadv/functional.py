@@ -195,6 +195,26 @@ class Conv1x1S2Fn(torch.autograd.Function):
         return dx, dw
 
 
+class StemConvFn(torch.autograd.Function):
+    """The stem Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (resnet.py:112-113): forward and weight gradient on MIOpen,
+    the gradient with respect to the image - what the attack loop is after - on ee_conv.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.ops.aten.convolution(x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.stem7x7s2_bwd_data(dy, weight, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw
+
+
 class PoolLinearFn(torch.autograd.Function):
     """fc(global_avgpool(feat).view(B, -1)) in one launch each way (resnet.py:157-160; ee_head.hip).  The weight and
     bias gradients (once per training step) are two BLAS calls on the saved pooled features."""

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops
-from .functional import BnActFn, Conv1x1S2Fn, MaxPool3s2Fn, PoolLinearFn
+from .functional import BnActFn, Conv1x1S2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -54,7 +54,7 @@ def bn_act(bn, x, residual=None, relu=True):
     return F.relu(out) if relu else out
 
 
-# EEADV_STOCK_GLUE=bn,pool,head,conv (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
+# EEADV_STOCK_GLUE=bn,pool,head,conv,stem (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
 # ee_bn.hip / ee_pool.hip / ee_head.hip / ee_conv.hip: an A/B switch for measurements, never needed for correctness.
 _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") if t)
 
@@ -96,6 +96,15 @@ def shortcut(block, x):
                 and cv.weight.is_contiguous()):
             return bn_act(ds[1], Conv1x1S2Fn.apply(x, cv.weight), relu=False)
     return ds(x)
+
+
+def stem_conv(conv, x):
+    """conv1 of the ResNets (resnet.py:112): when x needs a gradient (the attack loop), its backward-data runs on ee_conv.hip."""
+    if ("stem" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and x.requires_grad and conv.in_channels == 3
+            and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and conv.weight.is_contiguous()):
+        return StemConvFn.apply(x, conv.weight)
+    return conv(x)
 
 
 def _bump_bn_counters(model):
@@ -306,7 +315,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def body(self, x):
-        x = stem_pool(self.maxpool, bn_act(self.bn1, self.conv1(x)))
+        x = stem_pool(self.maxpool, bn_act(self.bn1, stem_conv(self.conv1, x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         _bump_bn_counters(self)
         return head(self.avgpool, self.fc, x)

@@ -502,6 +502,16 @@ def conv1x1s2_bwd(dy, weight, H, W):
     return dx
 
 
+def stem7x7s2_bwd_data(dy, weight, H, W):
+    """d loss / d image through Conv2d(3, K, 7, stride 2, padding 3) (resnet.py:112): dy [B,K,H/2,W/2] -> [B,3,H,W]."""
+    B, K = dy.shape[0], dy.shape[1]
+    dx = torch.empty((B, 3, H, W), dtype=torch.float32, device=dy.device)
+    N.check(N.lib.ee_stem7x7s2_bwd_data_f32(_chk(dy, torch.float32, "dy", (B, K, H // 2, W // 2)),
+                                            _chk(weight, torch.float32, "weight", (K, 3, 7, 7)), dx.data_ptr(), B, K, H, W, _stream()),
+            "ee_stem7x7s2_bwd_data_f32")
+    return dx
+
+
 def pool_linear_fwd(feat, weight, bias):
     """logits = fc(global_avgpool(feat)) (resnet.py:157-160) -> (logits [B,K], pooled [B,C])."""
     B, C = feat.shape[0], feat.shape[1]

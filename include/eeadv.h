@@ -272,6 +272,11 @@ int ee_maxpool3s2_bwd_f32(const float *dy, const uint8_t *code, float *dx, int p
 int ee_conv1x1s2_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream);
 int ee_conv1x1s2_bwd_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W, void *stream);
 
+/* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
+ * with respect to the image, i.e. the last step of every PGD iteration's backward pass.
+ *   dy [B,K,H/2,W/2], weight [K,3,7,7] -> dx [B,3,H,W];  H, W even. */
+int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int K, int H, int W, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Classifier head: logits = fc(avgpool(feat).view(B,-1)) for a global average pool
  * (Tiny_ImageNet/models_tinyimagenet/resnet.py:157-160).  feat [B,C,HW], weight [K,C], bias [K] (nullable);

@@ -550,3 +550,20 @@ def test_conv1x1s2_matches_aten(ops, B, Cin, Cout, H, W):
     torch.testing.assert_close(gx, ex, rtol=1e-5, atol=2e-5)
     # both weight gradients come from MIOpen (sums over B*OH*OW terms, possibly through different solvers)
     torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)
+
+
+@pytest.mark.parametrize("B,K,H,W", [(100, 64, 64, 64), (3, 64, 224, 224), (2, 5, 10, 6), (1, 64, 2, 2), (2, 17, 70, 66)])
+def test_stem_conv_bwd_data_matches_aten(ops, B, K, H, W):
+    """d loss / d image through the stem convolution (resnet.py:112) vs ATen's convolution_backward."""
+    import torch.nn.functional as F
+    from eeadv.functional import StemConvFn
+    g = torch.Generator(device="cpu").manual_seed(B + K + H)
+    x = torch.randn(B, 3, H, W, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(K, 3, 7, 7, generator=g) / 12.0).to(DEV).requires_grad_(True)
+    ref = F.conv2d(x, w, None, 2, 3)
+    got = StemConvFn.apply(x, w)
+    dy = torch.randn(ref.shape, generator=g).to(DEV)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
+    torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)
