@@ -169,6 +169,10 @@ EE_API int ee_conv1x1s2_bwd_f32(const float *dy, const float *weight, float *dx,
 // i.e. a 4x4-window correlation on the dy grid producing the 2x2x3 = 12 values of one input cell: one lane per cell, 12
 // accumulators, the 16 window values from LDS, and the 147 weights of one k as wave-uniform scalar operands (the loop index
 // is the only variable part of their address, so they are scalar loads, not vector traffic): 147 FMAs per 16 LDS reads.
+// Measured (rocprofv3, [100,64,32,32]): 97 us.  Two variants were slower and are not kept: forcing one v_fmac per weight
+// with the scalar as an operand (112 us: the 37 KB of weights miss the scalar cache and nothing hides the s_load
+// latency) and weights staged in LDS as broadcast reads (130 us: VALU moves to build packed operands).  The next step is
+// the 16x16x4 f32 MFMA form (12 of 16 columns used, K = 64*16), estimated at ~45 us - DESIGN.md.
 // =====================================================================================================================
 namespace {
 
