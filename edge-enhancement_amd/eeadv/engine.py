@@ -16,7 +16,7 @@ import weakref
 import torch
 
 from . import ops
-from .functional import input_grad_only
+from .functional import input_grad_only, refresh_dense_weights
 
 CE_SUM, CE_MEAN, KL, SOFTCE = "ce_sum", "ce_mean", "kl", "softce"
 
@@ -164,6 +164,7 @@ def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo
             attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi)
             x = x.detach()
         gs.load(x, x0, spec.payload)
+        refresh_dense_weights()  # weight-derived buffers the captured kernels read (functional.Conv3x3Map2Fn)
         for _ in range(num_steps - probe):
             gs.graph.replay()
         return gs.x.detach().clone()

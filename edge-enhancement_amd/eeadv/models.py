@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops
-from .functional import BnActFn, Conv1x1S2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import BnActFn, Conv1x1S2Fn, Conv3x3Map2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -54,7 +54,7 @@ def bn_act(bn, x, residual=None, relu=True):
     return F.relu(out) if relu else out
 
 
-# EEADV_STOCK_GLUE=bn,pool,head,conv,stem (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
+# EEADV_STOCK_GLUE=bn,pool,head,conv,stem,dense (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
 # ee_bn.hip / ee_pool.hip / ee_head.hip / ee_conv.hip: an A/B switch for measurements, never needed for correctness.
 _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") if t)
 
@@ -96,6 +96,15 @@ def shortcut(block, x):
                 and cv.weight.is_contiguous()):
             return bn_act(ds[1], Conv1x1S2Fn.apply(x, cv.weight), relu=False)
     return ds(x)
+
+
+def conv3(conv, x):
+    """A block's 3x3 convolution; on a 2x2 map (layer4 at 64x64 inputs) it is one dense product (functional.Conv3x3Map2Fn)."""
+    if ("dense" not in _STOCK and x.shape[2] == 2 and x.shape[3] == 2 and type(conv) is nn.Conv2d and _dense_f32(x)
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"):
+        return Conv3x3Map2Fn.apply(x, conv.weight)
+    return conv(x)
 
 
 def stem_conv(conv, x):
@@ -247,8 +256,8 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = bn_act(self.bn1, self.conv1(x))
-        return bn_act(self.bn2, self.conv2(out), shortcut(self, x))
+        out = bn_act(self.bn1, conv3(self.conv1, x))
+        return bn_act(self.bn2, conv3(self.conv2, out), shortcut(self, x))
 
 
 class Bottleneck(nn.Module):
@@ -268,7 +277,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out = bn_act(self.bn1, self.conv1(x))
-        out = bn_act(self.bn2, self.conv2(out))
+        out = bn_act(self.bn2, conv3(self.conv2, out))
         return bn_act(self.bn3, self.conv3(out), shortcut(self, x))
 
 

@@ -100,6 +100,11 @@ class _GraphedUpdate:
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
         optimizer.step()
+        if torch.cuda.is_current_stream_capturing():
+            # a replayed update moves the weights but not their version counters: the weight-derived buffers of
+            # functional.Conv3x3Map2Fn are rebuilt by the graph itself, right behind the update
+            from eeadv.functional import rebuild_dense_weights
+            rebuild_dense_weights()
         return loss.detach(), output.detach()
 
     def __call__(self, data_adv, target):
@@ -108,6 +113,8 @@ class _GraphedUpdate:
         if self.eager_left > 0:
             self.eager_left -= 1
             return self._body()
+        from eeadv.functional import refresh_dense_weights
+        refresh_dense_weights()  # eager updates since the last forward (version counters moved): before capture AND replay
         if self.graph is None:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()

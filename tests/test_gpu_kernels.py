@@ -567,3 +567,39 @@ def test_stem_conv_bwd_data_matches_aten(ops, B, K, H, W):
     (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
     torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout", [(100, 512, 512), (3, 5, 7), (1, 64, 32)])
+def test_conv3x3_on_2x2_map_as_dense_product(ops, B, Cin, Cout):
+    """Conv2d(3x3, stride 1, padding 1) on a 2x2 map (ResNet layer4 at 64x64 inputs) as one GEMM vs ATen, and the rearranged
+    weight matrix follows in-place weight updates (version counter) without changing its address (HIP graphs)."""
+    import torch.nn.functional as F
+    from eeadv import functional as EF
+    g = torch.Generator(device="cpu").manual_seed(B + Cin)
+    x = torch.randn(B, Cin, 2, 2, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
+    dy = torch.randn(B, Cout, 2, 2, generator=g).to(DEV)
+    for round_ in range(2):
+        ref = F.conv2d(x, w, None, 1, 1)
+        got = EF.Conv3x3Map2Fn.apply(x, w)
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+        (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
+        torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-3)
+        ptr = EF._DENSE_W[id(w)][2].data_ptr()
+        with torch.no_grad():
+            w.mul_(0.5).add_(0.01)  # an optimiser step: the next forward must see it
+        if round_ == 1:
+            assert EF._DENSE_W[id(w)][2].data_ptr() == ptr
+    # a captured forward reads the buffer refreshed by refresh_dense_weights()
+    with torch.no_grad():
+        xs = x.detach()
+        EF.Conv3x3Map2Fn.apply(xs, w)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            out = EF.Conv3x3Map2Fn.apply(xs, w)
+        w.add_(0.25)
+        EF.refresh_dense_weights()
+        gph.replay()
+        torch.testing.assert_close(out, F.conv2d(xs, w, None, 1, 1), rtol=1e-4, atol=1e-4)
