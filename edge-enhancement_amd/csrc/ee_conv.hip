@@ -243,6 +243,112 @@ __global__ __launch_bounds__(ST_TA *ST_TB) void stem_bwd_data_kernel(const float
                 make_float2(acc[ph][0][c], acc[ph][1][c]);
 }
 
+
+// ---- the same product on the exact-f32 matrix cores -------------------------------------------------------------------------
+// D[pixel][j] with j = (ph*2 + pw)*3 + c (12 of 16 columns used), K = (channel, u, v): one v_mfma_f32_16x16x4_f32 covers the four
+// v of one (channel, u) for 16 neighbouring cells of a dy row.  A workgroup (4 wavefronts) owns 8 x 32 cells = 16 M-tiles,
+// four per wavefront; per round 16 channels of the dy frame and their rearranged weights W'[ch][u][v][j] (zero where the
+// tap does not exist for that parity) sit in LDS; the A operand is one ds_read_b32 per MFMA, B is shared by the four M-tiles.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SM_TA = 8, SM_TB = 32, SM_KC = 16, SM_FH = SM_TA + 3, SM_FW = 36;
+
+__global__ __launch_bounds__(256) void stem_bwd_data_mfma_kernel(const float *__restrict__ dy, const float *__restrict__ w, float *__restrict__ dx,
+                                                                 int K, int OH, int OW, int tiles_a, int tiles_b) {
+    __shared__ __align__(16) float fr[SM_KC * SM_FH * SM_FW];  // [ch][frame row][frame col]; reused as the output tile [3][16][64]
+    __shared__ float wp[SM_KC * 4 * 4 * 16];                   // [ch][u][v][j]
+    static_assert(SM_KC * SM_FH * SM_FW >= 3 * 16 * 64, "output tile must fit the frame buffer");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    int bid = blockIdx.x;
+    const int tjb = bid % tiles_b;
+    bid /= tiles_b;
+    const int tia = bid % tiles_a;
+    const int n = bid / tiles_a;
+    const int a0 = tia * SM_TA, b0 = tjb * SM_TB;
+    const float *dyn = dy + static_cast<size_t>(n) * K * OH * OW;
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // column j of the product -> (ph, pw, c)
+    const int jc = i % 3, jq = i / 3, jph = jq >> 1, jpw = jq & 1;
+    // staging roles, fixed per thread for the whole kernel (no index arithmetic inside the channel loops):
+    //   weights: thread t fills wp[k][u][v][j] for (u, v, j) = (t >> 6, (t >> 4) & 3, t & 15) and every k of the round
+    //   frame  : the 11 x 36 frame positions go to threads t (position t) and t < 140 (position 256 + t)
+    const int su = threadIdx.x >> 6, sv = (threadIdx.x >> 4) & 3;
+    const bool wvalid = i < 12 && su < 3 + jph && sv < 3 + jpw;
+    const int woff = jc * 49 + (5 + jph - 2 * su) * 7 + (5 + jpw - 2 * sv);
+    int foff[2];
+    bool fin[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pos = q * 256 + static_cast<int>(threadIdx.x);
+        const int frow = pos / SM_FW, fc = pos - frow * SM_FW;
+        const int r = a0 - 1 + frow, c = b0 - 1 + fc;
+        fin[q] = pos < SM_FH * SM_FW && r >= 0 && r < OH && c >= 0 && c < OW;
+        foff[q] = fin[q] ? r * OW + c : 0;  // loads are unconditional (always in bounds) and masked afterwards, so that they batch
+    }
+    const size_t chan = static_cast<size_t>(OH) * OW;
+    for (int kc = 0; kc < K; kc += SM_KC) {
+        __syncthreads();
+        float v0[SM_KC], v1[SM_KC], vw[SM_KC];
+#pragma unroll
+        for (int k = 0; k < SM_KC; ++k) {
+            const size_t kch = static_cast<size_t>(kc + k < K ? kc + k : K - 1);
+            v0[k] = dyn[kch * chan + foff[0]];
+            v1[k] = dyn[kch * chan + foff[1]];
+            vw[k] = w[kch * 147 + (wvalid ? woff : 0)];
+        }
+#pragma unroll
+        for (int k = 0; k < SM_KC; ++k) {
+            const bool kin = kc + k < K;
+            fr[k * (SM_FH * SM_FW) + threadIdx.x] = (kin && fin[0]) ? v0[k] : 0.0f;
+            if (threadIdx.x < SM_FH * SM_FW - 256) fr[k * (SM_FH * SM_FW) + 256 + threadIdx.x] = (kin && fin[1]) ? v1[k] : 0.0f;
+            wp[k * 256 + threadIdx.x] = (kin && wvalid) ? vw[k] : 0.0f;
+        }
+        __syncthreads();
+        for (int k = 0; k < SM_KC; ++k) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float b = wp[((k * 4 + u) * 4 + kk) * 16 + i];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int row = wave * 2 + (mt >> 1), col0 = (mt & 1) * 16;
+                    const float a = fr[(k * SM_FH + row + u) * SM_FW + col0 + i + kk];
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();  // the frame is dead: it becomes the [3][16][64] output tile
+    if (i < 12) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int row = wave * 2 + (mt >> 1), col0 = (mt & 1) * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int px = col0 + kk * 4 + r;  // accumulator register r of lane (i, kk) holds D[pixel kk*4 + r][column i]
+                fr[(jc * 16 + 2 * row + jph) * 64 + 2 * px + jpw] = acc[mt][r];
+            }
+        }
+    }
+    __syncthreads();
+    const int H = 2 * OH, W = 2 * OW;
+    for (int e = threadIdx.x; e < 3 * 16 * 16; e += 256) {
+        const int q4 = e & 15, orow = (e >> 4) & 15, c = e >> 8;
+        const int h = 2 * a0 + orow, wcol = 2 * b0 + 4 * q4;
+        if (h < H && wcol < W) {  // W is even and wcol a multiple of 4: either the whole float4 or its first half is inside
+            float *o = dx + ((static_cast<size_t>(n) * 3 + c) * H + h) * W + wcol;
+            const float4 v = *reinterpret_cast<const float4 *>(fr + (c * 16 + orow) * 64 + 4 * q4);
+            if (wcol + 3 < W) {
+                *reinterpret_cast<float2 *>(o) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2 *>(o + 2) = make_float2(v.z, v.w);
+            } else {
+                *reinterpret_cast<float2 *>(o) = make_float2(v.x, v.y);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 EE_API int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int K, int H, int W, void *stream) {
@@ -255,7 +361,6 @@ EE_API int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float
     const int tiles_a = (OH + ST_TA - 1) / ST_TA, tiles_b = (OW + ST_TB - 1) / ST_TB;
     const int64_t grid = static_cast<int64_t>(B) * tiles_a * tiles_b;
     if (grid > 0x7fffffffLL) return EE_ERR_SHAPE;
-    EE_LAUNCH(stem_bwd_data_kernel, dim3(static_cast<unsigned>(grid)), dim3(ST_TA * ST_TB), 0, as_stream(stream), dy, weight, dx, K, OH, OW, tiles_a,
-              tiles_b);
+    EE_LAUNCH(stem_bwd_data_mfma_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, as_stream(stream), dy, weight, dx, K, OH, OW, tiles_a, tiles_b);
     return launch_status();
 }
