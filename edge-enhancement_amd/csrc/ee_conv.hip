@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void conv1x1s2_kernel(const float *__restrict_
     const int c0 = (static_cast<int>(blockIdx.y) * CT + ct) * 32;
     const int c = c0 + i;
     const bool pv = p < P, cv = c < Cdim;
-    const int n = pv ? p / OHW : 0, rem = pv ? p - n * OHW : 0;
-    const int oh = rem / d.OW, ow = rem - oh * d.OW;
+    const int n = pv ? p / OHW : 0, rem = pv ? p - n * OHW : 0;  // out-of-range lanes read pixel 0 / channel 0 and are masked:
+    const int oh = rem / d.OW, ow = rem - oh * d.OW;             // unconditional loads batch, predicated ones serialise
     const int steps = Kdim / (2 * KS);                 // k-steps of this wavefront (2 values of k per step)
     const int k0 = ks * (Kdim / KS) + kk * steps;      // this lane's first k
     const size_t plane = static_cast<size_t>(d.H) * d.W;
@@ -72,9 +72,13 @@ __global__ __launch_bounds__(256) void conv1x1s2_kernel(const float *__restrict_
         auto load = [&](float (&av)[16], float (&bv)[16], int t0) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const bool in = t0 + u < steps;
-                av[u] = (in && cv) ? ap[static_cast<size_t>(t0 + u) * astride] : 0.0f;
-                bv[u] = (in && pv) ? bp[static_cast<size_t>(t0 + u) * bstride] : 0.0f;
+                // every load is issued (clamped index, valid address) and masked afterwards: a predicated load becomes a
+                // branch around it, and sixteen branches serialise what should be sixteen loads in flight
+                const int tc = (t0 + u < steps) ? t0 + u : steps - 1;
+                const float keep = (t0 + u < steps) ? 1.0f : 0.0f;
+                const float a = ap[static_cast<size_t>(tc) * astride], b = bp[static_cast<size_t>(tc) * bstride];
+                av[u] = cv ? a * keep : 0.0f;
+                bv[u] = pv ? b : 0.0f;
             }
         };
         auto fma16 = [&](const float (&av)[16], const float (&bv)[16]) {
