@@ -205,20 +205,25 @@ __global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restri
     const int per = s.HW / 4, total = s.B * per;
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    float4 xv[MAXV];
+    const float4 *r4 = reinterpret_cast<const float4 *>(res);
+    float4 xv[MAXV], rv[RES ? MAXV : 1];
     unsigned off[MAXV];
     float acc = 0.0f;
+    // every load is issued unconditionally on a clamped (always valid) element and masked afterwards: a load under a
+    // predicate becomes a branch with its own s_waitcnt, i.e. MAXV serialised memory round trips instead of MAXV in flight
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
-        const int e = threadIdx.x + j * NT;
-        xv[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        off[j] = 0;
-        if (e < total) {
-            const int b = e / per, q = e - b * per;
-            off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
-            xv[j] = x4[off[j]];
-            acc += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
-        }
+        const int e0 = threadIdx.x + j * NT;
+        const int e = e0 < total ? e0 : total - 1;
+        const int b = e / per, q = e - b * per;
+        off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
+        xv[j] = x4[off[j]];
+        if (RES) rv[j] = r4[off[j]];  // needed only by the last pass: its latency hides behind the statistics
+    }
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        if (static_cast<int>(threadIdx.x) + j * NT >= total) xv[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        acc += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
     }
     float mean, invstd;
     if (training) {
@@ -247,14 +252,13 @@ __global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restri
     }
     const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
     float4 *y4 = reinterpret_cast<float4 *>(y);
-    const float4 *r4 = reinterpret_cast<const float4 *>(res);
 #pragma unroll
     for (int j = 0; j < MAXV; ++j)
         if (static_cast<int>(threadIdx.x) + j * NT < total) {
             const float4 v = xv[j];
             float4 r = make_float4((v.x - mean) * a + b0, (v.y - mean) * a + b0, (v.z - mean) * a + b0, (v.w - mean) * a + b0);
             if (RES) {
-                const float4 q = r4[off[j]];
+                const float4 q = rv[j];
                 r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
             }
             if (RELU) {
@@ -281,29 +285,36 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
     float4 gv[MAXV], hv[MAXV];  // masked gradient dz and xhat
     unsigned off[MAXV];
     float sdz = 0.0f, sdzx = 0.0f;
+    // unconditional clamped loads first (all in flight together), masking second - see bn_fwd_cached_kernel
+    float4 yv[RELU ? MAXV : 1];
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
-        const int e = threadIdx.x + j * NT;
-        off[j] = 0;
-        gv[j] = hv[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (e < total) {
-            const int b = e / per, q = e - b * per;
-            off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
-            float4 g = dy4[off[j]];
-            if (RELU) {
-                const float4 yy = y4[off[j]];
-                g.x = yy.x > 0.0f ? g.x : 0.0f;
-                g.y = yy.y > 0.0f ? g.y : 0.0f;
-                g.z = yy.z > 0.0f ? g.z : 0.0f;
-                g.w = yy.w > 0.0f ? g.w : 0.0f;
-            }
-            const float4 v = x4[off[j]];
-            const float4 h = make_float4((v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd);
-            sdz += (g.x + g.y) + (g.z + g.w);
-            sdzx += (g.x * h.x + g.y * h.y) + (g.z * h.z + g.w * h.w);
-            gv[j] = g;
-            hv[j] = h;
+        const int e0 = threadIdx.x + j * NT;
+        const int e = e0 < total ? e0 : total - 1;
+        const int b = e / per, q = e - b * per;
+        off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
+        gv[j] = dy4[off[j]];
+        hv[j] = x4[off[j]];
+        if (RELU) yv[j] = y4[off[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const bool in = static_cast<int>(threadIdx.x) + j * NT < total;
+        float4 g = gv[j];
+        if (RELU) {
+            const float4 yy = yv[j];
+            g.x = yy.x > 0.0f ? g.x : 0.0f;
+            g.y = yy.y > 0.0f ? g.y : 0.0f;
+            g.z = yy.z > 0.0f ? g.z : 0.0f;
+            g.w = yy.w > 0.0f ? g.w : 0.0f;
         }
+        const float4 v = hv[j];
+        float4 h = make_float4((v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd);
+        if (!in) g = h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        sdz += (g.x + g.y) + (g.z + g.w);
+        sdzx += (g.x * h.x + g.y * h.y) + (g.z * h.z + g.w * h.w);
+        gv[j] = g;
+        hv[j] = h;
     }
     sdz = block_sum<NT>(sdz, scratch);
     sdzx = block_sum<NT>(sdzx, scratch);
@@ -381,12 +392,26 @@ __device__ __forceinline__ Slice my_slice(int total, int S, int s) {
     return {b < total ? b : total, e < total ? e : total};
 }
 
-template <class F>
-__device__ __forceinline__ void for_slice(const BnShape s, int c, Slice sl, F f) {
+// walks the slice four elements per lane at a time: `load` (memory only, no side effects) runs unconditionally on clamped
+// offsets for all four - four round trips in flight - and `use` then runs on the valid ones
+template <class L, class U>
+__device__ __forceinline__ void for_slice(const BnShape s, int c, Slice sl, L load, U use) {
     const int per = s.HW / 4;
-    for (int e = sl.begin + threadIdx.x; e < sl.end; e += SPLIT_NT) {
-        const int b = e / per, q = e - b * per;
-        f((static_cast<size_t>(b) * s.C + c) * per + q);
+    if (sl.end <= sl.begin) return;
+    for (int e0 = sl.begin + threadIdx.x; e0 < sl.end; e0 += 4 * SPLIT_NT) {
+        size_t off[4];
+        decltype(load(size_t{})) val[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e1 = e0 + u * SPLIT_NT;
+            const int e = e1 < sl.end ? e1 : sl.end - 1;
+            const int b = e / per, q = e - b * per;
+            off[u] = (static_cast<size_t>(b) * s.C + c) * per + q;
+            val[u] = load(off[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + u * SPLIT_NT < sl.end) use(val[u], off[u]);
     }
 }
 
@@ -397,16 +422,12 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_stats_kernel(const float *_
     const Slice sl = my_slice(s.B * (s.HW / 4), S, sl_i);
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     float acc = 0.0f;
-    for_slice(s, c, sl, [&](size_t o) {
-        const float4 v = x4[o];
-        acc += (v.x + v.y) + (v.z + v.w);
-    });
+    for_slice(s, c, sl, [&](size_t o) { return x4[o]; }, [&](float4 v, size_t) { acc += (v.x + v.y) + (v.z + v.w); });
     const float sum = block_sum<SPLIT_NT>(acc, scratch);
     const float cnt = 4.0f * static_cast<float>(sl.end - sl.begin);
     const float mean = cnt > 0.0f ? sum / cnt : 0.0f;
     float m2 = 0.0f;
-    for_slice(s, c, sl, [&](size_t o) {
-        const float4 v = x4[o];
+    for_slice(s, c, sl, [&](size_t o) { return x4[o]; }, [&](float4 v, size_t) {
         const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
         m2 += (a * a + b * b) + (cc * cc + d * d);
     });
@@ -458,11 +479,15 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_apply_kernel(const float *_
     const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
     const float4 *x4 = reinterpret_cast<const float4 *>(x), *r4 = reinterpret_cast<const float4 *>(res);
     float4 *y4 = reinterpret_cast<float4 *>(y);
-    for_slice(s, c, my_slice(total, S, sl_i), [&](size_t o) {
-        const float4 v = x4[o];
+    struct XR {
+        float4 x, r;
+    };
+    for_slice(s, c, my_slice(total, S, sl_i), [&](size_t o) { return XR{x4[o], RES ? r4[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f)}; },
+              [&](XR in, size_t o) {
+        const float4 v = in.x;
         float4 r = make_float4((v.x - mean) * a + b0, (v.y - mean) * a + b0, (v.z - mean) * a + b0, (v.w - mean) * a + b0);
         if (RES) {
-            const float4 q = r4[o];
+            const float4 q = in.r;
             r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
         }
         if (RELU) {
@@ -472,14 +497,20 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_apply_kernel(const float *_
     });
 }
 
-__device__ __forceinline__ float4 masked_dz(const float4 *dy4, const float4 *y4, size_t o, bool relu) {
-    float4 g = dy4[o];
+struct BwdIn {
+    float4 dy, y, x;
+};
+__device__ __forceinline__ BwdIn bwd_load(const float4 *dy4, const float4 *y4, const float4 *x4, size_t o, bool relu, bool want_x) {
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return BwdIn{dy4[o], relu ? y4[o] : z, want_x ? x4[o] : z};
+}
+__device__ __forceinline__ float4 masked_dz(const BwdIn &in, bool relu) {
+    float4 g = in.dy;
     if (relu) {
-        const float4 yy = y4[o];
-        g.x = yy.x > 0.0f ? g.x : 0.0f;
-        g.y = yy.y > 0.0f ? g.y : 0.0f;
-        g.z = yy.z > 0.0f ? g.z : 0.0f;
-        g.w = yy.w > 0.0f ? g.w : 0.0f;
+        g.x = in.y.x > 0.0f ? g.x : 0.0f;
+        g.y = in.y.y > 0.0f ? g.y : 0.0f;
+        g.z = in.y.z > 0.0f ? g.z : 0.0f;
+        g.w = in.y.w > 0.0f ? g.w : 0.0f;
     }
     return g;
 }
@@ -498,9 +529,9 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const fl
     const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
     const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
     float sdz = 0.0f, sdzx = 0.0f;
-    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) {
-        const float4 g = masked_dz(dy4, y4, o, RELU);
-        const float4 v = x4[o];
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, y4, x4, o, RELU, true); }, [&](BwdIn in, size_t) {
+        const float4 g = masked_dz(in, RELU);
+        const float4 v = in.x;
         sdz += (g.x + g.y) + (g.z + g.w);
         sdzx += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) + (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
     });
@@ -538,11 +569,12 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const floa
     const float m1 = training ? sdz / n : 0.0f, m2 = training ? sdzx / n : 0.0f;
     const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
     float4 *dx4 = reinterpret_cast<float4 *>(dx), *dr4 = reinterpret_cast<float4 *>(dres);
-    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) {
-        const float4 g = masked_dz(dy4, y4, o, RELU);
+    const bool want_x = dx != nullptr;
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, y4, x4, o, RELU, want_x); }, [&](BwdIn in, size_t o) {
+        const float4 g = masked_dz(in, RELU);
         if (dres) dr4[o] = g;
         if (dx) {
-            const float4 v = x4[o];
+            const float4 v = in.x;
             dx4[o] = make_float4(w * ((g.x - m1) - ((v.x - mean) * invstd) * m2), w * ((g.y - m1) - ((v.y - mean) * invstd) * m2),
                                  w * ((g.z - m1) - ((v.z - mean) * invstd) * m2), w * ((g.w - m1) - ((v.w - mean) * invstd) * m2));
         }
