@@ -368,3 +368,183 @@ EE_API int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float
     EE_LAUNCH(stem_bwd_data_mfma_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, as_stream(stream), dy, weight, dx, K, OH, OW, tiles_a, tiles_b);
     return launch_status();
 }
+
+// =====================================================================================================================
+// Conv2d(3x3, stride 1, padding 1, bias=False) of the residual blocks (Tiny_ImageNet/models_tinyimagenet/resnet.py:26-31),
+// forward and backward-data, as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32).
+//
+// Why: at the reference batch (100 x 64x64 images) the 64-channel 16x16 layers are 1.9 GFLOP each; MIOpen's best fp32
+// solver (Winograd F(2,3)) needs 36 us for them either way, i.e. ~30 % of the f32 matrix rate, and they are 8 of the
+// ~40 convolution launches of a PGD iteration.
+//
+//   D[rc][p] = sum_{kc, tap} A[rc][(kc, tap)] * Bm[(kc, tap)][p]
+//   forward : rc = output channel, kc = input channel,  A = W[rc][kc][tap],      Bm = x [n, kc, h+kh-1, w+kw-1]
+//   backward: rc = input channel,  kc = output channel, A = W[kc][rc][8 - tap],  Bm = dy[n, kc, h+kh-1, w+kw-1]
+//
+// A workgroup (4 wavefronts) owns 64 result channels x 64 pixels = (64 / W) whole rows of the (image, row) sequence; per
+// round 16 reduction channels: their weights in LDS as [kc][tap][65] (result channel fastest: conflict-free operand reads)
+// and a zero-bordered frame [kc][rows + 2][W + 2].  One MFMA step takes the two channels 2c, 2c+1 (lane halves) at one tap.
+// The next round's operands are requested from global memory before this round's MFMAs (registers), so one L2 round trip
+// overlaps one round of multiplies.  Measured (rocprofv3, B=100): 64ch 16x16 31 us forward / 34 us backward (MIOpen 36);
+// 128ch 8x8 37 / 40 us (MIOpen 30-36: not used there).  An 8-channel round was latency-bound at every barrier (37 / 46 us);
+// a prefetch distance of two rounds needs 299 VGPRs and loses the second workgroup per CU (36-43 us).
+// =====================================================================================================================
+namespace {
+
+constexpr int C3_CK = 16, C3_WS = 65;
+
+struct Conv3Dims {
+    int B, KC, RC, H, W;  // reduction channels, result channels
+};
+
+template <bool BWD, int TW>
+__global__ __launch_bounds__(256) void conv3x3s1_kernel(const float *__restrict__ in, const float *__restrict__ w, float *__restrict__ out,
+                                                        Conv3Dims d) {
+    constexpr int PR = 64 / TW;                   // rows of the tile
+    constexpr int FRW = TW + 2, FRH = PR + 2;     // frame
+    constexpr int WTOT = C3_CK * 9 * 64, FTOT = C3_CK * FRH * FRW;
+    constexpr int WPT = WTOT / 256, FPT = (FTOT + 255) / 256;  // elements staged per thread and round
+    static_assert(WTOT % 256 == 0, "weight tile must divide over the workgroup");
+    __shared__ float ws[C3_CK * 9 * C3_WS];       // [kc][tap][result channel (+1 pad)]
+    __shared__ float fr[FTOT];                    // [kc][frame row][frame col]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int rt = wave >> 1, pt = wave & 1;      // result-channel tile and pixel tile of this wavefront
+    const int rc_base = static_cast<int>(blockIdx.y) * 64;
+    const int g0 = static_cast<int>(blockIdx.x) * PR;  // first (image, row) of the tile
+    const int rows_total = d.B * d.H;
+    // this lane's pixel (B-operand column)
+    const int pj = pt * 32 + i;
+    const int rj = pj / TW, wj = pj - rj * TW;
+    const int gj = g0 + rj;
+    const bool pv = gj < rows_total;
+    const int nj = pv ? gj / d.H : 0, hj = pv ? gj - nj * d.H : 0;
+    const bool top = hj == 0, bot = hj == d.H - 1;
+    const float *bbase = fr + kk * (FRH * FRW) + rj * FRW + wj;
+    const float *abase = ws + kk * (9 * C3_WS) + rt * 32 + i;
+    const size_t plane = static_cast<size_t>(d.H) * TW;
+
+    // ---- staging roles, fixed per thread: 32-bit element offsets relative to the round's first reduction channel ---------
+    // weights: global reads run along (kc, tap) (forward) or (rc, tap) (backward), both contiguous.  KC % 16 == 0 and
+    // RC % 64 == 0 are guaranteed by the launcher, so no load needs a predicate (a predicated load is a branch: it would
+    // serialise the round trips) and the per-round address update is one add of a wave-uniform stride.
+    unsigned wsrc[WPT], wdst[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        int kc, t, rl, tf;
+        if (!BWD) {
+            rl = idx / (C3_CK * 9);
+            const int rem = idx - rl * (C3_CK * 9);
+            kc = rem / 9;
+            t = tf = rem - kc * 9;
+        } else {
+            kc = idx / (64 * 9);
+            const int rem = idx - kc * (64 * 9);
+            rl = rem / 9;
+            tf = rem - rl * 9;
+            t = 8 - tf;
+        }
+        const int rc = rc_base + rl;
+        wsrc[j] = static_cast<unsigned>(BWD ? (kc * d.RC + rc) * 9 + tf : (rc * d.KC + kc) * 9 + tf);
+        wdst[j] = static_cast<unsigned>((kc * 9 + t) * C3_WS + rl);
+    }
+    unsigned fsrc[FPT];
+    bool fok[FPT];
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        const int fc = idx % FRW, tq = idx / FRW;
+        const int frow = tq % FRH, kc = idx < FTOT ? tq / FRH : 0;
+        const int g = g0 - 1 + frow, c = fc - 1;
+        fok[j] = idx < FTOT && g >= 0 && g < rows_total && c >= 0 && c < TW;
+        const int gc = fok[j] ? g : 0, cc = fok[j] ? c : 0;
+        const int n = gc / d.H, h = gc - n * d.H;
+        fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(plane) + h * TW + cc);
+    }
+    const unsigned wstep = static_cast<unsigned>(BWD ? C3_CK * d.RC * 9 : C3_CK * 9), fstep = static_cast<unsigned>(C3_CK * plane);
+    float wv[WPT], fv[FPT];
+    auto prefetch = [&](unsigned round) {
+        const unsigned wo = round * wstep, fo = round * fstep;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) wv[j] = w[wsrc[j] + wo];
+#pragma unroll
+        for (int j = 0; j < FPT; ++j) fv[j] = in[fsrc[j] + fo];
+    };
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned rounds = static_cast<unsigned>(d.KC / C3_CK);
+    prefetch(0);
+    for (unsigned round = 0; round < rounds; ++round) {
+        __syncthreads();  // the previous round's MFMAs have read their operands
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) ws[wdst[j]] = wv[j];
+#pragma unroll
+        for (int j = 0; j < FPT; ++j)
+            if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;
+        __syncthreads();
+        if (round + 1 < rounds) prefetch(round + 1);  // next round's operands travel while this round multiplies
+        // operands of half a round into registers first (LDS reads in flight together), then the MFMAs back to back
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float av[C3_CK / 4 * 9], bv[C3_CK / 4 * 9];
+#pragma unroll
+            for (int c2 = 0; c2 < C3_CK / 4; ++c2) {
+                const float *ap = abase + (half * (C3_CK / 4) + c2) * (2 * 9 * C3_WS);
+                const float *bp = bbase + (half * (C3_CK / 4) + c2) * (2 * FRH * FRW);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        av[c2 * 9 + kh * 3 + kw] = ap[(kh * 3 + kw) * C3_WS];
+                        float b = bp[kh * FRW + kw];
+                        if (kh == 0 && top) b = 0.0f;  // the frame row above belongs to the previous image
+                        if (kh == 2 && bot) b = 0.0f;
+                        bv[c2 * 9 + kh * 3 + kw] = b;
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < C3_CK / 4 * 9; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+        }
+    }
+    if (!pv) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rc = rc_base + rt * 32 + acc_row(r, lane);
+        out[(static_cast<size_t>(nj) * d.RC + rc) * plane + static_cast<size_t>(hj) * TW + wj] = acc[r];
+    }
+}
+
+template <bool BWD>
+int conv3_launch(const float *in, const float *w, float *out, int B, int KC, int RC, int H, int W, hipStream_t st) {
+    if (B < 0 || KC < 1 || RC < 1 || H < 1 || W < 1) return EE_ERR_SHAPE;
+    if (W > 64 || 64 % W != 0 || KC % C3_CK != 0 || RC % 64 != 0) return EE_ERR_UNSUPPORTED;
+    if (B == 0) return EE_OK;
+    if (!in || !w || !out) return EE_ERR_NULL;
+    const int PR = 64 / W;
+    const int64_t rows = static_cast<int64_t>(B) * H;
+    const int64_t gx = (rows + PR - 1) / PR;
+    if (gx > 0x7fffffffLL) return EE_ERR_SHAPE;
+    if (static_cast<int64_t>(B) * KC * H * W > 0x7fffffffLL || static_cast<int64_t>(KC) * RC * 9 > 0x7fffffffLL) return EE_ERR_SHAPE;  // 32-bit offsets
+    const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(RC / 64)), block(256);
+    const Conv3Dims dims{B, KC, RC, H, W};
+    switch (W) {
+        case 64: EE_LAUNCH((conv3x3s1_kernel<BWD, 64>), grid, block, 0, st, in, w, out, dims); break;
+        case 32: EE_LAUNCH((conv3x3s1_kernel<BWD, 32>), grid, block, 0, st, in, w, out, dims); break;
+        case 16: EE_LAUNCH((conv3x3s1_kernel<BWD, 16>), grid, block, 0, st, in, w, out, dims); break;
+        case 8: EE_LAUNCH((conv3x3s1_kernel<BWD, 8>), grid, block, 0, st, in, w, out, dims); break;
+        case 4: EE_LAUNCH((conv3x3s1_kernel<BWD, 4>), grid, block, 0, st, in, w, out, dims); break;
+        case 2: EE_LAUNCH((conv3x3s1_kernel<BWD, 2>), grid, block, 0, st, in, w, out, dims); break;
+        default: EE_LAUNCH((conv3x3s1_kernel<BWD, 1>), grid, block, 0, st, in, w, out, dims); break;
+    }
+    return launch_status();
+}
+
+}  // namespace
+
+EE_API int ee_conv3x3s1_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream) {
+    return conv3_launch<false>(x, weight, y, B, Cin, Cout, H, W, as_stream(stream));
+}
+
+EE_API int ee_conv3x3s1_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W, void *stream) {
+    return conv3_launch<true>(dy, weight, dx, B, Cout, Cin, H, W, as_stream(stream));
+}

@@ -197,6 +197,26 @@ class Conv1x1S2Fn(torch.autograd.Function):
         return dx, dw
 
 
+class Conv3x3Fn(torch.autograd.Function):
+    """Conv2d(3x3, stride 1, padding 1, bias=False) (resnet.py:26-31): forward and backward-data on ee_conv.hip's f32-MFMA
+    implicit GEMM, the weight gradient (once per training step) on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return ops.conv3x3s1_fwd(x, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.conv3x3s1_bwd_data(dy, weight) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw
+
+
 class StemConvFn(torch.autograd.Function):
     """The stem Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (resnet.py:112-113): forward and weight gradient on MIOpen,
     the gradient with respect to the image - what the attack loop is after - on ee_conv.hip."""

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops
-from .functional import BnActFn, Conv1x1S2Fn, Conv3x3Map2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import BnActFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -54,9 +54,12 @@ def bn_act(bn, x, residual=None, relu=True):
     return F.relu(out) if relu else out
 
 
-# EEADV_STOCK_GLUE=bn,pool,head,conv,stem,dense (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
+# EEADV_STOCK_GLUE=bn,pool,head,conv,stem,dense,conv3 (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
 # ee_bn.hip / ee_pool.hip / ee_head.hip / ee_conv.hip: an A/B switch for measurements, never needed for correctness.
 _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") if t)
+
+
+_CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "16"))  # narrowest map the MFMA 3x3 convolution takes (measured: pays at 16, not at 8)
 
 
 def _dense_f32(x):
@@ -104,6 +107,11 @@ def conv3(conv, x):
             and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"):
         return Conv3x3Map2Fn.apply(x, conv.weight)
+    if ("conv3" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.padding_mode == "zeros" and _CONV3_MINW <= x.shape[3] <= 64 and 64 % x.shape[3] == 0
+            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.weight.is_contiguous()):
+        return Conv3x3Fn.apply(x, conv.weight)  # 16x16 / 8x8 maps: implicit GEMM on the f32 matrix cores (ee_conv.hip)
     return conv(x)
 
 

@@ -272,6 +272,14 @@ int ee_maxpool3s2_bwd_f32(const float *dy, const uint8_t *code, float *dx, int p
 int ee_conv1x1s2_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream);
 int ee_conv1x1s2_bwd_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W, void *stream);
 
+/* Conv2d(Cin, Cout, kernel_size=3, stride=1, padding=1, bias=False) of the residual blocks (resnet.py:26-31), forward and
+ * backward-data, as an implicit GEMM on the exact-f32 matrix cores.  x / dx [B,Cin,H,W], y / dy [B,Cout,H,W], weight
+ * [Cout,Cin,3,3].  W must divide 64, the reduction channel count (Cin forward, Cout backward) be a multiple of 16 and the
+ * result channel count a multiple of 64 (EE_ERR_UNSUPPORTED otherwise: every ResNet stage qualifies both ways).  The weight gradient is not provided. */
+int ee_conv3x3s1_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream);
+int ee_conv3x3s1_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W,
+                              void *stream);
+
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.
  *   dy [B,K,H/2,W/2], weight [K,3,7,7] -> dx [B,3,H,W];  H, W even. */

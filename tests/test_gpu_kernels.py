@@ -603,3 +603,22 @@ def test_conv3x3_on_2x2_map_as_dense_product(ops, B, Cin, Cout):
         EF.refresh_dense_weights()
         gph.replay()
         torch.testing.assert_close(out, F.conv2d(xs, w, None, 1, 1), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(100, 64, 64, 16, 16), (100, 128, 128, 8, 8), (100, 256, 256, 4, 4), (3, 64, 128, 5, 8),
+                                            (2, 128, 64, 3, 2), (1, 64, 64, 1, 1), (2, 64, 64, 56, 32), (5, 64, 192, 7, 64)])
+def test_conv3x3s1_mfma_matches_aten(ops, B, Cin, Cout, H, W):
+    """The residual blocks' 3x3 convolution (resnet.py:26-31) as an implicit GEMM on the f32 matrix cores vs ATen: forward,
+    input gradient, and (through ATen) weight gradient; tiles that span image boundaries included (W = 4, 2, 1)."""
+    import torch.nn.functional as F
+    from eeadv.functional import Conv3x3Fn
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
+    ref = F.conv2d(x, w, None, 1, 1)
+    got = Conv3x3Fn.apply(x, w)
+    dy = torch.randn(ref.shape, generator=g).to(DEV)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
+    torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W) ** 0.5)
