@@ -59,7 +59,9 @@ def bn_act(bn, x, residual=None, relu=True):
 _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") if t)
 
 
-_CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "16"))  # narrowest map the MFMA 3x3 convolution takes (measured: pays at 16, not at 8)
+# ee_conv.hip's f32-MFMA 3x3 convolution is opt-in (EEADV_CONV3_MINW=16 takes maps 16..64 wide): measured equal to MIOpen's
+# Winograd on 16x16 maps and slower on 8x8, so the stock solver stays the default
+_CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "1000"))
 
 
 def _dense_f32(x):
