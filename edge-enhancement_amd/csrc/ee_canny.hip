@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void canny_fwd_kernel(CannyParams cp, Weigh
         dirs[threadIdx.x] = cd.dr[threadIdx.x];
         dirs[8 + threadIdx.x] = cd.dc[threadIdx.x];
     }
-    load_frame<FH, FW, 4>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, 4, vec);
+    load_frame<FH, FW, 4, C>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, 4, vec);
     for (int idx = threadIdx.x; idx < 3 * PL / 4; idx += kBlock) reinterpret_cast<float4 *>(magAs)[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
 
@@ -241,14 +241,18 @@ __global__ __launch_bounds__(kBlock) void canny_bwd_kernel(CannyParams cp, Weigh
 
     float4 gin[FUSED ? C : 1];
     uchar4 gtv[FUSED ? C : 1];
-    if (FUSED && live) {
+    if (FUSED && vec) {  // unconditional on clamped (always valid) addresses: the loads batch with the frame's; dead lanes never store
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const size_t o = ((static_cast<size_t>(n) * C + c) * H + (ti < H ? ti : H - 1)) * W + clamp_col4(tjb, W);
+            gin[c] = *reinterpret_cast<const float4 *>(p.g_in + o);
+            gtv[c] = *reinterpret_cast<const uchar4 *>(p.gate_in + o);
+        }
+    } else if (FUSED && live) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const size_t o = ((static_cast<size_t>(n) * C + c) * H + ti) * W + tjb;
-            if (vec) {
-                gin[c] = *reinterpret_cast<const float4 *>(p.g_in + o);
-                gtv[c] = *reinterpret_cast<const uchar4 *>(p.gate_in + o);
-            } else {
+            {
                 float gv[4] = {0, 0, 0, 0};
                 unsigned char tv[4] = {0, 0, 0, 0};
                 for (int k = 0; k < 4 && tjb + k < W; ++k) {
@@ -264,11 +268,11 @@ __global__ __launch_bounds__(kBlock) void canny_bwd_kernel(CannyParams cp, Weigh
         dirs[threadIdx.x] = cd.dr[threadIdx.x];
         dirs[8 + threadIdx.x] = cd.dc[threadIdx.x];
     }
-    load_frame<FH, FW, CH_>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, RH_, vec);
+    load_frame<FH, FW, CH_, C>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, RH_, vec);
     if (FUSED)
         load_u_fused<C, FH, FW>(us, p.g_in, p.gate_in, n, H, W, oi, oj, p.w, vec);
     else
-        load_frame<FH, FW, CH_>(us, p.u + static_cast<size_t>(n) * H * W, 1, H, W, i0, j0, RH_, vec);
+        load_frame<FH, FW, CH_, 1>(us, p.u + static_cast<size_t>(n) * H * W, 1, H, W, i0, j0, RH_, vec);
     for (int idx = threadIdx.x; idx < 4 * PL / 4; idx += kBlock) reinterpret_cast<float4 *>(gx1s)[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
 

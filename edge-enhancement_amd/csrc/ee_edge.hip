@@ -40,13 +40,15 @@ __global__ __launch_bounds__(kBlock) void edge_fwd_kernel(EdgeParams p, Weights 
 
     // low-pass branch values for this lane's pixels: issued before the barrier so the latency overlaps the stencil
     float4 xh[C];
-    if (FUSED && live) {
+    if (FUSED && vec) {  // unconditional on clamped addresses (dead lanes never store): no branch, the loads batch
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            xh[c] = *reinterpret_cast<const float4 *>(p.x_hfs + ((static_cast<size_t>(n) * C + c) * H + (i < H ? i : H - 1)) * W + clamp_col4(jb, W));
+    } else if (FUSED && live) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float *src = p.x_hfs + ((static_cast<size_t>(n) * C + c) * H + i) * W + jb;
-            if (vec) {
-                xh[c] = *reinterpret_cast<const float4 *>(src);
-            } else {
+            {
                 xh[c].x = src[0];
                 xh[c].y = (jb + 1 < W) ? src[1] : 0.0f;
                 xh[c].z = (jb + 2 < W) ? src[2] : 0.0f;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void edge_fwd_kernel(EdgeParams p, Weights 
             }
         }
     }
-    load_frame<FH, FW>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, 2, vec);
+    load_frame<FH, FW, kColHalo, C>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, 2, vec);
     __syncthreads();
     if (!live) return;
 
@@ -136,14 +138,18 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_kernel(EdgeParams p, Weights 
     // ---- stage 1 -------------------------------------------------------------------------------------
     float4 gin[FUSED ? C : 1];
     uchar4 gtv[FUSED ? C : 1];
-    if (FUSED && live) {
+    if (FUSED && vec) {  // unconditional on clamped (always valid) addresses: the loads batch with the frame's; dead lanes never store
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const size_t o = ((static_cast<size_t>(n) * C + c) * H + (ti < H ? ti : H - 1)) * W + clamp_col4(tjb, W);
+            gin[c] = *reinterpret_cast<const float4 *>(p.g_in + o);
+            gtv[c] = *reinterpret_cast<const uchar4 *>(p.gate_in + o);
+        }
+    } else if (FUSED && live) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const size_t o = ((static_cast<size_t>(n) * C + c) * H + ti) * W + tjb;
-            if (vec) {
-                gin[c] = *reinterpret_cast<const float4 *>(p.g_in + o);
-                gtv[c] = *reinterpret_cast<const uchar4 *>(p.gate_in + o);
-            } else {
+            {
                 float gv[4] = {0, 0, 0, 0};
                 unsigned char tv[4] = {0, 0, 0, 0};
                 for (int k = 0; k < 4 && tjb + k < W; ++k) {
@@ -155,11 +161,11 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_kernel(EdgeParams p, Weights 
             }
         }
     }
-    load_frame<FH, FW>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, 4, vec);
+    load_frame<FH, FW, kColHalo, C>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, 4, vec);
     if (FUSED) {
         load_u_fused<C, FH, FW>(us, p.g_in, p.gate_in, n, H, W, oi, oj, p.w, vec);
     } else {
-        load_frame<FH, FW>(us, p.u + static_cast<size_t>(n) * H * W, 1, H, W, i0, j0, 4, vec);
+        load_frame<FH, FW, kColHalo, 1>(us, p.u + static_cast<size_t>(n) * H * W, 1, H, W, i0, j0, 4, vec);
     }
     // gg / gb planes start as zeros: a cell outside the image, or outside the range a stage fills, then reads as
     // "contributes nothing" and the transposed correlations below need no per-tap bounds test

@@ -45,10 +45,42 @@ __device__ __forceinline__ void edge_from_sums(float ax, float ay, float alpha, 
 
 // frame[c][r][s] = src(c, clamp(i0 - hr + r), clamp(j0 - COLH + s)),  r < FH, s < FW (FW % 4 == 0); planes of `src`
 // are H*W apart.  16-B loads wherever a whole float4 lies inside the image.
-template <int FH, int FW, int COLH = kColHalo>
+// replicate-padded float4 at columns gj .. gj+3 of a row whose width is a multiple of 4 (gj a multiple of 4): ONE aligned,
+// always in-bounds 16-B load plus selects - a whole float4 left of the image is row[0] four times, right of it row[W-1]
+__device__ __forceinline__ int clamp_col4(int gj, int W) { return gj < 0 ? 0 : (gj > W - 4 ? W - 4 : gj); }
+__device__ __forceinline__ float4 replicate4(float4 v, int gj, int W) {
+    if (gj < 0) v = make_float4(v.x, v.x, v.x, v.x);
+    if (gj >= W) v = make_float4(v.w, v.w, v.w, v.w);
+    return v;
+}
+
+template <int FH, int FW, int COLH = kColHalo, int PLANES = 0>
 __device__ __forceinline__ void load_frame(float *frame, const float *__restrict__ src, int planes, int H, int W, int i0, int j0,
                                            int hr, bool vec) {
     constexpr int F4 = FW / 4;
+    if (PLANES > 0 && vec) {
+        // every lane's loads are issued back to back on clamped addresses (no predicate: a predicated load is a branch
+        // with its own wait, and the frame would cost one memory round trip per iteration instead of one in total)
+        constexpr int TOTAL = PLANES * FH * F4, PER = (TOTAL + kBlock - 1) / kBlock;
+        float4 v[PER];
+        int gjs[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx0 = threadIdx.x + q * kBlock;
+            const int idx = idx0 < TOTAL ? idx0 : TOTAL - 1;
+            const int c = idx / (FH * F4), rem = idx - c * (FH * F4);
+            const int r = rem / F4, f = rem - r * F4;
+            const int gi = clampi(i0 - hr + r, 0, H - 1);
+            gjs[q] = j0 - COLH + 4 * f;
+            v[q] = *reinterpret_cast<const float4 *>(src + (static_cast<size_t>(c) * H + gi) * W + clamp_col4(gjs[q], W));
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = threadIdx.x + q * kBlock;
+            if (idx < TOTAL) *reinterpret_cast<float4 *>(frame + idx * 4) = replicate4(v[q], gjs[q], W);
+        }
+        return;
+    }
     const int total = planes * FH * F4;
     for (int idx = threadIdx.x; idx < total; idx += kBlock) {
         const int c = idx / (FH * F4), rem = idx - c * (FH * F4);
@@ -75,6 +107,38 @@ template <int C, int FH, int FW>
 __device__ __forceinline__ void load_u_fused(float *us, const float *__restrict__ g_in, const uint8_t *__restrict__ gate, int n, int H, int W,
                                              int oi, int oj, float w, bool vec) {
     constexpr int F4 = FW / 4;
+    if (vec) {
+        constexpr int TOTAL = FH * F4, PER = (TOTAL + kBlock - 1) / kBlock;
+        float4 g4[PER][C];
+        uchar4 t4[PER][C];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx0 = threadIdx.x + q * kBlock;
+            const int idx = idx0 < TOTAL ? idx0 : TOTAL - 1;
+            const int r = idx / F4, f = idx - r * F4;
+            const int gi = clampi(oi + r, 0, H - 1), gj = clamp_col4(oj + 4 * f, W);  // columns outside the image are never used
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const size_t o = ((static_cast<size_t>(n) * C + c) * H + gi) * W + gj;
+                g4[q][c] = *reinterpret_cast<const float4 *>(g_in + o);
+                t4[q][c] = *reinterpret_cast<const uchar4 *>(gate + o);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = threadIdx.x + q * kBlock;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float v[4] = {t4[q][c].x ? g4[q][c].x : 0.0f, t4[q][c].y ? g4[q][c].y : 0.0f, t4[q][c].z ? g4[q][c].z : 0.0f,
+                                    t4[q][c].w ? g4[q][c].w : 0.0f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = (c == 0) ? v[k] : acc[k] + v[k];
+            }
+            if (idx < TOTAL) *reinterpret_cast<float4 *>(us + idx * 4) = make_float4(acc[0] * w, acc[1] * w, acc[2] * w, acc[3] * w);
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < FH * F4; idx += kBlock) {
         const int r = idx / F4, f = idx - r * F4;
         const int gi = clampi(oi + r, 0, H - 1), gj = oj + 4 * f;
@@ -83,19 +147,10 @@ __device__ __forceinline__ void load_u_fused(float *us, const float *__restrict_
         for (int c = 0; c < C; ++c) {
             const size_t o = ((static_cast<size_t>(n) * C + c) * H + gi) * W;
             float v[4];
-            if (vec && gj >= 0 && gj + 3 < W) {
-                const float4 g4 = *reinterpret_cast<const float4 *>(g_in + o + gj);
-                const uchar4 t4 = *reinterpret_cast<const uchar4 *>(gate + o + gj);
-                v[0] = t4.x ? g4.x : 0.0f;
-                v[1] = t4.y ? g4.y : 0.0f;
-                v[2] = t4.z ? g4.z : 0.0f;
-                v[3] = t4.w ? g4.w : 0.0f;
-            } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int cj = clampi(gj + k, 0, W - 1);
-                    v[k] = gate[o + cj] ? g_in[o + cj] : 0.0f;
-                }
+            for (int k = 0; k < 4; ++k) {
+                const int cj = clampi(gj + k, 0, W - 1);
+                v[k] = gate[o + cj] ? g_in[o + cj] : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] = (c == 0) ? v[k] : acc[k] + v[k];
