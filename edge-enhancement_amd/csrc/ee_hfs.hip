@@ -90,10 +90,68 @@ __global__ __launch_bounds__(kBlock) void hfs_kernel(const float *__restrict__ i
 
     // ---- load: tables (contiguous block of the device buffer, same layout as LDS from cwT to dv) and the plane -----
     const int ntab = L.m1T - L.cwT;  // multiple of 4; hipMalloc'd tables and the LDS offset are 16-B aligned
-    for (int i = threadIdx.x; i < ntab / 4; i += kBlock)
-        reinterpret_cast<float4 *>(lds + L.cwT)[i] = reinterpret_cast<const float4 *>(tables)[i];
     const int XS = L.xs, HS = L.hs;
     const bool vec_in = ((W & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    // compile-time shapes: every global load of the kernel (tables, plane, stripe; for SQ == 2 also the operands of the
+    // output stage) is issued here, unconditionally and back to back, so the whole kernel pays ONE memory round trip; with
+    // loops of predicated loads each iteration waited for its own (rocprofv3: 17.8 / 19.7 us per launch before)
+    constexpr bool FAST = HS_ > 0 && (WS_ % 4) == 0;
+    constexpr int cW4 = FAST ? WS_ / 4 : 1, cH = FAST ? HS_ : 1;
+    constexpr int cWp = (WS_ + 3) & ~3, cHp = (HS_ + 3) & ~3;
+    constexpr int cNTAB4 = FAST ? (2 * NVS_ * cWp + 2 * NUS_ * (cHp + 4) + 2 * HS_ * NUS_ + NVS_) / 4 : 1;
+    constexpr int PER_T = (cNTAB4 + kBlock - 1) / kBlock, PER_P = (cH * cW4 + kBlock - 1) / kBlock;
+    const bool fast = FAST && vec_in && (SQ == 0 || ((reinterpret_cast<uintptr_t>(stripe_row) & 15u) == 0)) &&
+                      (SQ != 2 || ((reinterpret_cast<uintptr_t>(sq_x) & 15u) == 0));
+    float4 o_x[SQ == 2 ? PER_P : 1], o_s[SQ == 2 ? PER_P : 1];  // SQ == 2: x and stripe at this lane's output positions
+    if (fast) {
+        float4 tv[PER_T], pv[PER_P], sv[SQ == 1 ? PER_P : 1];
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) {
+            const int i0 = threadIdx.x + q * kBlock;
+            tv[q] = reinterpret_cast<const float4 *>(tables)[i0 < cNTAB4 ? i0 : cNTAB4 - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < PER_P; ++q) {
+            const int i0 = threadIdx.x + q * kBlock;
+            const int i = i0 < cH * cW4 ? i0 : cH * cW4 - 1;
+            const int h = i / cW4, w0 = 4 * (i - h * cW4);
+            pv[q] = *reinterpret_cast<const float4 *>(src + h * W + w0);
+            if (SQ == 1) sv[q] = *reinterpret_cast<const float4 *>(stripe_row + w0);
+            if (SQ == 2) {
+                o_x[q] = *reinterpret_cast<const float4 *>(sq_x + static_cast<size_t>(plane) * H * W + h * W + w0);
+                o_s[q] = *reinterpret_cast<const float4 *>(stripe_row + w0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) {
+            const int i0 = threadIdx.x + q * kBlock;
+            if (i0 < cNTAB4) reinterpret_cast<float4 *>(lds + L.cwT)[i0] = tv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < PER_P; ++q) {
+            const int i0 = threadIdx.x + q * kBlock;
+            if (i0 < cH * cW4) {
+                const int h = i0 / cW4, w0 = 4 * (i0 - h * cW4);
+                float v[4] = {pv[q].x, pv[q].y, pv[q].z, pv[q].w};
+                if (SQ == 1) {
+                    const float st[4] = {sv[q].x, sv[q].y, sv[q].z, sv[q].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float dd;
+                        v[k] = square_elem<false>(sq, pl, v[k], st[k], c, h, w0 + k, dd);
+                    }
+                }
+                *reinterpret_cast<float4 *>(sx + h * XS + w0) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        // padding columns [W, XS) of every row read as zeros
+        for (int i = threadIdx.x; i < H * ((XS - W) / 4); i += kBlock) {
+            const int h = i / ((XS - W) / 4), w0 = W + 4 * (i - h * ((XS - W) / 4));
+            *reinterpret_cast<float4 *>(sx + h * XS + w0) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    } else {
+    for (int i = threadIdx.x; i < ntab / 4; i += kBlock)
+        reinterpret_cast<float4 *>(lds + L.cwT)[i] = reinterpret_cast<const float4 *>(tables)[i];
     for (int i = threadIdx.x; i < H * (XS / 4); i += kBlock) {
         const int h = i / (XS / 4), w0 = 4 * (i - h * (XS / 4));
         float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -114,6 +172,7 @@ __global__ __launch_bounds__(kBlock) void hfs_kernel(const float *__restrict__ i
                 }
         }
         *reinterpret_cast<float4 *>(sx + h * XS + w0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
     }
     __syncthreads();
 
@@ -194,7 +253,8 @@ __global__ __launch_bounds__(kBlock) void hfs_kernel(const float *__restrict__ i
     float *dst = out + static_cast<size_t>(plane) * H * W;
     const float *xo = (SQ == 2) ? sq_x + static_cast<size_t>(plane) * H * W : nullptr;
     const int W4 = Wp / 4;
-    for (int i = threadIdx.x; i < H * W4; i += kBlock) {
+    int oq = 0;  // fast path: W4 == W / 4, so this loop walks exactly the positions the prologue preloaded
+    for (int i = threadIdx.x; i < H * W4; i += kBlock, ++oq) {
         const int h = i / W4, w0 = 4 * (i - h * W4);
         float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll 8
@@ -206,7 +266,22 @@ __global__ __launch_bounds__(kBlock) void hfs_kernel(const float *__restrict__ i
             acc.x = fmaf(vv, s4.x, acc.x); acc.y = fmaf(vv, s4.y, acc.y); acc.z = fmaf(vv, s4.z, acc.z); acc.w = fmaf(vv, s4.w, acc.w);
         }
         float r[4] = {acc.x, acc.y, acc.z, acc.w};
-        if (SQ == 2) {
+        if (SQ == 2 && fast) {
+            float4 ox = o_x[0], os = o_s[0];
+#pragma unroll
+            for (int q = 1; q < PER_P; ++q)
+                if (oq == q) {
+                    ox = o_x[q];
+                    os = o_s[q];
+                }
+            const float xv[4] = {ox.x, ox.y, ox.z, ox.w}, st[4] = {os.x, os.y, os.z, os.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float dd = 0.0f;
+                (void)square_elem<true>(sq, pl, xv[k], st[k], c, h, w0 + k, dd);
+                r[k] = r[k] * dd;
+            }
+        } else if (SQ == 2) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (w0 + k < W) {
