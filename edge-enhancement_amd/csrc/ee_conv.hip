@@ -548,3 +548,139 @@ EE_API int ee_conv3x3s1_fwd_f32(const float *x, const float *weight, float *y, i
 EE_API int ee_conv3x3s1_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W, void *stream) {
     return conv3_launch<true>(dy, weight, dx, B, Cout, Cin, H, W, as_stream(stream));
 }
+
+// =====================================================================================================================
+// Conv2d(3x3, stride 2, padding 1, bias=False) - the first convolution of layers 2-4 (resnet.py:26-31 with stride 2),
+// forward, on the same f32-MFMA implicit GEMM.  0.94 GFLOP at the reference batch, for which MIOpen's solvers need ~50 us
+// (Winograd-stride2) or an NHWC implicit GEMM wrapped in three layout transposes and a zero fill.
+//   y[n,co,oh,ow] = sum_{ci,kh,kw} W[co][ci][kh][kw] * x[n, ci, 2oh-1+kh, 2ow-1+kw]
+// H even, so input row (n, 2oh-1+kh) is row 2g-1+kh of the flattened (image, row) sequence for output row g = n*OH + oh: a
+// tile of 64 / OW consecutive output rows reads 2*PR + 1 consecutive input rows, whatever images it spans; only the row above
+// an image's first row has to be masked (the column left of the image is a zero column of the frame).
+// =====================================================================================================================
+namespace {
+
+template <int TOW>
+__global__ __launch_bounds__(256) void conv3x3s2_fwd_kernel(const float *__restrict__ in, const float *__restrict__ w, float *__restrict__ out,
+                                                            Conv3Dims d) {  // d.H, d.W: INPUT size; KC = Cin, RC = Cout
+    constexpr int PR = 64 / TOW;                       // output rows of the tile
+    constexpr int FRH = 2 * PR + 1, FRW = 2 * TOW + 2;  // frame: input rows 2g0-1 .. 2(g0+PR)-1, columns -1 .. W-1 (+1 pad)
+    constexpr int TWI = 2 * TOW;                        // input width
+    constexpr int WTOT = C3_CK * 9 * 64, FTOT = C3_CK * FRH * FRW;
+    constexpr int WPT = WTOT / 256, FPT = (FTOT + 255) / 256;
+    __shared__ float ws[C3_CK * 9 * C3_WS];
+    __shared__ float fr[FTOT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int rt = wave >> 1, pt = wave & 1;
+    const int rc_base = static_cast<int>(blockIdx.y) * 64;
+    const int OH = d.H / 2;
+    const int g0 = static_cast<int>(blockIdx.x) * PR;   // first output (image, row)
+    const int orows_total = d.B * OH, irows_total = d.B * d.H;
+    const int pj = pt * 32 + i;
+    const int rj = pj / TOW, wj = pj - rj * TOW;
+    const int gj = g0 + rj;
+    const bool pv = gj < orows_total;
+    const int nj = pv ? gj / OH : 0, ohj = pv ? gj - nj * OH : 0;
+    const bool top = ohj == 0;
+    const float *bbase = fr + kk * (FRH * FRW) + (2 * rj) * FRW + 2 * wj;
+    const float *abase = ws + kk * (9 * C3_WS) + rt * 32 + i;
+    const size_t iplane = static_cast<size_t>(d.H) * TWI, oplane = static_cast<size_t>(OH) * TOW;
+
+    unsigned wsrc[WPT], wdst[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        const int rl = idx / (C3_CK * 9), rem = idx - rl * (C3_CK * 9);
+        const int kc = rem / 9, t = rem - kc * 9;
+        wsrc[j] = static_cast<unsigned>(((rc_base + rl) * d.KC + kc) * 9 + t);
+        wdst[j] = static_cast<unsigned>((kc * 9 + t) * C3_WS + rl);
+    }
+    unsigned fsrc[FPT];
+    bool fok[FPT];
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        const int fc = idx % FRW, tq = idx / FRW;
+        const int frow = tq % FRH, kc = idx < FTOT ? tq / FRH : 0;
+        const int g = 2 * g0 - 1 + frow, c = fc - 1;
+        fok[j] = idx < FTOT && g >= 0 && g < irows_total && c >= 0 && c < TWI;
+        const int gc = fok[j] ? g : 0, cc = fok[j] ? c : 0;
+        const int n = gc / d.H, h = gc - n * d.H;
+        fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(iplane) + h * TWI + cc);
+    }
+    const unsigned wstep = static_cast<unsigned>(C3_CK * 9), fstep = static_cast<unsigned>(C3_CK * iplane);
+    float wv[WPT], fv[FPT];
+    auto prefetch = [&](unsigned round) {
+        const unsigned wo = round * wstep, fo = round * fstep;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) wv[j] = w[wsrc[j] + wo];
+#pragma unroll
+        for (int j = 0; j < FPT; ++j) fv[j] = in[fsrc[j] + fo];
+    };
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned rounds = static_cast<unsigned>(d.KC / C3_CK);
+    prefetch(0);
+    for (unsigned round = 0; round < rounds; ++round) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) ws[wdst[j]] = wv[j];
+#pragma unroll
+        for (int j = 0; j < FPT; ++j)
+            if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;
+        __syncthreads();
+        if (round + 1 < rounds) prefetch(round + 1);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float av[C3_CK / 4 * 9], bv[C3_CK / 4 * 9];
+#pragma unroll
+            for (int c2 = 0; c2 < C3_CK / 4; ++c2) {
+                const float *ap = abase + (half * (C3_CK / 4) + c2) * (2 * 9 * C3_WS);
+                const float *bp = bbase + (half * (C3_CK / 4) + c2) * (2 * FRH * FRW);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        av[c2 * 9 + kh * 3 + kw] = ap[(kh * 3 + kw) * C3_WS];
+                        float b = bp[kh * FRW + kw];
+                        if (kh == 0 && top) b = 0.0f;  // the input row above an image's first row belongs to the previous image
+                        bv[c2 * 9 + kh * 3 + kw] = b;
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < C3_CK / 4 * 9; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+        }
+    }
+    if (!pv) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rc = rc_base + rt * 32 + acc_row(r, lane);
+        out[(static_cast<size_t>(nj) * d.RC + rc) * oplane + static_cast<size_t>(ohj) * TOW + wj] = acc[r];
+    }
+}
+
+}  // namespace
+
+EE_API int ee_conv3x3s2_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream) {
+    if (B < 0 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return EE_ERR_SHAPE;
+    const int OW = W / 2;
+    if ((H & 1) || (W & 1) || OW > 64 || 64 % OW != 0 || Cin % C3_CK != 0 || Cout % 64 != 0) return EE_ERR_UNSUPPORTED;
+    if (B == 0) return EE_OK;
+    if (!x || !weight || !y) return EE_ERR_NULL;
+    if (static_cast<int64_t>(B) * Cin * H * W > 0x7fffffffLL || static_cast<int64_t>(Cin) * Cout * 9 > 0x7fffffffLL) return EE_ERR_SHAPE;
+    const int PR = 64 / OW;
+    const int64_t orows = static_cast<int64_t>(B) * (H / 2);
+    const dim3 grid(static_cast<unsigned>((orows + PR - 1) / PR), static_cast<unsigned>(Cout / 64)), block(256);
+    const Conv3Dims dims{B, Cin, Cout, H, W};
+    hipStream_t st = as_stream(stream);
+    switch (OW) {
+        case 64: EE_LAUNCH((conv3x3s2_fwd_kernel<64>), grid, block, 0, st, x, weight, y, dims); break;
+        case 32: EE_LAUNCH((conv3x3s2_fwd_kernel<32>), grid, block, 0, st, x, weight, y, dims); break;
+        case 16: EE_LAUNCH((conv3x3s2_fwd_kernel<16>), grid, block, 0, st, x, weight, y, dims); break;
+        case 8: EE_LAUNCH((conv3x3s2_fwd_kernel<8>), grid, block, 0, st, x, weight, y, dims); break;
+        case 4: EE_LAUNCH((conv3x3s2_fwd_kernel<4>), grid, block, 0, st, x, weight, y, dims); break;
+        case 2: EE_LAUNCH((conv3x3s2_fwd_kernel<2>), grid, block, 0, st, x, weight, y, dims); break;
+        default: EE_LAUNCH((conv3x3s2_fwd_kernel<1>), grid, block, 0, st, x, weight, y, dims); break;
+    }
+    return launch_status();
+}

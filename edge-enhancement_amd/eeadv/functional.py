@@ -217,6 +217,25 @@ class Conv3x3Fn(torch.autograd.Function):
         return dx, dw
 
 
+class Conv3x3S2Fn(torch.autograd.Function):
+    """Conv2d(3x3, stride 2, padding 1, bias=False), the first convolution of ResNet layers 2-4: forward on ee_conv.hip's
+    f32-MFMA implicit GEMM; backward-data and weight gradient on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return ops.conv3x3s2_fwd(x, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        want_w = ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], want_w, False])
+        return dx, dw
+
+
 class StemConvFn(torch.autograd.Function):
     """The stem Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (resnet.py:112-113): forward and weight gradient on MIOpen,
     the gradient with respect to the image - what the attack loop is after - on ee_conv.hip."""

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops
-from .functional import BnActFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import BnActFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -62,6 +62,7 @@ _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") 
 # ee_conv.hip's f32-MFMA 3x3 convolution is opt-in (EEADV_CONV3_MINW=16 takes maps 16..64 wide): measured equal to MIOpen's
 # Winograd on 16x16 maps and slower on 8x8, so the stock solver stays the default
 _CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "1000"))
+_CONV3S2_MINOW = int(os.environ.get("EEADV_CONV3S2_MINOW", "8"))  # narrowest OUTPUT map the stride-2 MFMA convolution takes (24 us vs 50 at 8; no gain at 4)
 
 
 def _dense_f32(x):
@@ -109,6 +110,11 @@ def conv3(conv, x):
             and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"):
         return Conv3x3Map2Fn.apply(x, conv.weight)
+    if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.padding_mode == "zeros" and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and _CONV3S2_MINOW <= x.shape[3] // 2 <= 64
+            and 64 % (x.shape[3] // 2) == 0 and conv.in_channels % 16 == 0 and conv.out_channels % 64 == 0 and conv.weight.is_contiguous()):
+        return Conv3x3S2Fn.apply(x, conv.weight)
     if ("conv3" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
             and conv.padding_mode == "zeros" and _CONV3_MINW <= x.shape[3] <= 64 and 64 % x.shape[3] == 0

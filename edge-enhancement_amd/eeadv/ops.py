@@ -521,6 +521,16 @@ def conv3x3s1_bwd_data(dy, weight):
     return dx
 
 
+def conv3x3s2_fwd(x, weight):
+    """Conv2d(Cin, Cout, 3, stride 2, padding 1, bias=False) forward on ee_conv.hip's implicit GEMM."""
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    y = torch.empty((B, Cout, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_conv3x3s2_fwd_f32(_chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight", (Cout, Cin, 3, 3)), y.data_ptr(), B,
+                                       Cin, Cout, H, W, _stream()), "ee_conv3x3s2_fwd_f32")
+    return y
+
+
 def stem7x7s2_bwd_data(dy, weight, H, W):
     """d loss / d image through Conv2d(3, K, 7, stride 2, padding 3) (resnet.py:112): dy [B,K,H/2,W/2] -> [B,3,H,W]."""
     B, K = dy.shape[0], dy.shape[1]

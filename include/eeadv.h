@@ -280,6 +280,10 @@ int ee_conv3x3s1_fwd_f32(const float *x, const float *weight, float *y, int B, i
 int ee_conv3x3s1_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W,
                               void *stream);
 
+/* Conv2d(Cin, Cout, kernel_size=3, stride=2, padding=1, bias=False) - the first convolution of ResNet layers 2-4 - forward:
+ * x [B,Cin,H,W] -> y [B,Cout,H/2,W/2].  H, W even, W/2 divides 64, Cin % 16 == 0, Cout % 64 == 0 (else EE_ERR_UNSUPPORTED). */
+int ee_conv3x3s2_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream);
+
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.
  *   dy [B,K,H/2,W/2], weight [K,3,7,7] -> dx [B,3,H,W];  H, W even. */

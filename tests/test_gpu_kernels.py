@@ -622,3 +622,21 @@ def test_conv3x3s1_mfma_matches_aten(ops, B, Cin, Cout, H, W):
     (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
     torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W) ** 0.5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(100, 64, 128, 16, 16), (100, 128, 256, 8, 8), (100, 256, 512, 4, 4), (3, 16, 64, 6, 8),
+                                            (2, 32, 128, 2, 2), (2, 64, 64, 56, 64), (5, 16, 192, 10, 128)])
+def test_conv3x3s2_mfma_matches_aten(ops, B, Cin, Cout, H, W):
+    """The stride-2 3x3 convolution opening ResNet layers 2-4 as an implicit GEMM on the f32 matrix cores vs ATen."""
+    import torch.nn.functional as F
+    from eeadv.functional import Conv3x3S2Fn
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
+    ref = F.conv2d(x, w, None, 2, 1)
+    got = Conv3x3S2Fn.apply(x, w)
+    dy = torch.randn(ref.shape, generator=g).to(DEV)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
+    torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)
