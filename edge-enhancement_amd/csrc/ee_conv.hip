@@ -171,84 +171,14 @@ EE_API int ee_conv1x1s2_bwd_f32(const float *dy, const float *weight, float *dx,
 //
 // dx[n,c,2a+ph,2b+pw] = sum_k sum_{u,v} dy[n,k,a-1+u,b-1+v] * W[k,c,r(ph,u),s(pw,v)],  r(0,u) = 5-2u (u < 3), r(1,u) = 6-2u (u < 4)
 // i.e. a 4x4-window correlation on the dy grid producing the 2x2x3 = 12 values of one input cell: one lane per cell, 12
-// accumulators, the 16 window values from LDS, and the 147 weights of one k as wave-uniform scalar operands (the loop index
-// is the only variable part of their address, so they are scalar loads, not vector traffic): 147 FMAs per 16 LDS reads.
-// Measured (rocprofv3, [100,64,32,32]): 97 us.  Two variants were slower and are not kept: forcing one v_fmac per weight
-// with the scalar as an operand (112 us: the 37 KB of weights miss the scalar cache and nothing hides the s_load
-// latency) and weights staged in LDS as broadcast reads (130 us: VALU moves to build packed operands).  The next step is
-// the 16x16x4 f32 MFMA form (12 of 16 columns used, K = 64*16), estimated at ~45 us - DESIGN.md.
+// accumulators - which is a GEMM with 12 of 16 columns used.  History (rocprofv3, [100,64,32,32]): VALU version with the
+// 147 weights of one k as wave-uniform scalar operands 97 us; one v_fmac per weight forced 112 us (37 KB of weights miss the
+// scalar cache); weights as LDS broadcast reads 130 us; the MFMA form below 45 us.
 // =====================================================================================================================
 namespace {
 
-constexpr int ST_TA = 8, ST_TB = 32, ST_KC = 16;  // dy-grid tile (rows x cols) and channels staged per round
-constexpr int ST_FH = ST_TA + 3, ST_FW = ST_TB + 4;  // frame: rows a-1 .. a+TA+1, cols b-1 .. b+TB+1 (+1 pad)
+constexpr int ST_TA = 8, ST_TB = 32;  // dy-grid tile (rows x cols) of one workgroup
 
-__global__ __launch_bounds__(ST_TA *ST_TB) void stem_bwd_data_kernel(const float *__restrict__ dy, const float *__restrict__ w,
-                                                                      float *__restrict__ dx, int K, int OH, int OW, int tiles_a, int tiles_b) {
-    __shared__ float fr[ST_KC][ST_FH][ST_FW];
-    const int tb = threadIdx.x % ST_TB, ta = threadIdx.x / ST_TB;
-    int bid = blockIdx.x;
-    const int tjb = bid % tiles_b;
-    bid /= tiles_b;
-    const int tia = bid % tiles_a;
-    const int n = bid / tiles_a;
-    const int a0 = tia * ST_TA, b0 = tjb * ST_TB;
-    const int a = a0 + ta, b = b0 + tb;
-    float acc[2][2][3];
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-        for (int pw = 0; pw < 2; ++pw)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[ph][pw][c] = 0.0f;
-    const float *dyn = dy + static_cast<size_t>(n) * K * OH * OW;
-    for (int kc = 0; kc < K; kc += ST_KC) {
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < ST_KC * ST_FH * ST_FW; idx += ST_TA * ST_TB) {
-            const int fc = idx % ST_FW, t = idx / ST_FW;
-            const int frow = t % ST_FH, k = t / ST_FH;
-            const int i = a0 - 1 + frow, j = b0 - 1 + fc;
-            float v = 0.0f;
-            if (kc + k < K && i >= 0 && i < OH && j >= 0 && j < OW) v = dyn[(static_cast<size_t>(kc + k) * OH + i) * OW + j];
-            fr[k][frow][fc] = v;
-        }
-        __syncthreads();
-        const int kn = (K - kc) < ST_KC ? (K - kc) : ST_KC;
-        for (int k = 0; k < kn; ++k) {
-            const float *wk = w + static_cast<size_t>(kc + k) * 147;  // W[k][c][r][s], wave-uniform
-            float win[4][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) win[u][v] = fr[k][ta + u][tb + v];
-#pragma unroll
-            for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-                for (int u = 0; u < 3 + ph; ++u) {
-                    const int r = 5 + ph - 2 * u;
-#pragma unroll
-                    for (int pw = 0; pw < 2; ++pw)
-#pragma unroll
-                        for (int v = 0; v < 3 + pw; ++v) {
-                            const int s = 5 + pw - 2 * v;
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) acc[ph][pw][c] = fmaf(win[u][v], wk[c * 49 + r * 7 + s], acc[ph][pw][c]);
-                        }
-                }
-        }
-    }
-    if (a >= OH || b >= OW) return;
-    const int H = 2 * OH, W = 2 * OW;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph)
-            *reinterpret_cast<float2 *>(dx + ((static_cast<size_t>(n) * 3 + c) * H + 2 * a + ph) * W + 2 * b) =
-                make_float2(acc[ph][0][c], acc[ph][1][c]);
-}
-
-
-// ---- the same product on the exact-f32 matrix cores -------------------------------------------------------------------------
 // D[pixel][j] with j = (ph*2 + pw)*3 + c (12 of 16 columns used), K = (channel, u, v): one v_mfma_f32_16x16x4_f32 covers the four
 // v of one (channel, u) for 16 neighbouring cells of a dy row.  A workgroup (4 wavefronts) owns 8 x 32 cells = 16 M-tiles,
 // four per wavefront; per round 16 channels of the dy frame and their rearranged weights W'[ch][u][v][j] (zero where the
@@ -502,6 +432,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const float *__restrict_
                         bv[c2 * 9 + kh * 3 + kw] = b;
                     }
             }
+            // (two accumulator chains change nothing: the stalls counted by SQ_WAIT_INST_ANY are the MFMA issue cadence itself)
 #pragma unroll
             for (int q = 0; q < C3_CK / 4 * 9; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
         }
