@@ -321,7 +321,7 @@ EE_API int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float
 // =====================================================================================================================
 namespace {
 
-constexpr int C3_CK = 16, C3_WS = 65;
+constexpr int C3_CK = 16, C3_WS = 66;  // 66: the four weight-staging sub-roles of a wavefront land on disjoint bank groups
 
 struct Conv3Dims {
     int B, KC, RC, H, W;  // reduction channels, result channels
@@ -358,27 +358,12 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const float *__restrict_
     // weights: global reads run along (kc, tap) (forward) or (rc, tap) (backward), both contiguous.  KC % 16 == 0 and
     // RC % 64 == 0 are guaranteed by the launcher, so no load needs a predicate (a predicated load is a branch: it would
     // serialise the round trips) and the per-round address update is one add of a wave-uniform stride.
-    unsigned wsrc[WPT], wdst[WPT];
-#pragma unroll
-    for (int j = 0; j < WPT; ++j) {
-        const int idx = threadIdx.x + j * 256;
-        int kc, t, rl, tf;
-        if (!BWD) {
-            rl = idx / (C3_CK * 9);
-            const int rem = idx - rl * (C3_CK * 9);
-            kc = rem / 9;
-            t = tf = rem - kc * 9;
-        } else {
-            kc = idx / (64 * 9);
-            const int rem = idx - kc * (64 * 9);
-            rl = rem / 9;
-            tf = rem - rl * 9;
-            t = 8 - tf;
-        }
-        const int rc = rc_base + rl;
-        wsrc[j] = static_cast<unsigned>(BWD ? (kc * d.RC + rc) * 9 + tf : (rc * d.KC + kc) * 9 + tf);
-        wdst[j] = static_cast<unsigned>((kc * 9 + t) * C3_WS + rl);
-    }
+    // weights: each thread owns 36 CONTIGUOUS floats of the round (9 x 16-B loads, no index arithmetic per element):
+    //   forward : result channel rl = tid / 4, reduction channels 4*(tid % 4) .. +3, all 9 taps   (W[rc][kc][tap] is contiguous in kc, tap)
+    //   backward: reduction channel kc = tid / 16, result channels 4*(tid % 16) .. +3, all 9 taps (W[kc][rc][tap] is contiguous in rc, tap)
+    static_assert(WPT == 36 && C3_CK == 16, "the weight roles below assume 16-channel rounds");
+    const int wq = BWD ? (threadIdx.x >> 4) : (threadIdx.x >> 2), wp = BWD ? (threadIdx.x & 15) : (threadIdx.x & 3);
+    const unsigned wsrc0 = static_cast<unsigned>(BWD ? (wq * d.RC + rc_base + 4 * wp) * 9 : ((rc_base + wq) * d.KC + 4 * wp) * 9);
     unsigned fsrc[FPT];
     bool fok[FPT];
 #pragma unroll
@@ -393,11 +378,12 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const float *__restrict_
         fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(plane) + h * TW + cc);
     }
     const unsigned wstep = static_cast<unsigned>(BWD ? C3_CK * d.RC * 9 : C3_CK * 9), fstep = static_cast<unsigned>(C3_CK * plane);
-    float wv[WPT], fv[FPT];
+    float4 wv4[WPT / 4];
+    float fv[FPT];
     auto prefetch = [&](unsigned round) {
         const unsigned wo = round * wstep, fo = round * fstep;
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) wv[j] = w[wsrc[j] + wo];
+        for (int j = 0; j < WPT / 4; ++j) wv4[j] = *reinterpret_cast<const float4 *>(w + wsrc0 + wo + 4 * j);
 #pragma unroll
         for (int j = 0; j < FPT; ++j) fv[j] = in[fsrc[j] + fo];
     };
@@ -407,7 +393,15 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const float *__restrict_
     for (unsigned round = 0; round < rounds; ++round) {
         __syncthreads();  // the previous round's MFMAs have read their operands
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) ws[wdst[j]] = wv[j];
+        for (int j = 0; j < WPT / 4; ++j) {
+            const float v4[4] = {wv4[j].x, wv4[j].y, wv4[j].z, wv4[j].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * j + u;  // element e of the thread's 36: (sub-channel e / 9, tap e % 9), compile-time
+                if (!BWD) ws[((wp * 4 + e / 9) * 9 + e % 9) * C3_WS + wq] = v4[u];
+                else ws[(wq * 9 + 8 - e % 9) * C3_WS + 4 * wp + e / 9] = v4[u];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < FPT; ++j)
             if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;

@@ -59,9 +59,9 @@ def bn_act(bn, x, residual=None, relu=True):
 _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") if t)
 
 
-# ee_conv.hip's f32-MFMA 3x3 convolution is opt-in (EEADV_CONV3_MINW=16 takes maps 16..64 wide): measured equal to MIOpen's
-# Winograd on 16x16 maps and slower on 8x8, so the stock solver stays the default
-_CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "1000"))
+# ee_conv.hip's f32-MFMA 3x3 convolution takes maps 16..64 wide (29 us against 36 us for MIOpen's Winograd on the 64-channel
+# 16x16 layer; equal on 8x8, where the stock solver stays)
+_CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "16"))
 _CONV3S2_MINOW = int(os.environ.get("EEADV_CONV3S2_MINOW", "8"))  # narrowest OUTPUT map the stride-2 MFMA convolution takes (24 us vs 50 at 8; no gain at 4)
 
 
