@@ -19,6 +19,9 @@ from . import ops
 from .functional import input_grad_only, refresh_dense_weights
 
 CE_SUM, CE_MEAN, KL, SOFTCE = "ce_sum", "ce_mean", "kl", "softce"
+# the input-gradient pass runs on the calling thread: handing it to autograd's device thread puts cross-thread stream
+# synchronisation into the captured graph (a 40 us idle gap in front of the first backward kernel of every iteration)
+_MT_BACKWARD = os.environ.get("EEADV_MT_BACKWARD", "0") == "1"
 
 
 class LossSpec:
@@ -55,7 +58,7 @@ def input_gradient(model, x, spec):
     with torch.enable_grad():
         logits = model(x)
     d = spec.dlogits(logits.contiguous())
-    with input_grad_only():
+    with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
         (g,) = torch.autograd.grad(logits, [x], grad_outputs=d)
     return g
 
@@ -71,7 +74,7 @@ def attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi):
         with torch.enable_grad():
             logits = model.body(x_in)
         d = spec.dlogits(logits.contiguous())
-        with input_grad_only():
+        with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
             (g_in,) = torch.autograd.grad(logits, [x_in], grad_outputs=d)
         with torch.no_grad():
             g_lp, g_edge = model.front_manual_backward(g_in.contiguous(), ctx)
