@@ -205,6 +205,9 @@ def run(spec, build_model, argv=None):
     if use_cuda:
         torch.cuda.set_device(ddp.local_rank())
         device = torch.device("cuda", ddp.local_rank())
+        # the attack iteration and the parameter update replay captured HIP graphs unless the user says otherwise: eagerly
+        # the loop is bound by the host (one launch per ~10 us of Python + ctypes), 3-4x slower than the device can go
+        os.environ.setdefault("EEADV_GRAPH", "1")
     else:
         device = torch.device("cpu")
         runtime.allow_cpu_plumbing(True)  # --no-cuda: torch-op plumbing run on the host (BASELINE config 1)
