@@ -512,15 +512,10 @@ __global__ __launch_bounds__(256) void conv3x3s2_fwd_kernel(const float *__restr
     const float *abase = ws + kk * (9 * C3_WS) + rt * 32 + i;
     const size_t iplane = static_cast<size_t>(d.H) * TWI, oplane = static_cast<size_t>(OH) * TOW;
 
-    unsigned wsrc[WPT], wdst[WPT];
-#pragma unroll
-    for (int j = 0; j < WPT; ++j) {
-        const int idx = threadIdx.x + j * 256;
-        const int rl = idx / (C3_CK * 9), rem = idx - rl * (C3_CK * 9);
-        const int kc = rem / 9, t = rem - kc * 9;
-        wsrc[j] = static_cast<unsigned>(((rc_base + rl) * d.KC + kc) * 9 + t);
-        wdst[j] = static_cast<unsigned>((kc * 9 + t) * C3_WS + rl);
-    }
+    // weights: thread = (result channel tid / 4, reduction channels 4*(tid % 4) .. +3, all taps) = 36 contiguous floats, 9 x 16-B loads
+    static_assert(WPT == 36 && C3_CK == 16, "the weight roles below assume 16-channel rounds");
+    const int wq = threadIdx.x >> 2, wp = threadIdx.x & 3;
+    const unsigned wsrc0 = static_cast<unsigned>(((rc_base + wq) * d.KC + 4 * wp) * 9);
     unsigned fsrc[FPT];
     bool fok[FPT];
 #pragma unroll
@@ -535,11 +530,12 @@ __global__ __launch_bounds__(256) void conv3x3s2_fwd_kernel(const float *__restr
         fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(iplane) + h * TWI + cc);
     }
     const unsigned wstep = static_cast<unsigned>(C3_CK * 9), fstep = static_cast<unsigned>(C3_CK * iplane);
-    float wv[WPT], fv[FPT];
+    float4 wv4[WPT / 4];
+    float fv[FPT];
     auto prefetch = [&](unsigned round) {
         const unsigned wo = round * wstep, fo = round * fstep;
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) wv[j] = w[wsrc[j] + wo];
+        for (int j = 0; j < WPT / 4; ++j) wv4[j] = *reinterpret_cast<const float4 *>(w + wsrc0 + wo + 4 * j);
 #pragma unroll
         for (int j = 0; j < FPT; ++j) fv[j] = in[fsrc[j] + fo];
     };
@@ -549,7 +545,14 @@ __global__ __launch_bounds__(256) void conv3x3s2_fwd_kernel(const float *__restr
     for (unsigned round = 0; round < rounds; ++round) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) ws[wdst[j]] = wv[j];
+        for (int j = 0; j < WPT / 4; ++j) {
+            const float v4[4] = {wv4[j].x, wv4[j].y, wv4[j].z, wv4[j].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * j + u;
+                ws[((wp * 4 + e / 9) * 9 + e % 9) * C3_WS + wq] = v4[u];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < FPT; ++j)
             if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;
