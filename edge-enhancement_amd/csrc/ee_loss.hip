@@ -219,9 +219,9 @@ inline unsigned row_grid(int B) { return static_cast<unsigned>((B + kRowsPerBloc
 
 EE_API int ee_ce_f32(const float *logits, const int64_t *labels, int B, int K, float smoothing, float gscale, double *row_loss,
                      float *dlogits, void *stream) {
-    if (!logits || !labels) return EE_ERR_NULL;
     if (B < 0 || K < 1 || K > 65536 || (smoothing != 0.0f && K < 2)) return EE_ERR_SHAPE;
-    if (B == 0) return EE_OK;
+    if (B == 0) return EE_OK;  // an empty batch has no storage: its NULL pointers are not an error
+    if (!logits || !labels) return EE_ERR_NULL;
     ProfScope prof(EE_K_CE, as_stream(stream));
     EE_LAUNCH(ce_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), logits, labels, B, K, smoothing, gscale,
                        row_loss, dlogits);
@@ -230,18 +230,18 @@ EE_API int ee_ce_f32(const float *logits, const int64_t *labels, int B, int K, f
 
 EE_API int ee_kl_f32(const float *zq, const float *zp, int B, int K, float gscale, double *row_loss, float *dzq, float *dzp,
                      void *stream) {
-    if (!zq || !zp) return EE_ERR_NULL;
     if (B < 0 || K < 1 || K > 65536) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
+    if (!zq || !zp) return EE_ERR_NULL;
     EE_LAUNCH(kl_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), zq, zp, B, K, gscale, row_loss, dzq, dzp);
     return launch_status();
 }
 
 EE_API int ee_softce_f64(const float *z, const double *t, int B, int K, double gscale, double *row_loss, double *dz,
                          void *stream) {
-    if (!z || !t) return EE_ERR_NULL;
     if (B < 0 || K < 1 || K > 65536) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
+    if (!z || !t) return EE_ERR_NULL;
     EE_LAUNCH(softce_kernel, dim3(row_grid(B)), dim3(kBlock), 0, as_stream(stream), z, t, B, K, gscale, row_loss, dz);
     return launch_status();
 }
@@ -249,25 +249,25 @@ EE_API int ee_softce_f64(const float *z, const double *t, int B, int K, double g
 EE_API int64_t ee_mse_num_partials(int64_t n) { return n <= 0 ? 0 : (n + kMseChunk - 1) / kMseChunk; }
 
 EE_API int ee_mse_f32(const float *a, const float *b, int64_t n, float gscale, double *partial, float *da, void *stream) {
-    if (!a || !b) return EE_ERR_NULL;
     if (n < 0 || ee_mse_num_partials(n) > 0x7fffffffLL) return EE_ERR_SHAPE;
     if (n == 0) return EE_OK;
+    if (!a || !b) return EE_ERR_NULL;
     EE_LAUNCH(mse_kernel, dim3(static_cast<unsigned>(ee_mse_num_partials(n))), dim3(kBlock), 0, as_stream(stream), a, b, n,
                        gscale, partial, da);
     return launch_status();
 }
 
 EE_API int ee_reduce_rows_f64(const double *rows, int64_t n, double scale, double *out, void *stream) {
-    if (!rows || !out) return EE_ERR_NULL;
     if (n < 0) return EE_ERR_SHAPE;
+    if (!out || (n > 0 && !rows)) return EE_ERR_NULL;
     EE_LAUNCH(reduce_rows_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), rows, n, scale, out);
     return launch_status();
 }
 
 EE_API int ee_topk_i64(const float *logits, const int64_t *labels, int B, int K, int k, int64_t *idx, int64_t *correct,
                        void *stream) {
-    if (!logits || !idx) return EE_ERR_NULL;
     if (B < 0 || K < 1 || k < 1 || k > kMaxTopK || k > K) return EE_ERR_SHAPE;
+    if (B > 0 && (!logits || !idx)) return EE_ERR_NULL;
     if (correct) {
         hipError_t e = hipMemsetAsync(correct, 0, sizeof(int64_t) * k, as_stream(stream));
         if (e != hipSuccess) return static_cast<int>(e);

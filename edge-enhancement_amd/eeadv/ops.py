@@ -278,6 +278,11 @@ def canny_frontend_bwd(g_in, gate, x, wts, alpha, low, high, w):
 
 
 # ---- losses ------------------------------------------------------------------------------------------------------
+def _inv(n):
+    """1/n with torch's semantics for an empty reduction: the mean of nothing is NaN (0 * NaN in the reduce kernel)."""
+    return 1.0 / n if n else float("nan")
+
+
 def _reduce_rows(rows, scale):
     out = torch.empty(1, dtype=torch.float64, device=rows.device)
     N.check(N.lib.ee_reduce_rows_f64(_chk(rows, torch.float64, "rows"), rows.numel(), scale, _chk(out, torch.float64, "out"),
@@ -290,7 +295,7 @@ def ce(logits, labels, reduction="mean", smoothing=0.0, want_loss=True, want_gra
     B, K = logits.shape
     pz = _chk(logits, torch.float32, "logits")
     py = _chk(labels, torch.int64, "labels", (B,))
-    gscale = 1.0 / B if reduction == "mean" else 1.0
+    gscale = _inv(B) if reduction == "mean" else 1.0
     rows = torch.empty(B, dtype=torch.float64, device=logits.device) if want_loss else None
     d = torch.empty_like(logits) if want_grad else None
     N.check(N.lib.ee_ce_f32(pz, py, B, K, smoothing, gscale, _opt(rows, torch.float64, "rows"), _opt(d, torch.float32, "d"),
@@ -306,9 +311,9 @@ def kl_batchmean(zq, zp, want_loss=True, want_dq=True, want_dp=False):
     rows = torch.empty(B, dtype=torch.float64, device=zq.device) if want_loss else None
     dq = torch.empty_like(zq) if want_dq else None
     dp = torch.empty_like(zq) if want_dp else None
-    N.check(N.lib.ee_kl_f32(pq, pp, B, K, 1.0 / B, _opt(rows, torch.float64, "rows"), _opt(dq, torch.float32, "dq"),
+    N.check(N.lib.ee_kl_f32(pq, pp, B, K, _inv(B), _opt(rows, torch.float64, "rows"), _opt(dq, torch.float32, "dq"),
                             _opt(dp, torch.float32, "dp"), _stream()), "ee_kl_f32")
-    loss = _reduce_rows(rows, 1.0 / B)[0].to(torch.float32) if want_loss else None
+    loss = _reduce_rows(rows, _inv(B))[0].to(torch.float32) if want_loss else None
     return loss, dq, dp
 
 
@@ -332,9 +337,9 @@ def mse(a, b, want_loss=True, want_grad=True):
     nb = N.lib.ee_mse_num_partials(n)
     part = torch.empty(nb, dtype=torch.float64, device=a.device) if want_loss else None
     da = torch.empty_like(a) if want_grad else None
-    N.check(N.lib.ee_mse_f32(pa, pb, n, 2.0 / n, _opt(part, torch.float64, "part"), _opt(da, torch.float32, "da"), _stream()),
+    N.check(N.lib.ee_mse_f32(pa, pb, n, 2.0 * _inv(n), _opt(part, torch.float64, "part"), _opt(da, torch.float32, "da"), _stream()),
             "ee_mse_f32")
-    loss = _reduce_rows(part, 1.0 / n)[0].to(torch.float32) if want_loss else None
+    loss = _reduce_rows(part, _inv(n))[0].to(torch.float32) if want_loss else None
     return loss, da
 
 
