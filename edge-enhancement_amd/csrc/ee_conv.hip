@@ -612,3 +612,155 @@ EE_API int ee_conv3x3s2_fwd_f32(const float *x, const float *weight, float *y, i
     }
     return launch_status();
 }
+
+// =====================================================================================================================
+// Backward-data of the stride-2 3x3 convolution, on the dy grid (MIOpen: Winograd-dilation 52 us, or an NHWC implicit GEMM
+// plus three transposes and a zero fill, for 0.94 GFLOP).
+//   dx[n,ci,2a+ph,2b+pw] = sum_{co,u,v} dy[n,co,a+u,b+v] * W[co,ci,kh(ph,u),kw(pw,v)],   (ph,u) -> kh: (0,0)->1, (1,0)->2, (1,1)->0
+// i.e. every dy cell (a,b) produces the 2x2 input cell above it from the 2x2 window of dy cells at (a..a+1, b..b+1): a GEMM
+// D[(ci,ph,pw)][cell] with K = (co,u,v), 9 of every 16 weight entries non-zero (the zero ones are written once).  Rows are
+// ordered ci*4 + ph*2 + pw, so the four accumulator registers r..r+3 of a lane are the 2x2 cell of one input channel and
+// leave as two 8-byte stores.  Workgroup: 16 input channels x 64 cells, 32 output channels per round.
+// =====================================================================================================================
+namespace {
+
+constexpr int S2B_CK = 32;  // output channels (reduction) per round
+
+template <int TOW>
+__global__ __launch_bounds__(256) void conv3x3s2_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ w, float *__restrict__ dx,
+                                                            Conv3Dims d) {  // d.H, d.W: size of dx; KC = Cout, RC = Cin
+    constexpr int PR = 64 / TOW;
+    constexpr int FRH = PR + 1, FRW = TOW + 2;  // cells a .. a+PR, b .. b+TOW (+1 pad)
+    constexpr int FTOT = S2B_CK * FRH * FRW, FPT = (FTOT + 255) / 256;
+    constexpr int WROW = 66;
+    __shared__ float ws[S2B_CK * 4 * WROW];  // [kc][t = u*2+v][row = ci_l*4 + ph*2 + pw]
+    __shared__ float fr[FTOT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int rt = wave >> 1, pt = wave & 1;
+    const int ci_base = static_cast<int>(blockIdx.y) * 16;
+    const int OH = d.H / 2;
+    const int g0 = static_cast<int>(blockIdx.x) * PR;
+    const int rows_total = d.B * OH;
+    const int pj = pt * 32 + i;
+    const int rj = pj / TOW, wj = pj - rj * TOW;
+    const int gj = g0 + rj;
+    const bool pv = gj < rows_total;
+    const int nj = pv ? gj / OH : 0, aj = pv ? gj - nj * OH : 0;
+    const bool last_row = aj == OH - 1;
+    const float *bbase = fr + kk * (FRH * FRW) + rj * FRW + wj;
+    const float *abase = ws + kk * (4 * WROW) + rt * 32 + i;
+    const size_t oplane = static_cast<size_t>(OH) * TOW;
+
+    for (int idx = threadIdx.x; idx < S2B_CK * 4 * WROW; idx += 256) ws[idx] = 0.0f;  // the structural zeros, once
+
+    // weights: 32 co x 16 ci pairs per round, two pairs per thread, the nine taps of a pair are contiguous
+    unsigned wsrc[2], wdst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pair = threadIdx.x + j * 256;
+        const int kc = pair >> 4, cl = pair & 15;
+        wsrc[j] = static_cast<unsigned>((kc * d.RC + ci_base + cl) * 9);
+        wdst[j] = static_cast<unsigned>(kc * 4 * WROW + cl * 4);
+    }
+    unsigned fsrc[FPT];
+    bool fok[FPT];
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        const int fc = idx % FRW, tq = idx / FRW;
+        const int frow = tq % FRH, kc = idx < FTOT ? tq / FRH : 0;
+        const int g = g0 + frow;
+        fok[j] = idx < FTOT && g < rows_total && fc < TOW;
+        const int gc = fok[j] ? g : 0, cc = fok[j] ? fc : 0;
+        const int n = gc / OH, a = gc - n * OH;
+        fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(oplane) + a * TOW + cc);
+    }
+    const unsigned wstep = static_cast<unsigned>(S2B_CK * d.RC * 9), fstep = static_cast<unsigned>(S2B_CK * oplane);
+    float wv[2][9], fv[FPT];
+    auto prefetch = [&](unsigned round) {
+        const unsigned wo = round * wstep, fo = round * fstep;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wv[j][t] = w[wsrc[j] + wo + t];
+#pragma unroll
+        for (int j = 0; j < FPT; ++j) fv[j] = dy[fsrc[j] + fo];
+    };
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned rounds = static_cast<unsigned>(d.KC / S2B_CK);
+    prefetch(0);
+    for (unsigned round = 0; round < rounds; ++round) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ph = kh == 1 ? 0 : 1, u = kh == 0 ? 1 : 0, pw = kw == 1 ? 0 : 1, v = kw == 0 ? 1 : 0;
+                    ws[wdst[j] + (u * 2 + v) * WROW + ph * 2 + pw] = wv[j][kh * 3 + kw];
+                }
+#pragma unroll
+        for (int j = 0; j < FPT; ++j)
+            if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;
+        __syncthreads();
+        if (round + 1 < rounds) prefetch(round + 1);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float av[S2B_CK / 4 * 4], bv[S2B_CK / 4 * 4];
+#pragma unroll
+            for (int c2 = 0; c2 < S2B_CK / 4; ++c2) {
+                const float *ap = abase + (half * (S2B_CK / 4) + c2) * (2 * 4 * WROW);
+                const float *bp = bbase + (half * (S2B_CK / 4) + c2) * (2 * FRH * FRW);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        av[c2 * 4 + u * 2 + v] = ap[(u * 2 + v) * WROW];
+                        float b = bp[u * FRW + v];
+                        if (u == 1 && last_row) b = 0.0f;  // the dy row below an image's last row belongs to the next image
+                        bv[c2 * 4 + u * 2 + v] = b;
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < S2B_CK / 4 * 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+        }
+    }
+    if (!pv) return;
+    // registers 4j .. 4j+3 of a lane: rows (2j + (lane >> 5)) * 4 + {0,1,2,3} = input channel 2j + (lane >> 5) of this tile, (ph, pw)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci_base + rt * 8 + 2 * j + kk;
+        float *o = dx + ((static_cast<size_t>(nj) * d.RC + ci) * d.H + 2 * aj) * (2 * TOW) + 2 * wj;
+        *reinterpret_cast<float2 *>(o) = make_float2(acc[4 * j + 0], acc[4 * j + 1]);
+        *reinterpret_cast<float2 *>(o + 2 * TOW) = make_float2(acc[4 * j + 2], acc[4 * j + 3]);
+    }
+}
+
+}  // namespace
+
+EE_API int ee_conv3x3s2_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W, void *stream) {
+    if (B < 0 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return EE_ERR_SHAPE;
+    const int OW = W / 2;
+    if ((H & 1) || (W & 1) || OW > 64 || 64 % OW != 0 || Cout % S2B_CK != 0 || Cin % 16 != 0) return EE_ERR_UNSUPPORTED;
+    if (B == 0) return EE_OK;
+    if (!dy || !weight || !dx) return EE_ERR_NULL;
+    if (reinterpret_cast<uintptr_t>(dx) & 7u) return EE_ERR_ALIGN;
+    if (static_cast<int64_t>(B) * Cout * (H / 2) * OW > 0x7fffffffLL || static_cast<int64_t>(Cin) * Cout * 9 > 0x7fffffffLL) return EE_ERR_SHAPE;
+    const int PR = 64 / OW;
+    const int64_t rows = static_cast<int64_t>(B) * (H / 2);
+    const dim3 grid(static_cast<unsigned>((rows + PR - 1) / PR), static_cast<unsigned>(Cin / 16)), block(256);
+    const Conv3Dims dims{B, Cout, Cin, H, W};
+    hipStream_t st = as_stream(stream);
+    switch (OW) {
+        case 64: EE_LAUNCH((conv3x3s2_bwd_kernel<64>), grid, block, 0, st, dy, weight, dx, dims); break;
+        case 32: EE_LAUNCH((conv3x3s2_bwd_kernel<32>), grid, block, 0, st, dy, weight, dx, dims); break;
+        case 16: EE_LAUNCH((conv3x3s2_bwd_kernel<16>), grid, block, 0, st, dy, weight, dx, dims); break;
+        case 8: EE_LAUNCH((conv3x3s2_bwd_kernel<8>), grid, block, 0, st, dy, weight, dx, dims); break;
+        case 4: EE_LAUNCH((conv3x3s2_bwd_kernel<4>), grid, block, 0, st, dy, weight, dx, dims); break;
+        case 2: EE_LAUNCH((conv3x3s2_bwd_kernel<2>), grid, block, 0, st, dy, weight, dx, dims); break;
+        default: EE_LAUNCH((conv3x3s2_bwd_kernel<1>), grid, block, 0, st, dy, weight, dx, dims); break;
+    }
+    return launch_status();
+}

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ee_conv3x3s1_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s1_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "ee_conv3x3s2_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "ee_stem7x7s2_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_pool_linear_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_pool_linear_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],

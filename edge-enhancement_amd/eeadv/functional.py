@@ -218,22 +218,33 @@ class Conv3x3Fn(torch.autograd.Function):
 
 
 class Conv3x3S2Fn(torch.autograd.Function):
-    """Conv2d(3x3, stride 2, padding 1, bias=False), the first convolution of ResNet layers 2-4: forward on ee_conv.hip's
-    f32-MFMA implicit GEMM; backward-data and weight gradient on MIOpen."""
+    """Conv2d(3x3, stride 2, padding 1, bias=False), the first convolution of ResNet layers 2-4: forward and / or backward-data
+    on ee_conv.hip's f32-MFMA implicit GEMMs (each where it beats MIOpen, the caller decides); weight gradient on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, mfma_fwd, mfma_bwd):
         ctx.save_for_backward(x, weight)
-        return ops.conv3x3s2_fwd(x, weight)
+        ctx.mfma_bwd = mfma_bwd
+        if mfma_fwd:
+            return ops.conv3x3s2_fwd(x, weight)
+        return torch.ops.aten.convolution(x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         want_w = ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY
-        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
-                                                        [ctx.needs_input_grad[0], want_w, False])
-        return dx, dw
+        want_x = ctx.needs_input_grad[0]
+        dx = None
+        if want_x and ctx.mfma_bwd:
+            dx = ops.conv3x3s2_bwd_data(dy, weight, x.shape[2], x.shape[3])
+            want_x = False
+        dw = None
+        if want_x or want_w:
+            gx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [want_x, want_w, False])
+            if want_x:
+                dx = gx
+        return dx, dw, None, None
 
 
 class StemConvFn(torch.autograd.Function):

@@ -62,6 +62,7 @@ _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") 
 # ee_conv.hip's f32-MFMA 3x3 convolution takes maps 16..64 wide (29 us against 36 us for MIOpen's Winograd on the 64-channel
 # 16x16 layer; equal on 8x8, where the stock solver stays)
 _CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "16"))
+_CONV3S2_BWD_MINOW = int(os.environ.get("EEADV_CONV3S2_BWD_MINOW", "1000"))  # its backward-data kernel: equal to MIOpen end to end, opt-in
 _CONV3S2_MINOW = int(os.environ.get("EEADV_CONV3S2_MINOW", "8"))  # narrowest OUTPUT map the stride-2 MFMA convolution takes (24 us vs 50 at 8; no gain at 4)
 
 
@@ -112,9 +113,12 @@ def conv3(conv, x):
         return Conv3x3Map2Fn.apply(x, conv.weight)
     if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
-            and conv.padding_mode == "zeros" and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and _CONV3S2_MINOW <= x.shape[3] // 2 <= 64
+            and conv.padding_mode == "zeros" and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[3] // 2 <= 64
             and 64 % (x.shape[3] // 2) == 0 and conv.in_channels % 16 == 0 and conv.out_channels % 64 == 0 and conv.weight.is_contiguous()):
-        return Conv3x3S2Fn.apply(x, conv.weight)
+        ow = x.shape[3] // 2
+        mfma_fwd, mfma_bwd = ow >= _CONV3S2_MINOW, ow >= _CONV3S2_BWD_MINOW
+        if mfma_fwd or mfma_bwd:
+            return Conv3x3S2Fn.apply(x, conv.weight, mfma_fwd, mfma_bwd)
     if ("conv3" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
             and conv.padding_mode == "zeros" and _CONV3_MINW <= x.shape[3] <= 64 and 64 % x.shape[3] == 0

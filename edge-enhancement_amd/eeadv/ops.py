@@ -536,6 +536,17 @@ def conv3x3s2_fwd(x, weight):
     return y
 
 
+def conv3x3s2_bwd_data(dy, weight, H, W):
+    """d loss / d x of Conv2d(Cin, Cout, 3, stride 2, padding 1): dy [B,Cout,H/2,W/2] -> [B,Cin,H,W] (ee_conv.hip)."""
+    B, Cout = dy.shape[0], dy.shape[1]
+    Cin = weight.shape[1]
+    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
+    N.check(N.lib.ee_conv3x3s2_bwd_data_f32(_chk(dy, torch.float32, "dy", (B, Cout, H // 2, W // 2)),
+                                            _chk(weight, torch.float32, "weight", (Cout, Cin, 3, 3)), dx.data_ptr(), B, Cin, Cout, H, W, _stream()),
+            "ee_conv3x3s2_bwd_data_f32")
+    return dx
+
+
 def stem7x7s2_bwd_data(dy, weight, H, W):
     """d loss / d image through Conv2d(3, K, 7, stride 2, padding 3) (resnet.py:112): dy [B,K,H/2,W/2] -> [B,3,H,W]."""
     B, K = dy.shape[0], dy.shape[1]

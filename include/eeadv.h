@@ -283,6 +283,9 @@ int ee_conv3x3s1_bwd_data_f32(const float *dy, const float *weight, float *dx, i
 /* Conv2d(Cin, Cout, kernel_size=3, stride=2, padding=1, bias=False) - the first convolution of ResNet layers 2-4 - forward:
  * x [B,Cin,H,W] -> y [B,Cout,H/2,W/2].  H, W even, W/2 divides 64, Cin % 16 == 0, Cout % 64 == 0 (else EE_ERR_UNSUPPORTED). */
 int ee_conv3x3s2_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream);
+/* its backward-data: dy [B,Cout,H/2,W/2] -> dx [B,Cin,H,W] (all of dx is written).  Cout % 32 == 0, Cin % 16 == 0. */
+int ee_conv3x3s2_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W,
+                              void *stream);
 
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.

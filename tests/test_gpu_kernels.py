@@ -634,7 +634,7 @@ def test_conv3x3s2_mfma_matches_aten(ops, B, Cin, Cout, H, W):
     x = torch.randn(B, Cin, H, W, generator=g).to(DEV).requires_grad_(True)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
     ref = F.conv2d(x, w, None, 2, 1)
-    got = Conv3x3S2Fn.apply(x, w)
+    got = Conv3x3S2Fn.apply(x, w, True, Cout % 32 == 0 and Cin % 16 == 0)
     dy = torch.randn(ref.shape, generator=g).to(DEV)
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
     (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
