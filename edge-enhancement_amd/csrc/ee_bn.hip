@@ -6,10 +6,13 @@
 // and two (backward) launches per layer of pure HBM-bound element-wise work.  Fused: one launch each way, the
 // normalised tensor is written once, and the ReLU mask is taken from the output instead of a saved copy.
 //
-// One workgroup per channel.  Training mode: pass 1 mean, pass 2 centred variance (two-pass, fp32, fixed-order wave /
-// workgroup reductions -> bit-reproducible), pass 3 normalise + add + ReLU; the channel's slice (<= 410 KB) stays in the
-// XCD's L2 between passes.  Running statistics are updated in the kernel exactly as nn.BatchNorm2d does (momentum,
-// unbiased variance).  NCHW fp32; 16-B accesses when H*W % 4 == 0 (every ResNet stage: 1024, 256, 64, 16, 4).
+// Three families, chosen per shape by the launcher: (1) "cached": one workgroup per channel, the channel held in registers
+// (one read pass, all loads of a lane in flight together) - every layer but the stem at the reference batch; (2) "split":
+// a channel too large for that is cut into slices, one workgroup each, partial statistics through a small workspace and a
+// second launch (the 64-channel stem); (3) the generic three-pass loop (any shape, also unaligned).  Training mode: mean,
+// then centred variance (two-pass, fp32, fixed-order wave / workgroup reductions -> bit-reproducible), then normalise +
+// add + ReLU.  Running statistics are updated in the kernel exactly as nn.BatchNorm2d does (momentum, unbiased
+// variance).  NCHW fp32; 16-B accesses when H*W % 4 == 0 (every ResNet stage: 1024, 256, 64, 16, 4).
 //
 // This is CNN-body glue, not one of SURVEY.md section 8's rows: parity is "logits within 1e-4" through the model tests.
 #include "ee_common.hpp"
