@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run every PGD iteration eagerly (no HIP graph)")
     ap.add_argument("--probe-iters", type=int, default=1,
                     help="PGD iterations per attack that run outside the HIP graph so their kernels can be event-timed")
+    ap.add_argument("--probe-every", type=int, default=4,
+                    help="steps between two probed attacks (the eager probe iteration costs ~1 %% of a step; its kernels are the "
+                         "roofline samples, so at least one step of the timed region is always probed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-miopen-benchmark", action="store_true",
@@ -193,10 +196,13 @@ def main():
     B = cfg["batch"]
     batches = [(torch.rand(B, *cfg["shape"], device=dev), torch.randint(0, cfg["classes"], (B,), device=dev)) for _ in range(4)]
 
+    probe_iters = engine.PROBE_ITERS
+
     def run(n):
         last = None
         for i in range(n):
             x, y = batches[i % len(batches)]
+            engine.PROBE_ITERS = probe_iters if i % max(1, a.probe_every) == 0 else 0
             last = trainer.train_batch(run_model, criterion, optimizer, dargs, x, y, dev)
             ops.prof_mark_empty()  # one empty event bracket per step: the bracket's own cost, measured live
         return last
@@ -263,7 +269,7 @@ def main():
             "config": {"workload": "%s: %s %s, per-rank batch %d x %s, PGD-%d eps %.4f alpha %.4f, train step incl. SGD%s" % (
                 a.workload, cfg["arch"], cfg["method"], B, "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"],
                 ", DDP all-reduce (RCCL)" if world > 1 else ""),
-                "global_batch": world * B, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": engine.PROBE_ITERS,
+                "global_batch": world * B, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": probe_iters, "probe_every": a.probe_every,
                 "device": (N.lib.ee_device_name() or b"?").decode()},
             "roofline": roofline, "kernels": kernels, "final_loss": round(loss_val, 5),
             "note": "throughput is bounded by the CNN convolutions (MIOpen fp32), not by the hand-written kernels; "
