@@ -85,9 +85,11 @@ def attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi):
 
 
 class _GraphedStep:
-    """One captured PGD step bound to static buffers."""
+    """`iters` consecutive PGD steps captured into one graph, bound to static buffers (one replay per attack: consecutive
+    replays of a one-step graph leave a ~12 us bubble between them)."""
 
-    def __init__(self, model, x0, spec, step_size, eps, direction, lo, hi):
+    def __init__(self, model, x0, spec, step_size, eps, direction, lo, hi, iters=1):
+        self.iters = iters
         self.x = torch.empty_like(x0).requires_grad_(True)
         self.x0 = torch.empty_like(x0)
         self.payload = torch.empty_like(spec.payload)
@@ -111,7 +113,8 @@ class _GraphedStep:
         self.load(x_init, x0, payload)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self._body(model)
+            for _ in range(self.iters):
+                self._body(model)
 
     def load(self, x_init, x0, payload):
         with torch.no_grad():
@@ -124,6 +127,9 @@ _GRAPHS = {}
 # PGD iterations per attack that run OUTSIDE the captured graph even in graph mode, so that the library's
 # HIP-event hooks (ee_prof_*) can time their kernels live; bench.py sets it (DESIGN.md "Measurement").
 PROBE_ITERS = 0
+# a replay covers up to this many consecutive iterations (the largest divisor of the iteration count below it): one-step
+# graphs leave a ~12 us bubble between replays, very long graphs cost capture time and node memory for nothing
+MAX_ITERS_PER_GRAPH = 16
 
 
 def graphs_enabled():
@@ -141,14 +147,17 @@ def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo
     x0 = x0.detach().contiguous()
     if use_graph is None:
         use_graph = graphs_enabled()
-    if use_graph and num_steps > 0:
+    if use_graph and num_steps > min(PROBE_ITERS, num_steps):
+        probe = min(PROBE_ITERS, num_steps)
+        n_graph = num_steps - probe
+        chunk = max(c for c in range(1, min(n_graph, MAX_ITERS_PER_GRAPH) + 1) if n_graph % c == 0)  # iterations per replay
         key = (id(model), model.training, tuple(x0.shape), spec.kind, tuple(spec.payload.shape), spec.payload.dtype,
-               float(step_size), float(eps), direction, lo, hi, x0.device.index)
+               float(step_size), float(eps), direction, lo, hi, x0.device.index, chunk)
         gs = _GRAPHS.get(key)
         if gs is not None and gs.model() is not model:
             gs = None
         if gs is None:
-            gs = _GraphedStep(model, x0, spec, step_size, eps, direction, lo, hi)
+            gs = _GraphedStep(model, x0, spec, step_size, eps, direction, lo, hi, iters=chunk)
             # the two warm-up executions before capture are extra train-mode forwards: shield the BatchNorm statistics
             # from them.  Restored through .data so that autograd graphs the caller still holds (TRADES / ALP keep
             # `preds = model(x)` alive across the attack) do not see a version bump on the saved running statistics.
@@ -162,13 +171,12 @@ def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo
                     live[k].data.copy_(v)
             _GRAPHS[key] = gs
         x = x_init.detach().contiguous()
-        probe = min(PROBE_ITERS, num_steps)
         for _ in range(probe):
             attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi)
             x = x.detach()
         gs.load(x, x0, spec.payload)
         refresh_dense_weights()  # weight-derived buffers the captured kernels read (functional.Conv3x3Map2Fn)
-        for _ in range(num_steps - probe):
+        for _ in range(n_graph // chunk):
             gs.graph.replay()
         return gs.x.detach().clone()
 
