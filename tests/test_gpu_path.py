@@ -352,6 +352,29 @@ def test_hip_graph_replay_equals_eager(A):
     engine.clear_graphs()
 
 
+@pytest.mark.parametrize("num_steps,probe", [(1, 0), (7, 0), (18, 1), (34, 0), (3, 3), (40, 1)])
+def test_graph_chunking_covers_every_iteration_count(A, num_steps, probe):
+    """A replay covers the largest divisor <= 16 of the graphed iteration count (7 -> 7, 17 -> 17 x 1, 34 -> 2 x 17 replays,
+    39 -> 13 x 3), with `probe` eager iterations first: the trajectory is the eager one."""
+    from eeadv import engine, ops
+    torch.manual_seed(10)
+    net = TinyNet(3, 16, 10, 5).to(DEV).eval()
+    x = torch.rand(4, 3, 16, 16, device=DEV)
+    y = torch.randint(0, 10, (4,), device=DEV)
+    noise = torch.zeros_like(x).uniform_(-0.05, 0.05)
+    spec = engine.LossSpec(engine.CE_SUM, y)
+    eager = engine.pgd_loop(net, x, ops.pgd_init(x, noise), spec, num_steps, 0.003, 0.05, use_graph=False)
+    old = engine.PROBE_ITERS
+    engine.PROBE_ITERS = probe
+    try:
+        graphed = engine.pgd_loop(net, x, ops.pgd_init(x, noise), spec, num_steps, 0.003, 0.05, use_graph=True)
+    finally:
+        engine.PROBE_ITERS = old
+        engine.clear_graphs()
+    assert same_fraction(graphed.cpu().numpy(), eager.cpu().numpy()) > 0.995
+    assert float((graphed - x).abs().max()) <= 0.05 + 1e-6
+
+
 def test_accuracy_helper(golden):
     from utils.helper import accuracy
     rng = np.random.RandomState(0)
