@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Two DDP ranks sharing ONE GPU over gloo: an integration check of the multi-process path on a 1-GPU box (RCCL needs one
+device per rank, so the collective backend differs from production; DDP's hooks, buckets and the interplay with the captured
+attack graph, the custom autograd Functions and the eager update are the same).
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 scripts/ddp_same_gpu.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "edge-enhancement_amd"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from eeadv import engine, trainer  # noqa: E402
+from eeadv.models import make_resnet_ee  # noqa: E402
+
+
+class Args(dict):
+    __getattr__ = dict.get
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ["EEADV_GRAPH"] = "1"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1 + rank)
+    model = make_resnet_ee(18, "tiny", square=True, cize=64, r=16, w=0.5, low=60.0, high=120.0, alpha=0.0, sigma=1,
+                           type_canny="CannyFilter_step125_1", epsilon=0.05, n_queries=1).to(dev).train()
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=16, gradient_as_bucket_view=True)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=2e-4)
+    args = Args(method_name="EE_BPDA3_AT_square", random=True, epsilon=16 / 255, num_steps_1=4, step_size_1=2 / 255, num_classes=200)
+    crit = trainer.make_criterion(args)
+    for step in range(4):
+        x = torch.rand(16, 3, 64, 64, device=dev)
+        y = torch.randint(0, 200, (16,), device=dev)
+        loss, out = trainer.train_batch(net, crit, opt, args, x, y, dev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss), loss
+    # same initial weights (DDP broadcast) + averaged gradients -> identical parameters on every rank
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    ref = flat.clone()
+    dist.broadcast(ref, 0)
+    diff = float((flat - ref).abs().max())
+    stats = torch.cat([b.detach().flatten().float() for n, b in model.named_buffers() if "running" in n])
+    print("rank %d: loss %.4f  max |param - rank0 param| = %.3e  graphs %d  bn stats finite %s" % (
+        rank, float(loss), diff, len(engine._GRAPHS), bool(torch.isfinite(stats).all())), flush=True)
+    assert diff == 0.0
+    assert len(engine._GRAPHS) == 1  # the attack replayed a captured graph on the unwrapped module
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
