@@ -140,6 +140,38 @@ def cpu_baseline(cfg, seconds_target=25.0):
 SETUP_STEPS = 3
 
 
+def large_batch_kernels(cfg, dev, mult=16, iters=50):
+    """The section-8 kernels alone at `mult` x the per-rank batch (outside the timed region; one second in total): what they
+    reach once a launch is no longer latency-bound - the counterpart of `roofline`, which is quoted at the reference batch.
+    Torch events around `iters` back-to-back launches on the launch stream (launch overhead amortised)."""
+    from eeadv import ops
+    C, H, W = cfg["shape"]
+    B = cfg["batch"] * mult
+    x, xh, g = (torch.rand(B, C, H, W, device=dev) for _ in range(3))
+    wts = ops.EdgeWeights(1.0)
+    x_in, gate, _ = ops.frontend_fwd(x, xh, wts, 0.0, 0.2, 0.5)
+    x0 = x.clone()
+    runs = {
+        "ee_pgd_step": (lambda: ops.pgd_step_(x0, g, x, cfg["alpha"], cfg["eps"]), 16 * C),
+        "ee_frontend_fwd": (lambda: ops.frontend_fwd(x, xh, wts, 0.0, 0.2, 0.5), 12 * C),
+        "ee_frontend_bwd": (lambda: ops.frontend_bwd(g, gate, x, wts, 0.0, 0.2, 0.5), 16 * C),
+    }
+    res = {"batch": B}
+    for name, (fn, bytes_px) in runs.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / iters
+        gbs = bytes_px * B * H * W / us / 1e3
+        res[name] = {"avg_us": round(us, 2), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,6 +307,8 @@ def main():
             "note": "throughput is bounded by the CNN convolutions (MIOpen fp32), not by the hand-written kernels; "
                     "reference log (unrecorded GPU): ~143 img/s for this config (BASELINE.md)",
         }
+        if world == 1:
+            out["kernels_large_batch"] = large_batch_kernels(cfg, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
