@@ -149,12 +149,12 @@ def large_batch_kernels(cfg, dev, mult=16, iters=50):
     B = cfg["batch"] * mult
     x, xh, g = (torch.rand(B, C, H, W, device=dev) for _ in range(3))
     wts = ops.EdgeWeights(1.0)
-    x_in, gate, _ = ops.frontend_fwd(x, xh, wts, 0.0, 0.2, 0.5)
+    x_in, gate, _, sgx, sgy = ops.frontend_fwd_save(x, xh, wts, 0.0, 0.2, 0.5)
     x0 = x.clone()
     runs = {
         "ee_pgd_step": (lambda: ops.pgd_step_(x0, g, x, cfg["alpha"], cfg["eps"]), 16 * C),
-        "ee_frontend_fwd": (lambda: ops.frontend_fwd(x, xh, wts, 0.0, 0.2, 0.5), 12 * C),
-        "ee_frontend_bwd": (lambda: ops.frontend_bwd(g, gate, x, wts, 0.0, 0.2, 0.5), 16 * C),
+        "ee_frontend_fwd": (lambda: ops.frontend_fwd_save(x, xh, wts, 0.0, 0.2, 0.5), 12 * C),
+        "ee_frontend_bwd": (lambda: ops.frontend_bwd_saved(g, gate, sgx, sgy, wts, 0.0, 0.2, 0.5), 16 * C),
     }
     res = {"batch": B}
     for name, (fn, bytes_px) in runs.items():

@@ -62,21 +62,29 @@ __global__ __launch_bounds__(kBlock) void edge_fwd_kernel(EdgeParams p, Weights 
 
     float b[C][3][6];
     blur_group<C, FH, FW>(xs, wt, ly, 4 * lx + kColHalo - 2, i, jb, H, W, b);
-    float e[4], m[4];
+    float e[4], m[4], gxs[4], gys[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float ax, ay, gx1, gy1, s2, mag_a;
+        float ax, ay, s2, mag_a;
         sobel_px<C>(b, wt, k, ax, ay);
-        edge_from_sums<C>(ax, ay, p.alpha, p.high, gx1, gy1, s2, m[k], mag_a, e[k]);
+        edge_from_sums<C>(ax, ay, p.alpha, p.high, gxs[k], gys[k], s2, m[k], mag_a, e[k]);
     }
     const size_t pix = (static_cast<size_t>(n) * H + i) * W + jb;
     if (vec) {
         if (p.edge) *reinterpret_cast<float4 *>(p.edge + pix) = make_float4(e[0], e[1], e[2], e[3]);
         if (p.mag) *reinterpret_cast<float4 *>(p.mag + pix) = make_float4(m[0], m[1], m[2], m[3]);
+        if (p.gx_out) {
+            *reinterpret_cast<float4 *>(p.gx_out + pix) = make_float4(gxs[0], gxs[1], gxs[2], gxs[3]);
+            *reinterpret_cast<float4 *>(p.gy_out + pix) = make_float4(gys[0], gys[1], gys[2], gys[3]);
+        }
     } else {
         for (int k = 0; k < 4 && jb + k < W; ++k) {
             if (p.edge) p.edge[pix + k] = e[k];
             if (p.mag) p.mag[pix + k] = m[k];
+            if (p.gx_out) {
+                p.gx_out[pix + k] = gxs[k];
+                p.gy_out[pix + k] = gys[k];
+            }
         }
     }
     if (FUSED) {
@@ -223,6 +231,131 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_kernel(EdgeParams p, Weights 
             } else {
                 for (int k = 0; k < 4 && tjb + k < W; ++k) p.g_hfs[o + k] = r4[k];
             }
+        }
+    }
+}
+
+// =====================================================================================================
+// backward from SAVED Sobel responses: the forward keeps gx1, gy1 (8 B per pixel), so the backward neither
+// re-reads x nor recomputes blur + Sobel (~60 % of the recomputing kernel's instructions).  Same stages 2-4,
+// same arithmetic on the same values: results are bit-identical to edge_bwd_kernel.
+//   stage 1: u on the frame (LDS); this lane's stage-2 group of gx1 / gy1 straight into registers (issued first)
+//   stage 2: gg per pixel -> LDS;   stages 3 + 4: adjoint_tail
+// =====================================================================================================
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(kBlock) void edge_bwd_saved_kernel(EdgeParams p, Weights wt) {
+    constexpr int FH = TH + 8, FW = TW + 2 * kColHalo, PL = FH * FW, LX = TW / 4;
+    constexpr int GG_GX = (TW + 4 + 3) / 4, GG_ROWS = TH + 4;
+    static_assert(GG_ROWS * GG_GX <= kBlock, "stage 2 must be one round: its operands are preloaded per lane");
+    __shared__ __align__(16) float lds[4 * PL];
+    float *us = lds, *ggx = us + PL, *ggy = ggx + PL, *gb = ggy + PL;
+    const int H = p.H, W = p.W;
+    int n, i0, j0;
+    tile_origin(p, TH, TW, n, i0, j0);
+    const int oi = i0 - 4, oj = j0 - kColHalo;
+    const bool vec = p.vec != 0;
+    const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+    const int ti = i0 + ly, tjb = j0 + 4 * lx;
+    const bool live = (ly < TH) && (ti < H) && (tjb < W);
+
+    // ---- every global load of the kernel, issued up front on clamped addresses -----------------------------------------
+    // stage-2 role of this lane: 4-pixel group (r, g) of the (TH+4) x (TW+4) region, pixels (i, jb .. jb+3)
+    const int r2 = threadIdx.x / GG_GX, g2 = threadIdx.x - r2 * GG_GX;
+    const int fr2 = r2 + 2, fc2 = 2 + 4 * g2;
+    const int i2 = oi + fr2, jb2 = oj + fc2;
+    const bool grp = r2 < GG_ROWS && i2 >= 0 && i2 < H && jb2 < W && jb2 + 3 >= 0;
+    float gxv[4], gyv[4];
+    {
+        const int ic = i2 < 0 ? 0 : (i2 >= H ? H - 1 : i2);
+        const size_t row = (static_cast<size_t>(n) * H + ic) * W;
+        if (vec) {  // jb2 = j0 - 2 + 4 g2 is even: two 8-byte loads per plane, columns clamped into the row
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                int jc = jb2 + 2 * hlf;
+                jc = jc < 0 ? 0 : (jc > W - 2 ? W - 2 : jc);
+                const float2 a = *reinterpret_cast<const float2 *>(p.gx_in + row + jc);
+                const float2 b = *reinterpret_cast<const float2 *>(p.gy_in + row + jc);
+                gxv[2 * hlf] = a.x; gxv[2 * hlf + 1] = a.y;
+                gyv[2 * hlf] = b.x; gyv[2 * hlf + 1] = b.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int jc = clampi(jb2 + k, 0, W - 1);
+                gxv[k] = p.gx_in[row + jc];
+                gyv[k] = p.gy_in[row + jc];
+            }
+        }
+    }
+    float4 gin[C];
+    uchar4 gtv[C];
+    if (vec) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const size_t o = ((static_cast<size_t>(n) * C + c) * H + (ti < H ? ti : H - 1)) * W + clamp_col4(tjb, W);
+            gin[c] = *reinterpret_cast<const float4 *>(p.g_in + o);
+            gtv[c] = *reinterpret_cast<const uchar4 *>(p.gate_in + o);
+        }
+    } else if (live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const size_t o = ((static_cast<size_t>(n) * C + c) * H + ti) * W + tjb;
+            float gv[4] = {0, 0, 0, 0};
+            unsigned char tv[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4 && tjb + k < W; ++k) {
+                gv[k] = p.g_in[o + k];
+                tv[k] = p.gate_in[o + k];
+            }
+            gin[c] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            gtv[c] = make_uchar4(tv[0], tv[1], tv[2], tv[3]);
+        }
+    }
+    load_u_fused<C, FH, FW>(us, p.g_in, p.gate_in, n, H, W, oi, oj, p.w, vec);
+    for (int idx = threadIdx.x; idx < 3 * PL / 4; idx += kBlock) reinterpret_cast<float4 *>(ggx)[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
+
+    // ---- stage 2 (one round): the magnitude-stage gradient from the saved responses -------------------------------------
+    if (grp) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = jb2 + k;
+            if (j >= 0 && j < W && fc2 + k < FW) {
+                const float gx1 = gxv[k], gy1 = gyv[k];
+                const float s2 = gx1 * gx1 + gy1 * gy1;
+                const float mag = sqrtf(s2);
+                const float mag_a = (mag < p.alpha) ? 0.0f : mag;
+                float gm = us[fr2 * FW + fc2 + k];
+                if (mag_a <= p.high) gm = 0.0f;     // To_compare.backward core.py:356
+                if (mag_a > 1.001f) gm = 0.0f;      // core.py:357
+                if (mag < p.alpha) gm = 0.0f;       // where() backward core.py:575
+                const float rs = 1.0f / sqrtf(s2);  // pow(s2, -0.5): 0 -> inf
+                const float gs = gm * (0.5f * rs);  // 0*inf = NaN kept
+                ggx[fr2 * FW + fc2 + k] = (gs * (2.0f * gx1)) / static_cast<float>(C);
+                ggy[fr2 * FW + fc2 + k] = (gs * (2.0f * gy1)) / static_cast<float>(C);
+            }
+        }
+    }
+    __syncthreads();
+
+    float o4[4];
+    adjoint_tail<TH, TW, FW>(ggx, ggy, gb, wt, H, W, i0, j0, oi, oj, live, ti, tjb, o4);
+    if (!live) return;
+    const size_t pix = (static_cast<size_t>(n) * H + ti) * W + tjb;
+    if (vec) {
+        *reinterpret_cast<float4 *>(p.g_img + pix) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    } else {
+        for (int k = 0; k < 4 && tjb + k < W; ++k) p.g_img[pix + k] = o4[k];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const size_t o = ((static_cast<size_t>(n) * C + c) * H + ti) * W + tjb;
+        const float4 g = gin[c];
+        const uchar4 gt = gtv[c];
+        const float r4[4] = {gt.x ? g.x : 0.0f, gt.y ? g.y : 0.0f, gt.z ? g.z : 0.0f, gt.w ? g.w : 0.0f};
+        if (vec) {
+            *reinterpret_cast<float4 *>(p.g_hfs + o) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        } else {
+            for (int k = 0; k < 4 && tjb + k < W; ++k) p.g_hfs[o + k] = r4[k];
         }
     }
 }
@@ -374,4 +507,70 @@ EE_API int ee_frontend_bwd_f32(const float *g_in, const uint8_t *gate, const flo
     p.vec = (W % 4 == 0) && al16(x) && al16(g_in) && al16(g_hfs) && al16(g_edge) && al4(gate);
     ProfScope prof(EE_K_FRONTEND_BWD, as_stream(stream));
     return launch<true, true>(p, load_weights(weights27), B, C, as_stream(stream));
+}
+
+// ---- the pair that keeps the Sobel responses between forward and backward --------------------------------------------------
+namespace {
+
+template <int C>
+void launch_bwd_saved_c(const EdgeParams &p, const Weights &wt, int B, hipStream_t st) {
+    EdgeParams q = p;
+    const bool wide = p.W > 32;
+    const int th = wide ? kBwdTH64 : kBwdTH32, tw = wide ? 64 : 32;
+    q.tiles_x = (p.W + tw - 1) / tw;
+    q.tiles_y = (p.H + th - 1) / th;
+    const unsigned grid = static_cast<unsigned>(static_cast<int64_t>(B) * q.tiles_x * q.tiles_y);
+    if (wide)
+        EE_LAUNCH((edge_bwd_saved_kernel<C, kBwdTH64, 64>), dim3(grid), dim3(kBlock), 0, st, q, wt);
+    else
+        EE_LAUNCH((edge_bwd_saved_kernel<C, kBwdTH32, 32>), dim3(grid), dim3(kBlock), 0, st, q, wt);
+}
+
+}  // namespace
+
+EE_API int ee_frontend_fwd_save_f32(const float *x, const float *x_hfs, int B, int C, int H, int W, const float *weights27, float alpha,
+                                    float high, float w, float *x_in, uint8_t *gate, float *edge, float *gx, float *gy, void *stream) {
+    if (int rc = check_dims(B, C, H, W)) return rc;
+    if (B == 0) return EE_OK;
+    if (!x || !x_hfs || !weights27 || !x_in || !gx || !gy) return EE_ERR_NULL;
+    EdgeParams p{};
+    p.x = x;
+    p.x_hfs = x_hfs;
+    p.x_in = x_in;
+    p.gate = gate;
+    p.edge = edge;
+    p.gx_out = gx;
+    p.gy_out = gy;
+    p.H = H; p.W = W;
+    p.alpha = alpha; p.high = high; p.w = w;
+    p.vec = (W % 4 == 0) && al16(x) && al16(x_hfs) && al16(x_in) && al16(edge) && al4(gate) && al16(gx) && al16(gy);
+    ProfScope prof(EE_K_FRONTEND_FWD, as_stream(stream));
+    return launch<true, false>(p, load_weights(weights27), B, C, as_stream(stream));
+}
+
+EE_API int ee_frontend_bwd_saved_f32(const float *g_in, const uint8_t *gate, const float *gx, const float *gy, int B, int C, int H, int W,
+                                     const float *weights27, float alpha, float high, float w, float *g_hfs, float *g_edge, void *stream) {
+    if (int rc = check_dims(B, C, H, W)) return rc;
+    if (B == 0) return EE_OK;
+    if (!g_in || !gate || !gx || !gy || !weights27 || !g_hfs || !g_edge) return EE_ERR_NULL;
+    EdgeParams p{};
+    p.g_in = g_in;
+    p.gate_in = gate;
+    p.gx_in = gx;
+    p.gy_in = gy;
+    p.g_hfs = g_hfs;
+    p.g_img = g_edge;
+    p.H = H; p.W = W;
+    p.alpha = alpha; p.high = high; p.w = w;
+    p.vec = (W % 4 == 0) && al16(g_in) && al16(g_hfs) && al16(g_edge) && al4(gate) && al16(gx) && al16(gy);
+    const Weights wt = load_weights(weights27);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(EE_K_FRONTEND_BWD, st);
+    switch (C) {
+        case 1: launch_bwd_saved_c<1>(p, wt, B, st); break;
+        case 2: launch_bwd_saved_c<2>(p, wt, B, st); break;
+        case 3: launch_bwd_saved_c<3>(p, wt, B, st); break;
+        default: launch_bwd_saved_c<4>(p, wt, B, st); break;
+    }
+    return launch_status();
 }

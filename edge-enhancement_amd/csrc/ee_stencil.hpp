@@ -24,6 +24,8 @@ struct EdgeParams {
     uint8_t *gate;  // [B,C,H,W]
     float *g_hfs;   // [B,C,H,W]
     float *g_img;   // [B,1,H,W]
+    float *gx_out, *gy_out;        // [B,1,H,W] (forward, optional): the channel-mean Sobel responses, kept for the backward
+    const float *gx_in, *gy_in;    // [B,1,H,W] (backward from saved responses)
     int H, W, tiles_x, tiles_y;
     int vec;  // W % 4 == 0 and every pointer 16-B aligned: 16-B global accesses are legal
     float alpha, high, w;

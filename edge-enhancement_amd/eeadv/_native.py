@@ -38,6 +38,8 @@ SIGNATURES = {
     "ee_edge125_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_p, c_p],
     "ee_frontend_fwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
     "ee_frontend_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_p, c_p, c_p],
+    "ee_frontend_fwd_save_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p],
+    "ee_frontend_bwd_saved_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_p, c_p, c_p],
     "ee_canny_fwd_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
     "ee_canny_bwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_p, c_p, c_p],
     "ee_canny_bpda_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p],

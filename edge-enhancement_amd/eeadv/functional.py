@@ -48,17 +48,17 @@ class FrontEndFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x_hfs, wts, alpha, high, w):
         x, x_hfs = x.contiguous(), x_hfs.contiguous()
-        x_in, gate, _ = ops.frontend_fwd(x, x_hfs, wts, alpha, high, w)
-        ctx.save_for_backward(x, gate)
+        x_in, gate, _, sx, sy = ops.frontend_fwd_save(x, x_hfs, wts, alpha, high, w)
+        ctx.save_for_backward(gate, sx, sy)  # the Sobel responses instead of x: the backward recomputes nothing
         ctx.cfg = (wts, alpha, high, w)
         return x_in
 
     @staticmethod
     def backward(ctx, g_in):
-        x, gate = ctx.saved_tensors
+        gate, sx, sy = ctx.saved_tensors
         wts, alpha, high, w = ctx.cfg
-        g_hfs, g_edge = ops.frontend_bwd(g_in.contiguous(), gate, x, wts, alpha, high, w)
-        gx = g_edge.expand_as(x) if ctx.needs_input_grad[0] else None
+        g_hfs, g_edge = ops.frontend_bwd_saved(g_in.contiguous(), gate, sx, sy, wts, alpha, high, w)
+        gx = g_edge.expand_as(g_hfs) if ctx.needs_input_grad[0] else None
         return gx, g_hfs, None, None, None, None
 
 

@@ -192,13 +192,15 @@ class _EEFrontMixin:
                 x_lp = op.forward(ops.add_square_fwd(x, float(self.add_square.eps), d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"]))
         else:
             x_lp = op.forward(x)
-        x_in, gate, _ = ops.frontend_fwd(x, x_lp, self.canny.edge_weights, float(self.canny.alpha), float(self.high), float(self.w))
-        return x_in, (x, gate, d)
+        # the forward keeps the Sobel responses (8 B per pixel): the backward then skips x, blur and Sobel (ee_edge.hip)
+        x_in, gate, _, gx, gy = ops.frontend_fwd_save(x, x_lp, self.canny.edge_weights, float(self.canny.alpha), float(self.high), float(self.w))
+        return x_in, (x, gate, d, gx, gy)
 
     def front_manual_backward(self, g_in, ctx):
-        x, gate, d = ctx
+        x, gate, d, gx, gy = ctx
         op = self.hfs.operator(x.device)
-        g_hfs, g_edge = ops.frontend_bwd(g_in, gate, x, self.canny.edge_weights, float(self.canny.alpha), float(self.high), float(self.w))
+        g_hfs, g_edge = ops.frontend_bwd_saved(g_in, gate, gx, gy, self.canny.edge_weights, float(self.canny.alpha), float(self.high),
+                                               float(self.w))
         if d is None:
             g_lp = op.adjoint(g_hfs)
         elif op.kernel is not None:

@@ -219,6 +219,36 @@ def frontend_bwd(g_in, gate, x, wts, alpha, high, w):
     return g_hfs, g_edge
 
 
+def frontend_fwd_save(x, x_hfs, wts, alpha, high, w, want_edge=False):
+    """frontend_fwd that also keeps the Sobel responses for frontend_bwd_saved: returns (x_in, gate, edge, gx, gy)."""
+    B, C, H, W = x.shape
+    px = _chk(x, torch.float32, "x")
+    ph = _chk(x_hfs, torch.float32, "x_hfs", x.shape)
+    x_in = torch.empty_like(x)
+    gate = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device) if want_edge else None
+    gx = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    gy = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_frontend_fwd_save_f32(px, ph, B, C, H, W, wts.ptr, alpha, high, w, _chk(x_in, torch.float32, "x_in"),
+                                           _chk(gate, torch.uint8, "gate"), _opt(edge, torch.float32, "edge"), gx.data_ptr(), gy.data_ptr(),
+                                           _stream()), "ee_frontend_fwd_save_f32")
+    return x_in, gate, edge, gx, gy
+
+
+def frontend_bwd_saved(g_in, gate, gx, gy, wts, alpha, high, w):
+    """Backward of the front end from the saved Sobel responses (no x, no recomputation): (g_hfs, g_edge), bit-identical to
+    frontend_bwd."""
+    B, C, H, W = g_in.shape
+    pg = _chk(g_in, torch.float32, "g_in")
+    pt = _chk(gate, torch.uint8, "gate", g_in.shape)
+    g_hfs = torch.empty_like(g_in)
+    g_edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=g_in.device)
+    N.check(N.lib.ee_frontend_bwd_saved_f32(pg, pt, _chk(gx, torch.float32, "gx", (B, 1, H, W)), _chk(gy, torch.float32, "gy", (B, 1, H, W)),
+                                            B, C, H, W, wts.ptr, alpha, high, w, g_hfs.data_ptr(), g_edge.data_ptr(), _stream()),
+            "ee_frontend_bwd_saved_f32")
+    return g_hfs, g_edge
+
+
 def canny_fwd(x, wts, alpha, low, high):
     B, C, H, W = x.shape
     edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)

@@ -125,6 +125,16 @@ int ee_frontend_bwd_f32(const float *g_in, const uint8_t *gate, const float *x, 
                         const float *weights27, float alpha, float high, float w, float *g_hfs, float *g_edge,
                         void *stream);
 
+/* The same pair keeping the channel-mean Sobel responses gx, gy [B,1,H,W] between the two: the forward writes them (8 more
+ * bytes per pixel), the backward then needs neither x nor the blur / Sobel recomputation (about 60 % of the recomputing
+ * kernel's instructions) and is bit-identical to ee_frontend_bwd_f32. */
+int ee_frontend_fwd_save_f32(const float *x, const float *x_hfs, int B, int C, int H, int W, const float *weights27,
+                             float alpha, float high, float w, float *x_in, uint8_t *gate, float *edge, float *gx, float *gy,
+                             void *stream);
+int ee_frontend_bwd_saved_f32(const float *g_in, const uint8_t *gate, const float *gx, const float *gy, int B, int C, int H,
+                              int W, const float *weights27, float alpha, float high, float w, float *g_hfs, float *g_edge,
+                              void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Full CannyFilter (utils/core.py:148-326): blur, Sobel, magnitude, alpha mask, orientation-quantised non-maximum
  * suppression, straight-through double threshold, hysteresis - the path every model takes (low and high thresholds

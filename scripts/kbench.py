@@ -42,6 +42,7 @@ def main():
         x0 = x.clone()
         px = B * H * W
         _, gate, _ = ops.frontend_fwd(x, xh, wts, 0.0, 76 / 255, 1.0)
+        _, _, _, sgx, sgy = ops.frontend_fwd_save(x, xh, wts, 0.0, 76 / 255, 1.0)
         u = torch.randn(B, 1, H, W, device=dev)
         gl, ge = ops.frontend_bwd(g, gate, x, wts, 0.0, 76 / 255, 1.0)
         y = torch.randint(0, 200, (B,), device=dev)
@@ -66,6 +67,8 @@ def main():
             ("pgd_step_bcast", lambda: ops.pgd_step_bcast_(x, gl, ge, x0, 2 / 255, 16 / 255), (16 * C + 4) * px),
             ("frontend_fwd", lambda: ops.frontend_fwd(x, xh, wts, 0.0, 76 / 255, 1.0), 12 * C * px),
             ("frontend_bwd", lambda: ops.frontend_bwd(g, gate, x, wts, 0.0, 76 / 255, 1.0), 16 * C * px),
+            ("frontend_fwd_save", lambda: ops.frontend_fwd_save(x, xh, wts, 0.0, 76 / 255, 1.0), 12 * C * px),
+            ("frontend_bwd_saved", lambda: ops.frontend_bwd_saved(g, gate, sgx, sgy, wts, 0.0, 76 / 255, 1.0), 16 * C * px),
             ("edge125_fwd", lambda: ops.edge125_fwd(x, wts, 0.0, 76 / 255), (C + 1) * 4 * px),
             ("edge125_bwd", lambda: ops.edge125_bwd(x, u, wts, 0.0, 76 / 255), (C + 2) * 4 * px),
             ("ce_grad", lambda: ops.ce(z, y, "sum", 0.0, False, True), 2 * B * 200 * 4),

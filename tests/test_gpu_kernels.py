@@ -640,3 +640,28 @@ def test_conv3x3s2_mfma_matches_aten(ops, B, Cin, Cout, H, W):
     (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
     torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 64, 64), (3, 1, 28, 28), (2, 3, 17, 23), (2, 2, 5, 4), (1, 3, 80, 72), (2, 4, 224, 224)])
+def test_frontend_bwd_from_saved_responses_is_bit_identical(ops, shape):
+    """The forward that keeps gx, gy + the backward that consumes them (no x, no blur / Sobel recomputation) against the
+    recomputing pair: every output bit-identical, NaN gradients included; and against the C oracle."""
+    rng = np.random.default_rng(sum(shape) + 3)
+    x = rng.random(shape, dtype=np.float32)
+    x[0, :, : shape[2] // 2, : shape[3] // 2] = 0.25  # flat patch: zero magnitude -> NaN in the gradient
+    xh = (rng.random(shape, dtype=np.float32) * 1.2 - 0.1).astype(np.float32)
+    g_in = rng.standard_normal(shape).astype(np.float32)
+    wts = ops.EdgeWeights(1.0)
+    alpha, high, w = 0.05, 0.2, 0.5
+    a_in, a_gate, a_edge = ops.frontend_fwd(dev(x), dev(xh), wts, alpha, high, w, want_edge=True)
+    b_in, b_gate, b_edge, gx, gy = ops.frontend_fwd_save(dev(x), dev(xh), wts, alpha, high, w, want_edge=True)
+    assert torch.equal(a_in, b_in) and torch.equal(a_gate, b_gate) and torch.equal(a_edge, b_edge)
+    _, _, ogx, ogy = O.edge125_fwd(x, alpha, high, want_internals=True)[0:4]
+    assert_bitexact(gx.cpu().numpy(), ogx, "saved gx")
+    assert_bitexact(gy.cpu().numpy(), ogy, "saved gy")
+    r_hfs, r_edge = ops.frontend_bwd(dev(g_in), a_gate, dev(x), wts, alpha, high, w)
+    s_hfs, s_edge = ops.frontend_bwd_saved(dev(g_in), b_gate, gx, gy, wts, alpha, high, w)
+    assert_bitexact(s_hfs.cpu().numpy(), r_hfs.cpu().numpy(), "g_hfs")
+    assert_bitexact(s_edge.cpu().numpy(), r_edge.cpu().numpy(), "g_edge")
+    if shape[2] >= 16:
+        assert int(torch.isnan(s_edge).sum()) > 0
