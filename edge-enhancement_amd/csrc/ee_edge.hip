@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_kernel(EdgeParams p, Weights 
     }
     load_frame<FH, FW, kColHalo, C>(xs, p.x + static_cast<size_t>(n) * C * H * W, C, H, W, i0, j0, 4, vec);
     if (FUSED) {
-        load_u_fused<C, FH, FW>(us, p.g_in, p.gate_in, n, H, W, oi, oj, p.w, vec);
+        load_u_fused<C, FH, FW, 2>(us, p.g_in, p.gate_in, n, H, W, oi, oj, p.w, vec);  // u is read on frame rows [2, FH-2) only
     } else {
         load_frame<FH, FW, kColHalo, 1>(us, p.u + static_cast<size_t>(n) * H * W, 1, H, W, i0, j0, 4, vec);
     }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_saved_kernel(EdgeParams p, We
             gtv[c] = make_uchar4(tv[0], tv[1], tv[2], tv[3]);
         }
     }
-    load_u_fused<C, FH, FW>(us, p.g_in, p.gate_in, n, H, W, oi, oj, p.w, vec);
+    load_u_fused<C, FH, FW, 2>(us, p.g_in, p.gate_in, n, H, W, oi, oj, p.w, vec);  // u is read on frame rows [2, FH-2) only
     for (int idx = threadIdx.x; idx < 3 * PL / 4; idx += kBlock) reinterpret_cast<float4 *>(ggx)[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
 

@@ -105,12 +105,15 @@ __device__ __forceinline__ void load_frame(float *frame, const float *__restrict
 // us[r][s] = w * ((g_hfs_0 + g_hfs_1) + ...)(clamp(oi + r), clamp(oj + s)), g_hfs_c = gate_c ? g_in_c : 0: the gradient that
 // reaches the edge map through the broadcast add and the clamp of the front end (clamped coordinates; cells outside the
 // image are never used).  oj must be a multiple of 4.
-template <int C, int FH, int FW>
+// SKIP: frame rows [0, SKIP) and [FH - SKIP, FH) are not filled (callers that read u only on an inner band of the frame).
+template <int C, int FH, int FW, int SKIP = 0>
 __device__ __forceinline__ void load_u_fused(float *us, const float *__restrict__ g_in, const uint8_t *__restrict__ gate, int n, int H, int W,
                                              int oi, int oj, float w, bool vec) {
     constexpr int F4 = FW / 4;
     if (vec) {
-        constexpr int TOTAL = FH * F4, PER = (TOTAL + kBlock - 1) / kBlock;
+        constexpr int TOTAL = (FH - 2 * SKIP) * F4, PER = (TOTAL + kBlock - 1) / kBlock;
+        us += SKIP * FW;
+        oi += SKIP;
         float4 g4[PER][C];
         uchar4 t4[PER][C];
 #pragma unroll
