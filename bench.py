@@ -140,6 +140,39 @@ def cpu_baseline(cfg, seconds_target=25.0):
 SETUP_STEPS = 3
 
 
+def calibrate_bracket(ops, N, cfg, dev, n=200):
+    """Microseconds a HIP-event bracket adds to one launch, measured before the timed region on the update kernel at the bench
+    shape: (mean bracket around single launches) - (spacing of the same launches issued back to back, which is what
+    rocprofv3's per-kernel duration plus the inter-kernel gap amounts to)."""
+    C, H, W = cfg["shape"]
+    x0 = torch.rand(cfg["batch"], C, H, W, device=dev)
+    x, g = x0.clone(), torch.randn_like(x0)
+    for _ in range(10):
+        ops.pgd_step_(x, g, x0, cfg["alpha"], cfg["eps"])
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()  # back to back on the device: eager launches would be spaced by the host, not by the GPU
+    with torch.cuda.graph(graph):
+        for _ in range(50):
+            ops.pgd_step_(x, g, x0, cfg["alpha"], cfg["eps"])
+    graph.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n // 50):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    spacing_us = 1e3 * e0.elapsed_time(e1) / (n // 50 * 50)
+    ops.prof_reset()
+    ops.prof_enable(True)
+    for _ in range(n):
+        ops.pgd_step_(x, g, x0, cfg["alpha"], cfg["eps"])
+    torch.cuda.synchronize()
+    ms, cnt = ops.prof_read(N.K_PGD_STEP)
+    ops.prof_enable(False)
+    ops.prof_reset()
+    return max(1e3 * ms / cnt - spacing_us, 0.0) if cnt else 0.0
+
+
 def large_batch_kernels(cfg, dev, mult=16, iters=50):
     """The section-8 kernels alone at `mult` x the per-rank batch (outside the timed region; one second in total): what they
     reach once a launch is no longer latency-bound - the counterpart of `roofline`, which is quoted at the reference batch.
@@ -185,6 +218,9 @@ def main():
     ap.add_argument("--probe-every", type=int, default=4,
                     help="steps between two probed attacks (the eager probe iteration costs ~1 %% of a step; its kernels are the "
                          "roofline samples, so at least one step of the timed region is always probed)")
+    ap.add_argument("--large-batch", action="store_true",
+                    help="also time the section-8 kernels alone at 16x the batch (off by default: those launches would enter the "
+                         "rocprofv3 per-kernel averages of this command, which must agree with `roofline.avg_launch_us`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-miopen-benchmark", action="store_true",
@@ -245,6 +281,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    bracket_cost_us = calibrate_bracket(ops, N, cfg, dev)
     run(SETUP_STEPS)  # one-off setup, not warm-up: MIOpen algorithm search and the two HIP-graph captures (the update graph is
     fence()           # captured on the third step of a configuration) must not land in the timed region when W < 3
     run(a.warmup)
@@ -270,7 +307,11 @@ def main():
             "ee_pgd_step": (N.K_PGD_STEP, 16 * C * px), "ee_ce": (N.K_CE, 3 * B * cfg["classes"] * 4),
         }
         ems, ecnt = ops.prof_read(N.K_EMPTY)
-        overhead_us = 1e3 * ems / ecnt if ecnt else 0.0
+        empty_us = 1e3 * ems / ecnt if ecnt else 0.0
+        # what a bracket adds to a launch: calibrated against back-to-back launch spacing (calibrate_bracket); the empty
+        # bracket of the same region is reported next to it (it over-estimates: two markers with nothing between them are
+        # not what surrounds a kernel, and subtracting it put every kernel ~2.8 us under its rocprofv3 duration)
+        overhead_us = bracket_cost_us
         kernels = {}
         for name, (kid, nbytes) in per_launch.items():
             ms, cnt = ops.prof_read(kid)
@@ -292,7 +333,7 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": kernels[dom]["avg_us"],
-                        "event_pair_overhead_us": round(overhead_us, 3)}
+                        "event_pair_overhead_us": round(overhead_us, 3), "empty_bracket_us": round(empty_us, 3)}
         out = {
             "metric": "adversarial images/sec (PGD-%d, %s)" % (cfg["steps"], cfg["arch"]),
             "value": round(world * B * a.steps / dt, 2), "unit": "adversarial images/s", "n_gpus": world, "steps": a.steps,
@@ -307,7 +348,7 @@ def main():
             "note": "throughput is bounded by the CNN convolutions (MIOpen fp32), not by the hand-written kernels; "
                     "reference log (unrecorded GPU): ~143 img/s for this config (BASELINE.md)",
         }
-        if world == 1:
+        if world == 1 and a.large_batch:
             out["kernels_large_batch"] = large_batch_kernels(cfg, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
