@@ -62,6 +62,7 @@ _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") 
 # ee_conv.hip's f32-MFMA 3x3 convolution takes maps 16..64 wide (29 us against 36 us for MIOpen's Winograd on the 64-channel
 # 16x16 layer; equal on 8x8, where the stock solver stays)
 _CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "16"))
+_CONV3_EAGER = os.environ.get("EEADV_CONV3_EAGER", "0") == "1"  # use the MFMA 3x3 convolutions outside graph capture as well
 _CONV3S2_BWD_MINOW = int(os.environ.get("EEADV_CONV3S2_BWD_MINOW", "1000"))  # its backward-data kernel: equal to MIOpen end to end, opt-in
 _CONV3S2_MINOW = int(os.environ.get("EEADV_CONV3S2_MINOW", "8"))  # narrowest OUTPUT map the stride-2 MFMA convolution takes (24 us vs 50 at 8; no gain at 4)
 
@@ -111,6 +112,12 @@ def conv3(conv, x):
             and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"):
         return Conv3x3Map2Fn.apply(x, conv.weight)
+    # The MFMA convolutions below are a few us faster on the device and tens of us slower on the host (a Python autograd
+    # Function + ctypes launch + a separate ATen call for the weight gradient against one ATen call): they pay where the
+    # host cost vanishes, i.e. while a HIP graph is being captured, and lose in eager, host-bound passes (TRADES / ALP
+    # updates: 4.2 k -> 4.9 k img/s with this rule).
+    if not (_CONV3_EAGER or torch.cuda.is_current_stream_capturing()):
+        return conv(x)
     if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
             and conv.padding_mode == "zeros" and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[3] // 2 <= 64
