@@ -181,6 +181,59 @@ __global__ __launch_bounds__(kBlock) void avmix_labels_kernel(double *__restrict
     }
 }
 
+// ---- TRADES L2 step (attacks.py:389-400): per-sample RMS normalisation of the gradient, step, RMS-ball projection ----
+// One workgroup per sample; three sweeps over the sample (L2-resident at every reference shape: 12 KB .. 600 KB):
+//   1. ss_g = sum g^2                      -> gn = sqrt(float(ss_g / per))                         (l2_norm, :362-366: MEAN of squares)
+//   2. t = x + step * (g / (gn + 1e-8)),  d = t - x0,  ss_d = sum d^2 -> dn = sqrt(float(ss_d / per))
+//   3. d *= eps / dn  where dn > eps;  x = clamp(x0 + d, lo, hi)
+// The two sums are accumulated in double (fixed order: lane-strided, wave butterflies, waves in order), then rounded to
+// float once - ATen's fp32 pairwise sums differ from that by an ulp or so, which is why this kernel's parity test is a
+// tolerance test, the only one among the update kernels.
+constexpr int kL2Block = 1024;
+
+__device__ __forceinline__ double block_sum_1024(double v, double *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // sh may still be read from a previous reduction
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kL2Block / 64; ++w) t += sh[w];
+    return t;
+}
+
+__global__ __launch_bounds__(kL2Block) void l2_step_kernel(float *x, const float *__restrict__ g, const float *__restrict__ x0,
+                                                           int64_t per, float step, float eps, float lo, float hi) {
+    __shared__ double sh[kL2Block / 64];
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * per;
+    x += base;
+    g += base;
+    x0 += base;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < per; i += kL2Block) {
+        const float v = g[i];
+        acc += static_cast<double>(v * v);
+    }
+    const float gn = sqrtf(static_cast<float>(block_sum_1024(acc, sh) / static_cast<double>(per))) + 1e-8f;
+    acc = 0.0;
+    for (int64_t i = threadIdx.x; i < per; i += kL2Block) {
+        const float t = x[i] + step * (g[i] / gn);
+        const float d = t - x0[i];
+        acc += static_cast<double>(d * d);
+    }
+    const float dn = sqrtf(static_cast<float>(block_sum_1024(acc, sh) / static_cast<double>(per)));
+    const bool shrink = dn > eps;
+    const float f = eps / dn;
+    for (int64_t i = threadIdx.x; i < per; i += kL2Block) {
+        const float t = x[i] + step * (g[i] / gn);
+        float d = t - x0[i];
+        if (shrink) d *= f;
+        x[i] = tclamp(x0[i] + d, lo, hi);
+    }
+}
+
 int grid_for(int64_t n) {
     int64_t blocks = (n + kBlock - 1) / kBlock;
     return static_cast<int>(blocks > kMaxGrid ? kMaxGrid : (blocks < 1 ? 1 : blocks));
@@ -288,5 +341,16 @@ EE_API int ee_avmix_labels_f64(double *out, const int64_t *labels, const double 
     if (B == 0) return EE_OK;
     EE_LAUNCH(avmix_labels_kernel, dim3(grid_for(B * K)), dim3(kBlock), 0, as_stream(stream), out, labels, wgt, B, K,
                        lambda1, lambda2);
+    return launch_status();
+}
+
+EE_API int ee_l2_step_f32(float *x, const float *g, const float *x0, int64_t B, int64_t per_sample, float step, float eps,
+                          float lo, float hi, void *stream) {
+    if (B < 0 || per_sample < 1 || B > 0x7fffffff) return EE_ERR_SHAPE;
+    if (B == 0) return EE_OK;
+    if (!x || !g || !x0) return EE_ERR_NULL;
+    if (!aligned4(x) || !aligned4(g) || !aligned4(x0)) return EE_ERR_ALIGN;
+    EE_LAUNCH(l2_step_kernel, dim3(static_cast<unsigned>(B)), dim3(kL2Block), 0, as_stream(stream), x, g, x0, per_sample, step,
+              eps, lo, hi);
     return launch_status();
 }

@@ -28,6 +28,7 @@ SIGNATURES = {
     "ee_pgd_init_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_p],
     "ee_pgd_init_rng_f32": [c_p, c_p, c_l, c_f, c_i, c_u64, c_u64, c_f, c_f, c_p],
     "ee_pgd_step_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_p],
+    "ee_l2_step_f32": [c_p, c_p, c_p, c_l, c_l, c_f, c_f, c_f, c_f, c_p],
     "ee_fgsm_step_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_i, c_p],
     "ee_add_clamp_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_p],
     "ee_freeat_update_f32": [c_p, c_p, c_l, c_f, c_f, c_p],

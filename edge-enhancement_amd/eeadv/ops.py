@@ -114,6 +114,17 @@ def pgd_step_bcast_(x, g_lp, g_edge, x0, alpha, eps, lo=0.0, hi=1.0, direction=1
     return x
 
 
+def l2_step_(x, g, x0, step, eps, lo=0.0, hi=1.0):
+    """In place on x [B, ...]: the TRADES L2 update (attacks.py:389-400)."""
+    B = x.shape[0]
+    px = _chk(x, torch.float32, "x")
+    pg = _chk(g, torch.float32, "g", x.shape)
+    p0 = _chk(x0, torch.float32, "x0", x.shape)
+    if B:
+        N.check(N.lib.ee_l2_step_f32(px, pg, p0, B, x.numel() // B, step, eps, lo, hi, _stream()), "ee_l2_step_f32")
+    return x
+
+
 def fgsm_step(x, g, alpha, lo=0.0, hi=1.0, direction=1):
     px = _chk(x, torch.float32, "x")
     pg = _chk(g, torch.float32, "g", x.shape)

@@ -316,9 +316,19 @@ class Trades:
         self.perturb_steps = k
 
     def PGD_L2(self, model, x_natural, logits, noise=None):
-        """attacks.py:381-401: gradient normalised by its per-sample RMS, step alpha*g, RMS-ball projection.
-        Not on any BASELINE config; kept in torch ops on the tensor's device."""
+        """attacks.py:381-401: gradient normalised by its per-sample RMS, step alpha*g, RMS-ball projection, clamp -
+        one kernel per iteration (ee_l2_step_f32) behind the KL loss-gradient kernel."""
         model.eval()
+        x0 = x_natural.detach()
+        if runtime.require_device(x0, "Trades.PGD_L2"):
+            x0 = x0.contiguous()
+            x = _randn_start(x0, noise)
+            spec = engine.LossSpec(engine.KL, logits.detach().contiguous())
+            net = engine._unwrap(model)
+            for _ in range(self.perturb_steps):
+                g = engine.input_gradient(net, x, spec)
+                x = ops.l2_step_(x.detach(), g.contiguous(), x0, float(self.step_size), float(self.epsilon), 0.0, 1.0)
+            return x.detach()
         nz = torch.randn(x_natural.shape, device=x_natural.device) if noise is None else noise.to(x_natural.device)
         x_adv = x_natural.detach() + 0.001 * nz.detach()
         prob = F.softmax(logits, dim=-1)

@@ -63,6 +63,14 @@ int ee_pgd_init_rng_f32(float *x, const float *x0, int64_t n, float scale, int d
 int ee_pgd_step_f32(float *x, const float *g, const float *x0, int64_t n, float alpha, float eps, float lo,
                     float hi, int dir, void *stream);
 
+/* attacks.py:389-400 (Trades.PGD_L2), in place on x [B, per_sample]: per sample b
+ *     gn = sqrt(mean(g_b^2)) + 1e-8;  t = x_b + step * (g_b / gn);  d = t - x0_b;  dn = sqrt(mean(d^2));
+ *     if dn > eps: d *= eps / dn;     x_b = clamp(x0_b + d, lo, hi)
+ * (l2_norm is the root of the MEAN of squares, attacks.py:360-366).  The two means are accumulated in double and
+ * rounded to fp32 once; ATen's fp32 sum order is not reproduced - results agree to ~1e-7, not bit for bit. */
+int ee_l2_step_f32(float *x, const float *g, const float *x0, int64_t B, int64_t per_sample, float step, float eps,
+                   float lo, float hi, void *stream);
+
 /* attacks.py:121-126 FGSM:  out = clamp(x + dir*alpha*sign(g), lo, hi)   (no eps projection) */
 int ee_fgsm_step_f32(float *out, const float *x, const float *g, int64_t n, float alpha, float lo, float hi,
                      int dir, void *stream);

@@ -10,12 +10,16 @@ Every function cites the reference lines it follows.  Randomness is injectable (
 because device and host generators differ; with `None` the same torch CPU calls as the reference are made.
 
 Parity status
-  pinned   : PGD / targeted_PGD / FGSM / CW(targeted) / AVmixup.perturb / losses / CannyFilter_step125_1
-             (fwd + bwd) / Net_2 / resnet18  - fixtures generated from the reference itself.
+  pinned   : PGD / targeted_PGD / targeted_PGD_trick / tar_alp_imagenet / FGSM / CW(targeted) / AVmixup.perturb /
+             AVmixup.tar_perturb / losses / CannyFilter_step125_1 (fwd + bwd) / Net_2 / resnet18 - fixtures generated
+             from the reference itself; Trades.PGD_Linf / PGD_L2, ALP.PGD_Linf, targeted_ALP.{PGD_Linf,tarPGD_Linf}
+             (linf_loops.npz: the reference's methods run with their one `torch.randn(.., device='cuda')` drawing on the
+             host) and Add_Square (add_square.npz: the reference's forward run with `Tensor.cuda` as the identity, its
+             own draws recorded) - see tests/golden/make_golden.py for the two stand-ins.
   unpinned : HighFreqSuppress (torch.rfft is gone; behaviour on the non-Hermitian +-r row restated from
-             SURVEY.md a13), Add_Square and every *_Linf init with device='cuda' hard-coded (cannot run
-             on CPU in the reference), get_thin_kernels (needs cv2) and therefore CannyFilter /
-             CannyFilter_BPDA (fixtures in canny_full_unpinned.npz use the derived table below).
+             SURVEY.md a13), get_thin_kernels (needs cv2) and therefore CannyFilter / CannyFilter_BPDA
+             (fixtures in canny_full_unpinned.npz use the derived table below); the free-AT step (the script
+             parses argv and joins a process group at import - restated from its lines 286-309).
 """
 import math
 
@@ -219,8 +223,8 @@ class CannyFilter_BPDA(_CannyBase):
 
 
 class Add_Square(nn.Module):
-    """core.py:589-655.  PARITY UNPINNED (the reference hard-codes .cuda()).  `draws` injects the random
-    numbers: dict(stripe [B,C,1,W] in {-1,0,1}, sq_sign [nq,C,1,1], sq_pos [nq] int)."""
+    """core.py:589-655.  Pinned by tests/golden/add_square.npz (the reference's own forward and draws).  `draws`
+    injects the random numbers: dict(stripe [B,C,1,W] in {-1,0,1}, sq_sign [nq,C,1,1], sq_pos [nq] int)."""
 
     def __init__(self, channels=3, size=224, epsilon=0.05, p_init=0.8, n_queries=5000, rescale_schedule=False):
         super().__init__()
@@ -295,6 +299,45 @@ def targeted_PGD(model, args, inputs, labels, num_steps, step_size, nclass, devi
     if args.random:
         nz = torch.zeros_like(x).uniform_(-args.epsilon, args.epsilon) if noise is None else noise
         x = torch.clamp(x + nz, 0.0, 1.0)
+    for _ in range(num_steps):
+        x.requires_grad_()
+        with torch.enable_grad():
+            loss = F.cross_entropy(model(x), target_labels, reduction='sum')
+        grad = torch.autograd.grad(loss, [x])[0]
+        x = _step(x, grad, inputs, step_size, args.epsilon, -1)
+    return x, target_labels
+
+
+def targeted_PGD_trick(model, args, inputs, labels, num_steps, step_size, nclass, device, noise=None, label_offset=None,
+                       start_from_noise=None):
+    """attacks.py:59-86: x + b * U(-eps, eps) with ONE Bernoulli b per batch (:69-71), clamped either way (:73)."""
+    x = inputs.detach()
+    if label_offset is None:
+        label_offset = torch.randint(low=1, high=nclass, size=labels.shape).to(device)
+    target_labels = torch.fmod(labels + label_offset, nclass)
+    if args.random:
+        init_start = torch.Tensor(x.shape).uniform_(-args.epsilon, args.epsilon).to(device) if noise is None else noise
+        if start_from_noise is None:
+            start_from_noise = torch.gt(torch.rand([]), args.prob_start_from_clean)
+        b = torch.as_tensor(start_from_noise).type(torch.float32).to(device)
+        x = torch.clamp(x + b * init_start, 0.0, 1.0)
+    for _ in range(num_steps):
+        x.requires_grad_()
+        with torch.enable_grad():
+            loss = F.cross_entropy(model(x), target_labels, reduction='sum')
+        grad = torch.autograd.grad(loss, [x])[0]
+        x = _step(x, grad, inputs, step_size, args.epsilon, -1)
+    return x, target_labels
+
+
+def tar_alp_imagenet(model, args, inputs, labels, num_steps, step_size, device, noise=None, label_offset=None):
+    """attacks.py:337-357: 1000 classes hard-coded, start x + 0.001 * randn (not clamped), sum-CE descent."""
+    x = inputs.detach()
+    if label_offset is None:
+        label_offset = torch.randint(low=1, high=1000, size=labels.shape).to(device)
+    target_labels = torch.fmod(labels + label_offset, 1000)
+    nz = torch.randn(x.shape).to(device) if noise is None else noise
+    x = x + 0.001 * nz.detach()
     for _ in range(num_steps):
         x.requires_grad_()
         with torch.enable_grad():
@@ -402,7 +445,47 @@ class ALP:  # attacks.py:236-272
         return 0.5 * F.cross_entropy(logits, y) + 0.5 * F.cross_entropy(logits_adv, y) + self.beta * F.mse_loss(logits, logits_adv)
 
 
-class AVmixup:  # attacks.py:433-479
+class targeted_ALP(ALP):  # attacks.py:276-333 (PGD_Linf and loss are textual copies of ALP's)
+    def __init__(self, step_size=0.003, epsilon=0.047, perturb_steps=5, beta=1.0, n_class=200):
+        super().__init__(step_size, epsilon, perturb_steps, beta)
+        self.n_class = n_class
+
+    def tarPGD_Linf(self, model, x_natural, y, device, noise=None, label_offset=None):  # attacks.py:305-322
+        model.eval()
+        if label_offset is None:
+            label_offset = torch.randint(low=1, high=self.n_class, size=y.shape).to(device)
+        target_labels = torch.fmod(y + label_offset, self.n_class)
+        nz = torch.randn(x_natural.shape, device=x_natural.device) if noise is None else noise
+        x_adv = x_natural.detach() + 0.001 * nz.detach()
+        for _ in range(self.perturb_steps):
+            x_adv.requires_grad_()
+            with torch.enable_grad():
+                loss_c = F.cross_entropy(model(x_adv), target_labels)
+            grad = torch.autograd.grad(loss_c, [x_adv])[0].detach()
+            x_adv = _step(x_adv, grad, x_natural, self.step_size, self.epsilon, -1)
+        return x_adv
+
+
+def free_at_repeat(model, criterion, optimizer, x, y, noise, fgsm_step, clip_eps):
+    """One repeat of the free-AT inner loop, ImageNet/free_imagenet/AT_free_imagenet_ddp.py:287-309, on the persistent
+    buffer `noise` (updated in place on its first len(x) rows; the clamp covers the WHOLE buffer, :307).
+    Returns (loss, output).  PARITY UNPINNED: the script cannot be imported (argv + process group at import)."""
+    n = x.size(0)
+    noise_batch = noise[0:n].clone().requires_grad_(True)  # Variable(global_noise_data[0:n], requires_grad=True)
+    in1 = x + noise_batch
+    in1.clamp_(0, 1.0)  # in place: its backward masks the gradient where x + delta left [0, 1]
+    output = model(in1)
+    loss = criterion(output, y)
+    optimizer.zero_grad()
+    loss.backward()
+    pert = fgsm_step * torch.sign(noise_batch.grad)
+    noise[0:n] += pert.data
+    noise.clamp_(-clip_eps, clip_eps)
+    optimizer.step()
+    return loss.detach(), output.detach()
+
+
+class AVmixup:  # attacks.py:433-518
     def __init__(self, args, gamma, lambda1, lambda2, step_size, num_steps, num_classes=200, device='cpu'):
         self.args, self.gamma, self.lambda1, self.lambda2 = args, gamma, lambda1, lambda2
         self.step_size, self.num_steps, self.num_classes, self.device = step_size, num_steps, num_classes, device
@@ -430,6 +513,30 @@ class AVmixup:  # attacks.py:433-479
         x = inputs * xw + vertex * (1 - xw)
         y = y_nat * yw + y_vertex * (1 - yw)
         return x.to(torch.float), y
+
+    def tar_perturb(self, model, inputs, targets, noise=None, beta=None, label_offset=None):
+        """attacks.py:481-518: descent on -sum(log_softmax * fmod(targets + randint, K)); `targets` is whatever the caller
+        passes - the driver passes one-hot rows, so the "labels" are a [B,K] float matrix (experiments_tinyimagenet.py:266-269)."""
+        x = inputs.detach()
+        if label_offset is None:
+            label_offset = torch.randint(low=1, high=self.num_classes, size=targets.shape).to(self.device)
+        target_labels = torch.fmod(targets + label_offset, self.num_classes)
+        if self.args.random:
+            nz = torch.zeros_like(x).uniform_(-self.args.epsilon, self.args.epsilon) if noise is None else noise
+            x = torch.clamp(x + nz, 0, 1)
+        for _ in range(self.num_steps):
+            x.requires_grad_()
+            with torch.enable_grad():
+                loss = -torch.sum(F.log_softmax(model(x), dim=1) * target_labels)
+            grad = torch.autograd.grad(loss, [x])[0]
+            x = _step(x, grad, inputs, self.step_size, self.args.epsilon, -1)
+        vertex = torch.clamp(inputs + (x - inputs) * self.gamma, 0, 1)
+        y_nat = self._label_smoothing(targets, self.lambda1)
+        y_vertex = self._label_smoothing(targets, self.lambda2)
+        x_weight = np.random.beta(1.0, 1.0, [x.shape[0], 1, 1, 1]) if beta is None else beta
+        xw = torch.from_numpy(x_weight).to(self.device)
+        yw = torch.from_numpy(np.reshape(x_weight, [-1, 1])).to(self.device)
+        return (inputs * xw + vertex * (1 - xw)).to(torch.float), y_nat * yw + y_vertex * (1 - yw)
 
 
 def CWLinfAttack(x, y, model, magnitude, previous_p, max_eps, max_iters=20, target=None, n_class=10, noise=None):

@@ -401,7 +401,11 @@ def gen_e2e():
     x = torch.rand(6, 1, 28, 28)
     y = torch.randint(0, 10, (6,))
     torch.manual_seed(300)
-    xa = rattacks.PGD(net, Args(random=True, epsilon=0.3), x, y, 40, 0.01)
+    rec = Recorder(net).eval()
+    xa = rattacks.PGD(rec, Args(random=True, epsilon=0.3), x, y, 40, 0.01)
+    # every iterate the reference fed to the model and the gradient it got back (the step-by-step replay of
+    # tests/test_gpu_path.py feeds these x_k to the GPU model and explains every differing pixel by |g|)
+    out["net2_xs"], out["net2_gs"] = np.stack(rec.xs), np.stack(rec.gs)
     torch.manual_seed(300)
     out["net2_noise"] = torch.zeros_like(x).uniform_(-0.3, 0.3).numpy()
     with torch.no_grad():
@@ -425,7 +429,9 @@ def gen_e2e():
     y = torch.randint(0, 200, (2,))
     eps, alpha = 0.062745098039216, 0.007843137254902
     torch.manual_seed(301)
-    xa = rattacks.PGD(rn, Args(random=True, epsilon=eps), x, y, 3, alpha)
+    rec = Recorder(rn).eval()
+    xa = rattacks.PGD(rec, Args(random=True, epsilon=eps), x, y, 3, alpha)
+    out["rn18_xs"], out["rn18_gs"] = np.stack(rec.xs), np.stack(rec.gs)
     torch.manual_seed(301)
     out["rn18_noise"] = torch.zeros_like(x).uniform_(-eps, eps).numpy()
     with torch.no_grad():
@@ -462,6 +468,218 @@ def gen_canny_full():
     save("canny_full_unpinned", **out)
 
 
+# --------------------------------------------------------------------------
+# 8. the rest of the targeted family (attacks.py:59-86, 337-357, 481-518): all three take `device`
+# --------------------------------------------------------------------------
+def gen_targeted():
+    out = {}
+    B, C, HW, K = 3, 2, 8, 10
+    torch.manual_seed(61)
+    x0 = torch.rand(B, C, HW, HW)
+    x0[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 0.001, 0.999])
+    y = torch.tensor([2, 9, 5])
+    eps, alpha, steps = 0.062745098039216, 0.007843137254902, 5
+    out["x0"], out["y"] = x0.numpy(), y.numpy()
+    out["eps_alpha"] = np.array([eps, alpha], np.float64)
+
+    # (a) targeted_PGD_trick: ONE Bernoulli per batch (attacks.py:69-71); find a seed for each outcome
+    want = {True: None, False: None}
+    seed = 400
+    while any(v is None for v in want.values()):
+        torch.manual_seed(seed)
+        torch.randint(low=1, high=K, size=y.shape)
+        torch.Tensor(x0.shape).uniform_(-eps, eps)
+        outcome = bool(torch.gt(torch.rand([]), 0.5))
+        if want[outcome] is None:
+            want[outcome] = seed
+        seed += 1
+    for outcome, sd in want.items():
+        tag = "trick_noise" if outcome else "trick_clean"
+        rec = Recorder(TinyNet(C, HW, K, 71))
+        torch.manual_seed(sd)
+        xa, tl = rattacks.targeted_PGD_trick(rec, Args(random=True, epsilon=eps, prob_start_from_clean=0.5), x0, y, steps,
+                                             alpha, K, "cpu")
+        torch.manual_seed(sd)  # replay the generator calls of attacks.py:66, :69, :70 in their order
+        off = torch.randint(low=1, high=K, size=y.shape)
+        init = torch.Tensor(x0.shape).uniform_(-eps, eps)
+        u = torch.rand([])
+        assert bool(torch.gt(u, 0.5)) == outcome
+        out[tag + "_offset"], out[tag + "_init"], out[tag + "_u"] = off.numpy(), init.numpy(), np.float32(u.item())
+        out[tag + "_target"] = tl.numpy()
+        out[tag + "_xs"], out[tag + "_gs"], out[tag + "_final"] = np.stack(rec.xs), np.stack(rec.gs), xa.numpy()
+    # args.random = False: no generator call besides the label offset
+    rec = Recorder(TinyNet(C, HW, K, 71))
+    torch.manual_seed(410)
+    xa, tl = rattacks.targeted_PGD_trick(rec, Args(random=False, epsilon=eps, prob_start_from_clean=0.5), x0, y, steps, alpha, K, "cpu")
+    torch.manual_seed(410)
+    out["trick_norand_offset"] = torch.randint(low=1, high=K, size=y.shape).numpy()
+    out["trick_norand_target"], out["trick_norand_final"] = tl.numpy(), xa.numpy()
+
+    # (b) tar_alp_imagenet: nclass 1000 hard-coded (attacks.py:341-342), start x + 0.001 * randn, never clamped before step 1
+    K2 = 1000
+    y2 = torch.tensor([999, 0, 517])
+    rec = Recorder(TinyNet(C, HW, K2, 72))
+    torch.manual_seed(420)
+    xa, tl = rattacks.tar_alp_imagenet(rec, Args(epsilon=eps), x0, y2, steps, alpha, "cpu")
+    torch.manual_seed(420)
+    off = torch.randint(low=1, high=1000, size=y2.shape)
+    nz = torch.randn(x0.shape)
+    out["talp_y"], out["talp_offset"], out["talp_randn"], out["talp_target"] = y2.numpy(), off.numpy(), nz.numpy(), tl.numpy()
+    out["talp_xs"], out["talp_gs"], out["talp_final"] = np.stack(rec.xs), np.stack(rec.gs), xa.numpy()
+
+    # (c) AVmixup.tar_perturb with what the driver passes: ONE-HOT float targets (experiments_tinyimagenet.py:266-269);
+    #     the "labels" fmod(onehot + randint, K) are a [B,K] float matrix that multiplies the log-probabilities (:503)
+    rec = Recorder(TinyNet(C, HW, K, 73))
+    av = rattacks.AVmixup(Args(random=True, epsilon=eps), 2.0, 1.0, 0.1, alpha, steps, num_classes=K, device="cpu")
+    onehot = torch.eye(K)[y]
+    torch.manual_seed(430)
+    np.random.seed(431)
+    xm, ym = av.tar_perturb(rec, x0, onehot)
+    torch.manual_seed(430)
+    off = torch.randint(low=1, high=K, size=onehot.shape)
+    nz = torch.zeros_like(x0).uniform_(-eps, eps)
+    np.random.seed(431)
+    beta = np.random.beta(1.0, 1.0, [B, 1, 1, 1])
+    out["tav_offset"], out["tav_noise"], out["tav_beta"] = off.numpy(), nz.numpy(), beta
+    out["tav_xs"], out["tav_gs"] = np.stack(rec.xs), np.stack(rec.gs)
+    out["tav_x"], out["tav_y"] = xm.numpy(), ym.numpy()
+    assert ym.dtype == torch.float64 and xm.dtype == torch.float32
+    save("targeted", **out)
+
+
+# --------------------------------------------------------------------------
+# 9. the *_Linf / L2 loops whose start is `torch.randn(shape, device='cuda')` (attacks.py:250, 291, 311, 383, 406)
+# --------------------------------------------------------------------------
+class _RandnOnHost:
+    """This container has no ROCm device.  While active, `torch.randn(..., device='cuda')` - the ONE device-bound call in
+    each of these methods - draws from the CPU generator instead; every other line of the reference runs as written."""
+
+    def __enter__(self):
+        self._orig = torch.randn
+
+        def randn(*a, **k):
+            if str(k.get("device", "")).startswith("cuda"):
+                k = dict(k, device="cpu")
+            return self._orig(*a, **k)
+        torch.randn = randn
+
+    def __exit__(self, *exc):
+        torch.randn = self._orig
+
+
+def gen_linf():
+    out = {}
+    B, C, HW, K = 3, 2, 8, 10
+    torch.manual_seed(81)
+    x0 = torch.rand(B, C, HW, HW)
+    x0[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 0.0005, 0.9995])  # x0 + 0.001 * randn leaves [0, 1] here: the start is NOT clamped
+    y = torch.tensor([7, 3, 0])
+    eps, alpha, steps = 0.062745098039216, 0.003921568627451, 5
+    out["x0"], out["y"] = x0.numpy(), y.numpy()
+    out["eps_alpha"] = np.array([eps, alpha], np.float64)
+    with _RandnOnHost():
+        # TRADES (attacks.py:404-418): KL batchmean against softmax of the natural logits
+        net = TinyNet(C, HW, K, 91)
+        rec = Recorder(net)
+        logits = net(x0)
+        torch.manual_seed(500)
+        xa = rattacks.Trades(alpha, eps, steps, 6.0).PGD_Linf(rec, x0, logits)
+        assert not rec.training  # eval() side effect
+        torch.manual_seed(500)
+        out["trades_randn"] = torch.randn(x0.shape).numpy()
+        out["trades_logits"] = logits.detach().numpy()
+        out["trades_xs"], out["trades_gs"], out["trades_final"] = np.stack(rec.xs), np.stack(rec.gs), xa.numpy()
+
+        # TRADES L2 (attacks.py:381-401)
+        rec = Recorder(TinyNet(C, HW, K, 91))
+        torch.manual_seed(501)
+        xa = rattacks.Trades(0.05, 0.03, steps, 6.0).PGD_L2(rec, x0, logits)
+        torch.manual_seed(501)
+        out["tradesl2_randn"] = torch.randn(x0.shape).numpy()
+        out["tradesl2_step_eps"] = np.array([0.05, 0.03], np.float64)
+        out["tradesl2_xs"], out["tradesl2_gs"], out["tradesl2_final"] = np.stack(rec.xs), np.stack(rec.gs), xa.numpy()
+
+        # ALP (attacks.py:247-261): mean cross-entropy
+        rec = Recorder(TinyNet(C, HW, K, 92))
+        torch.manual_seed(502)
+        xa = rattacks.ALP(alpha, eps, steps, 1.0).PGD_Linf(rec, x0, y)
+        torch.manual_seed(502)
+        out["alp_randn"] = torch.randn(x0.shape).numpy()
+        out["alp_xs"], out["alp_gs"], out["alp_final"] = np.stack(rec.xs), np.stack(rec.gs), xa.numpy()
+
+        # targeted_ALP (attacks.py:288-322): both methods
+        rec = Recorder(TinyNet(C, HW, K, 93))
+        tal = rattacks.targeted_ALP(alpha, eps, steps, 1.0, n_class=K)
+        torch.manual_seed(503)
+        xa = tal.tarPGD_Linf(rec, x0, y, "cpu")
+        torch.manual_seed(503)
+        off = torch.randint(low=1, high=K, size=y.shape)
+        out["talpc_offset"], out["talpc_randn"] = off.numpy(), torch.randn(x0.shape).numpy()
+        out["talpc_xs"], out["talpc_gs"], out["talpc_final"] = np.stack(rec.xs), np.stack(rec.gs), xa.numpy()
+        rec = Recorder(TinyNet(C, HW, K, 93))
+        torch.manual_seed(504)
+        xa = tal.PGD_Linf(rec, x0, y)
+        torch.manual_seed(504)
+        out["talpu_randn"] = torch.randn(x0.shape).numpy()
+        out["talpu_final"] = xa.numpy()
+    save("linf_loops", **out)
+
+
+# --------------------------------------------------------------------------
+# 10. Add_Square (core.py:589-655): the reference's forward with its own draws recorded
+# --------------------------------------------------------------------------
+class _CudaIsHost:
+    """`Add_Square` calls `.cuda()` on freshly drawn CPU tensors (core.py:600, 604, 646).  While active, Tensor.cuda returns
+    the tensor itself, so the reference's forward runs on the host with the CPU generator; nothing else is replaced."""
+
+    def __enter__(self):
+        self._orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda t, *a, **k: t
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda = self._orig
+
+
+def gen_add_square():
+    out = {}
+    cases = {"tiny": (3, 3, 64, 16.0 / 255, 1, 600), "mnist": (2, 1, 28, 0.3, 1, 601), "nq12": (2, 3, 16, 16.0 / 255, 12, 602),
+             "nq60_resc": (2, 3, 16, 0.1, 60, 603)}
+    for tag, (B, C, n, eps, nq, seed) in cases.items():
+        mod = rcore.Add_Square(channels=C, size=n, epsilon=eps, n_queries=nq, rescale_schedule=tag.endswith("resc"))
+        choices, ints = [], []
+        rc, ri = mod.random_choice, mod.random_int
+
+        def random_choice(shape, rc=rc):
+            t = rc(shape)
+            choices.append(t.numpy().copy())
+            return t
+
+        def random_int(low=0, high=1, shape=[1], ri=ri):
+            t = ri(low, high, shape)
+            ints.append((int(t.item()), int(high)))
+            return t
+        mod.random_choice, mod.random_int = random_choice, random_int
+        torch.manual_seed(seed)
+        x = torch.rand(B, C, n, n)
+        x[0, 0, 0, :6] = torch.tensor([0.0, 1.0, eps, 1 - eps, eps / 2, 1 - eps / 2])
+        xg = x.clone().requires_grad_(True)
+        with _CudaIsHost():
+            y = mod(xg)
+        g = torch.Generator().manual_seed(seed + 50)
+        u = torch.randn(x.shape, generator=g)
+        (y * u).sum().backward()
+        assert len(choices) == nq + 1 and len(ints) == nq
+        out[tag + "__cfg"] = np.array([B, C, n, nq, int(tag.endswith("resc"))], np.int64)
+        out[tag + "__eps"] = np.float64(eps)
+        out[tag + "__x"], out[tag + "__y"], out[tag + "__u"], out[tag + "__gx"] = x.numpy(), y.detach().numpy(), u.numpy(), xg.grad.numpy()
+        out[tag + "__stripe"] = choices[0]                                   # [B,C,1,n]  (core.py:637)
+        out[tag + "__sq_sign"] = np.stack(choices[1:]).reshape(nq, C)        # [nq,C]     (core.py:648)
+        out[tag + "__sq_pos"] = np.array([v for v, _ in ints], np.int64)     # [nq]       (core.py:645)
+        out[tag + "__sq_size"] = np.array([n - hi for _, hi in ints], np.int32)  # s = h - high  (core.py:644-645)
+        print("  add_square", tag, "pos", out[tag + "__sq_pos"][:4], "size", out[tag + "__sq_size"][:4])
+    save("add_square", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_kernels()
@@ -471,3 +689,6 @@ if __name__ == "__main__":
     gen_avmix_cw()
     gen_e2e()
     gen_canny_full()
+    gen_targeted()
+    gen_linf()
+    gen_add_square()

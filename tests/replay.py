@@ -1,0 +1,52 @@
+"""Step-by-step replay of a reference attack trajectory on the GPU (shared by the -m gpu tests).
+
+The reference (run on the host when tests/golden/make_golden.py made the fixtures) recorded every iterate x_k it fed to
+the model and the gradient g_k it got back.  A free-running attack on the GPU cannot be bit-identical to that run: the
+classifier's convolutions are MIOpen's here and oneDNN's there, the two round differently, and a gradient entry whose
+magnitude is inside that rounding noise may change sign - which moves the pixel by 2*alpha and, from the next step on,
+every later iterate.  The replay separates the two effects.  For every recorded step k it feeds the REFERENCE's x_k to the
+GPU model and requires
+
+  (1) |g_gpu - g_ref| <= tol * max|g_ref|                   (the model + loss-gradient kernel agree with the reference),
+  (2) x_{k+1} from the HIP update kernel == the reference's x_{k+1} at every element with |g_ref| > tol * max|g_ref|
+      (an element can only differ if sign(g_gpu) != sign(g_ref), which (1) allows only below that magnitude),
+  (3) with the reference's own g_k the HIP update kernel reproduces x_{k+1} bit for bit everywhere.
+
+So every pixel in which a free-running GPU attack may leave the reference trajectory is one whose reference gradient
+was below `tol` of the step's largest gradient entry at the step where it diverged.
+"""
+import numpy as np
+import torch
+
+from oracle import ee_oracle as O
+
+
+def replay_trajectory(model, xs, gs, x0, spec, alpha, eps, direction=1, final=None, tol=1e-5, lo=0.0, hi=1.0, dev="cuda:0"):
+    """Returns per-step dicts(err, undecided, flipped); raises AssertionError when (1)-(3) fail."""
+    from eeadv import engine, ops
+    x0_d = torch.from_numpy(np.ascontiguousarray(x0)).to(dev)
+    stats = []
+    for k in range(len(gs)):
+        g_ref = gs[k]
+        want = O.pgd_step(xs[k], g_ref, x0, alpha, eps, lo, hi, direction)
+        nxt = xs[k + 1] if k + 1 < len(xs) else final
+        if nxt is not None:
+            assert np.array_equal(want, nxt), "oracle step %d is not the reference's" % k
+        xk = torch.from_numpy(np.ascontiguousarray(xs[k])).to(dev)
+        g = engine.input_gradient(model, xk.clone(), spec).detach().contiguous()
+        g_np = g.cpu().numpy()
+        scale = float(np.nanmax(np.abs(g_ref)))
+        assert np.array_equal(np.isnan(g_np), np.isnan(g_ref)), "step %d: NaN pattern of the gradient differs" % k
+        err = float(np.nanmax(np.abs(g_np - g_ref))) if g_ref.size else 0.0
+        assert err <= tol * scale, "step %d: gradient differs by %.3g (%.3g of its largest entry, allowed %.1g)" % (k, err, err / scale, tol)
+        x_next = xk.clone()
+        ops.pgd_step_(x_next, g, x0_d, alpha, eps, lo, hi, direction)
+        got = x_next.cpu().numpy()
+        decided = np.abs(np.nan_to_num(g_ref)) > tol * scale
+        assert np.array_equal(got[decided], want[decided]), "step %d: an element with a decided gradient sign moved differently" % k
+        x_ref = xk.clone()
+        ops.pgd_step_(x_ref, torch.from_numpy(np.ascontiguousarray(g_ref)).to(dev), x0_d, alpha, eps, lo, hi, direction)
+        assert np.array_equal(x_ref.cpu().numpy(), want), "step %d: update kernel is not bit-exact on the reference's gradient" % k
+        stats.append({"err": err / scale if scale else 0.0, "undecided": int((~decided).sum()), "flipped": int((got != want).sum()),
+                      "n": int(want.size)})
+    return stats

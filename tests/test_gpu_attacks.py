@@ -1,0 +1,241 @@
+"""GPU parity of the attack loops that round 1 left without a pinned comparison:
+utils.attacks on cuda:0 (HIP kernels through the C ABI) against the reference's own recorded trajectories
+(tests/golden/{targeted,linf_loops,add_square}.npz) and against the CPU oracle, eager and from a captured HIP graph.
+
+What is exact and what is not is spelled out in tests/replay.py: the update, start and loss kernels are bit-exact; the
+classifier runs on MIOpen, so a free-running attack is compared through predictions + the fraction of identical pixels,
+and the step-by-step replay bounds every possible divergence by the gradient magnitude at the step where it happened.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ee_oracle as O
+from oracle import ref_path as R
+from replay import replay_trajectory
+from tiny_models import Args, TinyNet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5  # gradient agreement GPU (MIOpen) vs reference (oneDNN), relative to the step's largest entry
+
+
+@pytest.fixture(scope="module")
+def A():
+    import utils.attacks as attacks
+    return attacks
+
+
+@pytest.fixture(params=["eager", "graph"])
+def mode(request, monkeypatch):
+    from eeadv import engine
+    monkeypatch.setenv("EEADV_GRAPH", "1" if request.param == "graph" else "0")
+    engine.clear_graphs()
+    yield request.param
+    engine.clear_graphs()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def same_fraction(a, b):
+    return float((np.asarray(a) == np.asarray(b)).mean())
+
+
+def check_free_run(got, want, net_cpu, what, frac=0.99):
+    """A free-running GPU attack against the reference's final iterate: same predictions, logits within the north-star
+    1e-4 wherever the inputs coincide is implied by the replay; here the end points are compared."""
+    got = got.detach().cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert same_fraction(got, want) > frac, (what, same_fraction(got, want))
+    with torch.no_grad():
+        la, lb = net_cpu(torch.from_numpy(got)), net_cpu(torch.from_numpy(want))
+    assert torch.equal(la.argmax(1), lb.argmax(1)), what
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a2: targeted_PGD_trick, tar_alp_imagenet, AVmixup.tar_perturb
+# ---------------------------------------------------------------------------------------------------------
+def test_targeted_trick_vs_reference(A, golden, mode):
+    from eeadv import engine
+    G = golden("targeted")
+    x0, y = dev(G["x0"]), dev(G["y"])
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    for tag, b in (("trick_noise", True), ("trick_clean", False)):
+        net = TinyNet(2, 8, 10, 71).to(DEV)
+        args = Args(random=True, epsilon=eps, prob_start_from_clean=0.5)
+        xa, tl = A.targeted_PGD_trick(net, args, x0, y, 5, alpha, 10, DEV, noise=dev(G[tag + "_init"]),
+                                      label_offset=dev(G[tag + "_offset"]), start_from_noise=b)
+        assert np.array_equal(tl.cpu().numpy(), G[tag + "_target"]) and not xa.requires_grad
+        check_free_run(xa, G[tag + "_final"], TinyNet(2, 8, 10, 71), tag)
+        if mode == "eager":
+            st = replay_trajectory(net, G[tag + "_xs"], G[tag + "_gs"], G["x0"], engine.LossSpec(engine.CE_SUM, dev(G[tag + "_target"])),
+                                   alpha, eps, -1, final=G[tag + "_final"], tol=TOL)
+            assert len(st) == 5
+    net = TinyNet(2, 8, 10, 71).to(DEV)
+    xa, tl = A.targeted_PGD_trick(net, Args(random=False, epsilon=eps, prob_start_from_clean=0.5), x0, y, 5, alpha, 10, DEV,
+                                  label_offset=dev(G["trick_norand_offset"]))
+    assert np.array_equal(tl.cpu().numpy(), G["trick_norand_target"])
+    check_free_run(xa, G["trick_norand_final"], TinyNet(2, 8, 10, 71), "trick_norand")
+    # the Bernoulli itself: prob_start_from_clean 1.0 never starts from noise, -1.0 always does (attacks.py:70)
+    x_clean, _ = A.targeted_PGD_trick(net, Args(random=True, epsilon=eps, prob_start_from_clean=1.0), x0, y, 0, alpha, 10, DEV)
+    assert torch.equal(x_clean, x0.clamp(0, 1))
+    x_noise, _ = A.targeted_PGD_trick(net, Args(random=True, epsilon=eps, prob_start_from_clean=-1.0), x0, y, 0, alpha, 10, DEV)
+    assert float((x_noise - x0).abs().max()) > 0 and float((x_noise - x0).abs().max()) <= eps + 1e-6
+
+
+def test_tar_alp_imagenet_vs_reference(A, golden, mode):
+    from eeadv import engine
+    G = golden("targeted")
+    x0, y2 = dev(G["x0"]), dev(G["talp_y"])
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    net = TinyNet(2, 8, 1000, 72).to(DEV)
+    xa, tl = A.tar_alp_imagenet(net, Args(epsilon=eps), x0, y2, 5, alpha, DEV, noise=dev(G["talp_randn"]), label_offset=dev(G["talp_offset"]))
+    assert np.array_equal(tl.cpu().numpy(), G["talp_target"])
+    check_free_run(xa, G["talp_final"], TinyNet(2, 8, 1000, 72), "tar_alp_imagenet")
+    if mode == "eager":
+        # start: x + 0.001 * randn, NOT clamped (attacks.py:344) - bit-exact from the init kernel
+        start = A._randn_start(x0, dev(G["talp_randn"]))
+        assert np.array_equal(start.cpu().numpy(), G["talp_xs"][0])
+        replay_trajectory(net, G["talp_xs"], G["talp_gs"], G["x0"], engine.LossSpec(engine.CE_SUM, dev(G["talp_target"])), alpha, eps, -1,
+                          final=G["talp_final"], tol=TOL)
+    # labels drawn on the device: fmod(y + randint(1, 1000), 1000) never returns y itself
+    _, tl2 = A.tar_alp_imagenet(net, Args(epsilon=eps), x0, y2, 0, alpha, DEV)
+    assert tl2.dtype == torch.int64 and bool(((tl2 != y2) & (tl2 >= 0) & (tl2 < 1000)).all())
+
+
+def test_avmixup_tar_perturb_vs_reference(A, golden, mode):
+    from eeadv import engine
+    G = golden("targeted")
+    x0, y = dev(G["x0"]), dev(G["y"])
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    net = TinyNet(2, 8, 10, 73).to(DEV)
+    av = A.AVmixup(Args(random=True, epsilon=eps), 2.0, 1.0, 0.1, alpha, 5, num_classes=10, device=DEV)
+    onehot = torch.eye(10, device=DEV)[y]
+    xm, ym = av.tar_perturb(net, x0, onehot, noise=dev(G["tav_noise"]), beta=G["tav_beta"], label_offset=dev(G["tav_offset"]))
+    assert xm.dtype == torch.float32 and ym.dtype == torch.float64
+    np.testing.assert_array_equal(ym.cpu().numpy(), G["tav_y"])  # float64 label mix: exact
+    assert same_fraction(xm.cpu().numpy(), G["tav_x"]) > 0.99
+    np.testing.assert_allclose(xm.cpu().numpy(), G["tav_x"], atol=4 * alpha + 1e-6)
+    if mode == "eager":
+        labels = torch.fmod(onehot + dev(G["tav_offset"]), 10).to(torch.float64).contiguous()  # the [B,K] float "labels" of :492
+        replay_trajectory(net, G["tav_xs"], G["tav_gs"], G["x0"], engine.LossSpec(engine.SOFTCE, labels), alpha, eps, -1, tol=TOL)
+        x_last = dev(O.pgd_step(G["tav_xs"][-1], G["tav_gs"][-1], G["x0"], alpha, eps, direction=-1))
+        xm2, _ = av._vertex_mix(x0, x_last, onehot, G["tav_beta"])
+        assert np.array_equal(xm2.cpu().numpy(), G["tav_x"])  # vertex + mix kernel from the reference's last iterate: bit-exact
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a4 / a5: the *_Linf loops (CE mean / KL batchmean, unclamped randn start) and Trades.PGD_L2
+# ---------------------------------------------------------------------------------------------------------
+def test_trades_pgd_linf_vs_reference(A, golden, mode):
+    from eeadv import engine
+    G = golden("linf_loops")
+    x0 = dev(G["x0"])
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    net = TinyNet(2, 8, 10, 91).to(DEV).train()
+    logits = net(x0)  # attached, as the drivers pass it (experiments_tinyimagenet.py:258-259)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), G["trades_logits"], atol=1e-5)
+    tr = A.Trades(alpha, eps, 5, 6.0)
+    xa = tr.PGD_Linf(net, x0, logits, noise=dev(G["trades_randn"]))
+    assert not net.training and not xa.requires_grad  # eval() side effect (attacks.py:405)
+    check_free_run(xa, G["trades_final"], TinyNet(2, 8, 10, 91), "Trades.PGD_Linf")
+    xa2 = tr.PGD_Linf(net, x0, logits, noise=dev(G["trades_randn"]))  # second call: cached graph in graph mode
+    assert torch.equal(xa, xa2)
+    if mode == "eager":
+        start = A._randn_start(x0, dev(G["trades_randn"]))
+        assert np.array_equal(start.cpu().numpy(), G["trades_xs"][0]) and float(start.min()) < 0
+        spec = engine.LossSpec(engine.KL, dev(G["trades_logits"]))
+        replay_trajectory(net, G["trades_xs"], G["trades_gs"], G["x0"], spec, alpha, eps, 1, final=G["trades_final"], tol=TOL)
+    # and against the oracle run here with fresh noise (not only the recorded case)
+    torch.manual_seed(5)
+    nz = torch.randn(3, 2, 8, 8)
+    cpu = TinyNet(2, 8, 10, 91)
+    want = R.Trades(alpha, eps, 5, 6.0).PGD_Linf(cpu, torch.from_numpy(G["x0"]), cpu(torch.from_numpy(G["x0"])), noise=nz)
+    got = tr.PGD_Linf(net, x0, logits, noise=nz.to(DEV))
+    check_free_run(got, want.numpy(), TinyNet(2, 8, 10, 91), "Trades.PGD_Linf fresh noise")
+
+
+def test_alp_and_targeted_alp_pgd_linf_vs_reference(A, golden, mode):
+    from eeadv import engine
+    G = golden("linf_loops")
+    x0, y = dev(G["x0"]), dev(G["y"])
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    net = TinyNet(2, 8, 10, 92).to(DEV).train()
+    xa = A.ALP(alpha, eps, 5, 1.0).PGD_Linf(net, x0, y, noise=dev(G["alp_randn"]))
+    assert not net.training
+    check_free_run(xa, G["alp_final"], TinyNet(2, 8, 10, 92), "ALP.PGD_Linf")
+    net3 = TinyNet(2, 8, 10, 93).to(DEV).train()
+    tal = A.targeted_ALP(alpha, eps, 5, 1.0, n_class=10)
+    xt = tal.tarPGD_Linf(net3, x0, y, DEV, noise=dev(G["talpc_randn"]), label_offset=dev(G["talpc_offset"]))
+    assert not net3.training
+    check_free_run(xt, G["talpc_final"], TinyNet(2, 8, 10, 93), "targeted_ALP.tarPGD_Linf")
+    xu = tal.PGD_Linf(net3, x0, y, noise=dev(G["talpu_randn"]))
+    check_free_run(xu, G["talpu_final"], TinyNet(2, 8, 10, 93), "targeted_ALP.PGD_Linf")
+    if mode == "eager":
+        replay_trajectory(net, G["alp_xs"], G["alp_gs"], G["x0"], engine.LossSpec(engine.CE_MEAN, y), alpha, eps, 1,
+                          final=G["alp_final"], tol=TOL)
+        tl = torch.fmod(y + dev(G["talpc_offset"]), 10)
+        replay_trajectory(net3, G["talpc_xs"], G["talpc_gs"], G["x0"], engine.LossSpec(engine.CE_MEAN, tl), alpha, eps, -1,
+                          final=G["talpc_final"], tol=TOL)
+
+
+def test_trades_pgd_l2_vs_reference(A, golden):
+    """attacks.py:381-401 on the HIP path (ee_l2_step_f32): per-sample RMS of the gradient and of delta are fp32 sums in a
+    different order than ATen's, so this one is a tolerance test: 1e-6 absolute on iterates in [0, 1]."""
+    G = golden("linf_loops")
+    x0 = dev(G["x0"])
+    step, eps = [float(v) for v in G["tradesl2_step_eps"]]
+    net = TinyNet(2, 8, 10, 91).to(DEV).train()
+    logits = net(x0)
+    xa = A.Trades(step, eps, 5, 6.0).PGD_L2(net, x0, logits, noise=dev(G["tradesl2_randn"]))
+    assert not net.training and not xa.requires_grad
+    np.testing.assert_allclose(xa.cpu().numpy(), G["tradesl2_final"], atol=2e-6)
+    # one update from the reference's recorded iterate and gradient: kernel vs the reference's next iterate
+    from eeadv import ops
+    xs, gs = G["tradesl2_xs"], G["tradesl2_gs"]
+    for k in range(len(gs)):
+        x = dev(xs[k]).clone()
+        ops.l2_step_(x, dev(gs[k]), x0, step, eps, 0.0, 1.0)
+        want = xs[k + 1] if k + 1 < len(xs) else G["tradesl2_final"]
+        np.testing.assert_allclose(x.cpu().numpy(), want, atol=5e-7, err_msg="step %d" % k)
+    d = (xa - x0).flatten(1)
+    assert float((d ** 2).mean(1).sqrt().max()) <= eps * (1 + 1e-5)  # inside the RMS ball (attacks.py:395-398)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a14: Add_Square against the reference's own forward (its draws recorded)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["tiny", "mnist", "nq12", "nq60_resc"])
+def test_add_square_vs_reference(golden, tag):
+    import utils.core as C
+    from eeadv import hfs as HF, ops
+    G = golden("add_square")
+    B, Cn, n, nq, resc = [int(v) for v in G[tag + "__cfg"]]
+    eps = float(G[tag + "__eps"])
+    mod = C.Add_Square(Cn, n, eps, n_queries=nq, rescale_schedule=bool(resc))
+    assert mod.square_sizes(DEV)[0] == G[tag + "__sq_size"].tolist()
+    draws = {"stripe": dev(G[tag + "__stripe"]), "sq_pos": dev(G[tag + "__sq_pos"]), "sq_sign": dev(G[tag + "__sq_sign"])}
+    x = dev(G[tag + "__x"]).requires_grad_(True)
+    y = mod(x, draws)
+    (y * dev(G[tag + "__u"])).sum().backward()
+    assert np.array_equal(y.detach().cpu().numpy(), G[tag + "__y"])       # ee_add_square_fwd_f32: bit for bit
+    assert np.array_equal(x.grad.cpu().numpy(), G[tag + "__gx"])          # ee_add_square_bwd_f32: bit for bit
+    # fused into the low-pass kernel's load (hfs sq_mode 1) == low-pass of the reference's Add_Square output
+    r = {64: 8, 28: 4, 16: 2}[n]
+    op = HF.HFSOperator(n, n, r, DEV)
+    assert op.kernel is not None
+    d = mod.prepare(x.detach(), draws)
+    fused = op.forward_square(x.detach(), eps, d)
+    assert torch.equal(fused, op.forward(dev(G[tag + "__y"])))
+    # and its backward (sq_mode 2): the derivative mask is the reference's own input gradient of sum(y * 1)
+    ones = torch.ones_like(x)
+    mask = ops.add_square_bwd(ones, x.detach(), eps, d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"])
+    xr = torch.from_numpy(G[tag + "__x"].copy()).requires_grad_(True)
+    R.Add_Square(Cn, n, eps, n_queries=nq, rescale_schedule=bool(resc))(xr, {
+        "stripe": torch.from_numpy(G[tag + "__stripe"]), "sq_pos": torch.from_numpy(G[tag + "__sq_pos"]),
+        "sq_sign": torch.from_numpy(G[tag + "__sq_sign"]).reshape(nq, Cn, 1, 1)}).sum().backward()
+    assert np.array_equal(mask.cpu().numpy(), xr.grad.numpy())
+    u = dev(G[tag + "__u"])
+    assert torch.equal(op.backward_square(u, x.detach(), eps, d), op.adjoint(u) * mask)

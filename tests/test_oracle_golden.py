@@ -240,3 +240,130 @@ def test_hfs_restatement_properties_UNPINNED():
         np.testing.assert_allclose(hfs(lowpass[None, None]).numpy()[0, 0], lowpass.numpy(), atol=1e-5)
         hi = torch.cos(2 * np.pi * (r + 2) * torch.arange(n) / n)[None, :] * torch.ones(n, 1)
         assert hfs(hi[None, None]).abs().max() < 1e-5
+
+
+def test_targeted_family_reproduces_reference(golden):
+    """targeted_PGD_trick (both Bernoulli outcomes and args.random False), tar_alp_imagenet, AVmixup.tar_perturb:
+    the restatements with the reference's recorded draws give the reference's outputs BIT FOR BIT, and the kernel-level
+    oracle replays every recorded step (attacks.py:59-86, 337-357, 481-518)."""
+    G = golden("targeted")
+    x0, y = torch.from_numpy(G["x0"]), torch.from_numpy(G["y"])
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    for tag, b in (("trick_noise", True), ("trick_clean", False)):
+        assert bool(G[tag + "_u"] > 0.5) == b
+        xa, tl = R.targeted_PGD_trick(TinyNet(2, 8, 10, 71), Args(random=True, epsilon=eps, prob_start_from_clean=0.5), x0, y, 5, alpha,
+                                      10, "cpu", noise=torch.from_numpy(G[tag + "_init"]), label_offset=torch.from_numpy(G[tag + "_offset"]),
+                                      start_from_noise=b)
+        assert np.array_equal(tl.numpy(), G[tag + "_target"]) and np.array_equal(xa.numpy(), G[tag + "_final"])
+        start = O.pgd_init(G["x0"], G[tag + "_init"] if b else np.zeros_like(G["x0"]))
+        assert np.array_equal(start, G[tag + "_xs"][0])
+        xs, gs = G[tag + "_xs"], G[tag + "_gs"]
+        for k in range(len(gs)):
+            want = xs[k + 1] if k + 1 < len(xs) else G[tag + "_final"]
+            assert np.array_equal(O.pgd_step(xs[k], gs[k], G["x0"], alpha, eps, direction=-1), want), (tag, k)
+    xa, tl = R.targeted_PGD_trick(TinyNet(2, 8, 10, 71), Args(random=False, epsilon=eps, prob_start_from_clean=0.5), x0, y, 5, alpha, 10,
+                                  "cpu", label_offset=torch.from_numpy(G["trick_norand_offset"]))
+    assert np.array_equal(tl.numpy(), G["trick_norand_target"]) and np.array_equal(xa.numpy(), G["trick_norand_final"])
+
+    y2 = torch.from_numpy(G["talp_y"])
+    xa, tl = R.tar_alp_imagenet(TinyNet(2, 8, 1000, 72), Args(epsilon=eps), x0, y2, 5, alpha, "cpu",
+                                noise=torch.from_numpy(G["talp_randn"]), label_offset=torch.from_numpy(G["talp_offset"]))
+    assert np.array_equal(tl.numpy(), G["talp_target"]) and np.array_equal(xa.numpy(), G["talp_final"])
+    assert int(tl.max()) < 1000 and bool((tl != y2).all())
+    # the start is x + 0.001 * randn WITHOUT a clamp: the first iterate leaves [0, 1] where x0 sits on the border
+    start = O.pgd_init(G["x0"], (np.float32(0.001) * G["talp_randn"]).astype(np.float32), -np.inf, np.inf)
+    assert np.array_equal(start, G["talp_xs"][0]) and (start.min() < 0 or start.max() > 1)
+
+    av = R.AVmixup(Args(random=True, epsilon=eps), 2.0, 1.0, 0.1, alpha, 5, num_classes=10, device="cpu")
+    xm, ym = av.tar_perturb(TinyNet(2, 8, 10, 73), x0, torch.eye(10)[y], noise=torch.from_numpy(G["tav_noise"]), beta=G["tav_beta"],
+                            label_offset=torch.from_numpy(G["tav_offset"]))
+    assert ym.dtype == torch.float64 and xm.dtype == torch.float32
+    assert np.array_equal(xm.numpy(), G["tav_x"]) and np.array_equal(ym.numpy(), G["tav_y"])
+    x_last = O.pgd_step(G["tav_xs"][-1], G["tav_gs"][-1], G["x0"], alpha, eps, direction=-1)
+    assert np.array_equal(O.avmix(x_last, G["x0"], G["tav_beta"], 2.0), G["tav_x"])
+
+
+def test_linf_loops_reproduce_reference(golden):
+    """Trades.PGD_Linf / PGD_L2, ALP.PGD_Linf, targeted_ALP.{tarPGD_Linf, PGD_Linf} against the reference's own methods
+    (their single `torch.randn(.., device='cuda')` drew on the host when the fixture was made): bit for bit."""
+    G = golden("linf_loops")
+    x0, y = torch.from_numpy(G["x0"]), torch.from_numpy(G["y"])
+    eps, alpha = [float(v) for v in G["eps_alpha"]]
+    net = TinyNet(2, 8, 10, 91)
+    logits = net(x0)
+    np.testing.assert_array_equal(logits.detach().numpy(), G["trades_logits"])
+    m = TinyNet(2, 8, 10, 91).train()
+    xa = R.Trades(alpha, eps, 5, 6.0).PGD_Linf(m, x0, logits, noise=torch.from_numpy(G["trades_randn"]))
+    assert not m.training and np.array_equal(xa.numpy(), G["trades_final"])
+    start = O.pgd_init(G["x0"], (np.float32(0.001) * G["trades_randn"]).astype(np.float32), -np.inf, np.inf)
+    assert np.array_equal(start, G["trades_xs"][0]) and start.min() < 0  # unclamped start
+    step_l2, eps_l2 = [float(v) for v in G["tradesl2_step_eps"]]
+    xa = R.Trades(step_l2, eps_l2, 5, 6.0).PGD_L2(TinyNet(2, 8, 10, 91), x0, logits, noise=torch.from_numpy(G["tradesl2_randn"]))
+    assert np.array_equal(xa.numpy(), G["tradesl2_final"])
+    xa = R.ALP(alpha, eps, 5, 1.0).PGD_Linf(TinyNet(2, 8, 10, 92), x0, y, noise=torch.from_numpy(G["alp_randn"]))
+    assert np.array_equal(xa.numpy(), G["alp_final"])
+    tal = R.targeted_ALP(alpha, eps, 5, 1.0, n_class=10)
+    xa = tal.tarPGD_Linf(TinyNet(2, 8, 10, 93), x0, y, "cpu", noise=torch.from_numpy(G["talpc_randn"]),
+                         label_offset=torch.from_numpy(G["talpc_offset"]))
+    assert np.array_equal(xa.numpy(), G["talpc_final"])
+    xa = tal.PGD_Linf(TinyNet(2, 8, 10, 93), x0, y, noise=torch.from_numpy(G["talpu_randn"]))
+    assert np.array_equal(xa.numpy(), G["talpu_final"])
+    for tag, d in (("trades", 1), ("alp", 1), ("talpc", -1)):  # every recorded step through the kernel-level oracle
+        xs, gs = G[tag + "_xs"], G[tag + "_gs"]
+        for k in range(len(gs)):
+            want = xs[k + 1] if k + 1 < len(xs) else G[tag + "_final"]
+            assert np.array_equal(O.pgd_step(xs[k], gs[k], G["x0"], alpha, eps, direction=d), want), (tag, k)
+
+
+ADD_SQUARE_CASES = ["tiny", "mnist", "nq12", "nq60_resc"]
+
+
+@pytest.mark.parametrize("tag", ADD_SQUARE_CASES)
+def test_add_square_reproduces_reference(golden, tag):
+    """Add_Square (core.py:589-655): the reference's forward run on the host with its draws recorded; the restatement with
+    those draws reproduces output and input gradient bit for bit, and derives the same square sizes (p_selection)."""
+    G = golden("add_square")
+    B, C, n, nq, resc = [int(v) for v in G[tag + "__cfg"]]
+    eps = float(G[tag + "__eps"])
+    mod = R.Add_Square(C, n, eps, n_queries=nq, rescale_schedule=bool(resc))
+    assert mod.sizes() == G[tag + "__sq_size"].tolist()
+    d = {"stripe": torch.from_numpy(G[tag + "__stripe"]), "sq_pos": torch.from_numpy(G[tag + "__sq_pos"]),
+         "sq_sign": torch.from_numpy(G[tag + "__sq_sign"]).reshape(nq, C, 1, 1)}
+    x = torch.from_numpy(G[tag + "__x"].copy()).requires_grad_(True)
+    yv = mod(x, d)
+    (yv * torch.from_numpy(G[tag + "__u"])).sum().backward()
+    assert np.array_equal(yv.detach().numpy(), G[tag + "__y"])
+    assert np.array_equal(x.grad.numpy(), G[tag + "__gx"])
+    assert set(np.unique(G[tag + "__stripe"]).tolist()) <= {-1.0, 0.0, 1.0}
+    assert (G[tag + "__sq_pos"] >= 0).all() and (G[tag + "__sq_pos"] + G[tag + "__sq_size"] <= n).all()
+
+
+def test_free_at_repeat_is_the_scripts_inner_loop_UNPINNED():
+    """PARITY UNPINNED (the free-AT script cannot be imported).  The restatement against the same lines written out with
+    explicit tensors: delta persists, only the live rows move, the clamp covers the whole buffer, the in-place clamp of
+    x + delta masks the gradient, the optimiser steps once per repeat (AT_free_imagenet_ddp.py:286-309)."""
+    torch.manual_seed(0)
+    net = TinyNet(2, 8, 10, 3)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+    x = torch.rand(3, 2, 8, 8)
+    x[0, 0, 0, :2] = torch.tensor([0.0, 1.0])
+    y = torch.tensor([1, 2, 3])
+    noise = torch.zeros(5, 2, 8, 8)
+    noise[3:] = 0.5  # rows beyond the batch: only the buffer-wide clamp touches them
+    a, e = 4 / 255, 4 / 255
+    w0 = net.w2.detach().clone()
+    for rep in range(3):
+        before = noise.clone()
+        xin = (x + before[:3]).clamp(0, 1).requires_grad_(True)
+        (g,) = torch.autograd.grad(F_ce(net(xin), y), xin)
+        mask = ((x + before[:3]) >= 0) & ((x + before[:3]) <= 1)
+        want = (before[:3] + a * torch.sign(g * mask)).clamp(-e, e)
+        R.free_at_repeat(net, F_ce, opt, x, y, noise, a, e)
+        assert torch.equal(noise[:3], want), rep
+        assert torch.equal(noise[3:], torch.full_like(noise[3:], e))
+    assert not torch.equal(net.w2.detach(), w0)
+    assert np.array_equal(O.freeat_update(before[:3].numpy(), (g * mask).numpy(), a, e), noise[:3].numpy())
+
+
+def F_ce(z, y):
+    return torch.nn.functional.cross_entropy(z, y)
