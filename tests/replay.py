@@ -7,13 +7,15 @@ magnitude is inside that rounding noise may change sign - which moves the pixel 
 every later iterate.  The replay separates the two effects.  For every recorded step k it feeds the REFERENCE's x_k to the
 GPU model and requires
 
-  (1) |g_gpu - g_ref| <= tol * max|g_ref|                   (the model + loss-gradient kernel agree with the reference),
-  (2) x_{k+1} from the HIP update kernel == the reference's x_{k+1} at every element with |g_ref| > tol * max|g_ref|
+  (1) |g_gpu - g_ref| <= bound := tol * max|g_ref| + atol     (the model + loss-gradient kernel agree with the reference),
+  (2) x_{k+1} from the HIP update kernel == the reference's x_{k+1} at every element with |g_ref| > bound
       (an element can only differ if sign(g_gpu) != sign(g_ref), which (1) allows only below that magnitude),
   (3) with the reference's own g_k the HIP update kernel reproduces x_{k+1} bit for bit everywhere.
 
 So every pixel in which a free-running GPU attack may leave the reference trajectory is one whose reference gradient
-was below `tol` of the step's largest gradient entry at the step where it diverged.
+was below `bound` at the step where it diverged.  `atol` is for the KL loops only: at their first step x_adv = x + 0.001 * randn,
+so d KL / d logits = (softmax(z_adv) - softmax(z_nat)) / B is a difference of nearly equal fp32 numbers (entries ~1e-5) whose
+rounding error (~1e-8, host libm vs device libm) is not small RELATIVE to the gradient it produces (largest entry ~1e-4).
 """
 import numpy as np
 import torch
@@ -21,7 +23,7 @@ import torch
 from oracle import ee_oracle as O
 
 
-def replay_trajectory(model, xs, gs, x0, spec, alpha, eps, direction=1, final=None, tol=1e-5, lo=0.0, hi=1.0, dev="cuda:0"):
+def replay_trajectory(model, xs, gs, x0, spec, alpha, eps, direction=1, final=None, tol=1e-5, atol=0.0, lo=0.0, hi=1.0, dev="cuda:0"):
     """Returns per-step dicts(err, undecided, flipped); raises AssertionError when (1)-(3) fail."""
     from eeadv import engine, ops
     x0_d = torch.from_numpy(np.ascontiguousarray(x0)).to(dev)
@@ -38,11 +40,12 @@ def replay_trajectory(model, xs, gs, x0, spec, alpha, eps, direction=1, final=No
         scale = float(np.nanmax(np.abs(g_ref)))
         assert np.array_equal(np.isnan(g_np), np.isnan(g_ref)), "step %d: NaN pattern of the gradient differs" % k
         err = float(np.nanmax(np.abs(g_np - g_ref))) if g_ref.size else 0.0
-        assert err <= tol * scale, "step %d: gradient differs by %.3g (%.3g of its largest entry, allowed %.1g)" % (k, err, err / scale, tol)
+        bound = tol * scale + atol
+        assert err <= bound, "step %d: gradient differs by %.3g (%.3g of its largest entry %.3g, allowed %.3g)" % (k, err, err / scale, scale, bound)
         x_next = xk.clone()
         ops.pgd_step_(x_next, g, x0_d, alpha, eps, lo, hi, direction)
         got = x_next.cpu().numpy()
-        decided = np.abs(np.nan_to_num(g_ref)) > tol * scale
+        decided = np.abs(np.nan_to_num(g_ref)) > bound
         assert np.array_equal(got[decided], want[decided]), "step %d: an element with a decided gradient sign moved differently" % k
         x_ref = xk.clone()
         ops.pgd_step_(x_ref, torch.from_numpy(np.ascontiguousarray(g_ref)).to(dev), x0_d, alpha, eps, lo, hi, direction)

