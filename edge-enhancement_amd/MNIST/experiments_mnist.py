@@ -14,7 +14,7 @@ from eeadv import driver  # noqa: E402
 from models_mnist import Net_2, Net2_EE, Net2_EE_square  # noqa: E402
 
 SPEC = {"description": "PyTorch Mnist Training", "ckpt_dir": "checkpoint_MNIST", "shape": (1, 28, 28), "num_classes": 10,
-        "mnist_top5_quirk": True}
+        "mnist_top5_quirk": True, "ckpt_module_prefix": True}  # checkpoints of nn.DataParallel(model): `module.` keys (:77,:168)
 
 
 def build_model(args):

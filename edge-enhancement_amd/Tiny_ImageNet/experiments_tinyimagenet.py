@@ -15,7 +15,8 @@ sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import models_tinyimagenet as zoo  # noqa: E402
 from eeadv import driver  # noqa: E402
 
-SPEC = {"description": "PyTorch Tiny ImageNet Training", "ckpt_dir": "checkpoint_Tiny_ImageNet", "shape": (3, 64, 64), "num_classes": 200}
+SPEC = {"description": "PyTorch Tiny ImageNet Training", "ckpt_dir": "checkpoint_Tiny_ImageNet", "shape": (3, 64, 64), "num_classes": 200,
+        "ckpt_module_prefix": True}  # the reference saves nn.DataParallel(model).state_dict() (:110,:196): `module.`-prefixed keys
 
 
 def build_model(args):

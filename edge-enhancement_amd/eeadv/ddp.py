@@ -65,7 +65,7 @@ def shard_indices(n, r=None, w=None):
     return idx[r:per * w:w]
 
 
-def wrap(model, device=None, sync_bn=False, bucket_cap_mb=16):
+def wrap(model, device=None, sync_bn=False, bucket_cap_mb=16, find_unused_parameters=False):
     """DistributedDataParallel around `model` (identity when world == 1).  SyncBatchNorm only where the
     reference converts (its ImageNet scripts, experiments_imagenet.py:125); the Tiny / MNIST configs keep
     per-rank BatchNorm statistics."""
@@ -74,8 +74,8 @@ def wrap(model, device=None, sync_bn=False, bucket_cap_mb=16):
     if sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     ids = [torch.device(device).index] if device is not None and torch.device(device).type == "cuda" else None
-    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
-                                                     gradient_as_bucket_view=True)
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
+                                                     find_unused_parameters=find_unused_parameters)
 
 
 def gather_mean(*scalars):

@@ -161,8 +161,22 @@ def train(train_loader, model, criterion, optimizer, epoch, args, device, log_di
                                                                   loss=losses, top1=top1, top5=top5), log_dir)
 
 
-def validate(val_loader, model, criterion, args, device, num_steps, step_size, log_dir, spec):
-    """experiments_tinyimagenet.py:326-432.  Returns (adv top-1, adv top-5) averaged over ranks."""
+def strip_module_prefix(state):
+    """DataParallel / DDP checkpoints (`module.`-prefixed keys, what the reference's MNIST / Tiny / free-AT scripts save) -> bare keys."""
+    return {k[len("module."):] if k.startswith("module.") else k: v for k, v in state.items()}
+
+
+def with_module_prefix(state):
+    """Bare keys -> the `module.`-prefixed keys of a wrapped model's state_dict(): the reference's MNIST and Tiny drivers save
+    nn.DataParallel(model).state_dict() (experiments_tinyimagenet.py:110,196) and its free-AT script the DDP model's
+    (AT_free_imagenet_ddp.py:236); their --resume loads into the wrapped model and needs these names.  The ImageNet driver
+    saves model.module.state_dict() (experiments_imagenet.py:206): bare keys."""
+    return {("module." + k if not k.startswith("module.") else k): v for k, v in state.items()}
+
+
+def validate(val_loader, model, criterion, args, device, num_steps, step_size, log_dir, spec, local_result=False):
+    """experiments_tinyimagenet.py:326-432.  Returns (adv top-1, adv top-5) averaged over ranks (the free-AT script returns
+    its rank-local averages, AT_free_imagenet_ddp.py:403: local_result=True)."""
     batch_time = AverageMeter()
     meters = _DeviceMeters(6, device)
     model.eval()
@@ -189,6 +203,10 @@ def validate(val_loader, model, criterion, args, device, num_steps, step_size, l
     c1, c5, a1, a5 = ddp.gather_mean(t1c.avg, t5c.avg, t1a.avg, t5a.avg)  # experiments_imagenet.py:369-384
     _log(' * Clean Prec@1 {0:.3f} Prec@5 {1:.3f}'.format(c1, c5), log_dir)
     _log(' * Adv Prec@1 {0:.3f} Prec@5 {1:.3f}'.format(a1, a5), log_dir)
+    if local_result:
+        _log(' * Cl Prec@1 {top1.avg:.3f} Prec@5 {top5.avg:.3f}'.format(top1=t1c, top5=t5c), log_dir)  # AT_free_imagenet_ddp.py:400-401
+        _log(' * Ad Prec@1 {top1.avg:.3f} Prec@5 {top5.avg:.3f}'.format(top1=t1a, top5=t5a), log_dir)
+        return t1a.avg, t5a.avg
     return a1, a5
 
 
@@ -207,7 +225,9 @@ def run(spec, build_model, argv=None):
         device = torch.device("cuda", ddp.local_rank())
         # the attack iteration and the parameter update replay captured HIP graphs unless the user says otherwise: eagerly
         # the loop is bound by the host (one launch per ~10 us of Python + ctypes), 3-4x slower than the device can go
-        os.environ.setdefault("EEADV_GRAPH", "1")
+        # ... except under multi-rank SyncBatchNorm (the ImageNet scripts): every train-mode forward of the attack loop would put
+        # RCCL all_gathers inside the captured graph, a combination that has not run on a multi-GPU node yet
+        os.environ.setdefault("EEADV_GRAPH", "0" if (ddp.world() > 1 and spec.get("sync_bn", False)) else "1")
     else:
         device = torch.device("cpu")
         runtime.allow_cpu_plumbing(True)  # --no-cuda: torch-op plumbing run on the host (BASELINE config 1)
@@ -228,8 +248,7 @@ def run(spec, build_model, argv=None):
             print("=> loading checkpoint '{}'".format(args.resume))
             ckpt = torch.load(args.resume, map_location=device, weights_only=True)
             args.start_epoch, best_prec1 = ckpt['epoch'], ckpt['best_prec1']
-            state = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ckpt['state_dict'].items()}
-            missing = model.load_state_dict(state, strict=False)  # reference EE checkpoints carry dead sobel.* / u2netp.* keys
+            missing = model.load_state_dict(strip_module_prefix(ckpt['state_dict']), strict=False)  # reference EE checkpoints carry dead sobel.* / u2netp.* keys
             print("=> loaded checkpoint '{}' (epoch {}); ignored keys: {}".format(args.resume, ckpt['epoch'], len(missing.unexpected_keys)))
             optimizer.load_state_dict(ckpt['optimizer'])
         else:
@@ -260,7 +279,8 @@ def run(spec, build_model, argv=None):
         best_prec1 = max(prec1, best_prec1)
         if ddp.rank() == 0:
             fname, best = checkpoint_names(args, dirs, epoch)
-            save_checkpoint({'epoch': epoch + 1, 'arch': args.arch, 'state_dict': model.state_dict(), 'best_prec1': best_prec1,
+            state = with_module_prefix(model.state_dict()) if spec.get("ckpt_module_prefix", False) else model.state_dict()
+            save_checkpoint({'epoch': epoch + 1, 'arch': args.arch, 'state_dict': state, 'best_prec1': best_prec1,
                              'optimizer': optimizer.state_dict()}, is_best, fname, best)
     ddp.teardown()
     return best_prec1

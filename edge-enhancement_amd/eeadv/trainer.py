@@ -166,6 +166,29 @@ def train_batch(model, criterion, optimizer, args, input, target, device, avmixu
     return loss.detach(), output.detach()
 
 
+def free_at_repeat(model, criterion, optimizer, input, target, noise, fgsm_step, clip_eps):
+    """One repeat of "free" adversarial training (ImageNet/free_imagenet/AT_free_imagenet_ddp.py:287-309): a single
+    forward/backward gives the weight gradient AND the input gradient; `noise` is the persistent buffer, its first
+    len(input) rows are read and updated in place.  Returns (loss, output), detached, still on the device.
+
+        in1 = clamp(input + noise[:n], 0, 1)                          ee_add_clamp_f32             (:289-290)
+        loss.backward()                                               DDP's all-reduce overlaps this backward
+        noise[:n] = clamp(noise[:n] + step * sign(dL/dnoise), +-eps)  ee_freeat_update_masked_f32  (:305-307)
+        optimizer.step()                                                                           (:309)
+    dL/dnoise of the reference is dL/din1 masked by the in-place clamp of :290; the kernel applies that mask itself."""
+    from eeadv import ops
+    n = input.size(0)
+    x = input.contiguous()
+    in1 = ops.add_clamp(x, noise[0:n], 0.0, 1.0).requires_grad_(True)
+    output = model(in1)
+    loss = criterion(output, target)
+    optimizer.zero_grad()
+    loss.backward()
+    ops.freeat_update_masked_(noise, in1.grad.contiguous(), x, float(fgsm_step), float(clip_eps))
+    optimizer.step()
+    return loss.detach(), output.detach()
+
+
 def attack_for_validation(model, args, input, target, device, num_steps, step_size, n_class):
     """experiments_tinyimagenet.py:354-374."""
     targeted = "tar" in args.method_name

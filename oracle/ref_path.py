@@ -466,7 +466,7 @@ class targeted_ALP(ALP):  # attacks.py:276-333 (PGD_Linf and loss are textual co
         return x_adv
 
 
-def free_at_repeat(model, criterion, optimizer, x, y, noise, fgsm_step, clip_eps):
+def free_at_repeat(model, criterion, optimizer, x, y, noise, fgsm_step, clip_eps, want_grad=False):
     """One repeat of the free-AT inner loop, ImageNet/free_imagenet/AT_free_imagenet_ddp.py:287-309, on the persistent
     buffer `noise` (updated in place on its first len(x) rows; the clamp covers the WHOLE buffer, :307).
     Returns (loss, output).  PARITY UNPINNED: the script cannot be imported (argv + process group at import)."""
@@ -482,6 +482,8 @@ def free_at_repeat(model, criterion, optimizer, x, y, noise, fgsm_step, clip_eps
     noise[0:n] += pert.data
     noise.clamp_(-clip_eps, clip_eps)
     optimizer.step()
+    if want_grad:
+        return loss.detach(), output.detach(), noise_batch.grad.detach()
     return loss.detach(), output.detach()
 
 

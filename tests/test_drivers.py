@@ -82,7 +82,15 @@ def test_mnist_standard_training_on_cpu_matches_oracle(tmp_path):
     assert any(os.path.basename(c) == "at_numstep40_epsilon76_r0_canny_sigma0_alpha0-bs50-lr_0.1-w0-gfFalse-l0-h0_0.pth" for c in ck)
     state = torch.load(ck[0], weights_only=True)
     assert set(state) == {"epoch", "arch", "state_dict", "best_prec1", "optimizer"} and state["epoch"] == 1 and state["arch"] == "Net2"
-    assert "conv1.weight" in state["state_dict"]
+    # nn.DataParallel(model).state_dict() in the reference (experiments_mnist.py:77,168): `module.`-prefixed keys, so that the
+    # reference's own --resume (which loads into the wrapped model) accepts the file; ours strips the prefix again
+    assert "module.conv1.weight" in state["state_dict"] and "conv1.weight" not in state["state_dict"]
+    first = [c for c in ck if "/model_pth/" in c][0]
+    r = subprocess.run([sys.executable, "experiments_mnist.py", "-c", "configs_mnist/standard_training.yml", "--no-cuda", "--data", "synthetic:2:1",
+                        "--output-root", str(tmp_path / "resumed"), "--resume", first, "--max-epochs", "1"],
+                       cwd=os.path.join(PKG, "MNIST"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "=> loaded checkpoint" in r.stdout and "(epoch 1)" in r.stdout and "Epoch: [1][0/2]" in r.stdout
 
 
 def test_unknown_arch_and_real_data_are_refused(tmp_path):
@@ -115,3 +123,32 @@ def test_gpu_configs_run_through_the_hip_path(tmp_path, ds, script, cfg):
     c1, _ = parse_like_read_log([l for l in lines if l.startswith(" * Clean")][0])
     a1, _ = parse_like_read_log([l for l in lines if l.startswith(" * Adv")][0])
     assert 0 <= a1 <= 100 and 0 <= c1 <= 100
+
+
+@pytest.mark.gpu
+def test_free_at_script_runs_config5_on_one_rank(tmp_path):
+    """BASELINE config 5 (ImageNet/free_imagenet/AT_free_imagenet_ddp.py) on one rank: resnet50, 224x224, per-rank batch 32,
+    2 batches x 4 repeats through the HIP kernels, the PGD evaluation (shortened to 2 steps), checkpoint with the
+    reference's keys / `module.`-prefixed names / file name, then --resume and --evaluate from it."""
+    script = os.path.join(PKG, "ImageNet", "free_imagenet", "AT_free_imagenet_ddp.py")
+    base = [sys.executable, script, "-a", "resnet50", "-b", "32", "--data", "synthetic:2:1", "--print-freq", "1", "--num-steps-1", "2",
+            "--output-root", str(tmp_path)]
+    r = subprocess.run(base + ["--max-epochs", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = r.stdout
+    assert "clip-eps:4,fgsm-step:4,n-repeats:4" in out and "epochs:23" in out  # ceil(90 / 4), :129
+    ep = [l for l in out.splitlines() if l.startswith("Epoch: [0]")]
+    assert len(ep) == 2 and ep[1].startswith("Epoch: [0][1/2]\tTime")
+    loss = float(re.search(r"Loss ([\d.]+) ", ep[0]).group(1))
+    assert 5.0 < loss < 12.0  # ln(1000) = 6.9 at initialisation
+    assert any(l.startswith(" * Adv Prec@1") for l in out.splitlines()) and any(l.startswith(" * Ad Prec@1") for l in out.splitlines())
+    ck = [os.path.join(d, f) for d, _, fs in os.walk(str(tmp_path)) for f in fs if f.endswith(".pth")]
+    name = "at_clip-eps4_fgsm-step4_n-repeats4_r0_canny_sigma0_alpha0-bs32-lr_0.1-w0-gfFalse-l0-h0-ty1_0.pth"
+    first = [c for c in ck if c.endswith("/resnet50Baseline_clip-eps4/model_pth/" + name)]
+    assert first, ck
+    state = torch.load(first[0], weights_only=True)
+    assert set(state) == {"epoch", "arch", "state_dict", "best_prec1", "optimizer"} and state["epoch"] == 1 and state["arch"] == "resnet50"
+    assert "module.layer4.2.bn3.running_var" in state["state_dict"] and "module.fc.weight" in state["state_dict"]
+    r = subprocess.run(base + ["--resume", first[0], "--max-epochs", "0", "--evaluate"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "=> loaded checkpoint" in r.stdout and " * Clean Prec@1" in r.stdout and "Epoch: [" not in r.stdout
