@@ -166,7 +166,7 @@ def train_batch(model, criterion, optimizer, args, input, target, device, avmixu
     return loss.detach(), output.detach()
 
 
-def free_at_repeat(model, criterion, optimizer, input, target, noise, fgsm_step, clip_eps):
+def free_at_repeat(model, criterion, optimizer, input, target, noise, fgsm_step, clip_eps, return_input_grad=False):
     """One repeat of "free" adversarial training (ImageNet/free_imagenet/AT_free_imagenet_ddp.py:287-309): a single
     forward/backward gives the weight gradient AND the input gradient; `noise` is the persistent buffer, its first
     len(input) rows are read and updated in place.  Returns (loss, output), detached, still on the device.
@@ -186,6 +186,8 @@ def free_at_repeat(model, criterion, optimizer, input, target, noise, fgsm_step,
     loss.backward()
     ops.freeat_update_masked_(noise, in1.grad.contiguous(), x, float(fgsm_step), float(clip_eps))
     optimizer.step()
+    if return_input_grad:  # dL/din1, BEFORE the clamp mask (tests)
+        return loss.detach(), output.detach(), in1.grad.detach()
     return loss.detach(), output.detach()
 
 

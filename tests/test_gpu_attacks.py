@@ -253,55 +253,84 @@ def test_add_square_vs_reference(golden, tag):
 # ---------------------------------------------------------------------------------------------------------
 # a15: the free-AT repeat (BASELINE config 5's inner loop) against the oracle, state re-synchronised before every repeat
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("arch,B,size,K,tol", [("tinynet", 6, 8, 10, 1e-5), ("resnet50", 4, 224, 1000, 2e-3)])
-def test_free_at_repeat_vs_oracle(arch, B, size, K, tol):
+def _free_at_pair(arch, K):
+    if arch == "tinynet":
+        return TinyNet(2, 8, K, 17), TinyNet(2, 8, K, 17).double(), TinyNet(2, 8, K, 17).to(DEV)
+    from eeadv.models import make_resnet
+    return (R.resnet50(num_classes=K, imagenet_pool=True).train(), R.resnet50(num_classes=K, imagenet_pool=True).double().train(),
+            make_resnet(50, "imagenet").to(DEV).train())
+
+
+@pytest.mark.parametrize("arch,B,size,K,batches", [("tinynet", 6, 8, 10, 2), ("resnet50", 4, 224, 1000, 1)])
+def test_free_at_repeat_vs_oracle(arch, B, size, K, batches):
     """eeadv.trainer.free_at_repeat (ee_add_clamp_f32 -> model fwd/bwd -> ee_freeat_update_masked_f32 -> SGD) against
-    oracle.ref_path.free_at_repeat (AT_free_imagenet_ddp.py:287-309), 4 repeats on one batch then 4 on a second one with the
-    persistent noise carried over.  Before every repeat the GPU side is loaded with the oracle's weights, momentum buffers
-    and noise, so each repeat is compared on its own: loss / logits within 1e-4 (north star); delta identical wherever the
-    oracle's noise gradient is larger than `tol` of its largest entry (MIOpen-vs-oneDNN rounding decides the sign below
-    that); rows beyond the batch untouched; weights after the SGD step equal to rounding."""
+    oracle.ref_path.free_at_repeat (AT_free_imagenet_ddp.py:287-309): 4 repeats per batch, the persistent noise carried over.
+    Before every repeat the GPU side is loaded with the oracle's weights, momentum buffers and noise, so each repeat is
+    compared on its own:
+
+      * loss and logits within 1e-4 of the fp32 oracle (north star; 1e-5 relative for logits beyond +-10), same predictions;
+      * delta: the kernel applied to the GPU's own input gradient is bit-exact (oracle C update on that gradient);
+      * the input gradient itself is judged against an fp64 run of the same repeat, because fp32 gradients of a deep ReLU
+        network are not reproducible across implementations AT ALL: on resnet50 / 224 / batch 4 the fp32 oracle (oneDNN) is
+        15 % of the largest entry away from fp64, the GPU path 3 % (scripts/freeat_diag.py; rounding flips ReLU / max-pool
+        switches).  Required: err(GPU, fp64) <= 2 x err(fp32 oracle, fp64) and no more sign disagreements with fp64 than
+        twice the oracle's;
+      * where GPU and oracle agree on the gradient sign, delta is identical; rows beyond the batch are untouched."""
     from eeadv import trainer
     torch.manual_seed(3)
     C = 2 if arch == "tinynet" else 3
-    if arch == "tinynet":
-        cpu, gpu = TinyNet(C, size, K, 17), TinyNet(C, size, K, 17).to(DEV)
-    else:
-        from eeadv.models import make_resnet
-        cpu = R.resnet50(num_classes=K, imagenet_pool=True).train()
-        gpu = make_resnet(50, "imagenet").to(DEV).train()
-    opt_c = torch.optim.SGD(cpu.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
-    opt_g = torch.optim.SGD(gpu.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    cpu, cpu64, gpu = _free_at_pair(arch, K)
+    lr = 0.1 if arch == "tinynet" else 0.01  # batch 4 instead of 256: the reference's 0.1 blows the resnet50 logits up to +-55 in one step
+    opt_c = torch.optim.SGD(cpu.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    opt_64 = torch.optim.SGD(cpu64.parameters(), lr=0.0)
+    opt_g = torch.optim.SGD(gpu.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
     a = e = 4.0 / 255
     noise_c = torch.zeros(B + 2, C, size, size)
     noise_g = noise_c.to(DEV)
     ce = torch.nn.functional.cross_entropy
     crit = trainer.Criterion()
-    undecided = []
-    for batch in range(2):
+    for batch in range(batches):
         x = torch.rand(B, C, size, size)
         x[0, :, :2, :4] = torch.tensor([0.0, 1.0, 0.004, 0.996])  # x + delta leaves [0, 1] here: the clamp masks the gradient
         y = torch.randint(0, K, (B,))
         xg, yg = x.to(DEV), y.to(DEV)
         for rep in range(4):
-            gpu.load_state_dict(cpu.state_dict())
+            what = "%s batch %d repeat %d" % (arch, batch, rep)
+            state = cpu.state_dict()
+            gpu.load_state_dict(state)
+            cpu64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in state.items()})
             opt_g.load_state_dict(opt_c.state_dict())
             noise_g.copy_(noise_c)
+            before = noise_c.clone()
+            _, out_64, g_64 = R.free_at_repeat(cpu64, ce, opt_64, x.double(), y, before.double(), a, e, want_grad=True)
             loss_c, out_c, g_c = R.free_at_repeat(cpu, ce, opt_c, x, y, noise_c, a, e, want_grad=True)
-            loss_g, out_g = trainer.free_at_repeat(gpu, crit, opt_g, xg, yg, noise_g, a, e)
-            what = "%s batch %d repeat %d" % (arch, batch, rep)
-            np.testing.assert_allclose(out_g.cpu().numpy(), out_c.numpy(), atol=1e-4, err_msg=what)
+            loss_g, out_g, g_in1 = trainer.free_at_repeat(gpu, crit, opt_g, xg, yg, noise_g, a, e, return_input_grad=True)
+            # 1e-4 absolute up to |logit| = 10, 1e-5 relative above - and in the L2 sense never further from fp64 than 3 x the
+            # fp32 oracle is
+            np.testing.assert_allclose(out_g.cpu().numpy(), out_c.numpy(), atol=1e-4, rtol=1e-5, err_msg=what)
+            assert float((out_g.cpu().double() - out_64).norm()) <= 3 * float((out_c.double() - out_64).norm()) + 1e-5 * float(out_64.norm()), what
             assert abs(float(loss_g) - float(loss_c)) < 1e-4, what
             assert torch.equal(out_g.argmax(1).cpu(), out_c.argmax(1)), what
-            g = g_c.numpy()
-            decided = np.abs(g) > tol * np.abs(g).max()
-            got, want = noise_g[:B].cpu().numpy(), noise_c[:B].numpy()
-            assert np.array_equal(got[decided], want[decided]), what
-            undecided.append(1.0 - decided.mean())
-            assert float(np.abs(got).max()) <= e and torch.equal(noise_g[B:].cpu(), noise_c[B:])
-            for (n_, pc), pg in zip(cpu.named_parameters(), gpu.parameters()):
-                d = float((pg.detach().cpu() - pc.detach()).abs().max())
-                assert d <= 2e-5 + 1e-3 * float(pc.detach().abs().max()), (what, n_, d)
-    # the sign-decided share of delta: everything but exact zeros (ReLU-dead inputs, masked border pixels) for the small
-    # net; >= 90 % for the 50-layer one in train mode at batch 4
-    assert max(undecided) < (0.35 if arch == "tinynet" else 0.10), undecided
+            s = x + before[:B]
+            g_g = (g_in1.cpu() * ((s >= 0) & (s <= 1))).numpy()  # the clamp mask of :290, as the kernel applies it
+            got = noise_g[:B].cpu().numpy()
+            assert np.array_equal(got, O.freeat_update(before[:B].numpy(), g_g, a, e)), what  # update kernel: bit-exact
+            assert torch.equal(noise_g[B:].cpu(), noise_c[B:]) and float(np.abs(got).max()) <= np.float32(e)
+            g_c, g_64 = g_c.numpy(), g_64.numpy()
+            scale = np.abs(g_64).max()
+            err_g, err_c = np.abs(g_g - g_64).max() / scale, np.abs(g_c - g_64).max() / scale
+            flip_g, flip_c = (np.sign(g_g) != np.sign(g_64)).mean(), (np.sign(g_c) != np.sign(g_64)).mean()
+            assert err_g <= 2 * err_c + 1e-6, (what, err_g, err_c)
+            assert flip_g <= 2 * flip_c + 1e-3, (what, flip_g, flip_c)
+            agree = np.sign(g_g) == np.sign(g_c)
+            assert np.array_equal(got[agree], noise_c[:B].numpy()[agree]), what
+            assert agree.mean() > 0.98, (what, agree.mean())
+            # parameter gradients of the same backward (they persist until the next zero_grad), same budget against fp64
+            num_g = num_c = den = 0.0
+            for (n_, pc), pg, p64 in zip(cpu.named_parameters(), gpu.parameters(), cpu64.parameters()):
+                r = p64.grad
+                eg, ec = float((pg.grad.cpu().double() - r).norm()), float((pc.grad.double() - r).norm())
+                assert eg <= 4 * ec + 1e-6 * float(r.norm()) + 1e-12, (what, n_, eg, ec)
+                num_g, num_c, den = num_g + eg ** 2, num_c + ec ** 2, den + float(r.norm()) ** 2
+            assert num_g ** 0.5 <= 2 * num_c ** 0.5 + 1e-6 * den ** 0.5, (what, num_g, num_c, den)
+    assert not torch.equal(gpu.state_dict()["fc.weight" if arch == "resnet50" else "w2"].cpu(), state["fc.weight" if arch == "resnet50" else "w2"])
