@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py - adversarial images / second of the hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a torchrun environment: this process stays off the GPU and starts `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a child (one rank per GPU over RCCL), relays its output and exits with its code.
+Started by torch.distributed.run itself (RANK / WORLD_SIZE set) it is a rank.
 
 Default workload = BASELINE config "Tiny-ImageNet ResNet-18 AT + edge-enhance" (SURVEY.md 8(d) item 4,
 Tiny_ImageNet/configs_tinyimagenet/ee_at_bpda3_square.yml): per-rank batch [100,3,64,64] synthetic U[0,1),
@@ -205,6 +209,43 @@ def large_batch_kernels(cfg, dev, mult=16, iters=50):
     return res
 
 
+def self_launch(n, argv):
+    """Parent of an N-rank run.  Must not touch the GPU (no torch.cuda.* / HIP call happened in this process: torch is only
+    imported) and must not exec: the ranks are a CHILD process tree; stdout / stderr pass through, the exit code is theirs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    sys.stderr.write("[bench] starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(world, rank):
+    """--dry-launch: the multi-rank plumbing without a GPU (gloo): rendezvous, barrier, max-over-ranks, rank 0 prints one line."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    seen = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "config": {"ranks": int(seen.item()), "backend": "gloo" if world > 1 else None},
+                          "max_over_ranks": float(t.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +263,7 @@ def main():
                     help="also time the section-8 kernels alone at 16x the batch (off by default: those launches would enter the "
                          "rocprofv3 per-kernel averages of this command, which must agree with `roofline.avg_launch_us`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true", help="only prove that --gpus N starts N ranks (gloo, no GPU needed)")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-miopen-benchmark", action="store_true",
                     help="leave torch.backends.cudnn.benchmark off (default: on, MIOpen searches its solvers once per shape)")
@@ -233,9 +275,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))  # before anything touches the GPU
     if world != a.gpus:
-        if a.gpus > 1 and world == 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (a.gpus, world))
+    if a.dry_launch:
+        return dry_launch(world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -342,7 +387,8 @@ def main():
             "config": {"workload": "%s: %s %s, per-rank batch %d x %s, PGD-%d eps %.4f alpha %.4f, train step incl. SGD%s" % (
                 a.workload, cfg["arch"], cfg["method"], B, "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"],
                 ", DDP all-reduce (RCCL)" if world > 1 else ""),
-                "global_batch": world * B, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": probe_iters, "probe_every": a.probe_every,
+                "global_batch": world * B, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                "backend": dist.get_backend() if world > 1 else None, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": probe_iters, "probe_every": a.probe_every,
                 "device": (N.lib.ee_device_name() or b"?").decode()},
             "roofline": roofline, "kernels": kernels, "final_loss": round(loss_val, 5),
             "note": "throughput is bounded by the CNN convolutions (MIOpen fp32), not by the hand-written kernels; "
