@@ -321,7 +321,7 @@ EE_API int ee_hfs_f32(const float *in, float *out, int B, int C, int H, int W, c
     const size_t lds_bytes = sizeof(float) * static_cast<size_t>(L.total);
     SquareArgs sq{stripe, sq_sign, sq_pos, sq_size, nq, C, H, W, eps, static_cast<float>(2.0 * static_cast<double>(eps))};
     const unsigned grid = static_cast<unsigned>(static_cast<int64_t>(B) * C);
-    ProfScope prof(EE_K_HFS, as_stream(stream));
+    ProfScope prof(sq_mode == 0 ? EE_K_HFS : (sq_mode == 1 ? EE_K_HFS_SQ_FWD : EE_K_HFS_SQ_BWD), as_stream(stream));
     hipStream_t st = as_stream(stream);
 #define EE_HFS_LAUNCH(H_, W_, NU_, NV_)                                                                                      \
     do {                                                                                                                    \

@@ -122,6 +122,7 @@ EE_API int ee_square_draw_f32(float *stripe, int64_t n_stripe, int64_t *sq_pos, 
     if (n_stripe < 0 || nq < 0 || C < 1 || h < 1) return EE_ERR_SHAPE;
     if (!state) return EE_ERR_NULL;
     if ((n_stripe && !stripe) || (nq && (!sq_pos || !sq_sign || !sq_size))) return EE_ERR_NULL;
+    ProfScope prof(EE_K_SQUARE_DRAW, as_stream(stream));
     EE_LAUNCH(square_draw_kernel, dim3(1), dim3(DRAW_NT), 0, as_stream(stream), stripe, n_stripe, sq_pos, sq_sign, sq_size, nq, C, h,
               reinterpret_cast<unsigned long long *>(state));
     return launch_status();

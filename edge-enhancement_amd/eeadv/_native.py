@@ -58,6 +58,10 @@ SIGNATURES = {
     "ee_square_draw_f32": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "ee_hfs_table_floats": [c_i, c_i, c_i, c_i],
     "ee_hfs_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_f, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],
+    "ee_chain_supported": [c_i, c_i, c_i],
+    "ee_chain_table_floats": [c_i, c_i],
+    "ee_chain_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_f, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "ee_chain_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
     "ee_bn_workspace_floats": [c_i, c_i, c_i],
     "ee_bn_act_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_bn_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -80,7 +84,8 @@ SIGNATURES = {
 _RESTYPE = {"ee_strerror": ctypes.c_char_p, "ee_device_name": ctypes.c_char_p, "ee_mse_num_partials": c_l}
 
 # kernel-family ids of include/eeadv.h (ee_prof_*)
-K_PGD_STEP, K_FRONTEND_FWD, K_FRONTEND_BWD, K_EDGE_FWD, K_EDGE_BWD, K_CE, K_PGD_STEP_BCAST, K_EMPTY, K_HFS = range(9)
+(K_PGD_STEP, K_FRONTEND_FWD, K_FRONTEND_BWD, K_EDGE_FWD, K_EDGE_BWD, K_CE, K_PGD_STEP_BCAST, K_EMPTY, K_HFS, K_CHAIN_FWD, K_CHAIN_BWD,
+ K_HFS_SQ_FWD, K_HFS_SQ_BWD, K_SQUARE_DRAW) = range(14)
 
 
 class EEError(RuntimeError):

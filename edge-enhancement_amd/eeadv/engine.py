@@ -67,6 +67,20 @@ def attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi):
     """One PGD iteration in place on x (attacks.py:20-27).  Edge-enhanced models that expose their front end
     (eeadv.models._EEFrontMixin) run it as explicit kernel calls around an autograd pass over the CNN body only:
     the input gradient then never exists as one tensor - the update kernel adds its two parts in registers."""
+    if getattr(model, "chain_ok", None) is not None and model.chain_ok(x):
+        # two launches around the CNN body: ee_chain_fwd_f32 (draws, Add_Square, low-pass, edge filter, combine) and
+        # ee_chain_bwd_f32 (gate, edge adjoint, low-pass, d Add_Square, update) - nothing of the front end's gradient reaches HBM
+        with torch.no_grad():
+            x_in, ctx = model.front_chain(x.detach())
+        x_in.requires_grad_(True)
+        with torch.enable_grad():
+            logits = model.body(x_in)
+        d = spec.dlogits(logits.contiguous())
+        with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
+            (g_in,) = torch.autograd.grad(logits, [x_in], grad_outputs=d)
+        with torch.no_grad():
+            model.front_chain_update_(x.detach(), g_in.contiguous(), ctx, x0, step_size, eps, lo, hi, direction)
+        return
     if getattr(model, "manual_ok", None) is not None and model.manual_ok(x):
         with torch.no_grad():
             x_in, ctx = model.front_manual(x.detach())

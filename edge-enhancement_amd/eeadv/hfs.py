@@ -75,6 +75,36 @@ def lowrank_tables(H, W, r):
     return flat, NU, NV
 
 
+def chain_tables(H, W, r):
+    """The constant operands of the low-pass operator in v_mfma_f32_16x16x4_f32 fragment order, for the fused front-end
+    kernels (csrc/ee_chain.hip).  Layout = scripts/chain_emulate.py (which checks the index algebra against hfs_matrices):
+    t1 [Wp/4][64] | t2 [2][Hp/16][4][64] | t3 [Hp/16][2][4][64] | t4 [Wp/16][4][64], lane l <-> (l & 15, l >> 4).
+    cos / sin column blocks are padded to 8 (v) and 16 (u) entries with zeros, Hp / Wp = H / W rounded up to 16."""
+    us = np.array([u if u < H / 2 else u - H for u in keep_set(H, r)], dtype=np.float64)
+    vs = np.array([v for v in keep_set(W, r) if v <= W // 2], dtype=np.float64)
+    kap = np.array([1.0 if (v == 0 or (W % 2 == 0 and v == W // 2)) else 2.0 for v in vs])
+    NU, NV = len(us), len(vs)
+    if NU > 16 or NV > 8 or H > 64 or W > 64:
+        raise ValueError("chain_tables: %dx%d r=%d is outside the fused kernels' shape class" % (H, W, r))
+    Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+    lanes = np.arange(64)
+    li, lg = lanes & 15, lanes >> 4
+    h, w = np.arange(H)[:, None], np.arange(W)[:, None]
+    Ch, Sh, Cw, Sw = np.zeros((Hp, 16)), np.zeros((Hp, 16)), np.zeros((Wp, 8)), np.zeros((Wp, 8))
+    Ch[:H, :NU], Sh[:H, :NU] = np.cos(2 * np.pi * h * us[None, :] / H), np.sin(2 * np.pi * h * us[None, :] / H)
+    Cw[:W, :NV], Sw[:W, :NV] = np.cos(2 * np.pi * w * vs[None, :] / W), np.sin(2 * np.pi * w * vs[None, :] / W)
+    dv = np.zeros(8)
+    dv[:NV] = kap / W
+    T1 = np.concatenate([Cw * dv, Sw * dv], 1)   # [Wp, 16]: [P | Q] = X T1
+    CS = np.concatenate([Ch, Sh], 1)             # [Hp, 32]: R = CS^T [P | Q];  [U | V] = CS EF / H
+    T4 = np.concatenate([Cw.T, Sw.T], 0)         # [16, Wp]: y = [U | V] T4
+    t1 = [T1[4 * s + lg, li] for s in range(Wp // 4)]
+    t2 = [CS[16 * t + 4 * lg + rr, 16 * mt + li] for mt in range(2) for t in range(Hp // 16) for rr in range(4)]
+    t3 = [CS[16 * ht + li, 16 * t + 4 * lg + rr] / H for ht in range(Hp // 16) for t in range(2) for rr in range(4)]
+    t4 = [T4[4 * lg + rr, 16 * wt + li] for wt in range(Wp // 16) for rr in range(4)]
+    return np.ascontiguousarray(np.concatenate(t1 + t2 + t3 + t4), dtype=np.float32)
+
+
 class HFSOperator:
     """Device-resident factors of the operator (which equals its own adjoint).  ROCm planes up to 64x64 go through the
     single-launch LDS kernel ee_hfs_f32; larger planes (ImageNet 224x224) and the CPU plumbing path use the dense form."""
@@ -86,6 +116,9 @@ class HFSOperator:
             flat, NU, NV = lowrank_tables(H, W, r)
             if H <= 64 and W <= 64 and NU <= 16 and NV <= 8:
                 self.kernel = (torch.from_numpy(flat).to(device), NU, NV)
+        self.chain = None  # fragment-ordered factors of the fused front-end kernels (ee_chain.hip), where the shape allows
+        if self.kernel is not None:
+            self.chain = torch.from_numpy(chain_tables(H, W, r)).to(device)
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=torch.float32)
         self.H, self.W = H, W
         self.Bcat = f(np.concatenate([B1, B2], axis=1))      # [W, 2W]   x @ Bcat = [x B1 | x B2]

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_step125_1, HighFreqSuppress, ee_front_end,
                         get_gaussian_kernel)
 
-from . import hfs as _hfs, ops
+from . import hfs as _hfs, ops, runtime
 from .functional import BnActFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
@@ -61,6 +61,7 @@ _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") 
 
 # ee_conv.hip's f32-MFMA 3x3 convolution takes maps 16..64 wide (29 us against 36 us for MIOpen's Winograd on the 64-channel
 # 16x16 layer; equal on 8x8, where the stock solver stays)
+_CHAIN = os.environ.get("EEADV_CHAIN", "1") == "1"  # the front end of a PGD iteration as two launches (ee_chain.hip) instead of six
 _CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "16"))
 _CONV3_EAGER = os.environ.get("EEADV_CONV3_EAGER", "0") == "1"  # use the MFMA 3x3 convolutions outside graph capture as well
 _CONV3S2_BWD_MINOW = int(os.environ.get("EEADV_CONV3S2_BWD_MINOW", "1000"))  # its backward-data kernel: equal to MIOpen end to end, opt-in
@@ -187,6 +188,38 @@ class _EEFrontMixin:
     # kernel can add them in registers --------------------------------------------------------------------------------
     def manual_ok(self, x):
         return x.is_cuda and isinstance(self.canny, CannyFilter_step125_1) and not self.with_gf
+
+    # ---- ... and the whole thing in ONE launch each way (ee_chain.hip): draws -> Add_Square -> low-pass -> edge filter -> combine
+    # forward; gate -> edge adjoint -> low-pass -> d Add_Square -> PGD update backward.  One workgroup per image; shapes of the
+    # reference configs (ops.chain_supported), CannyFilter_step125_1, at most one Add_Square query.  EEADV_CHAIN=0 switches it off.
+    def chain_ok(self, x):
+        if not _CHAIN or not self.manual_ok(x) or x.dtype != torch.float32 or x.dim() != 4:
+            return False
+        if not ops.chain_supported(x.shape[1], x.shape[2], x.shape[3]):
+            return False
+        if self.add_square is not None and (self.add_square.n_queries != 1 or self.add_square.h != x.shape[2]):
+            return False
+        return self.hfs.operator(x.device).chain is not None
+
+    def front_chain(self, x, draws=None):
+        """x -> (x_in, ctx) through ee_chain_fwd_f32."""
+        op = self.hfs.operator(x.device)
+        sq = self.add_square
+        if sq is None:
+            x_in, gate, gx, gy, _ = ops.chain_fwd(x, op.chain, self.canny.edge_weights, float(self.canny.alpha), float(self.high), float(self.w))
+        else:
+            d = None if draws is None else sq.prepare(x, draws)
+            x_in, gate, gx, gy, _ = ops.chain_fwd(x, op.chain, self.canny.edge_weights, float(self.canny.alpha), float(self.high), float(self.w),
+                                                  True, float(sq.eps), sq.square_sizes(x.device)[0][0],
+                                                  None if d is not None else runtime.draw_state(x.device), d)
+        return x_in, (gate, gx, gy)
+
+    def front_chain_update_(self, x, g_in, ctx, x0, step_size, eps, lo, hi, direction):
+        """In place on x: backward of the front end + the PGD update through ee_chain_bwd_f32."""
+        gate, gx, gy = ctx
+        op = self.hfs.operator(x.device)
+        ops.chain_bwd_(x, g_in, gate, gx, gy, x0, op.chain, self.canny.edge_weights, float(self.canny.alpha), float(self.high), float(self.w),
+                       float(step_size), float(eps), float(lo), float(hi), direction)
 
     def front_manual(self, x, draws=None):
         op = self.hfs.operator(x.device)

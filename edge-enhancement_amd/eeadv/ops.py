@@ -429,7 +429,7 @@ def square_draw(batch, C, h, sq_size, state):
     sq_pos = torch.empty((nq,), dtype=torch.int64, device=dev)
     sq_sign = torch.empty((nq, C), dtype=torch.float32, device=dev)
     N.check(N.lib.ee_square_draw_f32(stripe.data_ptr(), stripe.numel(), sq_pos.data_ptr(), sq_sign.data_ptr(),
-                                     _chk(sq_size, torch.int32, "sq_size"), nq, C, h, _chk(state, torch.int64, "state", (2,)), _stream()),
+                                     _chk(sq_size, torch.int32, "sq_size"), nq, C, h, _chk(state, torch.int64, "state", (4,)), _stream()),
             "ee_square_draw_f32")
     return stripe, sq_pos, sq_sign
 
@@ -454,6 +454,51 @@ def hfs(x, tables, NU, NV, sq_mode=0, sq_x=None, eps=0.0, stripe=None, sq_sign=N
     N.check(N.lib.ee_hfs_f32(px, _chk(out, torch.float32, "out"), B, C, H, W, pt, NU, NV, 1.0 / H, sq_mode, pxo, eps, ps, pg, pp, pz, nq,
                              _stream()), "ee_hfs_f32")
     return out
+
+
+# ---- the fused front end of one PGD iteration (ee_chain.hip) ------------------------------------------------------------------------
+def chain_supported(C, H, W):
+    return bool(N.lib.ee_chain_supported(int(C), int(H), int(W)))
+
+
+def chain_fwd(x, tables, wts, alpha, high, w, square=False, eps=0.0, sq_size=0, state=None, draws=None, want_edge=False):
+    """x [B,C,H,W] -> (x_in, gate, gx, gy, edge): clamp(hfs(add_square(x)) + w * edge125(x), 0, 1) in ONE launch.  `draws`
+    (dict stripe [B,C,1,W], sq_pos [1], sq_sign [1,C]) injects the Add_Square draws; otherwise they come from the Philox `state`
+    (int64[4] device tensor {seed, offset, ticket, -}, advanced by the kernel)."""
+    B, C, H, W = x.shape
+    px = _chk(x, torch.float32, "x")
+    pt = _chk(tables, torch.float32, "tables", (N.lib.ee_chain_table_floats(H, W),))
+    x_in = torch.empty_like(x)
+    gate = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    gx = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    gy = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    edge = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device) if want_edge else None
+    ps = pp = pg = pst = None
+    if square:
+        if draws is not None:
+            ps = _chk(draws["stripe"], torch.float32, "stripe", (B, C, 1, W))
+            pp = _chk(draws["sq_pos"], torch.int64, "sq_pos", (1,))
+            pg = _chk(draws["sq_sign"], torch.float32, "sq_sign", (1, C))
+        else:
+            pst = _chk(state, torch.int64, "state", (4,))
+    N.check(N.lib.ee_chain_fwd_f32(px, B, C, H, W, pt, wts.ptr, alpha, high, w, 1 if square else 0, eps, int(sq_size), pst, ps, pp, pg,
+                                   x_in.data_ptr(), gate.data_ptr(), gx.data_ptr(), gy.data_ptr(), _opt(edge, torch.float32, "edge"), _stream()),
+            "ee_chain_fwd_f32")
+    return x_in, gate, gx, gy, edge
+
+
+def chain_bwd_(x, g_in, gate, gx, gy, x0, tables, wts, alpha, high, w, step, eps, lo=0.0, hi=1.0, direction=1):
+    """In place on x: the front end's backward (edge adjoint from gx / gy, low-pass of gate * g_in times d add_square) and the PGD
+    update (attacks.py:25-27) in ONE launch."""
+    B, C, H, W = x.shape
+    px = _chk(x, torch.float32, "x")
+    pg = _chk(g_in, torch.float32, "g_in", x.shape)
+    pt = _chk(gate, torch.uint8, "gate", x.shape)
+    p0 = _chk(x0, torch.float32, "x0", x.shape)
+    N.check(N.lib.ee_chain_bwd_f32(pg, pt, _chk(gx, torch.float32, "gx", (B, 1, H, W)), _chk(gy, torch.float32, "gy", (B, 1, H, W)), px, p0, B, C, H, W,
+                                   _chk(tables, torch.float32, "tables", (N.lib.ee_chain_table_floats(H, W),)), wts.ptr, alpha, high, w, step, eps, lo,
+                                   hi, direction, _stream()), "ee_chain_bwd_f32")
+    return x
 
 
 # ---- BatchNorm2d (+ residual) (+ ReLU) ----------------------------------------------------------------------------------

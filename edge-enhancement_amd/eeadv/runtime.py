@@ -41,14 +41,15 @@ _DRAW_STATE = {}
 
 
 def draw_state(device):
-    """Device-resident {seed, offset} of the in-graph random draws (Add_Square): an int64[2] tensor the draw kernel
-    advances by itself, so that a replayed HIP graph never repeats its numbers.  Seeded from torch's CUDA generator of
+    """Device-resident {seed, offset, ticket, -} of the in-graph random draws (Add_Square): an int64[4] tensor whose offset the
+    drawing kernel advances by itself (ee_square_draw_f32, ee_chain_fwd_f32: the last workgroup to finish, counted by the ticket),
+    so that a replayed HIP graph never repeats its numbers.  Seeded from torch's CUDA generator of
     the device at first use (torch.manual_seed before the first forward governs it); reseed() re-reads the generator."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _DRAW_STATE.get(idx)
     if st is None:
         seed, off = philox_ticket(torch.device("cuda", idx), 4)
-        st = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off], dtype=torch.int64, device=torch.device("cuda", idx))
+        st = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off, 0, 0], dtype=torch.int64, device=torch.device("cuda", idx))
         _DRAW_STATE[idx] = st
     return st
 

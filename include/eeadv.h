@@ -321,6 +321,37 @@ int ee_pool_linear_fwd_f32(const float *feat, const float *weight, const float *
 int ee_pool_linear_bwd_f32(const float *dlogits, const float *weight, float *dfeat, int B, int C, int HW, int K, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The whole EE front end of one PGD iteration in two launches (csrc/ee_chain.hip): one workgroup per image.
+ *   (Tiny_ImageNet/models_tinyimagenet/resnet_EE_square.py:187-206, MNIST/models_mnist/Net2_EE_square.py:48-63,
+ *    utils/core.py:15-55, 509-585, 636-655, utils/attacks.py:25-27)
+ * Shapes: ee_chain_supported(C, H, W) != 0 - (3,64,64), (1,28,28), (3,32,32), (1,64,64); others EE_ERR_UNSUPPORTED
+ * (callers then use ee_hfs_f32 + ee_frontend_* + ee_pgd_step_bcast_f32, same results).
+ * `tables`: ee_chain_table_floats(H, W) floats, the constant operands of the low-pass operator in MFMA fragment order
+ * (eeadv/hfs.py: chain_tables; scripts/chain_emulate.py is the layout's specification).
+ * ------------------------------------------------------------------------------------------- */
+int ee_chain_supported(int C, int H, int W);
+int ee_chain_table_floats(int H, int W);
+
+/* forward: x[B,C,H,W] -> x_in = clamp(hfs(add_square(x)) + w * edge125(x), 0, 1) [B,C,H,W], gate[B,C,H,W] (uint8: bit 0 = clamp
+ * passes the gradient, bits 1-2 = d add_square/dx in {0,1/2,3/4,1} coded 0..3), gx / gy [B,1,H,W] (the Sobel responses the backward
+ * starts from), edge (nullable) [B,1,H,W].  square = 0: no Add_Square (resnet_EE.py:176-191).  square = 1: n_queries = 1 with
+ * side `sq_size` (core.py:644); the draws (core.py:637, :645, :648) are either injected (stripe_in [B,C,1,W], sq_pos_in [1],
+ * sq_sign_in [1,C]: all three) or made in the kernel from Philox4x32-10 with draw_state = uint64[4] {seed, offset, ticket, -}: the
+ * element <-> counter mapping is ee_square_draw_f32's, and the last workgroup to finish advances `offset`, so a replayed HIP graph
+ * draws fresh numbers.  HBM traffic: read 4C, write 5C + 8 bytes per pixel. */
+int ee_chain_fwd_f32(const float *x, int B, int C, int H, int W, const float *tables, const float *weights27, float alpha, float high,
+                     float w, int square, float eps, int sq_size, uint64_t *draw_state, const float *stripe_in, const int64_t *sq_pos_in,
+                     const float *sq_sign_in, float *x_in, uint8_t *gate, float *gx, float *gy, float *edge, void *stream);
+
+/* backward + update, in place on x: g_in = dL/dx_in [B,C,H,W];
+ *     g = dsquare * hfs(gate * g_in) + edge125_adjoint(w * sum_c gate_c * g_in_c)   (NaN where the edge magnitude is 0)
+ *     x = clamp(min(max(x + dir*step*sign(g), x0 - eps), x0 + eps), lo, hi)           (attacks.py:25-27)
+ * HBM traffic: read 13C + 8, write 4C bytes per pixel. */
+int ee_chain_bwd_f32(const float *g_in, const uint8_t *gate, const float *gx, const float *gy, float *x, const float *x0, int B, int C,
+                     int H, int W, const float *tables, const float *weights27, float alpha, float high, float w, float step, float eps,
+                     float lo, float hi, int dir, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optional built-in timing of the last launch of each kernel family (HIP events on `stream`).
  * Off by default; bench.py switches it on outside graph capture to measure kernel durations live.
  * ------------------------------------------------------------------------------------------- */
@@ -332,8 +363,13 @@ int ee_pool_linear_bwd_f32(const float *dlogits, const float *weight, float *dfe
 #define EE_K_CE 5
 #define EE_K_PGD_STEP_BCAST 6
 #define EE_K_EMPTY 7 /* an event pair with nothing in between: the bracket's own cost, see ee_prof_mark_empty */
-#define EE_K_HFS 8
-#define EE_K_COUNT 9
+#define EE_K_HFS 8          /* ee_hfs_f32, sq_mode 0 */
+#define EE_K_CHAIN_FWD 9    /* ee_chain_fwd_f32 */
+#define EE_K_CHAIN_BWD 10   /* ee_chain_bwd_f32 */
+#define EE_K_HFS_SQ_FWD 11  /* ee_hfs_f32, sq_mode 1 (Add_Square on load) */
+#define EE_K_HFS_SQ_BWD 12  /* ee_hfs_f32, sq_mode 2 (times d Add_Square / dx on store) */
+#define EE_K_SQUARE_DRAW 13 /* ee_square_draw_f32 */
+#define EE_K_COUNT 14
 int ee_prof_enable(int on);
 /* records one empty start/stop bracket on `stream` (family EE_K_EMPTY): callers subtract its mean from the other
  * families' means, because a HIP event pair costs ~4-5 us on gfx950 - comparable to the kernels being timed */

@@ -503,15 +503,15 @@ def test_square_draw_one_launch_statistics_and_graph_replay(ops):
     reproducible from the state, and a replayed HIP graph draws NEW numbers (the kernel advances the state itself)."""
     h, C, B = 64, 3, 100
     sizes = torch.tensor([41, 29, 1, 64, 7], dtype=torch.int32, device=DEV)
-    state = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    state = torch.tensor([1234, 0, 0, 0], dtype=torch.int64, device=DEV)
     stripe, pos, sign = ops.square_draw(B, C, h, sizes, state)
     assert stripe.shape == (B, C, 1, h) and pos.shape == (5,) and sign.shape == (5, C) and pos.dtype == torch.int64
     assert set(np.unique(stripe.cpu().numpy())) <= {-1.0, 0.0, 1.0}
     assert abs(float(stripe.mean())) < 0.03 and float((stripe == 0).float().mean()) < 1e-3
     assert bool(((pos >= 0) & (pos <= (h - sizes).clamp(min=0))).all()) and int(pos[3]) == 0
     n_used = (B * C * h + 5 * (1 + C) + 3) // 4
-    assert state.tolist() == [1234, n_used]
-    state2 = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    assert state.tolist() == [1234, n_used, 0, 0]
+    state2 = torch.tensor([1234, 0, 0, 0], dtype=torch.int64, device=DEV)
     again = ops.square_draw(B, C, h, sizes, state2)
     assert torch.equal(again[0], stripe) and torch.equal(again[1], pos) and torch.equal(again[2], sign)
     nxt = ops.square_draw(B, C, h, sizes, state2)
