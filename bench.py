@@ -16,10 +16,11 @@ random start) + forward on the adversarial batch + cross-entropy + backward + SG
 (+ the gradient all-reduce over RCCL when N > 1).  value = N * B * K / time (weak scaling), fp32 throughout.
 
 Printed JSON also carries
-  roofline     : the dominant hand-written kernel (fused front-end backward), algorithmic bytes per launch
-                 (16*C B/pixel) / its mean duration measured with HIP events on the launch
+  roofline     : the dominant hand-written kernel = the family with the largest (launches x mean duration) among those
+                 timed: algorithmic bytes per launch / its mean duration measured with HIP events on the launch
                  stream inside the timed region (one PGD iteration per attack runs outside the HIP graph so
-                 that its kernels can be bracketed by events - see DESIGN.md "Measurement").
+                 that its kernels can be bracketed by events - see DESIGN.md "Measurement"); the rocprofv3 figure of
+                 the same command (profiles/) is carried next to it.
   kernels      : the same measurement for every hand-written kernel family.
   cpu_baseline : the CPU oracle (oracle/ref_path.py, pinned to the reference) running the SAME step with
                  plain PyTorch CPU ops on the host cores, rank 0 at N = 1 only, bounded sample.
@@ -347,9 +348,13 @@ def main():
     if rank == 0:
         C, H, W = cfg["shape"]
         px = B * H * W
-        per_launch = {  # algorithmic bytes per launch, SURVEY.md 8(d)
+        # algorithmic bytes per launch: what the kernel must move once, whatever it re-reads
+        per_launch = {
+            "ee_chain_bwd": (N.K_CHAIN_BWD, (17 * C + 8) * px), "ee_chain_fwd": (N.K_CHAIN_FWD, (9 * C + 8) * px),
             "ee_frontend_bwd": (N.K_FRONTEND_BWD, 16 * C * px), "ee_frontend_fwd": (N.K_FRONTEND_FWD, 12 * C * px),
-            "ee_pgd_step": (N.K_PGD_STEP, 16 * C * px), "ee_ce": (N.K_CE, 3 * B * cfg["classes"] * 4),
+            "ee_hfs": (N.K_HFS, 8 * C * px), "ee_hfs_square_fwd": (N.K_HFS_SQ_FWD, 8 * C * px), "ee_hfs_square_bwd": (N.K_HFS_SQ_BWD, 12 * C * px),
+            "ee_pgd_step": (N.K_PGD_STEP, 16 * C * px), "ee_pgd_step_bcast": (N.K_PGD_STEP_BCAST, (16 * C + 4) * px),
+            "ee_square_draw": (N.K_SQUARE_DRAW, 4 * (B * C * W + 1 + C)), "ee_ce": (N.K_CE, 3 * B * cfg["classes"] * 4),
         }
         ems, ecnt = ops.prof_read(N.K_EMPTY)
         empty_us = 1e3 * ems / ecnt if ecnt else 0.0
@@ -362,10 +367,15 @@ def main():
             ms, cnt = ops.prof_read(kid)
             if cnt:
                 raw = 1e3 * ms / cnt
-                us = max(raw - overhead_us, 0.5)  # event pair cost removed (empty brackets timed in the same region)
+                us = max(raw - overhead_us, 0.5)  # event pair cost removed
                 kernels[name] = {"launches_timed": cnt, "avg_us": round(us, 3), "avg_bracket_us": round(raw, 3), "bytes": nbytes,
-                                 "GBps": round(nbytes / us / 1e3, 1)}
-        dom = "ee_frontend_bwd" if "ee_frontend_bwd" in kernels else (max(kernels, key=lambda k: kernels[k]["avg_us"]) if kernels else None)
+                                 "GBps": round(nbytes / us / 1e3, 1), "share_of_timed_us": None}
+        # the dominant hand-written kernel of the path = the family with the largest launches x duration among the timed probes
+        # (every family is launched once per PGD iteration, so the probe counts are proportional to the real ones)
+        tot = sum(k["launches_timed"] * k["avg_us"] for k in kernels.values()) or 1.0
+        for k in kernels.values():
+            k["share_of_timed_us"] = round(k["launches_timed"] * k["avg_us"] / tot, 4)
+        dom = max(kernels, key=lambda k: kernels[k]["launches_timed"] * kernels[k]["avg_us"]) if kernels else None
         roofline = None
         traffic = None
         try:  # HBM bytes per launch from the TCC counters, measured with rocprofv3 --pmc at this exact shape (profiles/)
@@ -375,10 +385,17 @@ def main():
             pass
         if dom:
             ach = kernels[dom]["GBps"]
+            rp = None
+            try:  # the rocprofv3 --kernel-trace --stats average of the same command, committed under profiles/ (per round)
+                rp = json.load(open(os.path.join(ROOT, "profiles", "rocprof_kernel_us.json"))).get(dom)
+            except (OSError, ValueError):
+                pass
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": kernels[dom]["avg_us"],
-                        "event_pair_overhead_us": round(overhead_us, 3), "empty_bracket_us": round(empty_us, 3)}
+                        "avg_bracket_us": kernels[dom]["avg_bracket_us"], "event_pair_overhead_us": round(overhead_us, 3),
+                        "empty_bracket_us": round(empty_us, 3), "rocprofv3_avg_us": rp,
+                        "frac_from_rocprofv3": round(kernels[dom]["bytes"] / rp / 1e3 / HBM_PEAK_GBS, 4) if rp else None}
         out = {
             "metric": "adversarial images/sec (PGD-%d, %s)" % (cfg["steps"], cfg["arch"]),
             "value": round(world * B * a.steps / dt, 2), "unit": "adversarial images/s", "n_gpus": world, "steps": a.steps,

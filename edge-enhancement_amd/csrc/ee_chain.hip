@@ -26,6 +26,7 @@
 // gate byte written by the forward: bit 0 = 1[0 <= x_lp + w*e <= 1] (clamp passes the gradient), bits 1-2 = d add_square / dx
 // in {0, 1/2, 3/4, 1} coded 0..3 (n_queries <= 1; 3 when the model has no Add_Square) - the backward needs neither x nor the draws.
 #include <math.h>
+#include <stdlib.h>
 
 #include "ee_common.hpp"
 #include "ee_square.hpp"
@@ -37,8 +38,8 @@ using namespace ee;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kSW = 4;             // stencil waves
-constexpr int kST = kSW * kWave;   // 256 stencil threads (the helpers of ee_stencil.hpp assume 4-pixel groups, not a block size)
+constexpr int kSW = 8;             // stencil waves: two per SIMD, the edge loop is latency-bound with one (34 -> 2x fewer rounds)
+constexpr int kST = kSW * kWave;   // 512 stencil threads (the helpers of ee_stencil.hpp assume 4-pixel groups, not a block size)
 
 template <int H, int W>
 struct Dims {
@@ -128,6 +129,7 @@ struct FwdParams {
     unsigned long long *state;    // {seed, offset, ticket, -}: Philox state of the device-side draws, advanced by the last workgroup
     int B, sq_size;
     float eps, two_eps, alpha, high, w;
+    int dbg;  // EEADV_CHAIN_DBG (measurement only): bit 0 skips the edge loop, bit 1 the low-pass, bit 2 combine + stage out
 };
 
 template <int C, int H, int W, bool SQUARE>
@@ -136,55 +138,20 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
     constexpr int FH = H + 4, FW = W + 2 * kColHalo, F4 = FW / 4, PL = FH * FW, W4 = W / 4;
     static_assert(W % 4 == 0 && H <= 64 && W <= 64 && C <= 3, "shape class of the reference configs");
     extern __shared__ __align__(16) float lds[];
-    float *xr = lds;                       // [C][FH][FW] clamped frame of x (rows -2..H+1, cols -4..W+3); later x_in in place
-    float *tab = xr + C * PL;              // MFMA constant fragments
-    float *emap = tab + D::NTAB;           // [H][W] edge map
-    float *stripe = emap + H * W;          // [C][W] stripe signs of this image
-    uint8_t *gst = reinterpret_cast<uint8_t *>(stripe + C * W);  // [C][H][W] gate bytes
+    float *xr = lds;                       // [C][FH][FW] clamped frame of x (rows -2..H+1, cols -4..W+3): the edge filter's input
+    float *xs = xr + C * PL;               // [C][HP][AS] add_square(x): the MFMA A operand, later the low-pass result in place
+    float *tab = xs + C * D::HP * D::AS;   // MFMA constant fragments
+    float *stripe = tab + D::NTAB;         // [C][W] stripe signs of this image
+    uint8_t *emap = reinterpret_cast<uint8_t *>(stripe + C * W + 4);  // [H][W] edge map, one byte per pixel (4 floats of square draws before it)
+    uint8_t *gst = emap + H * W;                                  // [C][H][W] derivative codes (bits 1-2 of the gate byte)
     const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     const float *xn = p.x + static_cast<size_t>(n) * C * H * W;
 
-    // ---- draws (core.py:637, :645, :648): the same element <-> Philox mapping as square_draw_kernel (ee_square.hip) ------------
-    int vh = 0;
-    float sq_delta[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) sq_delta[c] = 0.0f;
-    if (SQUARE) {
-        if (p.stripe_in) {
-            if (tid < C * W) stripe[tid] = p.stripe_in[static_cast<size_t>(n) * C * W + tid];
-            vh = static_cast<int>(p.sq_pos_in[0]);
-#pragma unroll
-            for (int c = 0; c < C; ++c) sq_delta[c] = p.two_eps * p.sq_sign_in[c];
-        } else {
-            const unsigned long long seed = p.state[0], base = p.state[1];
-            const Philox rng(seed);
-            const long long n_stripe = static_cast<long long>(p.B) * C * W;
-            if (tid < C * W4) {  // C * W / 4 counters per image (W % 4 == 0: an image's stripe starts on a counter boundary)
-                const uint4 r = rng(base + static_cast<unsigned long long>(n) * (C * W4) + tid);
-                *reinterpret_cast<float4 *>(stripe + 4 * tid) =
-                    make_float4(sgn(2.0f * u01(r.x) - 1.0f), sgn(2.0f * u01(r.y) - 1.0f), sgn(2.0f * u01(r.z) - 1.0f), sgn(2.0f * u01(r.w) - 1.0f));
-            }
-            // the square's offset and per-channel signs are shared by the whole batch: elements n_stripe .. n_stripe + C
-            float uu[1 + C];
-#pragma unroll
-            for (int k = 0; k < 1 + C; ++k) {
-                const long long e = n_stripe + k;
-                const uint4 r = rng(base + static_cast<unsigned long long>(e >> 2));
-                const unsigned rr[4] = {r.x, r.y, r.z, r.w};
-                uu[k] = u01(rr[e & 3]);
-            }
-            const float span = static_cast<float>(H) - static_cast<float>(p.sq_size);
-            vh = static_cast<int>(static_cast<long long>(0.0f + (span - 0.0f) * uu[0]));
-#pragma unroll
-            for (int c = 0; c < C; ++c) sq_delta[c] = p.two_eps * sgn(2.0f * uu[1 + c] - 1.0f);
-        }
-    }
-
-    // ---- stage in: x frame (stencil waves), constant fragments (matrix waves) ---------------------------------------------------
+    // ---- x frame: every global load of the stencil waves first, on clamped addresses --------------------------------------------------
+    constexpr int TOTAL = C * FH * F4, PER = (TOTAL + kST - 1) / kST;
+    float4 v[PER];
+    int gjs[PER];
     if (wave < kSW) {
-        constexpr int TOTAL = C * FH * F4, PER = (TOTAL + kST - 1) / kST;
-        float4 v[PER];
-        int gjs[PER];
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int idx0 = tid + q * kST;
@@ -195,32 +162,131 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
             gjs[q] = 4 * f - kColHalo;
             v[q] = *reinterpret_cast<const float4 *>(xn + (static_cast<size_t>(c) * H + gi) * W + clamp_col4(gjs[q], W));
         }
+    }
+
+    // ---- draws (core.py:637, :645, :648) by wave 0: the same element <-> Philox mapping as square_draw_kernel (ee_square.hip).
+    // stripe[C][W] signs and {vh, 2 eps sign_c} go to LDS.  Device-side draws: every lane of wave 0 reads {seed, offset}, then
+    // lane 0 takes a ticket; the workgroup holding the last ticket advances the offset - every workgroup has read it by then
+    // (its ticket came after its reads), and the latency of the atomic hides under the rest of the kernel ------------------------
+    float *sqp = stripe + C * W;  // [0] = vh (as float bits), [1 + c] = 2 eps sign_c
+    if (SQUARE && wave == 0) {
+        if (p.stripe_in) {
+            for (int i = tid; i < C * W; i += kWave) stripe[i] = p.stripe_in[static_cast<size_t>(n) * C * W + i];
+            if (tid == 0) sqp[0] = __int_as_float(static_cast<int>(p.sq_pos_in[0]));
+            if (tid < C) sqp[1 + tid] = p.two_eps * p.sq_sign_in[tid];
+        } else {
+            const unsigned long long seed = p.state[0], base = p.state[1];
+            const Philox rng(seed);
+            const long long n_stripe = static_cast<long long>(p.B) * C * W;
+            if (tid < C * W4) {  // C * W / 4 counters per image (W % 4 == 0: an image's stripe starts on a counter boundary)
+                const uint4 r = rng(base + static_cast<unsigned long long>(n) * (C * W4) + tid);
+                *reinterpret_cast<float4 *>(stripe + 4 * tid) =
+                    make_float4(sgn(2.0f * u01(r.x) - 1.0f), sgn(2.0f * u01(r.y) - 1.0f), sgn(2.0f * u01(r.z) - 1.0f), sgn(2.0f * u01(r.w) - 1.0f));
+            } else if (tid < C * W4 + 1 + C) {  // the square's offset and per-channel signs, shared by the batch: elements n_stripe + k
+                const int k = tid - C * W4;
+                const long long e = n_stripe + k;
+                const uint4 r = rng(base + static_cast<unsigned long long>(e >> 2));
+                const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+                const float u = u01(rr[e & 3]);
+                if (k == 0) {
+                    const float span = static_cast<float>(H) - static_cast<float>(p.sq_size);
+                    sqp[0] = __int_as_float(static_cast<int>(static_cast<long long>(0.0f + (span - 0.0f) * u)));
+                } else {
+                    sqp[k] = p.two_eps * sgn(2.0f * u - 1.0f);
+                }
+            }
+            __threadfence();  // the state has been read by this wave ...
+            if (tid == 0) {   // ... before its ticket is taken
+                const unsigned long long done = atomicAdd(p.state + 2, 1ull);
+                if (done + 1ull == static_cast<unsigned long long>(p.B)) {
+                    const long long total = n_stripe + 1 + C;
+                    p.state[1] = base + static_cast<unsigned long long>((total + 3) >> 2);
+                    p.state[2] = 0ull;
+                }
+            }
+        }
+    }
+    static_assert(C * (W / 4) + 1 + C <= kWave, "one wavefront makes all draws of an image");
+    int vh = 0;
+    float sq_delta[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sq_delta[c] = 0.0f;
+    if (SQUARE) {
+        __syncthreads();  // the draws are in LDS
+        vh = __float_as_int(sqp[0]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) sq_delta[c] = sqp[1 + c];
+    }
+
+    // ---- stage in: frame -> LDS; its interior also through Add_Square (value -> A plane, derivative code -> gate byte) ----------------
+    if (wave < kSW) {
+        SquareArgs sa{};
+        sa.nq = 1; sa.C = C; sa.H = H; sa.W = W; sa.eps = p.eps; sa.two_eps = p.two_eps;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int idx = tid + q * kST;
-            if (idx < TOTAL) *reinterpret_cast<float4 *>(xr + idx * 4) = replicate4(v[q], gjs[q], W);
+            if (idx < TOTAL) {
+                *reinterpret_cast<float4 *>(xr + idx * 4) = replicate4(v[q], gjs[q], W);
+                const int c = idx / (FH * F4), rem = idx - c * (FH * F4);
+                const int r = rem / F4, f = rem - r * F4;
+                const int h = r - 2, w0 = 4 * f - kColHalo;
+                if (h >= 0 && h < H && w0 >= 0 && w0 < W) {
+                    const float xv[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                    float o[4];
+                    unsigned code[4];
+                    if (SQUARE) {
+                        SquarePlane pl{};
+                        pl.vh[0] = vh; pl.s[0] = p.sq_size;
+#pragma unroll
+                        for (int cc = 0; cc < C; ++cc)
+                            if (cc == c) pl.delta[0] = sq_delta[cc];
+                        const float4 st = *reinterpret_cast<const float4 *>(stripe + c * W + w0);
+                        const float sv[4] = {st.x, st.y, st.z, st.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float d;
+                            o[k] = square_elem<true>(sa, pl, xv[k], sv[k], c, h, w0 + k, d);
+                            code[k] = dsq_code(d) << 1;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            o[k] = xv[k];
+                            code[k] = 3u << 1;
+                        }
+                    }
+                    *reinterpret_cast<float4 *>(xs + (c * D::HP + h) * D::AS + w0) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<uchar4 *>(gst + (c * H + h) * W + w0) = make_uchar4(code[0], code[1], code[2], code[3]);
+                }
+            }
+        }
+        if (D::HP != H || D::WP != W) {  // padding rows / columns of the A planes (28 -> 32): zeros (their table entries are zero too)
+            for (int idx = tid; idx < C * D::HP * D::AS; idx += kST) {
+                const int rem = idx % (D::HP * D::AS);
+                const int h = rem / D::AS, w = rem - h * D::AS;
+                if (h >= H || w >= W) xs[idx] = 0.0f;
+            }
         }
     } else {
-        constexpr int MT = C * kWave, NT4 = D::NTAB / 4, PER = (NT4 + MT - 1) / MT;
+        constexpr int MT = C * kWave, NT4 = D::NTAB / 4, PERT = (NT4 + MT - 1) / MT;
         const int mt_id = tid - kST;
-        float4 v[PER];
+        float4 tv[PERT];
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
+        for (int q = 0; q < PERT; ++q) {
             const int i = mt_id + q * MT;
-            v[q] = reinterpret_cast<const float4 *>(p.tables)[i < NT4 ? i : NT4 - 1];
+            tv[q] = reinterpret_cast<const float4 *>(p.tables)[i < NT4 ? i : NT4 - 1];
         }
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
+        for (int q = 0; q < PERT; ++q) {
             const int i = mt_id + q * MT;
-            if (i < NT4) reinterpret_cast<float4 *>(tab)[i] = v[q];
+            if (i < NT4) reinterpret_cast<float4 *>(tab)[i] = tv[q];
         }
     }
     __syncthreads();
 
-    f32x4 y[D::HT][D::WT];
     if (wave < kSW) {
         // ---- edge filter on 4-pixel groups: ee_edge.hip's arithmetic, whole image in the frame ----------------------------------
-        for (int idx = tid; idx < H * W4; idx += kST) {
+        for (int idx = tid; idx < ((p.dbg & 1) ? 0 : H * W4); idx += kST) {
             const int i = idx / W4, lx = idx - i * W4, jb = 4 * lx;
             float b[C][3][6];
             blur_group<C, FH, FW>(xr, wt, i, jb + kColHalo - 2, i, jb, H, W, b);
@@ -231,80 +297,47 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
                 sobel_px<C>(b, wt, k, ax, ay);
                 edge_from_sums<C>(ax, ay, p.alpha, p.high, gxs[k], gys[k], s2, mag, mag_a, e[k]);
             }
-            *reinterpret_cast<float4 *>(emap + i * W + jb) = make_float4(e[0], e[1], e[2], e[3]);
+            // e is 0 or 1 (To_compare.forward of a finite magnitude; NaN cannot occur: x is finite): one byte per pixel
+            *reinterpret_cast<uchar4 *>(emap + i * W + jb) = make_uchar4(e[0] != 0.0f, e[1] != 0.0f, e[2] != 0.0f, e[3] != 0.0f);
             const size_t pix = (static_cast<size_t>(n) * H + i) * W + jb;
             *reinterpret_cast<float4 *>(p.gx + pix) = make_float4(gxs[0], gxs[1], gxs[2], gxs[3]);
             *reinterpret_cast<float4 *>(p.gy + pix) = make_float4(gys[0], gys[1], gys[2], gys[3]);
             if (p.edge) *reinterpret_cast<float4 *>(p.edge + pix) = make_float4(e[0], e[1], e[2], e[3]);
         }
-    } else {
-        // ---- low-pass of add_square(x), plane c = wave - 4; the gate byte's derivative code is written on the way -----------------
-        const int c = wave - kSW;
-        const float *xc = xr + c * PL;
-        uint8_t *gc = gst + c * H * W;
-        const float *sc = stripe + c * W;
-        SquareArgs sa{};
-        sa.nq = 1; sa.C = C; sa.H = H; sa.W = W; sa.eps = p.eps; sa.two_eps = p.two_eps;
-        SquarePlane pl{};
-        pl.vh[0] = vh; pl.s[0] = p.sq_size; pl.delta[0] = sq_delta[c];
-        f32x4 ef[2];
-        lowpass_front<H, W>(tab, [&](int h, int w) -> float {
-            const int hc = h < H ? h : H - 1, wc = w < W ? w : W - 1;  // padding rows / cols: any finite value (zero table entries)
-            const float xv = xc[(hc + 2) * FW + wc + kColHalo];
-            if (!SQUARE) {
-                if (h < H && w < W) gc[h * W + w] = static_cast<uint8_t>(3u << 1);
-                return xv;
-            }
-            float d;
-            const float v = square_elem<true>(sa, pl, xv, sc[wc], c, hc, wc, d);
-            if (h < H && w < W) gc[h * W + w] = static_cast<uint8_t>(dsq_code(d) << 1);
-            return v;
-        }, ef);
-        lowpass_back<H, W>(tab, ef, y);
-    }
-    __syncthreads();
-
-    // ---- combine (matrix waves): x_in = clamp(x_lp + w * e) written over the frame's interior, gate bit 0 ---------------------------
-    if (wave >= kSW) {
+    } else if (!(p.dbg & 2)) {
+        // ---- low-pass of add_square(x), plane c = wave - kSW; the result replaces the plane (this wave is its only reader) -----------
         const int c = wave - kSW, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        float *xc = xr + c * PL;
-        uint8_t *gc = gst + c * H * W;
+        float *xc = xs + c * D::HP * D::AS;
+        f32x4 y[D::HT][D::WT], ef[2];
+        lowpass_front<H, W>(tab, [&](int h, int w) -> float { return xc[h * D::AS + w]; }, ef);
+        lowpass_back<H, W>(tab, ef, y);
 #pragma unroll
         for (int ht = 0; ht < D::HT; ++ht)
 #pragma unroll
             for (int wt_ = 0; wt_ < D::WT; ++wt_)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int h = 16 * ht + 4 * lg + r, w = 16 * wt_ + li;
-                    if (h < H && w < W) {
-                        const float s = y[ht][wt_][r] + p.w * emap[h * W + w];
-                        xc[(h + 2) * FW + w + kColHalo] = tclamp(s, 0.0f, 1.0f);
-                        gc[h * W + w] = static_cast<uint8_t>(gc[h * W + w] | ((s >= 0.0f && s <= 1.0f) ? 1u : 0u));
-                    }
-                }
+                for (int r = 0; r < 4; ++r) xc[(16 * ht + 4 * lg + r) * D::AS + 16 * wt_ + li] = y[ht][wt_][r];
     }
     __syncthreads();
+    if (p.dbg & 4) return;
 
-    // ---- stage out: 16 B (x_in) / 4 B (gate) per lane -----------------------------------------------------------------------------------
+    // ---- combine + stage out (everybody): x_in = clamp(x_lp + w * e), gate = code | 1[0 <= x_lp + w * e <= 1]; 16 B / 4 B per lane --------
     constexpr int NT = (kSW + C) * kWave;
     float *xo = p.x_in + static_cast<size_t>(n) * C * H * W;
     uint8_t *go = p.gate + static_cast<size_t>(n) * C * H * W;
     for (int idx = tid; idx < C * H * W4; idx += NT) {
         const int c = idx / (H * W4), rem = idx - c * (H * W4);
         const int h = rem / W4, w0 = 4 * (rem - h * W4);
+        const float4 lp = *reinterpret_cast<const float4 *>(xs + (c * D::HP + h) * D::AS + w0);
+        const uchar4 e4 = *reinterpret_cast<const uchar4 *>(emap + h * W + w0);
+        const uchar4 cd = *reinterpret_cast<const uchar4 *>(gst + (c * H + h) * W + w0);
+        const float s0 = lp.x + p.w * (e4.x ? 1.0f : 0.0f), s1 = lp.y + p.w * (e4.y ? 1.0f : 0.0f);
+        const float s2 = lp.z + p.w * (e4.z ? 1.0f : 0.0f), s3 = lp.w + p.w * (e4.w ? 1.0f : 0.0f);
         *reinterpret_cast<float4 *>(xo + (static_cast<size_t>(c) * H + h) * W + w0) =
-            *reinterpret_cast<const float4 *>(xr + c * PL + (h + 2) * FW + w0 + kColHalo);
-        *reinterpret_cast<uchar4 *>(go + (static_cast<size_t>(c) * H + h) * W + w0) = *reinterpret_cast<const uchar4 *>(gst + (c * H + h) * W + w0);
-    }
-    // ---- the last workgroup to finish advances the Philox state (every workgroup has read it by then) --------------------------------
-    if (SQUARE && !p.stripe_in && tid == 0) {
-        __threadfence();
-        const unsigned long long done = atomicAdd(p.state + 2, 1ull);
-        if (done + 1ull == static_cast<unsigned long long>(p.B)) {
-            const long long total = static_cast<long long>(p.B) * C * W + 1 + C;
-            p.state[1] += static_cast<unsigned long long>((total + 3) >> 2);
-            p.state[2] = 0ull;
-        }
+            make_float4(tclamp(s0, 0.0f, 1.0f), tclamp(s1, 0.0f, 1.0f), tclamp(s2, 0.0f, 1.0f), tclamp(s3, 0.0f, 1.0f));
+        *reinterpret_cast<uchar4 *>(go + (static_cast<size_t>(c) * H + h) * W + w0) =
+            make_uchar4(cd.x | (s0 >= 0.0f && s0 <= 1.0f), cd.y | (s1 >= 0.0f && s1 <= 1.0f), cd.z | (s2 >= 0.0f && s2 <= 1.0f),
+                        cd.w | (s3 >= 0.0f && s3 <= 1.0f));
     }
 }
 
@@ -317,6 +350,7 @@ struct BwdParams {
     const float *tables;
     float alpha, high, w;       // edge filter / front end
     float step, eps, lo, hi;    // update (step carries the direction's sign)
+    int dbg;                    // EEADV_CHAIN_DBG (measurement only): bit 0 skips stages 3 + 4, bit 1 the low-pass
 };
 
 template <int C, int H, int W>
@@ -402,6 +436,7 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_bwd_kernel(BwdParams 
                 *reinterpret_cast<float4 *>(ggx + (i - OI) * FW + jb - OJ) = make_float4(ox[0], ox[1], ox[2], ox[3]);
                 *reinterpret_cast<float4 *>(ggy + (i - OI) * FW + jb - OJ) = make_float4(oy[0], oy[1], oy[2], oy[3]);
             }
+            __builtin_amdgcn_sched_barrier(0);  // one group at a time: interleaving the IEEE divisions of all groups spills registers
         }
     } else {
         constexpr int MT = C * kWave, NT4 = D::NTAB / 4, PERT = (NT4 + MT - 1) / MT;
@@ -421,21 +456,9 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_bwd_kernel(BwdParams 
     __syncthreads();  // A
 
     if (wave < kSW) {
-        // the update's operands: issued now (the registers of phase 1 are free again), consumed after stages 3 and 4
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int idx0 = tid + q * kST, idx = idx0 < NPOS ? idx0 : NPOS - 1;
-            const int i = idx / W4, jb = 4 * (idx - i * W4);
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const size_t o = img + (static_cast<size_t>(c) * H + i) * W + jb;
-                xv[q][c] = *reinterpret_cast<const float4 *>(p.x + o);
-                x0v[q][c] = *reinterpret_cast<const float4 *>(p.x0 + o);
-            }
-        }
         // ---- stage 3: gb = pad^T(Sx^T ggx + Sy^T ggy) ------------------------------------------------------------------------------------
 #pragma unroll 1
-        for (int idx = tid; idx < NPOS; idx += kST) {
+        for (int idx = tid; idx < ((p.dbg & 1) ? 0 : NPOS); idx += kST) {
             const int i = idx / W4, jb = 4 * (idx - i * W4);
             float cells[3][6];
 #pragma unroll
@@ -453,9 +476,21 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_bwd_kernel(BwdParams 
             *reinterpret_cast<float4 *>(gb + (i - OI) * FW + jb - OJ) = make_float4(o[0], o[1], o[2], o[3]);
         }
         __syncthreads();  // B
+        // the update's operands: issued before stage 4 (stage 3 needs the registers), consumed after barrier C
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx0 = tid + q * kST, idx = idx0 < NPOS ? idx0 : NPOS - 1;
+            const int i = idx / W4, jb = 4 * (idx - i * W4);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const size_t o = img + (static_cast<size_t>(c) * H + i) * W + jb;
+                xv[q][c] = *reinterpret_cast<const float4 *>(p.x + o);
+                x0v[q][c] = *reinterpret_cast<const float4 *>(p.x0 + o);
+            }
+        }
         // ---- stage 4: g_edge = pad^T(G^T gb), parked in the (now dead) ggx frame at this thread's own groups -----------------------------
 #pragma unroll 1
-        for (int idx = tid; idx < NPOS; idx += kST) {
+        for (int idx = tid; idx < ((p.dbg & 1) ? 0 : NPOS); idx += kST) {
             const int i = idx / W4, jb = 4 * (idx - i * W4);
             float cells[3][6];
 #pragma unroll
@@ -474,9 +509,9 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_bwd_kernel(BwdParams 
         const int c = wave - kSW, lane = tid & 63, li = lane & 15, lg = lane >> 4;
         float *gc = gh + c * D::HP * D::AS;
         f32x4 y[D::HT][D::WT], ef[2];
-        lowpass_front<H, W>(tab, [&](int h, int w) -> float { return gc[h * D::AS + w]; }, ef);
+        if (!(p.dbg & 2)) lowpass_front<H, W>(tab, [&](int h, int w) -> float { return gc[h * D::AS + w]; }, ef);
         __syncthreads();  // B - in the middle of the chain, so that neither side waits long for the other
-        lowpass_back<H, W>(tab, ef, y);
+        if (!(p.dbg & 2)) lowpass_back<H, W>(tab, ef, y);
 #pragma unroll
         for (int ht = 0; ht < D::HT; ++ht)
 #pragma unroll
@@ -514,6 +549,7 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_bwd_kernel(BwdParams 
                     *reinterpret_cast<float4 *>(p.x + img + (static_cast<size_t>(c) * H + i) * W + jb) = make_float4(r4[0], r4[1], r4[2], r4[3]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -531,7 +567,8 @@ Weights load_weights(const float *w27) {
 template <int H, int W>
 size_t fwd_lds_bytes(int C) {
     using D = Dims<H, W>;
-    return sizeof(float) * (static_cast<size_t>(C) * (H + 4) * (W + 2 * kColHalo) + D::NTAB + H * W + C * W) + static_cast<size_t>(C) * H * W;
+    return sizeof(float) * (static_cast<size_t>(C) * (H + 4) * (W + 2 * kColHalo) + static_cast<size_t>(C) * D::HP * D::AS + D::NTAB + C * W + 4) +
+           static_cast<size_t>(H) * W + static_cast<size_t>(C) * H * W;
 }
 
 template <int H, int W>
@@ -586,6 +623,14 @@ Shape shape_of(int C, int H, int W) {
 
 inline bool al16(const void *q) { return !q || aligned16(q); }
 
+int chain_dbg() {
+    static const int v = [] {
+        const char *e = getenv("EEADV_CHAIN_DBG");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 }  // namespace
 
 EE_API int ee_chain_supported(int C, int H, int W) { return shape_of(C, H, W) != S_NONE; }
@@ -618,6 +663,7 @@ EE_API int ee_chain_fwd_f32(const float *x, int B, int C, int H, int W, const fl
     p.B = B; p.sq_size = sq_size;
     p.eps = eps; p.two_eps = static_cast<float>(2.0 * static_cast<double>(eps));
     p.alpha = alpha; p.high = high; p.w = w;
+    p.dbg = chain_dbg();
     const Weights wt = load_weights(weights27);
     hipStream_t st = as_stream(stream);
     ProfScope prof(EE_K_CHAIN_FWD, st);
@@ -642,6 +688,7 @@ EE_API int ee_chain_bwd_f32(const float *g_in, const uint8_t *gate, const float 
     p.g_in = g_in; p.gate = gate; p.gx = gx; p.gy = gy; p.x = x; p.x0 = x0; p.tables = tables;
     p.alpha = alpha; p.high = high; p.w = w;
     p.step = dir > 0 ? step : -step; p.eps = eps; p.lo = lo; p.hi = hi;
+    p.dbg = chain_dbg();
     const Weights wt = load_weights(weights27);
     hipStream_t st = as_stream(stream);
     ProfScope prof(EE_K_CHAIN_BWD, st);

@@ -41,27 +41,33 @@ __device__ __forceinline__ SquarePlane square_plane(const SquareArgs &a, int c) 
 template <bool WANT_D>
 __device__ __forceinline__ float square_elem(const SquareArgs &a, const SquarePlane &pl, float x, float stripe_v, int c, int h, int w,
                                              float &d) {
+    // x finite (an image): hardware min / max (one instruction each) give torch.min / max / clamp exactly; a NaN x - which torch
+    // propagates through every step - is patched in at the end (value NaN, derivative 0: every comparison on the way is false)
     const float t0 = x + a.eps * stripe_v;
-    float y = tclamp(t0, 0.0f, 1.0f);
+    float y = fminf(fmaxf(t0, 0.0f), 1.0f);
     if (WANT_D) d = (t0 >= 0.0f && t0 <= 1.0f) ? 1.0f : 0.0f;
     const float lb = x - a.eps, ub = x + a.eps;
     auto query = [&](int vh, int s, float dq) {
         const bool inside = (h >= vh && h < vh + s && w >= vh && w < vh + s);
         const float y1 = y + (inside ? dq : 0.0f);
-        const float m = tmax(y1, lb);
-        const float y2 = tmin(m, ub);
+        const float m = fmaxf(y1, lb);
+        const float y2 = fminf(m, ub);
         if (WANT_D) {
             const float dm = (y1 > lb) ? d : ((y1 < lb) ? 1.0f : 0.5f * d + 0.5f);
             const float d2 = (m < ub) ? dm : ((m > ub) ? 1.0f : 0.5f * dm + 0.5f);
             d = (y2 >= 0.0f && y2 <= 1.0f) ? d2 : 0.0f;
         }
-        y = tclamp(y2, 0.0f, 1.0f);
+        y = fminf(fmaxf(y2, 0.0f), 1.0f);
     };
 #pragma unroll
     for (int q = 0; q < kSquareCached; ++q)
         if (q < a.nq) query(pl.vh[q], pl.s[q], pl.delta[q]);
     for (int q = kSquareCached; q < a.nq; ++q)
         query(static_cast<int>(a.sq_pos[q]), a.sq_size[q], a.two_eps * a.sq_sign[q * a.C + c]);
+    if (x != x) {
+        y = x;
+        if (WANT_D) d = 0.0f;
+    }
     return y;
 }
 

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""rocprofv3 *_kernel_stats.csv -> {bench.py kernel family: average microseconds per launch} (profiles/rocprof_kernel_us.json),
+the figure bench.py carries next to its live HIP-event measurement (roofline.rocprofv3_avg_us)."""
+import csv
+import json
+import sys
+
+FAMILIES = {  # bench.py family -> substring of the kernel symbol (every template instance of the bench shape)
+    "ee_chain_fwd": "chain_fwd_kernel", "ee_chain_bwd": "chain_bwd_kernel", "ee_frontend_fwd": "edge_fwd_kernel",
+    "ee_frontend_bwd": "edge_bwd_saved_kernel", "ee_hfs": "hfs_kernel<0", "ee_hfs_square_fwd": "hfs_kernel<1", "ee_hfs_square_bwd": "hfs_kernel<2",
+    "ee_pgd_step": "PgdStepOp", "ee_pgd_step_bcast": "pgd_step_bcast_kernel", "ee_square_draw": "square_draw_kernel", "ee_ce": "ce_kernel",
+}
+rows = list(csv.DictReader(open(sys.argv[1])))
+out = {"_provenance": sys.argv[3] if len(sys.argv) > 3 else ""}
+for fam, pat in FAMILIES.items():
+    tot = calls = 0
+    for r in rows:
+        if pat in r["Name"]:
+            tot += float(r["TotalDurationNs"])
+            calls += int(r["Calls"])
+    if calls:
+        out[fam] = round(tot / calls / 1e3, 3)
+        out[fam + "__calls"] = calls
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out))
