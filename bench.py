@@ -301,10 +301,11 @@ def main():
     if a.channels_last:
         model = model.to(memory_format=torch.channels_last)
     optimizer = torch.optim.SGD(model.parameters(), lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"])
+    from eeadv import ddp
+    # N > 1: one flat gradient buffer all-reduced over RCCL between the two captured halves of the update (eeadv.ddp.FlatGradSync);
+    # the attack needs no collective at all.  The model is not wrapped: DistributedDataParallel's reducer needs an eager backward
     run_model = model
-    if world > 1:
-        run_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=16,
-                                                              gradient_as_bucket_view=True)
+    sync = ddp.FlatGradSync(model) if world > 1 else None
     dargs = driver_args(cfg)
     criterion = trainer.make_criterion(dargs)
     B = cfg["batch"]
@@ -317,7 +318,9 @@ def main():
         for i in range(n):
             x, y = batches[i % len(batches)]
             engine.PROBE_ITERS = probe_iters if i % max(1, a.probe_every) == 0 else 0
-            last = trainer.train_batch(run_model, criterion, optimizer, dargs, x, y, dev)
+            if trainer.PHASE_EVENTS is not None:
+                trainer.PHASE_EVENTS.start()
+            last = trainer.train_batch(run_model, criterion, optimizer, dargs, x, y, dev, sync=sync)
             ops.prof_mark_empty()  # one empty event bracket per step: the bracket's own cost, measured live
         return last
 
@@ -334,11 +337,15 @@ def main():
     fence()
     ops.prof_reset()
     ops.prof_enable(True)
+    if world > 1:
+        trainer.PHASE_EVENTS = trainer.PhaseEvents()  # per-rank device time of attack / backward / all-reduce / SGD
     t0 = time.perf_counter()
     last = run(a.steps)
     fence()
     dt = time.perf_counter() - t0
     ops.prof_enable(False)
+    phases = trainer.PHASE_EVENTS.summary() if trainer.PHASE_EVENTS is not None else None
+    trainer.PHASE_EVENTS = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -405,7 +412,9 @@ def main():
                 a.workload, cfg["arch"], cfg["method"], B, "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"],
                 ", DDP all-reduce (RCCL)" if world > 1 else ""),
                 "global_batch": world * B, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-                "backend": dist.get_backend() if world > 1 else None, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": probe_iters, "probe_every": a.probe_every,
+                "backend": dist.get_backend() if world > 1 else None, "grad_sync": None if sync is None else
+                "flat %.1f MB in %d pieces, between the captured backward and the captured SGD step" % (sync.flat.numel() * 4 / 1e6, len(sync.pieces)),
+                "rank0_phase_ms": phases, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": probe_iters, "probe_every": a.probe_every,
                 "device": (N.lib.ee_device_name() or b"?").decode()},
             "roofline": roofline, "kernels": kernels, "final_loss": round(loss_val, 5),
             "note": "throughput is bounded by the CNN convolutions (MIOpen fp32), not by the hand-written kernels; "

@@ -105,7 +105,7 @@ def _say(line, log_dir):
             print(line, file=f)
 
 
-def train(train_loader, net, criterion, optimizer, epoch, args, device, log_dir, noise):
+def train(train_loader, net, criterion, optimizer, epoch, args, device, log_dir, noise, sync=None):
     """:263-327."""
     batch_time, data_time, losses, top1, top5 = (AverageMeter() for _ in range(5))
     net.train()
@@ -116,7 +116,7 @@ def train(train_loader, net, criterion, optimizer, epoch, args, device, log_dir,
         target, input = target.to(device), input.to(device)
         data_time.update(time.time() - end)
         for _ in range(args.n_repeats):
-            loss, output = trainer.free_at_repeat(net, criterion, optimizer, input, target, noise, args.fgsm_step, args.clip_eps)
+            loss, output = trainer.free_at_repeat(net, criterion, optimizer, input, target, noise, args.fgsm_step, args.clip_eps, sync=sync)
             batch_time.update(time.time() - end)
             end = time.time()
         if i % args.print_freq == 0:  # the reference syncs with .item() on every repeat (:296); here only when it prints
@@ -158,7 +158,11 @@ def main(argv=None):
     # on a multi-GPU node - the PGD evaluation of a multi-rank SyncBatchNorm job therefore runs eagerly unless the user insists
     if ddp.world() > 1:
         os.environ.setdefault("EEADV_GRAPH", "0")
-    net = ddp.wrap(model, device, sync_bn=True, find_unused_parameters=True)  # :149-152
+    # :149-152: SyncBatchNorm, and instead of DistributedDataParallel one flat gradient buffer all-reduced per repeat (ddp.FlatGradSync)
+    if ddp.world() > 1:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    sync = ddp.FlatGradSync(model) if ddp.world() > 1 else None
+    net = model
     criterion = trainer.Criterion()
     optimizer = torch.optim.SGD(net.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
     if ddp.rank() == 0:
@@ -188,7 +192,9 @@ def main(argv=None):
     last = args.epochs if args.max_epochs is None else min(args.epochs, args.start_epoch + args.max_epochs)
     for epoch in range(args.start_epoch, last):
         adjust_learning_rate_free(optimizer, epoch, args.lr, args.n_repeats)
-        train(train_loader, net, criterion, optimizer, epoch, args, device, dirs["log"], noise)
+        train(train_loader, net, criterion, optimizer, epoch, args, device, dirs["log"], noise, sync)
+        if sync is not None:
+            sync.broadcast_buffers()
         prec1, _ = validate(val_loader, net, criterion, args, device, dirs["log"])
         is_best = prec1 > best_prec1
         best_prec1 = max(prec1, best_prec1)

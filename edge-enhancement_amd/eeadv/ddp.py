@@ -78,6 +78,81 @@ def wrap(model, device=None, sync_bn=False, bucket_cap_mb=16, find_unused_parame
                                                      find_unused_parameters=find_unused_parameters)
 
 
+class FlatGradSync:
+    """The gradient exchange of the data-parallel training step without DistributedDataParallel's autograd hooks, so that the
+    forward + backward and the optimiser step stay CAPTURABLE as HIP graphs at N > 1 (DDP's reducer needs an eager backward: at
+    N = 1 the update replays one graph, under DDP it was ~600 eager launches - a step-time gap that has nothing to do with RCCL).
+
+      * every parameter's .grad is a view into ONE flat fp32 buffer (45.1 MB for ResNet-18/200, 102 MB for ResNet-50/1000);
+        backward accumulates into the views, `zero_()` is one memset;
+      * `all_reduce_()` sums the buffer over the ranks in `chunks` contiguous pieces (async, on RCCL's stream; the caller's
+        stream waits on the device, the host does not block) - pieces >= 8 MB keep every xGMI peer link busy (SURVEY 5.8);
+        the 1 / world scaling is ONE pass over the buffer, done where the caller wants it (`scale_()`, captured with the SGD step);
+      * parameters are broadcast from rank 0 once, buffers (BatchNorm statistics) on request - DistributedDataParallel
+        broadcasts rank 0's buffers before every forward, which amounts to "rank 0's running statistics are the model's";
+        `broadcast_buffers()` before a validation pass gives the same statistics.
+    ImageNet/experiments_imagenet.py:128-129, free_imagenet/AT_free_imagenet_ddp.py:151-152 (DDP(model)), README.md:21."""
+
+    def __init__(self, model, chunks=3, broadcast=True):
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FlatGradSync: fp32 parameters only")
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.world = world() if dist.is_initialized() else 1
+        # contiguous pieces, element counts rounded to 64 (256 B)
+        k = max(1, min(int(chunks), (n + (1 << 21) - 1) >> 21))  # never below ~8 MB a piece
+        step = ((n + k - 1) // k + 63) // 64 * 64
+        self.pieces = [self.flat[i:min(i + step, n)] for i in range(0, n, step)]
+        self.attach()
+        if broadcast and self.world > 1:
+            self.broadcast_parameters()
+
+    def attach(self):
+        """(Re-)install the views as the parameters' .grad: anything that set them to None (optimizer.zero_grad(), the .loss()
+        methods of ALP / TRADES, attacks.py:265-266) is undone; gradient VALUES are not touched."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+    def zero_(self):
+        self.attach()
+        self.flat.zero_()
+
+    def all_reduce_(self):
+        if self.world == 1:
+            return
+        works = [dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True) for piece in reversed(self.pieces)]  # deepest layers first
+        for w in works:
+            w.wait()
+
+    def scale_(self):
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+
+    def broadcast_parameters(self):
+        with torch.no_grad():
+            buf = torch.cat([p.detach().reshape(-1) for p in self.params])
+            dist.broadcast(buf, 0)
+            off = 0
+            for p in self.params:
+                p.copy_(buf[off:off + p.numel()].view_as(p))
+                off += p.numel()
+
+    def broadcast_buffers(self):
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for b in self.model.buffers():
+                dist.broadcast(b, 0)
+
+
 def gather_mean(*scalars):
     """experiments_imagenet.py:369-384: all_gather each 1-element metric, then average over ranks."""
     if world() == 1:

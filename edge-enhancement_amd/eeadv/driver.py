@@ -124,7 +124,7 @@ class _DeviceMeters:
         return out
 
 
-def train(train_loader, model, criterion, optimizer, epoch, args, device, log_dir, spec):
+def train(train_loader, model, criterion, optimizer, epoch, args, device, log_dir, spec, sync=None):
     """experiments_tinyimagenet.py:215-323."""
     batch_time, data_time = AverageMeter(), AverageMeter()
     meters = _DeviceMeters(3, device)
@@ -143,7 +143,7 @@ def train(train_loader, model, criterion, optimizer, epoch, args, device, log_di
         data_time.update(time.time() - end)
         if add_square is not None:
             input = add_square(input).detach()
-        loss, output = trainer.train_batch(model, criterion, optimizer, args, input, target, device, avmixup)
+        loss, output = trainer.train_batch(model, criterion, optimizer, args, input, target, device, avmixup, sync=sync)
         prec1, prec5 = trainer.accuracy(output, target, topk=(1, min(5, spec["num_classes"])))
         if spec.get("mnist_top5_quirk"):
             prec5 = prec1  # MNIST/experiments_mnist.py:246 logs prec1 as top5 (visible in the shipped MNIST log)
@@ -236,7 +236,12 @@ def run(spec, build_model, argv=None):
 
     print("=> creating model '{}'".format(args.arch))
     model = build_model(args).to(device)
-    net = ddp.wrap(model, device if use_cuda else None, sync_bn=spec.get("sync_bn", False))
+    # N > 1: the bare model + one flat gradient buffer all-reduced per step (ddp.FlatGradSync) instead of DistributedDataParallel
+    # (experiments_imagenet.py:125-129): same averaged gradients, and the update stays capturable as HIP graphs
+    if ddp.world() > 1 and spec.get("sync_bn", False):
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    sync = ddp.FlatGradSync(model) if ddp.world() > 1 else None
+    net = model
     if use_cuda:
         torch.backends.cudnn.benchmark = False  # experiments_tinyimagenet.py:111-112
         torch.backends.cudnn.deterministic = True
@@ -261,6 +266,8 @@ def run(spec, build_model, argv=None):
     schedule = spec.get("lr_schedule", "half_three_quarters")
 
     if args.evaluate:
+        if sync is not None:
+            sync.broadcast_buffers()
         for k, s in ((args.num_steps_1, args.step_size_1), (args.num_steps_2, args.step_size_2), (args.num_steps_3, args.step_size_3)):
             print("=> evaluate.tar_num_step:{},step_size:{}".format(k, s))
             validate(val_loader, net, criterion, args, device, k, s, dirs["log"], spec)
@@ -273,7 +280,9 @@ def run(spec, build_model, argv=None):
             adjust_learning_rate(optimizer, epoch, args.lr)  # experiments_imagenet.py
         else:
             adjust_learning_rate_1(optimizer, epoch, args.lr, args.epochs)
-        train(train_loader, net, criterion, optimizer, epoch, args, device, dirs["log"], spec)
+        train(train_loader, net, criterion, optimizer, epoch, args, device, dirs["log"], spec, sync)
+        if sync is not None:
+            sync.broadcast_buffers()  # rank 0's BatchNorm statistics are the model's, as under DistributedDataParallel
         prec1, _ = validate(val_loader, net, criterion, args, device, args.num_steps_1, args.step_size_1, dirs["log"], spec)
         is_best = prec1 > best_prec1
         best_prec1 = max(prec1, best_prec1)

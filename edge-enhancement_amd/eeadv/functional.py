@@ -307,15 +307,18 @@ def _dense_weight(weight):
     return ent[2]
 
 
-def rebuild_dense_weights():
-    """Unconditional in-place rebuild of every rearranged matrix - capturable: a captured optimiser step ends with it, because
-    replaying a graph updates the weights without moving their Python-side version counters."""
+def rebuild_dense_weights(model=None):
+    """Unconditional in-place rebuild of the rearranged matrices - capturable: a captured optimiser step ends with it, because
+    replaying a graph updates the weights without moving their Python-side version counters.  `model`: only ITS weights - a
+    captured graph must not bake in copies into the buffers of another live model (tests, A/B scripts), which would write
+    freed memory once that model is gone."""
+    own = None if model is None else {id(p) for p in model.parameters()}
     with torch.no_grad():
         for key in list(_DENSE_W):
             w = _DENSE_W[key][0]()
             if w is None:
                 del _DENSE_W[key]
-            else:
+            elif own is None or key in own:
                 _DENSE_W[key][2].copy_(_rearranged(w))
                 _DENSE_W[key][1] = w._version
 

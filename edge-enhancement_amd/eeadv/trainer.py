@@ -86,26 +86,45 @@ def _sgd_signature(optimizer):
 
 
 class _GraphedUpdate:
-    def __init__(self, model, criterion, optimizer, data_adv, target):
+    """sync = None: forward + loss + backward + SGD as ONE graph.  sync = ddp.FlatGradSync (N > 1): TWO graphs with the gradient
+    all-reduce between them - [forward, loss, memset of the flat gradient, backward] | RCCL all-reduce of the flat buffer in a few
+    pieces | [1 / world scaling, SGD step] - the collective itself is not captured."""
+
+    def __init__(self, model, criterion, optimizer, data_adv, target, sync=None):
         self.model, self.criterion, self.optimizer = weakref.ref(model), criterion, weakref.ref(optimizer)
         self.x = torch.empty_like(data_adv)
         self.y = torch.empty_like(target)
-        self.graph = None
+        self.sync = sync
+        self.graph = self.graph2 = None
         self.eager_left = EAGER_UPDATES_BEFORE_CAPTURE
 
-    def _body(self):
+    def _fwd_bwd(self):
         model, optimizer = self.model(), self.optimizer()
         output = model(self.x)
         loss = self.criterion(output, self.y)
-        optimizer.zero_grad(set_to_none=True)
+        if self.sync is None:
+            optimizer.zero_grad(set_to_none=True)
+        else:
+            self.sync.zero_()
         loss.backward()
-        optimizer.step()
+        return loss.detach(), output.detach()
+
+    def _step(self):
+        if self.sync is not None:
+            self.sync.scale_()
+        self.optimizer().step()
         if torch.cuda.is_current_stream_capturing():
             # a replayed update moves the weights but not their version counters: the weight-derived buffers of
             # functional.Conv3x3Map2Fn are rebuilt by the graph itself, right behind the update
             from eeadv.functional import rebuild_dense_weights
-            rebuild_dense_weights()
-        return loss.detach(), output.detach()
+            rebuild_dense_weights(self.model())
+
+    def _body(self):
+        out = self._fwd_bwd()
+        if self.sync is not None:
+            self.sync.all_reduce_()
+        self._step()
+        return out
 
     def __call__(self, data_adv, target):
         self.x.copy_(data_adv)
@@ -118,10 +137,57 @@ class _GraphedUpdate:
         if self.graph is None:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.loss, self.output = self._body()
+            if self.sync is None:
+                with torch.cuda.graph(self.graph):
+                    self.loss, self.output = self._body()
+            else:
+                with torch.cuda.graph(self.graph):
+                    self.loss, self.output = self._fwd_bwd()
+                self.sync.all_reduce_()  # the captured backward did not run: this reduces the warm-up's gradients, harmlessly,
+                self.graph2 = torch.cuda.CUDAGraph()  # and keeps every rank's collective count equal
+                with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                    self._step()
         self.graph.replay()
+        if self.sync is not None:
+            if PHASE_EVENTS is not None:
+                PHASE_EVENTS.mark("backward")
+            self.sync.all_reduce_()
+            if PHASE_EVENTS is not None:
+                PHASE_EVENTS.mark("all_reduce")
+            self.graph2.replay()
+            if PHASE_EVENTS is not None:
+                PHASE_EVENTS.mark("sgd")
         return self.loss.clone(), self.output.clone()
+
+
+class PhaseEvents:
+    """Per-rank device time of the phases of a data-parallel training step (bench.py, N > 1): HIP events on the current stream at
+    the phase boundaries, read after the timed region."""
+
+    def __init__(self):
+        self.marks = []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append(("start", e))
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append((name, e))
+
+    def summary(self):
+        tot, cnt = {}, {}
+        for (_, a), (name, b) in zip(self.marks, self.marks[1:]):
+            if name == "start":
+                continue
+            tot[name] = tot.get(name, 0.0) + a.elapsed_time(b)
+            cnt[name] = cnt.get(name, 0) + 1
+        return {k: round(tot[k] / cnt[k], 4) for k in tot}
+
+
+PHASE_EVENTS = None  # bench.py installs a PhaseEvents for the timed steps of an N > 1 run
 
 
 def _graphable_update(model, criterion, optimizer, args, data_adv):
@@ -131,9 +197,27 @@ def _graphable_update(model, criterion, optimizer, args, data_adv):
             and args.method_name not in ('ALP', 'tarALP', 'TRADES', 'AVmixup', 'tarAVmixup'))
 
 
-def train_batch(model, criterion, optimizer, args, input, target, device, avmixup=None):
-    """One optimisation step; returns (loss, output) detached, both still on the device."""
+def backward_and_step(loss, optimizer, sync=None):
+    """zero_grad / backward / step of the drivers (experiments_tinyimagenet.py:304-306), with the gradient all-reduce of a
+    data-parallel run in between when `sync` (ddp.FlatGradSync) is given."""
+    if sync is None:
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        return
+    sync.zero_()
+    loss.backward()
+    sync.all_reduce_()
+    sync.scale_()
+    optimizer.step()
+
+
+def train_batch(model, criterion, optimizer, args, input, target, device, avmixup=None, sync=None):
+    """One optimisation step; returns (loss, output) detached, both still on the device.  sync: ddp.FlatGradSync of a
+    data-parallel run (the model is then NOT wrapped in DistributedDataParallel)."""
     data_adv, preds, new_target = attack_for_training(model, criterion, args, input, target, device, avmixup)
+    if PHASE_EVENTS is not None:
+        PHASE_EVENTS.mark("attack")
     if _graphable_update(model, criterion, optimizer, args, data_adv):
         owner = (id(model), id(optimizer))
         sig = _sgd_signature(optimizer)
@@ -144,7 +228,7 @@ def train_batch(model, criterion, optimizer, args, input, target, device, avmixu
         key = (tuple(data_adv.shape), tuple(target.shape), target.dtype, data_adv.device.index)
         update = slot[3].get(key)
         if update is None:
-            update = slot[3][key] = _GraphedUpdate(model, criterion, optimizer, data_adv, target)
+            update = slot[3][key] = _GraphedUpdate(model, criterion, optimizer, data_adv, target, sync)
         return update(data_adv.detach(), target)
     output = model(data_adv)
     m = args.method_name
@@ -160,13 +244,11 @@ def train_batch(model, criterion, optimizer, args, input, target, device, avmixu
             loss = -torch.sum(nn.functional.log_softmax(output, dim=1) * new_target) / input.shape[0]
     else:
         loss = criterion(output, target)
-    optimizer.zero_grad()
-    loss.backward()
-    optimizer.step()
+    backward_and_step(loss, optimizer, sync)
     return loss.detach(), output.detach()
 
 
-def free_at_repeat(model, criterion, optimizer, input, target, noise, fgsm_step, clip_eps, return_input_grad=False):
+def free_at_repeat(model, criterion, optimizer, input, target, noise, fgsm_step, clip_eps, return_input_grad=False, sync=None):
     """One repeat of "free" adversarial training (ImageNet/free_imagenet/AT_free_imagenet_ddp.py:287-309): a single
     forward/backward gives the weight gradient AND the input gradient; `noise` is the persistent buffer, its first
     len(input) rows are read and updated in place.  Returns (loss, output), detached, still on the device.
@@ -182,9 +264,16 @@ def free_at_repeat(model, criterion, optimizer, input, target, noise, fgsm_step,
     in1 = ops.add_clamp(x, noise[0:n], 0.0, 1.0).requires_grad_(True)
     output = model(in1)
     loss = criterion(output, target)
-    optimizer.zero_grad()
+    if sync is None:
+        optimizer.zero_grad()
+    else:
+        sync.zero_()
     loss.backward()
+    if sync is not None:
+        sync.all_reduce_()  # on RCCL's stream; the noise update below runs meanwhile
     ops.freeat_update_masked_(noise, in1.grad.contiguous(), x, float(fgsm_step), float(clip_eps))
+    if sync is not None:
+        sync.scale_()
     optimizer.step()
     if return_input_grad:  # dL/din1, BEFORE the clamp mask (tests)
         return loss.detach(), output.detach(), in1.grad.detach()

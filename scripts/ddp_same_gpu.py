@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Two DDP ranks sharing ONE GPU over gloo: an integration check of the multi-process path on a 1-GPU box (RCCL needs one
-device per rank, so the collective backend differs from production; DDP's hooks, buckets and the interplay with the captured
-attack graph, the custom autograd Functions and the eager update are the same).
+"""Two data-parallel ranks sharing ONE GPU over gloo: an integration check of the multi-process path on a 1-GPU box (RCCL needs
+one device per rank, so the collective backend differs from production; everything else is the N > 1 path of bench.py: the
+captured attack graph, the captured forward + backward writing one flat gradient buffer, its all-reduce (eeadv.ddp.FlatGradSync),
+the captured SGD step).
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 scripts/ddp_same_gpu.py"""
 import os
 import sys
@@ -12,7 +13,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from eeadv import engine, trainer  # noqa: E402
+from eeadv import ddp, engine, trainer  # noqa: E402
 from eeadv.models import make_resnet_ee  # noqa: E402
 
 
@@ -29,14 +30,17 @@ def main():
     torch.manual_seed(1 + rank)
     model = make_resnet_ee(18, "tiny", square=True, cize=64, r=16, w=0.5, low=60.0, high=120.0, alpha=0.0, sigma=1,
                            type_canny="CannyFilter_step125_1", epsilon=0.05, n_queries=1).to(dev).train()
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=16, gradient_as_bucket_view=True)
+    sync = ddp.FlatGradSync(model)  # broadcasts rank 0's weights (the ranks were seeded differently)
+    net = model
     opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=2e-4)
     args = Args(method_name="EE_BPDA3_AT_square", random=True, epsilon=16 / 255, num_steps_1=4, step_size_1=2 / 255, num_classes=200)
     crit = trainer.make_criterion(args)
-    for step in range(4):
+    trainer.PHASE_EVENTS = trainer.PhaseEvents()
+    for step in range(6):  # two eager updates, the capture, three replays
         x = torch.rand(16, 3, 64, 64, device=dev)
         y = torch.randint(0, 200, (16,), device=dev)
-        loss, out = trainer.train_batch(net, crit, opt, args, x, y, dev)
+        trainer.PHASE_EVENTS.start()
+        loss, out = trainer.train_batch(net, crit, opt, args, x, y, dev, sync=sync)
     torch.cuda.synchronize()
     assert torch.isfinite(loss), loss
     # same initial weights (DDP broadcast) + averaged gradients -> identical parameters on every rank
@@ -48,7 +52,10 @@ def main():
     print("rank %d: loss %.4f  max |param - rank0 param| = %.3e  graphs %d  bn stats finite %s" % (
         rank, float(loss), diff, len(engine._GRAPHS), bool(torch.isfinite(stats).all())), flush=True)
     assert diff == 0.0
-    assert len(engine._GRAPHS) == 1  # the attack replayed a captured graph on the unwrapped module
+    assert len(engine._GRAPHS) == 1  # the attack replayed a captured graph
+    upd = list(trainer._UPDATES.values())[0][3]
+    assert len(upd) == 1 and list(upd.values())[0].graph2 is not None  # ... and the update replayed its two graphs around the all-reduce
+    print("rank %d phases (ms): %s" % (rank, trainer.PHASE_EVENTS.summary()), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -103,3 +103,84 @@ def test_shard_indices_and_padding():
             ddp.per_rank_batch(100)
         finally:
             os.environ.pop("WORLD_SIZE")
+
+
+def _flat_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "edge-enhancement_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    from eeadv import ddp, runtime, trainer
+    from utils import attacks as A
+    runtime.allow_cpu_plumbing(True)
+    ddp.setup(device="cpu")
+    torch.manual_seed(rank)  # DIFFERENT initial weights: FlatGradSync must broadcast rank 0's
+    model = TinyNet(2, 8, 10, 7 + rank)
+    sync = ddp.FlatGradSync(model, chunks=3)
+    assert all(p.grad is v for p, v in zip(sync.params, sync.views)) and sync.flat.numel() == sum(p.numel() for p in model.parameters())
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(123)
+    X, Y = torch.rand(8, 2, 8, 8, generator=g), torch.randint(0, 10, (8,), generator=g)
+    idx = ddp.shard_indices(8)
+    x, y = X[idx], Y[idx]
+    losses = []
+    for step in range(3):
+        args = Args(method_name="AT", random=False, epsilon=0.1, num_steps_1=2, step_size_1=0.02, num_classes=10, attack_method="PGD", beta=6.0)
+        crit = trainer.make_criterion(args)
+        loss, out = trainer.train_batch(model, crit, opt, args, x, y, "cpu", sync=sync)
+        losses.append(float(loss))
+        assert all(p.grad is v for p, v in zip(sync.params, sync.views))
+        if step == 0:
+            opt.zero_grad(set_to_none=True)  # what the .loss() methods of ALP / TRADES do (attacks.py:265-266): the views must come back
+            assert model.w1.grad is None
+    saved = {"params": [p.detach().clone() for p in model.parameters()], "losses": losses, "flat": sync.flat.clone()}
+    # a TRADES step (random start: not emulated below, but the ranks must still agree afterwards)
+    args = Args(method_name="TRADES", random=False, epsilon=0.1, num_steps_1=2, step_size_1=0.02, num_classes=10, attack_method="PGD", beta=6.0)
+    trainer.train_batch(model, trainer.make_criterion(args), opt, args, x, y, "cpu", sync=sync)
+    saved["params_after_trades"] = [p.detach().clone() for p in model.parameters()]
+    torch.save(saved, os.path.join(out_dir, "f%d.pt" % rank))
+    ddp.teardown()
+
+
+def test_flat_gradient_sync_two_ranks(tmp_path):
+    """eeadv.ddp.FlatGradSync (the N > 1 update without DistributedDataParallel): rank 0's weights everywhere, gradients as
+    views of one flat buffer that survive zero_grad(set_to_none), averaged over the ranks, identical parameters afterwards -
+    and the same trajectory as one process that averages the two shards' gradients by hand."""
+    port = _free_port()
+    mp.spawn(_flat_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(str(tmp_path / "f0.pt"), weights_only=False)
+    r1 = torch.load(str(tmp_path / "f1.pt"), weights_only=False)
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    assert torch.equal(r0["flat"], r1["flat"])  # the averaged gradient of the last step, on both ranks
+    for a, b in zip(r0["params_after_trades"], r1["params_after_trades"]):
+        assert torch.equal(a, b)
+    from eeadv import runtime, trainer
+    import torch.nn.functional as F
+    runtime.allow_cpu_plumbing(True)
+    try:
+        net = TinyNet(2, 8, 10, 7)  # rank 0's initial weights
+        opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        g = torch.Generator().manual_seed(123)
+        X, Y = torch.rand(8, 2, 8, 8, generator=g), torch.randint(0, 10, (8,), generator=g)
+        shards = ([0, 2, 4, 6], [1, 3, 5, 7])
+        for step in range(3):
+            args = Args(method_name="AT", random=False, epsilon=0.1, num_steps_1=2, step_size_1=0.02, num_classes=10, attack_method="PGD", beta=6.0)
+            crit = trainer.make_criterion(args)
+            grads = []
+            for idx in shards:
+                x, y = X[idx], Y[idx]
+                adv, _, _ = trainer.attack_for_training(net, crit, args, x, y, "cpu")
+                net.zero_grad()
+                F.cross_entropy(net(adv), y).backward()
+                grads.append([p.grad.clone() for p in net.parameters()])
+            for p, g0, g1 in zip(net.parameters(), *grads):
+                p.grad = (g0 + g1) / 2
+            opt.step()
+        for p, q in zip(net.parameters(), r0["params"]):
+            np.testing.assert_allclose(p.detach().numpy(), q.numpy(), rtol=1e-5, atol=1e-6)
+    finally:
+        runtime.allow_cpu_plumbing(False)
