@@ -15,7 +15,7 @@ import weakref
 
 import torch
 
-from . import ops
+from . import ops, runtime
 from .functional import input_grad_only, refresh_dense_weights
 
 CE_SUM, CE_MEAN, KL, SOFTCE = "ce_sum", "ce_mean", "kl", "softce"
@@ -126,7 +126,7 @@ class _GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         self.load(x_init, x0, payload)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=runtime.capture_mode()):
             for _ in range(self.iters):
                 self._body(model)
 

@@ -56,3 +56,11 @@ def draw_state(device):
 
 def reseed():
     _DRAW_STATE.clear()
+
+
+def capture_mode():
+    """capture_error_mode for torch.cuda.graph: with a process group alive its watchdog thread polls HIP events while we capture;
+    under the default "global" mode a call from ANY thread that the runtime deems unsafe invalidates the capture, "thread_local"
+    confines the check to the capturing thread (the launches that get captured are the same)."""
+    import torch.distributed as dist
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"

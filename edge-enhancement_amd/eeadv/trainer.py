@@ -10,6 +10,7 @@ import weakref
 import torch
 import torch.nn as nn
 
+from eeadv import runtime
 from utils import attacks as A
 from utils.helper import accuracy
 
@@ -138,14 +139,14 @@ class _GraphedUpdate:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             if self.sync is None:
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, capture_error_mode=runtime.capture_mode()):
                     self.loss, self.output = self._body()
             else:
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, capture_error_mode=runtime.capture_mode()):
                     self.loss, self.output = self._fwd_bwd()
                 self.sync.all_reduce_()  # the captured backward did not run: this reduces the warm-up's gradients, harmlessly,
                 self.graph2 = torch.cuda.CUDAGraph()  # and keeps every rank's collective count equal
-                with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=runtime.capture_mode()):
                     self._step()
         self.graph.replay()
         if self.sync is not None:
