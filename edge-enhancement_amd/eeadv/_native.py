@@ -58,6 +58,8 @@ SIGNATURES = {
     "ee_square_draw_f32": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "ee_hfs_table_floats": [c_i, c_i, c_i, c_i],
     "ee_hfs_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_f, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],
+    "ee_hfs_mfma_table_floats": [c_i, c_i, c_i],
+    "ee_hfs_mfma_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],
     "ee_chain_supported": [c_i, c_i, c_i],
     "ee_chain_table_floats": [c_i, c_i],
     "ee_chain_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_f, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],

@@ -105,9 +105,41 @@ def chain_tables(H, W, r):
     return np.ascontiguousarray(np.concatenate(t1 + t2 + t3 + t4), dtype=np.float32)
 
 
+def band_tables(H, W, r):
+    """Fragment-ordered constant operands of ee_hfs_mfma_f32 (planes up to 256 x 256; csrc/ee_hfs_mfma.hip).  Layout =
+    scripts/chain_emulate.py big_tables: t1 [Wp/4][2][64] | t2 [Hp/16][MT2][4][64] | t3 [Hp/16][MT2][4][64] | t4 [Wp/16][2][4][64];
+    cos / sin blocks padded to 16 column frequencies and NUp = 16 or 32 row frequencies.  Returns (float32 array, NUp)."""
+    us = np.array([u if u < H / 2 else u - H for u in keep_set(H, r)], dtype=np.float64)
+    vs = np.array([v for v in keep_set(W, r) if v <= W // 2], dtype=np.float64)
+    kap = np.array([1.0 if (v == 0 or (W % 2 == 0 and v == W // 2)) else 2.0 for v in vs])
+    NU, NV = len(us), len(vs)
+    if NU > 32 or NV > 16 or H > 256 or W > 256:
+        raise ValueError("band_tables: %dx%d r=%d is outside ee_hfs_mfma_f32's shape class" % (H, W, r))
+    NUp = 16 if NU <= 16 else 32
+    MT2 = 2 * NUp // 16
+    Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+    lanes = np.arange(64)
+    li, lg = lanes & 15, lanes >> 4
+    h, w = np.arange(H)[:, None], np.arange(W)[:, None]
+    Ch, Sh, Cw, Sw = np.zeros((Hp, NUp)), np.zeros((Hp, NUp)), np.zeros((Wp, 16)), np.zeros((Wp, 16))
+    Ch[:H, :NU], Sh[:H, :NU] = np.cos(2 * np.pi * h * us[None, :] / H), np.sin(2 * np.pi * h * us[None, :] / H)
+    Cw[:W, :NV], Sw[:W, :NV] = np.cos(2 * np.pi * w * vs[None, :] / W), np.sin(2 * np.pi * w * vs[None, :] / W)
+    dv = np.zeros(16)
+    dv[:NV] = kap / W
+    T1 = np.concatenate([Cw * dv, Sw * dv], 1)   # [Wp, 32]
+    CS = np.concatenate([Ch, Sh], 1)             # [Hp, 2 NUp]
+    T4 = np.concatenate([Cw.T, Sw.T], 0)         # [32, Wp]
+    t1 = [T1[4 * s + lg, 16 * nt + li] for s in range(Wp // 4) for nt in range(2)]
+    t2 = [CS[16 * t + 4 * lg + rr, 16 * mt + li] for t in range(Hp // 16) for mt in range(MT2) for rr in range(4)]
+    t3 = [CS[16 * ht + li, 16 * kt + 4 * lg + rr] / H for ht in range(Hp // 16) for kt in range(MT2) for rr in range(4)]
+    t4 = [T4[16 * nt + 4 * lg + rr, 16 * wt + li] for wt in range(Wp // 16) for nt in range(2) for rr in range(4)]
+    return np.ascontiguousarray(np.concatenate(t1 + t2 + t3 + t4), dtype=np.float32), NUp
+
+
 class HFSOperator:
     """Device-resident factors of the operator (which equals its own adjoint).  ROCm planes up to 64x64 go through the
-    single-launch LDS kernel ee_hfs_f32; larger planes (ImageNet 224x224) and the CPU plumbing path use the dense form."""
+    single-launch LDS kernel ee_hfs_f32, planes up to 256x256 (ImageNet 224x224, r = 16) through the matrix-core kernel
+    ee_hfs_mfma_f32; anything larger and the CPU plumbing path use the dense form."""
 
     def __init__(self, H, W, r, device):
         Ar, Ai, B1, B2 = hfs_matrices(H, W, r)
@@ -119,6 +151,13 @@ class HFSOperator:
         self.chain = None  # fragment-ordered factors of the fused front-end kernels (ee_chain.hip), where the shape allows
         if self.kernel is not None:
             self.chain = torch.from_numpy(chain_tables(H, W, r)).to(device)
+        self.mfma = None   # ... and of the band kernel for larger planes (ee_hfs_mfma.hip)
+        if torch.device(device).type == "cuda" and H <= 256 and W <= 256:
+            try:
+                flat, nu_pad = band_tables(H, W, r)
+                self.mfma = (torch.from_numpy(flat).to(device), nu_pad)
+            except ValueError:
+                pass
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=torch.float32)
         self.H, self.W = H, W
         self.Bcat = f(np.concatenate([B1, B2], axis=1))      # [W, 2W]   x @ Bcat = [x B1 | x B2]
@@ -137,29 +176,52 @@ class HFSOperator:
         y = torch.baddbmm(y, Ar_.unsqueeze(0).expand(n, H, H), t[:, :, W:])
         return y.view(B, C, H, W)
 
+    @property
+    def _use_lds_kernel(self):
+        """The VALU / LDS kernel for small planes (28 x 28: 3.7 us against 5.8), the matrix-core band kernel from 48 x 48 up
+        (64 x 64, B = 100: 8.4 us against 10.4; B = 1600: 54 against 71; scripts/hfs_bench.py)."""
+        return self.kernel is not None and (self.mfma is None or self.H * self.W < 48 * 48)
+
+    @property
+    def fused_square(self):
+        """True when Add_Square can be fused into the low-pass kernel's load / store (one launch each way)."""
+        return self.kernel is not None or self.mfma is not None
+
     def forward(self, x):
-        if self.kernel is not None and x.is_cuda:
+        if x.is_cuda and self._use_lds_kernel:
             from . import ops
             return ops.hfs(x.contiguous(), *self.kernel)
+        if x.is_cuda and self.mfma is not None:
+            from . import ops
+            return ops.hfs_mfma(x.contiguous(), *self.mfma)
         return self._apply(x, self.Bcat, self.Ar, self.Ai)
 
     def adjoint(self, g):
-        if self.kernel is not None and g.is_cuda:
+        if g.is_cuda and self._use_lds_kernel:
             from . import ops
             return ops.hfs(g.contiguous(), *self.kernel)  # self-adjoint
+        if g.is_cuda and self.mfma is not None:
+            from . import ops
+            return ops.hfs_mfma(g.contiguous(), *self.mfma)
         return self._apply(g, self.BcatT, self.ArT, self.AiT)
 
     def forward_square(self, x, eps, draws):
-        """F(add_square(x)) in one launch (ROCm, small planes)."""
+        """F(add_square(x)) in one launch."""
         from . import ops
-        t, NU, NV = self.kernel
-        return ops.hfs(x.contiguous(), t, NU, NV, 1, None, eps, draws["stripe"], draws["sq_sign"], draws["sq_pos"], draws["sq_size"])
+        if self._use_lds_kernel:
+            t, NU, NV = self.kernel
+            return ops.hfs(x.contiguous(), t, NU, NV, 1, None, eps, draws["stripe"], draws["sq_sign"], draws["sq_pos"], draws["sq_size"])
+        t, nu_pad = self.mfma
+        return ops.hfs_mfma(x.contiguous(), t, nu_pad, 1, None, eps, draws["stripe"], draws["sq_sign"], draws["sq_pos"], draws["sq_size"])
 
     def backward_square(self, g, x, eps, draws):
         """F(g) * d add_square/dx (x): the backward of forward_square, one launch."""
         from . import ops
-        t, NU, NV = self.kernel
-        return ops.hfs(g.contiguous(), t, NU, NV, 2, x, eps, draws["stripe"], draws["sq_sign"], draws["sq_pos"], draws["sq_size"])
+        if self._use_lds_kernel:
+            t, NU, NV = self.kernel
+            return ops.hfs(g.contiguous(), t, NU, NV, 2, x, eps, draws["stripe"], draws["sq_sign"], draws["sq_pos"], draws["sq_size"])
+        t, nu_pad = self.mfma
+        return ops.hfs_mfma(g.contiguous(), t, nu_pad, 2, x, eps, draws["stripe"], draws["sq_sign"], draws["sq_pos"], draws["sq_size"])
 
 
 class _HFSFn(torch.autograd.Function):

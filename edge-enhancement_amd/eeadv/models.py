@@ -177,7 +177,7 @@ class _EEFrontMixin:
             x_lp = self.hfs(x)
         else:
             op = self.hfs.operator(x.device) if x.is_cuda else None
-            if op is not None and op.kernel is not None:  # Add_Square fused into the low-pass kernel's load / store
+            if op is not None and op.fused_square:  # Add_Square fused into the low-pass kernel's load / store
                 x_lp = _hfs.square_hfs_apply(x, op, self.add_square.eps, self.add_square.prepare(x, draws))
             else:
                 x_lp = self.hfs(self.add_square(x, draws))
@@ -226,7 +226,7 @@ class _EEFrontMixin:
         d = None
         if self.add_square is not None:
             d = self.add_square.prepare(x, draws)
-            if op.kernel is not None:
+            if op.fused_square:
                 x_lp = op.forward_square(x, self.add_square.eps, d)
             else:
                 x_lp = op.forward(ops.add_square_fwd(x, float(self.add_square.eps), d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"]))
@@ -243,7 +243,7 @@ class _EEFrontMixin:
                                                float(self.w))
         if d is None:
             g_lp = op.adjoint(g_hfs)
-        elif op.kernel is not None:
+        elif op.fused_square:
             g_lp = op.backward_square(g_hfs, x, self.add_square.eps, d)
         else:
             g_lp = ops.add_square_bwd(op.adjoint(g_hfs), x, float(self.add_square.eps), d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"])

@@ -456,6 +456,27 @@ def hfs(x, tables, NU, NV, sq_mode=0, sq_x=None, eps=0.0, stripe=None, sq_sign=N
     return out
 
 
+def hfs_mfma(x, tables, nu_pad, sq_mode=0, sq_x=None, eps=0.0, stripe=None, sq_sign=None, sq_pos=None, sq_size=None):
+    """The same operator as `hfs` for planes up to 256 x 256, on the matrix cores (ee_hfs_mfma.hip)."""
+    B, C, H, W = x.shape
+    px = _chk(x, torch.float32, "x")
+    pt = _chk(tables, torch.float32, "tables", (N.lib.ee_hfs_mfma_table_floats(H, W, nu_pad),))
+    out = torch.empty_like(x)
+    nq = 0
+    ps = pg = pp = pz = pxo = None
+    if sq_mode:
+        nq = int(sq_size.numel())
+        ps = _chk(stripe, torch.float32, "stripe", (B, C, 1, W))
+        pg = _chk(sq_sign, torch.float32, "sq_sign", (nq, C))
+        pp = _chk(sq_pos, torch.int64, "sq_pos", (nq,))
+        pz = _chk(sq_size, torch.int32, "sq_size", (nq,))
+        if sq_mode == 2:
+            pxo = _chk(sq_x, torch.float32, "sq_x", x.shape)
+    N.check(N.lib.ee_hfs_mfma_f32(px, _chk(out, torch.float32, "out"), B, C, H, W, pt, nu_pad, sq_mode, pxo, eps, ps, pg, pp, pz, nq, _stream()),
+            "ee_hfs_mfma_f32")
+    return out
+
+
 # ---- the fused front end of one PGD iteration (ee_chain.hip) ------------------------------------------------------------------------
 def chain_supported(C, H, W):
     return bool(N.lib.ee_chain_supported(int(C), int(H), int(W)))

@@ -320,6 +320,16 @@ int ee_pool_linear_fwd_f32(const float *feat, const float *weight, const float *
                            int C, int HW, int K, void *stream);
 int ee_pool_linear_bwd_f32(const float *dlogits, const float *weight, float *dfeat, int B, int C, int HW, int K, void *stream);
 
+/* HighFreqSuppress for planes up to 256 x 256 (ImageNet 224 x 224, r = 16: utils/core.py:15-55 with cize 224) on the f32 matrix
+ * cores, one workgroup per plane, one wavefront per 16-row band (csrc/ee_hfs_mfma.hip).  Same operator, same sq_mode fusions and
+ * draw arrays as ee_hfs_f32.  `tables`: ee_hfs_mfma_table_floats(H, W, nu_pad) floats in MFMA fragment order (eeadv/hfs.py:
+ * band_tables; scripts/chain_emulate.py big_tables is the layout's specification); nu_pad = 16 or 32 = the kept row frequencies
+ * rounded up.  8 B of HBM traffic per element (12 with sq_mode 2). */
+int ee_hfs_mfma_table_floats(int H, int W, int nu_pad);
+int ee_hfs_mfma_f32(const float *in, float *out, int B, int C, int H, int W, const float *tables, int nu_pad, int sq_mode,
+                    const float *sq_x, float eps, const float *stripe, const float *sq_sign, const int64_t *sq_pos, const int32_t *sq_size,
+                    int nq, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The whole EE front end of one PGD iteration in two launches (csrc/ee_chain.hip): one workgroup per image.
  *   (Tiny_ImageNet/models_tinyimagenet/resnet_EE_square.py:187-206, MNIST/models_mnist/Net2_EE_square.py:48-63,

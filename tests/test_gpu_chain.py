@@ -189,3 +189,76 @@ def test_engine_uses_the_chain_and_matches_the_manual_path(monkeypatch):
         cur = res[True]
     a = cur.cpu().numpy()
     assert np.array_equal(a[1, :, 24:36, 12:26], x.cpu().numpy()[1, :, 24:36, 12:26])  # NaN gradient inside the flat patch: no update
+
+
+@pytest.mark.parametrize("H,W,r,C,B", [(224, 224, 16, 3, 4), (64, 64, 8, 3, 5), (28, 28, 4, 1, 3), (7, 9, 2, 2, 3), (96, 128, 12, 1, 2), (256, 256, 16, 1, 2),
+                                       (50, 70, 6, 2, 2)])
+def test_band_lowpass_kernel_vs_float64_operator_UNPINNED(ops, H, W, r, C, B):
+    """ee_hfs_mfma_f32 (planes up to 256 x 256 on the matrix cores, one wavefront per 16-row band) against the dense operator in
+    float64 and the FFT restatement of the oracle; linear, self-adjoint, reproducible bit for bit from run to run."""
+    from eeadv import hfs as HF
+    from oracle import ref_path as R
+    torch.manual_seed(H * W + r)
+    x = torch.rand(B, C, H, W, device=DEV)
+    flat, nu_pad = HF.band_tables(H, W, r)
+    tab = torch.from_numpy(flat).to(DEV)
+    y = ops.hfs_mfma(x, tab, nu_pad)
+    Ar, Ai, B1, B2 = HF.hfs_matrices(H, W, r)
+    xd = x.cpu().double().numpy()
+    want = np.einsum("hk,bckw->bchw", Ar, xd @ B1) + np.einsum("hk,bckw->bchw", Ai, xd @ B2)
+    assert np.abs(y.cpu().numpy() - want).max() < 2e-6
+    np.testing.assert_allclose(y.cpu().numpy(), R.HighFreqSuppress(H, W, r)(x.cpu()).numpy(), atol=3e-6)
+    assert torch.equal(y, ops.hfs_mfma(x, tab, nu_pad))  # band-ordered reduction: reproducible
+    u = torch.randn_like(x)
+    lhs, rhs = float((ops.hfs_mfma(x, tab, nu_pad) * u).sum()), float((x * ops.hfs_mfma(u, tab, nu_pad)).sum())
+    assert abs(lhs - rhs) < 1e-3 * (abs(lhs) + 1)  # self-adjoint
+
+
+@pytest.mark.parametrize("n,r,C", [(224, 16, 3), (64, 8, 3), (96, 12, 1)])
+def test_band_lowpass_fused_add_square(ops, n, r, C):
+    """sq_mode 1 / 2 of ee_hfs_mfma_f32 against Add_Square (its own kernels, pinned to the reference) around the plain operator."""
+    import utils.core as core
+    from eeadv import hfs as HF
+    torch.manual_seed(n)
+    B, eps = 3, 16 / 255
+    x = torch.rand(B, C, n, n, device=DEV)
+    x[0, 0, 0, :4] = torch.tensor([0.0, 1.0, eps, 1 - eps], device=DEV)
+    sq = core.Add_Square(C, n, eps, n_queries=1)
+    d = sq.prepare(x)
+    flat, nu_pad = HF.band_tables(n, n, r)
+    tab = torch.from_numpy(flat).to(DEV)
+    xs = ops.add_square_fwd(x, eps, d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"])
+    fused = ops.hfs_mfma(x, tab, nu_pad, 1, None, eps, d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"])
+    assert torch.equal(fused, ops.hfs_mfma(xs, tab, nu_pad))  # same kernel, same staged values
+    g = torch.randn_like(x)
+    mask = ops.add_square_bwd(torch.ones_like(x), x, eps, d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"])
+    back = ops.hfs_mfma(g, tab, nu_pad, 2, x, eps, d["stripe"], d["sq_sign"], d["sq_pos"], d["sq_size"])
+    assert torch.equal(back, ops.hfs_mfma(g, tab, nu_pad) * mask)
+
+
+def test_imagenet_ee_square_front_end_runs_on_the_band_kernel():
+    """ImageNet/configs_imagenet/ee_at_bpda3_square.yml (cize 224, r 16): HighFreqSuppress no longer falls back to three rocBLAS
+    launches - forward and input gradient of the front end against the oracle's FFT restatement."""
+    from eeadv import models
+    from oracle import ref_path as R
+    torch.manual_seed(5)
+    m = models.make_resnet_ee(18, "imagenet", True, cize=224, r=16, w=1.0, with_gf=False, low=38.0, high=76.0, alpha=0.0, sigma=1.0,
+                              type_canny="CannyFilter_step125_1", epsilon=16 / 255, n_queries=1).to(DEV).eval()
+    op = m.hfs.operator(torch.device(DEV))
+    assert op.kernel is None and op.mfma is not None and op.fused_square
+    x = torch.rand(2, 3, 224, 224)
+    front = R.EEFront(224, 3, 16, 1.0, 38.0, 76.0, 0.0, 1.0, "CannyFilter_step125_1", False, True, 16 / 255, 1)
+    draws = front.add_square.draw(2)
+    ddev = {"stripe": draws["stripe"].to(DEV), "sq_pos": draws["sq_pos"].to(DEV), "sq_sign": draws["sq_sign"].reshape(1, 3).to(DEV)}
+    xr = x.clone().requires_grad_(True)
+    want = front(xr, draws)
+    xd = x.to(DEV).requires_grad_(True)
+    got = m.front(xd, ddev)
+    assert float(((got.detach().cpu() - want.detach()).abs() > 1e-5).float().mean()) == 0.0
+    u = torch.randn_like(x)
+    (want * u).sum().backward()
+    (got * u.to(DEV)).sum().backward()
+    g, gr = xd.grad.cpu().numpy(), xr.grad.numpy()
+    assert np.array_equal(np.isnan(g), np.isnan(gr))
+    fin = ~np.isnan(gr)
+    assert np.abs(g[fin] - gr[fin]).max() < 2e-5 * np.abs(gr[fin]).max() + 1e-6
