@@ -15,6 +15,14 @@ from eeadv import hfs as HF, ops  # noqa: E402
 def timeit(fn, iters=50, reps=4):
     fn()
     torch.cuda.synchronize()
+    if os.environ.get("CHAIN_BENCH_EAGER"):  # plain launches (for rocprofv3 --pmc passes): time is host-bound, counters are not
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return 1e3 * a.elapsed_time(b) / iters
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(iters):

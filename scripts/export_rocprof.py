@@ -5,17 +5,29 @@ import csv
 import json
 import sys
 
+
+def _match(pat, name):
+    """every '*'-separated piece of `pat` occurs in `name`, in order"""
+    pos = 0
+    for piece in pat.split("*"):
+        pos = name.find(piece, pos)
+        if pos < 0:
+            return False
+        pos += len(piece)
+    return True
+
+
 FAMILIES = {  # bench.py family -> substring of the kernel symbol (every template instance of the bench shape)
     "ee_chain_fwd": "chain_fwd_kernel", "ee_chain_bwd": "chain_bwd_kernel", "ee_frontend_fwd": "edge_fwd_kernel",
-    "ee_frontend_bwd": "edge_bwd_saved_kernel", "ee_hfs": "hfs_kernel<0", "ee_hfs_square_fwd": "hfs_kernel<1", "ee_hfs_square_bwd": "hfs_kernel<2",
-    "ee_pgd_step": "PgdStepOp", "ee_pgd_step_bcast": "pgd_step_bcast_kernel", "ee_square_draw": "square_draw_kernel", "ee_ce": "ce_kernel",
+    "ee_frontend_bwd": "edge_bwd_saved_kernel", "ee_hfs": "hfs_*kernel<0", "ee_hfs_square_fwd": "hfs_*kernel<1", "ee_hfs_square_bwd": "hfs_*kernel<2",
+    "ee_pgd_step": "map3_kernel*PgdStepOp", "ee_pgd_step_bcast": "pgd_step_bcast_kernel", "ee_square_draw": "square_draw_kernel", "ee_ce": "ce_kernel",
 }
 rows = list(csv.DictReader(open(sys.argv[1])))
 out = {"_provenance": sys.argv[3] if len(sys.argv) > 3 else ""}
 for fam, pat in FAMILIES.items():
     tot = calls = 0
     for r in rows:
-        if pat in r["Name"]:
+        if _match(pat, r["Name"]):
             tot += float(r["TotalDurationNs"])
             calls += int(r["Calls"])
     if calls:
