@@ -11,6 +11,8 @@
 // The weight gradient (once per training step) stays on MIOpen.
 //
 // CNN-body glue, not a row of SURVEY.md section 8: parity is "logits within 1e-4" through the model tests.
+#include <stdlib.h>
+
 #include "ee_common.hpp"
 
 namespace {
@@ -325,6 +327,7 @@ constexpr int C3_CK = 16, C3_WS = 66;  // 66: the four weight-staging sub-roles 
 
 struct Conv3Dims {
     int B, KC, RC, H, W;  // reduction channels, result channels
+    int dbg;              // EEADV_CONV3_DBG (measurement only, grouped kernel): 1 no weight loads, 2 no frame loads, 4 no MFMAs, 8 no LDS staging
 };
 
 template <bool BWD, int TW>
@@ -439,6 +442,186 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Software-pipelined version (round 2).  Counters on the kernel above (rocprofv3 --pmc, 128ch 8x8): matrix pipe 28 % busy, LDS
+// 14 %, 5 % of wave cycles waiting on LDS - nothing is saturated; each round is a serial chain [barrier, stage, barrier, 72
+// operand reads, wait, 36 multiplies, 72 reads, wait, 36 multiplies] and phase-skipping (EEADV_CONV3_DBG) shows the multiply
+// time (15 us) ADDED to everything else (16 us) instead of hiding it; a second wavefront per SIMD does not change that (it
+// runs the same phases at the same time).  Here one wavefront overlaps its own phases:
+//   * operands come out of LDS through a ring of 4 register pairs, requested 3 multiplies ahead of their use: the ds_reads sit
+//     between the (dependent, 64-cycle) MFMAs in program order and issue while the previous MFMA executes;
+//   * LDS is double-buffered: the next round's weights / frame (prefetched from global memory one round earlier) are written
+//     into the other buffer one element per multiply, so a round needs ONE barrier, at its end;
+//   * the global prefetch for the round after next is issued as soon as the staging registers are free.
+// Same tiles, same operand order (bit-identical sums) as the kernel above.  RT = 2, KG = 1: 64 result channels x 64 pixels,
+// 4 wavefronts; RT = 1, KG = 2: 32 x 64 with the reduction split over two 2-wavefront groups (twice the workgroups on the
+// 4x4 layers), partial tiles added in group order through LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+// A barrier among the wavefronts of ONE reduction group (gfx950 has no named barriers): an LDS counter that only grows; every
+// wavefront adds 1 and sleeps until the count reaches `target` (generation x wavefronts per group).  All wavefronts of a
+// workgroup are resident together, so the wait cannot deadlock.
+__device__ __forceinline__ void group_barrier(unsigned *ctr, unsigned target) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <bool BWD, int TW, int RT, int KG>
+__global__ __launch_bounds__(256) void conv3x3s1_pipe_kernel(const float *__restrict__ in, const float *__restrict__ w, float *__restrict__ out,
+                                                             Conv3Dims d) {
+    constexpr int PR = 64 / TW, FRW = TW + 2, FRH = PR + 2;
+    constexpr int RCW = 32 * RT, WSS = RCW + 2, GT = 128 * RT;
+    constexpr int WTOT = C3_CK * 9 * RCW, FTOT = C3_CK * FRH * FRW;
+    constexpr int WPT = WTOT / GT, FPT = (FTOT + GT - 1) / GT;
+    constexpr int BUF = (C3_CK * 9 * WSS + FTOT + 3) & ~3;  // floats of one (weights, frame) buffer
+    constexpr int NQ = C3_CK / 2 * 9;                        // multiplies per round and wavefront (72)
+    constexpr int LOOK = 3, RING = 4;  // 3 x (2 reads + 1 write) = 9 LDS operations in flight: lgkmcnt counts to 15
+    static_assert(WPT == 36 && 2 * RT * KG == 4 && WPT + FPT <= NQ - 8, "4 wavefronts; staging fits inside the multiply stream");
+    extern __shared__ __align__(16) float lds[];
+    __shared__ unsigned gctr[KG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kg = wave / (2 * RT), tw = wave - kg * (2 * RT), rt = tw >> 1, pt = tw & 1;
+    const int gtid = static_cast<int>(threadIdx.x) - kg * GT;
+    float *gbuf = lds + kg * (2 * BUF);
+    if (KG > 1) {
+        if (threadIdx.x < KG) gctr[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    unsigned gen = 0;
+    auto gsync = [&]() {
+        if (KG == 1) __syncthreads();
+        else group_barrier(&gctr[kg], ++gen * (2 * RT));
+    };
+    const int i = lane & 31, kk = lane >> 5;
+    const int rc_base = static_cast<int>(blockIdx.y) * RCW;
+    const int g0 = static_cast<int>(blockIdx.x) * PR;
+    const int rows_total = d.B * d.H;
+    const int pj = pt * 32 + i;
+    const int rj = pj / TW, wj = pj - rj * TW;
+    const int gj = g0 + rj;
+    const bool pv = gj < rows_total;
+    const int nj = pv ? gj / d.H : 0, hj = pv ? gj - nj * d.H : 0;
+    const bool top = hj == 0, bot = hj == d.H - 1;
+    const int boff = C3_CK * 9 * WSS + kk * (FRH * FRW) + rj * FRW + wj;  // this lane's frame operand, relative to a buffer
+    const int aoff = kk * (9 * WSS) + rt * 32 + i;
+    const size_t plane = static_cast<size_t>(d.H) * TW;
+    const int wq = BWD ? gtid / (8 * RT) : (gtid >> 2), wp = BWD ? gtid % (8 * RT) : (gtid & 3);
+    const unsigned wsrc0 = static_cast<unsigned>(BWD ? (wq * d.RC + rc_base + 4 * wp) * 9 : ((rc_base + wq) * d.KC + 4 * wp) * 9);
+    unsigned fsrc[FPT];
+    bool fok[FPT];
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+        const int idx = gtid + j * GT;
+        const int fc = idx % FRW, tq = idx / FRW;
+        const int frow = tq % FRH, kc = idx < FTOT ? tq / FRH : 0;
+        const int g = g0 - 1 + frow, c = fc - 1;
+        fok[j] = idx < FTOT && g >= 0 && g < rows_total && c >= 0 && c < TW;
+        const int gc = fok[j] ? g : 0, cc = fok[j] ? c : 0;
+        const int n = gc / d.H, h = gc - n * d.H;
+        fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(plane) + h * TW + cc);
+    }
+    const unsigned wstep = static_cast<unsigned>(BWD ? C3_CK * d.RC * 9 : C3_CK * 9), fstep = static_cast<unsigned>(C3_CK * plane);
+    float wv[WPT], fv[FPT];
+    auto prefetch = [&](unsigned round) {
+        const unsigned wo = round * wstep, fo = round * fstep;
+#pragma unroll
+        for (int j = 0; j < WPT / 4; ++j) {
+            const float4 t = *reinterpret_cast<const float4 *>(w + wsrc0 + wo + 4 * j);
+            wv[4 * j] = t.x; wv[4 * j + 1] = t.y; wv[4 * j + 2] = t.z; wv[4 * j + 3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < FPT; ++j) fv[j] = in[fsrc[j] + fo];
+    };
+    // staging element e of this thread (e < WPT: weight, else frame) into buffer `b`
+    auto stage = [&](float *b, int e) {
+        if (e < WPT) {
+            if (!BWD) b[((wp * 4 + e / 9) * 9 + e % 9) * WSS + wq] = wv[e];
+            else b[(wq * 9 + 8 - e % 9) * WSS + 4 * wp + e / 9] = wv[e];
+        } else {
+            const int j = e - WPT;
+            if (gtid + j * GT < FTOT) b[C3_CK * 9 * WSS + gtid + j * GT] = fok[j] ? fv[j] : 0.0f;
+        }
+    };
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned iters = static_cast<unsigned>(d.KC / C3_CK / KG);
+    prefetch(kg);
+#pragma unroll
+    for (int e = 0; e < WPT + FPT; ++e) stage(gbuf, e);
+    if (iters > 1) prefetch(kg + KG);
+    gsync();
+    for (unsigned it = 0; it < iters; ++it) {
+        const float *cur = gbuf + (it & 1) * BUF;
+        float *nxt = gbuf + ((it + 1) & 1) * BUF;
+        const bool more = it + 1 < iters, more2 = it + 2 < iters;
+        float ra[RING], rb[RING];
+        auto fetch = [&](int q) {  // operands of multiply q: channels 2 (q / 9) + kk, tap q % 9
+            const int c2 = q / 9, tap = q % 9, kh = tap / 3, kw = tap % 3;
+            ra[q % RING] = cur[aoff + c2 * (2 * 9 * WSS) + tap * WSS];
+            float b = cur[boff + c2 * (2 * FRH * FRW) + kh * FRW + kw];
+            if (kh == 0 && top) b = 0.0f;  // the frame row above belongs to the previous image
+            if (kh == 2 && bot) b = 0.0f;
+            rb[q % RING] = b;
+        };
+#pragma unroll
+        for (int q = 0; q < LOOK; ++q) fetch(q);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + LOOK < NQ) fetch(q + LOOK);
+            if (more && q < WPT + FPT) stage(nxt, q);
+            if (more2 && q == WPT + FPT) prefetch(kg + (it + 2) * KG);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[q % RING], rb[q % RING], acc, 0, 0, 0);
+        }
+        gsync();  // everybody has read `cur` and written `nxt`
+    }
+    if (KG > 1) {  // partial tiles meet in LDS, group 0 adds them in group order
+        __syncthreads();
+        float *red = lds;  // [KG - 1][2 RT][16][64]
+        if (kg > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((kg - 1) * (2 * RT) + tw) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (kg != 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[(((g - 1) * (2 * RT) + tw) * 16 + r) * 64 + lane];
+    }
+    if (!pv) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rc = rc_base + rt * 32 + acc_row(r, lane);
+        out[(static_cast<size_t>(nj) * d.RC + rc) * plane + static_cast<size_t>(hj) * TW + wj] = acc[r];
+    }
+}
+
+template <bool BWD, int TW, int RT, int KG>
+void conv3_pipe_launch(const float *in, const float *w, float *out, const Conv3Dims &dims, int64_t gx, hipStream_t st) {
+    constexpr int PR = 64 / TW, FRW = TW + 2, FRH = PR + 2, WSS = 32 * RT + 2;
+    constexpr int BUF = (C3_CK * 9 * WSS + C3_CK * FRH * FRW + 3) & ~3;
+    constexpr size_t bytes = sizeof(float) * static_cast<size_t>(KG) * 2 * BUF;
+    static bool opted = false;
+    if (!opted && bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3s1_pipe_kernel<BWD, TW, RT, KG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(bytes)) != hipSuccess)
+            (void)hipGetLastError();
+        opted = true;
+    }
+    const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(dims.RC / (32 * RT))), block(256);
+    EE_LAUNCH((conv3x3s1_pipe_kernel<BWD, TW, RT, KG>), grid, block, bytes, st, in, w, out, dims);
+}
+
+// EEADV_CONV3_KG: 0 forces the 4-wavefront kernel, 10 / 11 the pipelined kernel (64 x 64 tiles / 32 x 64 tiles with a 2-way
+// reduction split) wherever its tiling exists - A/B measurements; unset: the measured choice below
+int conv3_variant() {
+    static const int v = [] {
+        const char *e = getenv("EEADV_CONV3_KG");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
+}
+
 template <bool BWD>
 int conv3_launch(const float *in, const float *w, float *out, int B, int KC, int RC, int H, int W, hipStream_t st) {
     if (B < 0 || KC < 1 || RC < 1 || H < 1 || W < 1) return EE_ERR_SHAPE;
@@ -451,7 +634,39 @@ int conv3_launch(const float *in, const float *w, float *out, int B, int KC, int
     if (gx > 0x7fffffffLL) return EE_ERR_SHAPE;
     if (static_cast<int64_t>(B) * KC * H * W > 0x7fffffffLL || static_cast<int64_t>(KC) * RC * 9 > 0x7fffffffLL) return EE_ERR_SHAPE;  // 32-bit offsets
     const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(RC / 64)), block(256);
-    const Conv3Dims dims{B, KC, RC, H, W};
+    static const int dbg = [] {
+        const char *e = getenv("EEADV_CONV3_DBG");
+        return e ? atoi(e) : 0;
+    }();
+    const Conv3Dims dims{B, KC, RC, H, W, dbg};
+    const int rounds = KC / C3_CK, var = conv3_variant();
+    const int64_t wgs64 = gx * (RC / 64);
+    // Measured, un-profiled, B = 100 (fwd us: 4-wavefront kernel / pipelined 64x64 / pipelined 32x64 split / MIOpen Winograd):
+    //   64ch 16x16  28.5 / 35 / -  / 32.3      128ch 8x8  31.9 / 31.6 / - / 29.4      256ch 4x4  57.8 / 59 / 34 / 37.5
+    // so the pipelined kernel is the default only where the 64-channel tiling leaves most of the chip idle (<= 128 workgroups).
+    int pipe = 0;
+    if (var == 10 && W >= 4) pipe = 10;
+    else if (var == 11 && W >= 4 && W <= 16) pipe = 11;
+    else if (var == -1 && W == 4 && wgs64 <= 128) pipe = 11;
+    if (pipe == 11 && rounds % 2 != 0) pipe = 0;
+    if (pipe == 10) {
+        switch (W) {
+            case 64: conv3_pipe_launch<BWD, 64, 2, 1>(in, w, out, dims, gx, st); break;
+            case 32: conv3_pipe_launch<BWD, 32, 2, 1>(in, w, out, dims, gx, st); break;
+            case 16: conv3_pipe_launch<BWD, 16, 2, 1>(in, w, out, dims, gx, st); break;
+            case 8: conv3_pipe_launch<BWD, 8, 2, 1>(in, w, out, dims, gx, st); break;
+            default: conv3_pipe_launch<BWD, 4, 2, 1>(in, w, out, dims, gx, st); break;
+        }
+        return launch_status();
+    }
+    if (pipe == 11) {
+        switch (W) {
+            case 16: conv3_pipe_launch<BWD, 16, 1, 2>(in, w, out, dims, gx, st); break;
+            case 8: conv3_pipe_launch<BWD, 8, 1, 2>(in, w, out, dims, gx, st); break;
+            default: conv3_pipe_launch<BWD, 4, 1, 2>(in, w, out, dims, gx, st); break;
+        }
+        return launch_status();
+    }
     switch (W) {
         case 64: EE_LAUNCH((conv3x3s1_kernel<BWD, 64>), grid, block, 0, st, in, w, out, dims); break;
         case 32: EE_LAUNCH((conv3x3s1_kernel<BWD, 32>), grid, block, 0, st, in, w, out, dims); break;
@@ -599,7 +814,7 @@ EE_API int ee_conv3x3s2_fwd_f32(const float *x, const float *weight, float *y, i
     const int PR = 64 / OW;
     const int64_t orows = static_cast<int64_t>(B) * (H / 2);
     const dim3 grid(static_cast<unsigned>((orows + PR - 1) / PR), static_cast<unsigned>(Cout / 64)), block(256);
-    const Conv3Dims dims{B, Cin, Cout, H, W};
+    const Conv3Dims dims{B, Cin, Cout, H, W, 0};
     hipStream_t st = as_stream(stream);
     switch (OW) {
         case 64: EE_LAUNCH((conv3x3s2_fwd_kernel<64>), grid, block, 0, st, x, weight, y, dims); break;
@@ -751,7 +966,7 @@ EE_API int ee_conv3x3s2_bwd_data_f32(const float *dy, const float *weight, float
     const int PR = 64 / OW;
     const int64_t rows = static_cast<int64_t>(B) * (H / 2);
     const dim3 grid(static_cast<unsigned>((rows + PR - 1) / PR), static_cast<unsigned>(Cin / 16)), block(256);
-    const Conv3Dims dims{B, Cout, Cin, H, W};
+    const Conv3Dims dims{B, Cout, Cin, H, W, 0};
     hipStream_t st = as_stream(stream);
     switch (OW) {
         case 64: EE_LAUNCH((conv3x3s2_bwd_kernel<64>), grid, block, 0, st, dy, weight, dx, dims); break;

@@ -63,6 +63,7 @@ _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") 
 # 16x16 layer; equal on 8x8, where the stock solver stays)
 _CHAIN = os.environ.get("EEADV_CHAIN", "1") == "1"  # the front end of a PGD iteration as two launches (ee_chain.hip) instead of six
 _CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "16"))
+_CONV3_W4 = os.environ.get("EEADV_CONV3_W4", "1") == "1"  # ... and the 4x4 maps of layer3 (split-reduction kernel: 34 us against 37.5)
 _CONV3_EAGER = os.environ.get("EEADV_CONV3_EAGER", "0") == "1"  # use the MFMA 3x3 convolutions outside graph capture as well
 _CONV3S2_BWD_MINOW = int(os.environ.get("EEADV_CONV3S2_BWD_MINOW", "1000"))  # its backward-data kernel: equal to MIOpen end to end, opt-in
 _CONV3S2_MINOW = int(os.environ.get("EEADV_CONV3S2_MINOW", "8"))  # narrowest OUTPUT map the stride-2 MFMA convolution takes (24 us vs 50 at 8; no gain at 4)
@@ -129,7 +130,7 @@ def conv3(conv, x):
             return Conv3x3S2Fn.apply(x, conv.weight, mfma_fwd, mfma_bwd)
     if ("conv3" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
-            and conv.padding_mode == "zeros" and _CONV3_MINW <= x.shape[3] <= 64 and 64 % x.shape[3] == 0
+            and conv.padding_mode == "zeros" and (_CONV3_MINW <= x.shape[3] <= 64 or (x.shape[3] == 4 and _CONV3_W4)) and 64 % x.shape[3] == 0
             and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.weight.is_contiguous()):
         return Conv3x3Fn.apply(x, conv.weight)  # 16x16 / 8x8 maps: implicit GEMM on the f32 matrix cores (ee_conv.hip)
     return conv(x)

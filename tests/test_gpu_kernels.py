@@ -606,7 +606,8 @@ def test_conv3x3_on_2x2_map_as_dense_product(ops, B, Cin, Cout):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(100, 64, 64, 16, 16), (100, 128, 128, 8, 8), (100, 256, 256, 4, 4), (3, 64, 128, 5, 8),
-                                            (2, 128, 64, 3, 2), (1, 64, 64, 1, 1), (2, 64, 64, 56, 32), (5, 64, 192, 7, 64)])
+                                            (2, 128, 64, 3, 2), (1, 64, 64, 1, 1), (2, 64, 64, 56, 32), (5, 64, 192, 7, 64), (3, 64, 64, 5, 4),
+                                            (7, 192, 64, 4, 4)])
 def test_conv3x3s1_mfma_matches_aten(ops, B, Cin, Cout, H, W):
     """The residual blocks' 3x3 convolution (resnet.py:26-31) as an implicit GEMM on the f32 matrix cores vs ATen: forward,
     input gradient, and (through ATen) weight gradient; tiles that span image boundaries included (W = 4, 2, 1)."""
