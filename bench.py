@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (same guide: v_mfma_f32_32x32x2_f32 at the f32 vector rate)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 WORKLOADS = {
@@ -377,32 +378,59 @@ def main():
                 us = max(raw - overhead_us, 0.5)  # event pair cost removed
                 kernels[name] = {"launches_timed": cnt, "avg_us": round(us, 3), "avg_bracket_us": round(raw, 3), "bytes": nbytes,
                                  "GBps": round(nbytes / us / 1e3, 1), "share_of_timed_us": None}
+        # matrix-core families (the residual blocks' 3x3 convolutions, ee_conv.hip): the library sums the floating-point
+        # operations its timed launches declared (2 * 9 * Cin * Cout * B * H * W each), so mixed shapes average correctly
+        mfma_fams = {"ee_conv3x3s1_fwd": N.K_CONV3_FWD, "ee_conv3x3s1_bwd_data": N.K_CONV3_BWD,
+                     "ee_conv3x3s1_pipe_fwd": N.K_CONV3P_FWD, "ee_conv3x3s1_pipe_bwd_data": N.K_CONV3P_BWD}
+        for name, kid in mfma_fams.items():
+            ms, cnt = ops.prof_read(kid)
+            if cnt:
+                raw = 1e3 * ms / cnt
+                us = max(raw - overhead_us, 0.5)
+                flops = ops.prof_read_work(kid) / cnt
+                kernels[name] = {"launches_timed": cnt, "avg_us": round(us, 3), "avg_bracket_us": round(raw, 3), "flops": flops,
+                                 "TFLOPs": round(flops / us / 1e6, 2), "share_of_timed_us": None}
         # the dominant hand-written kernel of the path = the family with the largest launches x duration among the timed probes
-        # (every family is launched once per PGD iteration, so the probe counts are proportional to the real ones)
+        # (a probe iteration launches every family as often as a graph replay does, so the probe counts are proportional to
+        # the real ones)
         tot = sum(k["launches_timed"] * k["avg_us"] for k in kernels.values()) or 1.0
         for k in kernels.values():
             k["share_of_timed_us"] = round(k["launches_timed"] * k["avg_us"] / tot, 4)
-        dom = max(kernels, key=lambda k: kernels[k]["launches_timed"] * kernels[k]["avg_us"]) if kernels else None
-        roofline = None
-        traffic = None
-        try:  # HBM bytes per launch from the TCC counters, measured with rocprofv3 --pmc at this exact shape (profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = pmc.get("%dx%dx%dx%d" % (B, C, H, W), {}).get(dom)
-        except (OSError, ValueError):
-            pass
-        if dom:
-            ach = kernels[dom]["GBps"]
-            rp = None
-            try:  # the rocprofv3 --kernel-trace --stats average of the same command, committed under profiles/ (per round)
-                rp = json.load(open(os.path.join(ROOT, "profiles", "rocprof_kernel_us.json"))).get(dom)
+        weight = lambda k: kernels[k]["launches_timed"] * kernels[k]["avg_us"]
+        dom = max(kernels, key=weight) if kernels else None
+        hbm_fams = [k for k in kernels if "bytes" in kernels[k]]
+        dom_hbm = max(hbm_fams, key=weight) if hbm_fams else None
+
+        def committed(fname, key, sub=None):
+            try:
+                d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                return (d.get(sub, {}) if sub else d).get(key)
             except (OSError, ValueError):
-                pass
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": kernels[dom]["avg_us"],
-                        "avg_bracket_us": kernels[dom]["avg_bracket_us"], "event_pair_overhead_us": round(overhead_us, 3),
-                        "empty_bracket_us": round(empty_us, 3), "rocprofv3_avg_us": rp,
-                        "frac_from_rocprofv3": round(kernels[dom]["bytes"] / rp / 1e3 / HBM_PEAK_GBS, 4) if rp else None}
+                return None
+
+        def roofline_of(name):
+            """HBM-bound families: algorithmic bytes / launch time against 8 TB/s; matrix-core families: declared flops /
+            launch time against the dense f32 MFMA peak.  `traffic` = HBM bytes per launch from the TCC counters and
+            `rocprofv3_avg_us` = the rocprofv3 --kernel-trace --stats average, both measured with the same command at this
+            exact shape and committed under profiles/ (per round)."""
+            if name is None:
+                return None
+            k = kernels[name]
+            rp = committed("rocprof_kernel_us.json", name)
+            traffic = committed("pmc_traffic.json", name, "%dx%dx%dx%d" % (B, C, H, W))
+            common = {"traffic": traffic, "avg_launch_us": k["avg_us"], "avg_bracket_us": k["avg_bracket_us"],
+                      "event_pair_overhead_us": round(overhead_us, 3), "empty_bracket_us": round(empty_us, 3), "rocprofv3_avg_us": rp}
+            if "bytes" in k:
+                return dict({"kernel": name, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(k["GBps"] / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": k["bytes"],
+                             "frac_from_rocprofv3": round(k["bytes"] / rp / 1e3 / HBM_PEAK_GBS, 4) if rp else None}, **common)
+            return dict({"kernel": name, "bound": "mfma", "achieved": k["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(k["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": k["flops"],
+                         "frac_from_rocprofv3": round(k["flops"] / rp / 1e6 / F32_MFMA_PEAK_TFLOPS, 4) if rp else None}, **common)
+
+        roofline = roofline_of(dom)
+        # the largest HBM-bound family as well (the fused front end), when a matrix-core family dominates
+        roofline_hbm = roofline_of(dom_hbm) if dom_hbm != dom else None
         out = {
             "metric": "adversarial images/sec (PGD-%d, %s)" % (cfg["steps"], cfg["arch"]),
             "value": round(world * B * a.steps / dt, 2), "unit": "adversarial images/s", "n_gpus": world, "steps": a.steps,
@@ -416,7 +444,7 @@ def main():
                 "flat %.1f MB in %d pieces, between the captured backward and the captured SGD step" % (sync.flat.numel() * 4 / 1e6, len(sync.pieces)),
                 "rank0_phase_ms": phases, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": probe_iters, "probe_every": a.probe_every,
                 "device": (N.lib.ee_device_name() or b"?").decode()},
-            "roofline": roofline, "kernels": kernels, "final_loss": round(loss_val, 5),
+            "roofline": roofline, "roofline_front_end": roofline_hbm, "kernels": kernels, "final_loss": round(loss_val, 5),
             "note": "throughput is bounded by the CNN convolutions (MIOpen fp32), not by the hand-written kernels; "
                     "reference log (unrecorded GPU): ~143 img/s for this config (BASELINE.md)",
         }

@@ -31,11 +31,11 @@ from utils.helper import AverageMeter, accuracy, adjust_learning_rate_free, save
 ARCHS = ('resnet18', 'resnet50', 'resnet101', 'resnet152')  # :137-146
 
 
-def make_parser():
+def make_parser(archs=ARCHS, default_arch='resnet152'):
     """AT_free_imagenet_ddp.py:36-108, flag for flag."""
     p = argparse.ArgumentParser(description='PyTorch ImageNet Training')
     p.add_argument('--data', metavar='DIR', default='synthetic', help='path to dataset, or synthetic[:train_batches[:val_batches]]')
-    p.add_argument('-a', '--arch', metavar='ARCH', default='resnet152', choices=ARCHS)
+    p.add_argument('-a', '--arch', metavar='ARCH', default=default_arch, choices=archs)
     p.add_argument('--epochs', default=90, type=int, metavar='N')
     p.add_argument('--start-epoch', default=0, type=int, metavar='N')
     p.add_argument('-b', '--batch-size', '--batch_size', default=256, type=int, metavar='N')
@@ -133,18 +133,27 @@ def train(train_loader, net, criterion, optimizer, epoch, args, device, log_dir,
                                                                   loss=losses, top1=top1, top5=top5), log_dir)
 
 
-def validate(val_loader, net, criterion, args, device, log_dir):
+def validate(val_loader, net, criterion, args, device, log_dir, num_steps=None, step_size=None):
     """:329-403: PGD(num_steps_1, step_size_1) in eval mode, clean + adversarial forward, metrics averaged over ranks;
     returns the LOCAL adversarial (top-1, top-5) like the reference (:403)."""
     spec = {"shape": (3, args.crop_size, args.crop_size), "num_classes": args.num_classes}
     vargs = argparse.Namespace(**vars(args))
     vargs.method_name, vargs.attack_method, vargs.print_freq = "AT", "PGD", args.print_freq
     vargs.get = lambda k, d=None: getattr(vargs, k, d)
-    return driver.validate(val_loader, net, criterion, vargs, device, args.num_steps_1, args.step_size_1, log_dir, spec, local_result=True)
+    return driver.validate(val_loader, net, criterion, vargs, device, args.num_steps_1 if num_steps is None else num_steps,
+                           args.step_size_1 if step_size is None else step_size, log_dir, spec, local_result=True)
 
 
-def main(argv=None):
-    args = make_parser().parse_args(argv)
+def build_model(args):
+    """:137-146"""
+    return getattr(zoo, args.arch)(num_classes=args.num_classes)
+
+
+def main(argv=None, parser=None, build=build_model, dirs_of=output_dirs, eval_attack=lambda args: (args.num_steps_1, args.step_size_1),
+         log_args=False):
+    """`parser`, `build`, `dirs_of`, `eval_attack`, `log_args`: what AT_hfs_canny_free_imagenet_ddp.py (the same loop over the
+    edge-enhanced models) changes."""
+    args = (parser or make_parser()).parse_args(argv)
     torch.cuda.set_device(ddp.local_rank())
     device = torch.device("cuda", ddp.local_rank())
     ddp.setup(device)
@@ -153,7 +162,7 @@ def main(argv=None):
     args.fgsm_step /= args.max_color_value
     args.clip_eps /= args.max_color_value
     print("=> creating model '{}'".format(args.arch))
-    model = getattr(zoo, args.arch)(num_classes=args.num_classes).to(device)
+    model = build(args).to(device)
     # SyncBatchNorm issues collectives in every forward: a captured attack graph would have to contain them, which has never run
     # on a multi-GPU node - the PGD evaluation of a multi-rank SyncBatchNorm job therefore runs eagerly unless the user insists
     if ddp.world() > 1:
@@ -169,7 +178,10 @@ def main(argv=None):
         print('arch:{},bs:{},lr:{},wd:{},momentum:{},epochs:{}'.format(args.arch, args.batch_size, args.lr, args.weight_decay, args.momentum, args.epochs))
         print('clip-eps:{},fgsm-step:{},n-repeats:{},world:{}'.format(int(round(args.clip_eps * 255)), int(round(args.fgsm_step * 255)),
                                                                      args.n_repeats, ddp.world()))
-    dirs = output_dirs(args)
+    dirs = dirs_of(args)
+    if log_args and ddp.rank() == 0:
+        with open(dirs["log"] + 'log.txt', 'a') as f:
+            print(args, file=f)
     best_prec1 = 0.0
     if args.resume:  # :194-206
         if os.path.isfile(args.resume):
@@ -185,7 +197,7 @@ def main(argv=None):
     spec = {"shape": (3, args.crop_size, args.crop_size), "num_classes": args.num_classes}
     train_loader, val_loader = driver.make_loaders(args, spec, device, B)
     if args.evaluate:
-        validate(val_loader, net, criterion, args, device, dirs["log"])
+        validate(val_loader, net, criterion, args, device, dirs["log"], *eval_attack(args))
         ddp.teardown()
         return best_prec1
     noise = torch.zeros([args.batch_size, 3, args.crop_size, args.crop_size], device=device)  # :261, global batch size on every rank
@@ -195,7 +207,7 @@ def main(argv=None):
         train(train_loader, net, criterion, optimizer, epoch, args, device, dirs["log"], noise, sync)
         if sync is not None:
             sync.broadcast_buffers()
-        prec1, _ = validate(val_loader, net, criterion, args, device, dirs["log"])
+        prec1, _ = validate(val_loader, net, criterion, args, device, dirs["log"], *eval_attack(args))
         is_best = prec1 > best_prec1
         best_prec1 = max(prec1, best_prec1)
         if ddp.rank() == 0:

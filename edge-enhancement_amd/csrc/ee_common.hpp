@@ -23,7 +23,7 @@ struct ProfScope {
     int id;
     hipStream_t stream;
     void *slot;
-    ProfScope(int kernel_id, hipStream_t s);
+    ProfScope(int kernel_id, hipStream_t s, double work = 0.0);
     ~ProfScope();
 };
 

@@ -649,6 +649,8 @@ int conv3_launch(const float *in, const float *w, float *out, int B, int KC, int
     else if (var == 11 && W >= 4 && W <= 16) pipe = 11;
     else if (var == -1 && W == 4 && wgs64 <= 128) pipe = 11;
     if (pipe == 11 && rounds % 2 != 0) pipe = 0;
+    const double flops = 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * W;
+    ProfScope prof(pipe ? (BWD ? EE_K_CONV3P_BWD : EE_K_CONV3P_FWD) : (BWD ? EE_K_CONV3_BWD : EE_K_CONV3_FWD), st, flops);
     if (pipe == 10) {
         switch (W) {
             case 64: conv3_pipe_launch<BWD, 64, 2, 1>(in, w, out, dims, gx, st); break;

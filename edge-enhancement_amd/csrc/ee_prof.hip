@@ -13,7 +13,7 @@ struct Pair {
 struct Family {
     std::vector<Pair> pending;
     std::vector<Pair> pool;
-    double total_ms = 0.0;
+    double total_ms = 0.0, work = 0.0;
     int64_t launches = 0;
 };
 Family g_fam[EE_K_COUNT];
@@ -49,7 +49,7 @@ int drain(Family &f) {
 
 namespace ee {
 
-ProfScope::ProfScope(int kernel_id, hipStream_t s) : id(kernel_id), stream(s), slot(nullptr) {
+ProfScope::ProfScope(int kernel_id, hipStream_t s, double work) : id(kernel_id), stream(s), slot(nullptr) {
     if (!g_on || capturing(s)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Family &f = g_fam[id];
@@ -62,6 +62,7 @@ ProfScope::ProfScope(int kernel_id, hipStream_t s) : id(kernel_id), stream(s), s
     }
     (void)hipEventRecord(p.start, s);
     f.pending.push_back(p);
+    f.work += work;
     slot = &f;
 }
 
@@ -120,12 +121,20 @@ EE_API int ee_prof_read(int kernel_id, double *total_ms, int64_t *launches) {
     return rc;
 }
 
+EE_API int ee_prof_read_work(int kernel_id, double *work) {
+    if (kernel_id < 0 || kernel_id >= EE_K_COUNT) return EE_ERR_SHAPE;
+    if (!work) return EE_ERR_NULL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    *work = g_fam[kernel_id].work;
+    return EE_OK;
+}
+
 EE_API int ee_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (Family &f : g_fam) {
         int rc = drain(f);
         if (rc != EE_OK) return rc;
-        f.total_ms = 0.0;
+        f.total_ms = f.work = 0.0;
         f.launches = 0;
     }
     return EE_OK;

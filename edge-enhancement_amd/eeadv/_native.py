@@ -81,13 +81,14 @@ SIGNATURES = {
     "ee_prof_enable": [c_i],
     "ee_prof_mark_empty": [c_p],
     "ee_prof_read": [c_i, c_p, c_p],
+    "ee_prof_read_work": [c_i, c_p],
     "ee_prof_reset": [],
 }
 _RESTYPE = {"ee_strerror": ctypes.c_char_p, "ee_device_name": ctypes.c_char_p, "ee_mse_num_partials": c_l}
 
 # kernel-family ids of include/eeadv.h (ee_prof_*)
 (K_PGD_STEP, K_FRONTEND_FWD, K_FRONTEND_BWD, K_EDGE_FWD, K_EDGE_BWD, K_CE, K_PGD_STEP_BCAST, K_EMPTY, K_HFS, K_CHAIN_FWD, K_CHAIN_BWD,
- K_HFS_SQ_FWD, K_HFS_SQ_BWD, K_SQUARE_DRAW) = range(14)
+ K_HFS_SQ_FWD, K_HFS_SQ_BWD, K_SQUARE_DRAW, K_CONV3_FWD, K_CONV3_BWD, K_CONV3P_FWD, K_CONV3P_BWD) = range(18)
 
 
 class EEError(RuntimeError):

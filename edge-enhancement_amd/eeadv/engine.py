@@ -185,9 +185,15 @@ def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo
                     live[k].data.copy_(v)
             _GRAPHS[key] = gs
         x = x_init.detach().contiguous()
-        for _ in range(probe):
-            attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi)
-            x = x.detach()
+        if probe:
+            from . import models as _models
+            _models.PROBE_MFMA_CONV = True  # the probe launches what the graph replays (MFMA convolutions included)
+            try:
+                for _ in range(probe):
+                    attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi)
+                    x = x.detach()
+            finally:
+                _models.PROBE_MFMA_CONV = False
         gs.load(x, x0, spec.payload)
         refresh_dense_weights()  # weight-derived buffers the captured kernels read (functional.Conv3x3Map2Fn)
         for _ in range(n_graph // chunk):

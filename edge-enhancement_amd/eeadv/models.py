@@ -65,6 +65,9 @@ _CHAIN = os.environ.get("EEADV_CHAIN", "1") == "1"  # the front end of a PGD ite
 _CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "16"))
 _CONV3_W4 = os.environ.get("EEADV_CONV3_W4", "1") == "1"  # ... and the 4x4 maps of layer3 (split-reduction kernel: 34 us against 37.5)
 _CONV3_EAGER = os.environ.get("EEADV_CONV3_EAGER", "0") == "1"  # use the MFMA 3x3 convolutions outside graph capture as well
+# bench.py's probe iterations (engine.PROBE_ITERS) run outside the captured graph so that the library's event hooks can time
+# their kernels: engine sets this around them, and the probe then launches the same convolution kernels the graph replays
+PROBE_MFMA_CONV = False
 _CONV3S2_BWD_MINOW = int(os.environ.get("EEADV_CONV3S2_BWD_MINOW", "1000"))  # its backward-data kernel: equal to MIOpen end to end, opt-in
 _CONV3S2_MINOW = int(os.environ.get("EEADV_CONV3S2_MINOW", "8"))  # narrowest OUTPUT map the stride-2 MFMA convolution takes (24 us vs 50 at 8; no gain at 4)
 
@@ -118,7 +121,7 @@ def conv3(conv, x):
     # Function + ctypes launch + a separate ATen call for the weight gradient against one ATen call): they pay where the
     # host cost vanishes, i.e. while a HIP graph is being captured, and lose in eager, host-bound passes (TRADES / ALP
     # updates: 4.2 k -> 4.9 k img/s with this rule).
-    if not (_CONV3_EAGER or torch.cuda.is_current_stream_capturing()):
+    if not (_CONV3_EAGER or PROBE_MFMA_CONV or torch.cuda.is_current_stream_capturing()):
         return conv(x)
     if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None

@@ -707,3 +707,10 @@ def prof_read(kernel_id):
     ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
     N.check(N.lib.ee_prof_read(kernel_id, ctypes.byref(ms), ctypes.byref(cnt)), "ee_prof_read")
     return ms.value, cnt.value
+
+
+def prof_read_work(kernel_id):
+    """Floating-point operations the timed launches of a matrix-core family declared (0 for the HBM-bound families)."""
+    w = ctypes.c_double(0.0)
+    N.check(N.lib.ee_prof_read_work(kernel_id, ctypes.byref(w)), "ee_prof_read_work")
+    return w.value

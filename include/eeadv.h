@@ -379,13 +379,20 @@ int ee_chain_bwd_f32(const float *g_in, const uint8_t *gate, const float *gx, co
 #define EE_K_HFS_SQ_FWD 11  /* ee_hfs_f32, sq_mode 1 (Add_Square on load) */
 #define EE_K_HFS_SQ_BWD 12  /* ee_hfs_f32, sq_mode 2 (times d Add_Square / dx on store) */
 #define EE_K_SQUARE_DRAW 13 /* ee_square_draw_f32 */
-#define EE_K_COUNT 14
+#define EE_K_CONV3_FWD 14   /* ee_conv3x3s1_fwd_f32, 4-wavefront kernel */
+#define EE_K_CONV3_BWD 15   /* ee_conv3x3s1_bwd_data_f32, 4-wavefront kernel */
+#define EE_K_CONV3P_FWD 16  /* ee_conv3x3s1_fwd_f32, pipelined kernel (256-channel 4x4 maps) */
+#define EE_K_CONV3P_BWD 17  /* ee_conv3x3s1_bwd_data_f32, pipelined kernel */
+#define EE_K_COUNT 18
 int ee_prof_enable(int on);
 /* records one empty start/stop bracket on `stream` (family EE_K_EMPTY): callers subtract its mean from the other
  * families' means, because a HIP event pair costs ~4-5 us on gfx950 - comparable to the kernels being timed */
 int ee_prof_mark_empty(void *stream);
 /* synchronises the recorded events and returns accumulated milliseconds / launch count since the last reset */
 int ee_prof_read(int kernel_id, double *total_ms, int64_t *launches);
+/* sum of the `work` the timed launches of a family declared (floating-point operations for the matrix-core families; 0 for
+ * the HBM-bound ones, whose bytes follow from the shapes the caller knows) */
+int ee_prof_read_work(int kernel_id, double *work);
 int ee_prof_reset(void);
 
 #ifdef __cplusplus

@@ -52,4 +52,4 @@ for name, c, hw in LAYERS:
          timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])),
          timeit(lambda: ops.conv3x3s1_bwd_data(dy, w))]
     gf = 2.0 * B * c * c * 9 * hw * hw / 1e9
-    print("%-12s %10.1f %10.1f %10.1f %10.1f   %.1f" % (name, t[0], t[1], t[2], t[3], gf / min(t[0], t[1]) * 1e3 / 1e3))
+    print("%-12s %10.1f %10.1f %10.1f %10.1f   %.1f" % (name, t[0], t[1], t[2], t[3], gf / max(min(t[0], t[1]), 1e-9)))

@@ -3,7 +3,8 @@
 #   1. the default bench line (with cpu_baseline)                              -> <tag>_bench.json
 #   2. rocprofv3 --kernel-trace --stats of the same command (no cpu baseline)  -> <tag>_kernel_stats.txt, <tag>_rocprof_kernel_us.json
 #   3. steady-state breakdown of that trace (last 200 ms)                      -> <tag>_trace_breakdown.txt
-#   4. HBM traffic of the front-end kernels at the bench shape, two --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only)
+#   4. HBM traffic of the front-end kernels and of the 3x3 convolution kernels at the bench shape, two --pmc passes each
+#      (FETCH_SIZE, WRITE_SIZE; counters only)
 #                                                                              -> <tag>_pmc_traffic.txt, <tag>_pmc_traffic.json
 # Usage: scripts/prof_round.sh <tag>
 set -e
@@ -22,10 +23,12 @@ python3 scripts/trace_breakdown.py "$t" 200 60 > gpurun_out/${tag}_trace_breakdo
 echo "kernel trace done"
 for ctr in FETCH_SIZE WRITE_SIZE; do
   CHAIN_BENCH_EAGER=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$ctr -- python3 scripts/chain_bench.py 100x3x64x64 > gpurun_out/${tag}_pmc_$ctr.log 2>&1
+  PROBE_EAGER=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${tag}_conv_$ctr -- python3 scripts/conv3_probe.py 100 > gpurun_out/${tag}_pmc_conv_$ctr.log 2>&1
 done
 rm -f gpurun_out/${tag}_pmc_traffic.json
 python3 scripts/pmc_to_json.py /tmp/pmc_${tag}_FETCH_SIZE /tmp/pmc_${tag}_WRITE_SIZE 100x3x64x64 gpurun_out/${tag}_pmc_traffic.json \
   "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over scripts/chain_bench.py 100x3x64x64 (plain launches); KiB counters, FETCH doubled per guides/MI355X_MICROARCH.md" > gpurun_out/${tag}_pmc_traffic.txt
+python3 scripts/pmc_to_json.py /tmp/pmc_${tag}_conv_FETCH_SIZE /tmp/pmc_${tag}_conv_WRITE_SIZE 100x3x64x64 gpurun_out/${tag}_pmc_traffic.json >> gpurun_out/${tag}_pmc_traffic.txt
 echo "pmc done"
 cut -c1-600 gpurun_out/${tag}_bench.json
 cat gpurun_out/${tag}_pmc_traffic.txt

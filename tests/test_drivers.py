@@ -125,6 +125,36 @@ def test_gpu_configs_run_through_the_hip_path(tmp_path, ds, script, cfg):
     assert 0 <= a1 <= 100 and 0 <= c1 <= 100
 
 
+def test_free_at_scripts_keep_the_reference_command_line(tmp_path):
+    """Both free-AT scripts on CPU (no launch): every flag of the reference's parsers (AT_free_imagenet_ddp.py:38-108,
+    AT_hfs_canny_free_imagenet_ddp.py:39-115) with its default, directory layout and checkpoint names (:172-173 / :197, :241-254)."""
+    import importlib
+    sys.path.insert(0, os.path.join(PKG, "ImageNet", "free_imagenet"))
+    try:
+        base = importlib.import_module("AT_free_imagenet_ddp")
+        ee = importlib.import_module("AT_hfs_canny_free_imagenet_ddp")
+    finally:
+        sys.path.pop(0)
+    a = base.make_parser().parse_args([])
+    assert (a.arch, a.epochs, a.batch_size, a.lr, a.momentum, a.weight_decay, a.print_freq) == ("resnet152", 90, 256, 0.1, 0.9, 1e-4, 100)
+    assert (a.epsilon, a.num_steps_1, a.step_size_1, a.clip_eps, a.fgsm_step, a.n_repeats, a.crop_size) == (4 / 255, 50, 1 / 255, 4.0, 4.0, 4, 224)
+    assert (a.w, a.r, a.low, a.high, a.sigma, a.alpha, a.gf, a.seed, a.max_color_value) == (0, 0, 0, 0, 0, 0, False, 1, 255.0)
+    e = ee.make_parser().parse_args([])
+    assert (e.arch, e.num_steps_1, e.num_steps_2, e.num_steps_3, e.step_size_3) == ("resnet50_EE_square", 10, 50, 100, 1 / 255)
+    assert (e.w, e.r, e.low, e.high, e.sigma, e.type_canny, e.n_queries) == (1, 16, 38, 76, 1, "CannyFilter_step125_1", 1)
+    with pytest.raises(SystemExit):
+        base.make_parser().parse_args(["-a", "resnet50_EE_square"])  # the plain script does not know the EE models
+    for args, mod in ((a, base), (e, ee)):
+        args.output_root, args.clip_eps, args.fgsm_step = str(tmp_path), args.clip_eps / 255, args.fgsm_step / 255
+    d = base.output_dirs(a)
+    assert d["model"].endswith("/checkpoint_free_imagenet/free_AT_ddp/resnet152Baseline_clip-eps4/model_pth/")
+    d2 = ee.output_dirs(e)
+    assert d2["log"].endswith("/checkpoint_free_imagenet/free_AT_ddp/resnet50_EE_square/CannyFilter_step125_1_clip-eps4/log/") and os.path.isdir(d2["log"])
+    f, best = base.checkpoint_names(e, d2, 7)
+    assert f.endswith("model_pth/at_clip-eps4_fgsm-step4_n-repeats4_r16_canny_sigma1_alpha0-bs256-lr_0.1-w1-gfFalse-l38-h76-ty1_7.pth")
+    assert best.endswith("best_model_pth/at_clip-eps4_fgsm-step4_n-repeats4_r16_canny_sigma1_alpha0-bs256-lr_0.1-w1-gfFalse-l38-h76-ty1_.pth")
+
+
 @pytest.mark.gpu
 def test_free_at_script_runs_config5_on_one_rank(tmp_path):
     """BASELINE config 5 (ImageNet/free_imagenet/AT_free_imagenet_ddp.py) on one rank: resnet50, 224x224, per-rank batch 32,
@@ -152,3 +182,32 @@ def test_free_at_script_runs_config5_on_one_rank(tmp_path):
     r = subprocess.run(base + ["--resume", first[0], "--max-epochs", "0", "--evaluate"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "=> loaded checkpoint" in r.stdout and " * Clean Prec@1" in r.stdout and "Epoch: [" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_free_at_ee_script_runs_on_one_rank(tmp_path):
+    """ImageNet/free_imagenet/AT_hfs_canny_free_imagenet_ddp.py on one rank at its defaults: `-a
+    resnet50_EE_square` (which, as in the reference, builds resnet18_EE_square), 224 x 224, HighFreqSuppress r = 16 on the band
+    kernel, CannyFilter_step125_1, 2 batches x 4 repeats, evaluation with the num_steps_3 attack (shortened), the
+    `<arch>/<type_canny>_clip-eps<e>/` layout, the argument dump at the head of log.txt, the checkpoint name with the integer
+    defaults of the reference (`sigma1`, `w1`, `l38`, `h76`)."""
+    script = os.path.join(PKG, "ImageNet", "free_imagenet", "AT_hfs_canny_free_imagenet_ddp.py")
+    cmd = [sys.executable, script, "-b", "16", "--data", "synthetic:2:1", "--print-freq", "1", "--num-steps-3", "2", "--num-classes", "100",
+           "--output-root", str(tmp_path), "--max-epochs", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = r.stdout
+    assert "=> creating model 'resnet50_EE_square'" in out and "CannyFilter; sigma:1" in out
+    ep = [l for l in out.splitlines() if l.startswith("Epoch: [0]")]
+    assert len(ep) == 2
+    loss = float(re.search(r"Loss ([\d.]+) ", ep[0]).group(1))
+    assert 0.5 < loss < 9.0  # ln(100) = 4.6 at initialisation; the first line is printed after the batch's four updates
+    assert any(l.startswith(" * Adv Prec@1") for l in out.splitlines())
+    root = os.path.join(str(tmp_path), "checkpoint_free_imagenet", "free_AT_ddp", "resnet50_EE_square", "CannyFilter_step125_1_clip-eps4")
+    name = "at_clip-eps4_fgsm-step4_n-repeats4_r16_canny_sigma1_alpha0-bs16-lr_0.1-w1-gfFalse-l38-h76-ty1_0.pth"
+    assert os.path.isfile(os.path.join(root, "model_pth", name)), os.listdir(os.path.join(root, "model_pth"))
+    log = open(os.path.join(root, "log", "log.txt")).read()
+    assert log.startswith("Namespace(") and "type_canny='CannyFilter_step125_1'" in log.splitlines()[0] and "Epoch: [0][1/2]" in log
+    state = torch.load(os.path.join(root, "model_pth", name), weights_only=True)
+    assert state["arch"] == "resnet50_EE_square" and "module.layer4.1.bn2.running_var" in state["state_dict"]  # two blocks: resnet18
+    assert "module.layer4.2.bn1.weight" not in state["state_dict"]
