@@ -106,12 +106,15 @@ class FlatGradSync:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.world = world() if dist.is_initialized() else 1
+        # EEADV_FORCE_COLLECTIVES=1: issue the collectives at world size 1 as well (scripts/ddp_same_gpu.py with RCCL on a
+        # one-GPU box: communicator set-up, the async all-reduce between the two captured graphs, the watchdog next to a capture)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("EEADV_FORCE_COLLECTIVES", "0") == "1")
         # contiguous pieces, element counts rounded to 64 (256 B)
         k = max(1, min(int(chunks), (n + (1 << 21) - 1) >> 21))  # never below ~8 MB a piece
         step = ((n + k - 1) // k + 63) // 64 * 64
         self.pieces = [self.flat[i:min(i + step, n)] for i in range(0, n, step)]
         self.attach()
-        if broadcast and self.world > 1:
+        if broadcast and self.active:
             self.broadcast_parameters()
 
     def attach(self):
@@ -126,7 +129,7 @@ class FlatGradSync:
         self.flat.zero_()
 
     def all_reduce_(self):
-        if self.world == 1:
+        if not self.active:
             return
         works = [dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True) for piece in reversed(self.pieces)]  # deepest layers first
         for w in works:
@@ -146,7 +149,7 @@ class FlatGradSync:
                 off += p.numel()
 
     def broadcast_buffers(self):
-        if self.world == 1:
+        if not self.active:
             return
         with torch.no_grad():
             for b in self.model.buffers():

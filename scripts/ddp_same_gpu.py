@@ -3,7 +3,11 @@
 one device per rank, so the collective backend differs from production; everything else is the N > 1 path of bench.py: the
 captured attack graph, the captured forward + backward writing one flat gradient buffer, its all-reduce (eeadv.ddp.FlatGradSync),
 the captured SGD step).
-    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 scripts/ddp_same_gpu.py"""
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 scripts/ddp_same_gpu.py
+RCCL itself on a one-GPU box: ONE rank with the collectives forced on (communicator set-up, async all-reduce of the flat buffer
+between the two captured graphs, RCCL's watchdog thread next to a stream capture):
+    DDP_BACKEND=nccl EEADV_FORCE_COLLECTIVES=1 python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 \
+        --master-port 29512 scripts/ddp_same_gpu.py"""
 import os
 import sys
 
@@ -26,7 +30,11 @@ def main():
     os.environ["EEADV_GRAPH"] = "1"
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("DDP_BACKEND", "gloo")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(1 + rank)
     model = make_resnet_ee(18, "tiny", square=True, cize=64, r=16, w=0.5, low=60.0, high=120.0, alpha=0.0, sigma=1,
                            type_canny="CannyFilter_step125_1", epsilon=0.05, n_queries=1).to(dev).train()
