@@ -584,6 +584,204 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const floa
     });
 }
 
+// ---- the stem: relu(bn(x)) followed by MaxPool2d(3, 2, 1) (resnet.py:113-117) without the full-resolution activation -----------------
+// The stem's [100,64,32,32] map is the largest tensor of the network (26 MB): writing relu(bn(x)) and reading it back for the pool,
+// then - backward - writing the pool's input gradient and reading it together with y and x twice, made the stem's BatchNorm + pool
+// 36 us forward and 49 us backward (242 MB of traffic).  Here the forward reads x once and writes the pooled map and its one-byte
+// argmax codes (34 MB); the backward never sees a full-resolution gradient or activation: both of its passes gather the pooled
+// gradient through the codes (ATen's accumulation order) and recompute the ReLU mask from x (the same expression, the same bits).
+// One workgroup = one channel x a few images; a plane is staged in LDS as y = relu(bn(x)) and pooled from there with
+// ee_pool.hip's scan (first maximum wins, a NaN always wins): values, codes and gradients equal the unfused sequence's bit for bit
+// (the gradient sums are taken over a different partition, so dgamma / dbeta / dx agree to rounding).
+struct PoolShape {
+    int B, C, H, W, OH, OW, IPW, G;  // IPW images per workgroup, G = ceil(B / IPW) groups
+};
+
+// Chan's recombination of the S per-slice (sum, M2) partials of bn_split_stats_kernel, in slice order (as bn_split_apply_kernel)
+__device__ __forceinline__ void combine_slices(const float *__restrict__ ws, int c, int S, int total, float n, float &mean, float &var) {
+    float sum = 0.0f;
+    for (int i = 0; i < S; ++i) sum += ws[(static_cast<size_t>(c) * S + i) * 2];
+    mean = sum / n;
+    float m2 = 0.0f;
+    for (int i = 0; i < S; ++i) {
+        const Slice sl = my_slice(total, S, i);
+        const float cnt = 4.0f * static_cast<float>(sl.end - sl.begin);
+        if (cnt > 0.0f) {
+            const float d = ws[(static_cast<size_t>(c) * S + i) * 2] / cnt - mean;
+            m2 += ws[(static_cast<size_t>(c) * S + i) * 2 + 1] + cnt * (d * d);
+        }
+    }
+    var = m2 / n;
+}
+
+__global__ __launch_bounds__(SPLIT_NT) void bn_pool_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, float *running_mean, float *running_var,
+                                                               float momentum, float eps, int training, float *__restrict__ yp,
+                                                               uint8_t *__restrict__ code, float *__restrict__ save_mean,
+                                                               float *__restrict__ save_invstd, const float *__restrict__ ws, PoolShape p, int S) {
+    extern __shared__ __align__(16) float plane[];  // y = relu(bn(x)) of one image plane
+    const int c = blockIdx.x, g = blockIdx.y;
+    const int HW = p.H * p.W, HWq = HW / 4, OHW = p.OH * p.OW;
+    const float n = static_cast<float>(p.B) * static_cast<float>(HW);
+    float mean, invstd;
+    if (training) {
+        float var;
+        combine_slices(ws, c, S, p.B * HWq, n, mean, var);
+        invstd = 1.0f / sqrtf(var + eps);
+        if (g == 0 && threadIdx.x == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = invstd;
+            if (running_mean) {
+                const float unbiased = (n > 1.0f) ? var * (n / (n - 1.0f)) : var;
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
+    const int b_end = (g + 1) * p.IPW < p.B ? (g + 1) * p.IPW : p.B;
+    for (int b = g * p.IPW; b < b_end; ++b) {
+        const size_t pl = static_cast<size_t>(b) * p.C + c;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x) + pl * HWq;
+        for (int q = threadIdx.x; q < HWq; q += SPLIT_NT) {
+            const float4 v = x4[q];
+            reinterpret_cast<float4 *>(plane)[q] = make_float4(relu_nan((v.x - mean) * a + b0), relu_nan((v.y - mean) * a + b0),
+                                                               relu_nan((v.z - mean) * a + b0), relu_nan((v.w - mean) * a + b0));
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < OHW; o += SPLIT_NT) {
+            const int oh = o / p.OW, ow = o - oh * p.OW;
+            const int h0 = oh * 2 - 1, w0 = ow * 2 - 1;
+            const int hs = h0 < 0 ? 0 : h0, wsx = w0 < 0 ? 0 : w0;
+            const int he = h0 + 3 > p.H ? p.H : h0 + 3, we = w0 + 3 > p.W ? p.W : w0 + 3;
+            float best = -INFINITY;
+            int bc = (hs - h0) * 3 + (wsx - w0);
+            for (int h = hs; h < he; ++h)
+                for (int w = wsx; w < we; ++w) {
+                    const float v = plane[h * p.W + w];
+                    if (v > best || v != v) {  // ATen's max_pool2d: first maximum wins, a NaN always wins (ee_pool.hip)
+                        best = v;
+                        bc = (h - h0) * 3 + (w - w0);
+                    }
+                }
+            yp[pl * OHW + o] = best;
+            code[pl * OHW + o] = static_cast<uint8_t>(bc);
+        }
+        __syncthreads();
+    }
+}
+
+// pass 1 (APPLY = false): ws[(c*G + g)*2 + {0,1}] = (sum dz, sum dz*xhat) of the group's images; pass 2 (APPLY = true): dx
+template <bool APPLY>
+__global__ __launch_bounds__(SPLIT_NT) void bn_pool_bwd_kernel(const float *__restrict__ dyp, const uint8_t *__restrict__ code,
+                                                               const float *__restrict__ x, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, const float *__restrict__ save_mean,
+                                                               const float *__restrict__ save_invstd, const float *__restrict__ running_mean,
+                                                               const float *__restrict__ running_var, float eps, int training,
+                                                               float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                               float *__restrict__ ws, PoolShape p) {
+    extern __shared__ __align__(16) float lds[];
+    __shared__ float scratch[SPLIT_NT / 64];
+    const int c = blockIdx.x, g = blockIdx.y;
+    const int HW = p.H * p.W, HWq = HW / 4, OHW = p.OH * p.OW, Wq = p.W / 4;
+    float *gp = lds;                                            // pooled gradient of one plane
+    uint8_t *cd = reinterpret_cast<uint8_t *>(lds + OHW);       // its argmax codes
+    const float mean = training ? save_mean[c] : running_mean[c];
+    const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
+    const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
+    float m1 = 0.0f, m2 = 0.0f;
+    if (APPLY) {
+        float sdz = 0.0f, sdzx = 0.0f;
+        for (int i = 0; i < p.G; ++i) {
+            sdz += ws[(static_cast<size_t>(c) * p.G + i) * 2];
+            sdzx += ws[(static_cast<size_t>(c) * p.G + i) * 2 + 1];
+        }
+        if (g == 0 && threadIdx.x == 0) {
+            if (dgamma) dgamma[c] = sdzx;
+            if (dbeta) dbeta[c] = sdz;
+        }
+        if (!dx) return;
+        const float n = static_cast<float>(p.B) * static_cast<float>(HW);
+        m1 = training ? sdz / n : 0.0f;
+        m2 = training ? sdzx / n : 0.0f;
+    }
+    float sdz = 0.0f, sdzx = 0.0f;
+    const int b_end = (g + 1) * p.IPW < p.B ? (g + 1) * p.IPW : p.B;
+    for (int b = g * p.IPW; b < b_end; ++b) {
+        const size_t pl = static_cast<size_t>(b) * p.C + c;
+        for (int o = threadIdx.x; o < OHW; o += SPLIT_NT) {
+            gp[o] = dyp[pl * OHW + o];
+            cd[o] = code[pl * OHW + o];
+        }
+        __syncthreads();
+        const float4 *x4 = reinterpret_cast<const float4 *>(x) + pl * HWq;
+        for (int q = threadIdx.x; q < HWq; q += SPLIT_NT) {
+            const float4 v4 = x4[q];
+            const int h = q / Wq, w_base = 4 * (q - h * Wq);
+            // the 2 x 3 candidate windows of these four pixels (ee_pool.hip: maxpool_bwd_kernel<4>), from LDS
+            const int oh0 = h >> 1, ow0 = w_base >> 1;
+            const bool row2 = (h & 1) && oh0 + 1 < p.OH;
+            float gv[2][3];
+            int cv[2][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const bool ok = (r == 0 || row2) && ow0 + k < p.OW;
+                    const int idx = ok ? (oh0 + r) * p.OW + ow0 + k : 0;
+                    gv[r][k] = ok ? gp[idx] : 0.0f;
+                    cv[r][k] = ok ? cd[idx] : 255;
+                }
+            const float xv[4] = {v4.x, v4.y, v4.z, v4.w};
+            float out[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int w = w_base + v, k0 = v >> 1;
+                float acc = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        if (kb == 1 && !(v & 1)) continue;  // even pixels belong to one window column only
+                        const int k = k0 + kb;
+                        const int want = (h - ((oh0 + r) * 2 - 1)) * 3 + (w - ((ow0 + k) * 2 - 1));
+                        if (cv[r][k] == want) acc += gv[r][k];
+                    }
+                const float pre = (xv[v] - mean) * a + b0;  // the forward's expression: the same bits, hence the same mask as y > 0
+                const float dz = pre > 0.0f ? acc : 0.0f;
+                const float xhat = (xv[v] - mean) * invstd;
+                if (!APPLY) {
+                    sdz += dz;
+                    sdzx += dz * xhat;
+                } else {
+                    out[v] = a * ((dz - m1) - xhat * m2);
+                }
+            }
+            if (APPLY) reinterpret_cast<float4 *>(dx)[pl * HWq + q] = make_float4(out[0], out[1], out[2], out[3]);
+        }
+        __syncthreads();
+    }
+    if (!APPLY) {
+        sdz = block_sum<SPLIT_NT>(sdz, scratch);
+        sdzx = block_sum<SPLIT_NT>(sdzx, scratch);
+        if (threadIdx.x == 0) {
+            ws[(static_cast<size_t>(c) * p.G + g) * 2 + 0] = sdz;
+            ws[(static_cast<size_t>(c) * p.G + g) * 2 + 1] = sdzx;
+        }
+    }
+}
+
+inline bool pool_shape(int B, int C, int H, int W, PoolShape &p) {
+    if (B < 1 || C < 1 || H < 1 || W < 4 || W % 4 || static_cast<int64_t>(H) * W > 16000) return false;  // one plane in 64 KB of LDS (ImageNet: 112 x 112)
+    if (static_cast<int64_t>(B) * C * H * W / 4 > 0x7fffffffLL) return false;
+    const int ipw = (B + SPLIT_MAX - 1) / SPLIT_MAX;
+    p = PoolShape{B, C, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, ipw, (B + ipw - 1) / ipw};
+    return true;
+}
+
 template <int NT, int VEC>
 void launch_fwd(bool relu, bool has_res, hipStream_t st, const float *x, const float *res, const float *gamma, const float *beta, float *rm,
                 float *rv, float momentum, float eps, int training, float *y, float *sm, float *si, BnShape s) {
@@ -689,3 +887,53 @@ EE_API int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, co
     else launch_bwd<256, 1>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     return launch_status();
 }
+
+// floats of workspace ee_bn_relu_pool_fwd/bwd_f32 want (statistics partials forward, gradient-sum partials backward); 0 = unsupported shape
+EE_API int ee_bn_relu_pool_workspace_floats(int B, int C, int H, int W) {
+    PoolShape p;
+    if (!pool_shape(B, C, H, W, p)) return 0;
+    return C * SPLIT_MAX * 2;
+}
+
+EE_API int ee_bn_relu_pool_fwd_f32(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                   float momentum, float eps, int training, float *y_pool, uint8_t *code, float *save_mean,
+                                   float *save_invstd, float *workspace, int B, int C, int H, int W, void *stream) {
+    if (B < 0 || C < 1 || H < 1 || W < 1) return EE_ERR_SHAPE;
+    if (B == 0) return EE_OK;
+    PoolShape p;
+    if (!pool_shape(B, C, H, W, p)) return EE_ERR_UNSUPPORTED;
+    if (!x || !y_pool || !code || !workspace) return EE_ERR_NULL;
+    if (training && (!save_mean || !save_invstd)) return EE_ERR_NULL;
+    if (!training && (!running_mean || !running_var)) return EE_ERR_NULL;
+    if (!aligned16(x)) return EE_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    const BnShape s{B, C, H * W};
+    const int S = split_slices(static_cast<int64_t>(B) * (H * W / 4));
+    if (training) EE_LAUNCH(bn_split_stats_kernel, dim3(static_cast<unsigned>(C), static_cast<unsigned>(S)), dim3(SPLIT_NT), 0, st, x, workspace, s, S);
+    EE_LAUNCH(bn_pool_fwd_kernel, dim3(static_cast<unsigned>(C), static_cast<unsigned>(p.G)), dim3(SPLIT_NT), static_cast<size_t>(H) * W * sizeof(float), st,
+              x, gamma, beta, running_mean, running_var, momentum, eps, training, y_pool, code, save_mean, save_invstd, workspace, p, S);
+    return launch_status();
+}
+
+EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const uint8_t *code, const float *x, const float *gamma, const float *beta,
+                                   const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
+                                   float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
+                                   int W, void *stream) {
+    if (B < 0 || C < 1 || H < 1 || W < 1) return EE_ERR_SHAPE;
+    if (B == 0) return EE_OK;
+    PoolShape p;
+    if (!pool_shape(B, C, H, W, p)) return EE_ERR_UNSUPPORTED;
+    if (!dy_pool || !code || !x || !workspace) return EE_ERR_NULL;
+    if (training && (!save_mean || !save_invstd)) return EE_ERR_NULL;
+    if (!training && (!running_mean || !running_var)) return EE_ERR_NULL;
+    if (!aligned16(x) || (dx && !aligned16(dx))) return EE_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(p.G)), block(SPLIT_NT);
+    const size_t lds = (static_cast<size_t>(p.OH) * p.OW * 5 + 15) / 16 * 16;  // floats + bytes
+    EE_LAUNCH((bn_pool_bwd_kernel<false>), grid, block, lds, st, dy_pool, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
+              training, dx, dgamma, dbeta, workspace, p);
+    EE_LAUNCH((bn_pool_bwd_kernel<true>), grid, block, lds, st, dy_pool, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
+              training, dx, dgamma, dbeta, workspace, p);
+    return launch_status();
+}
+

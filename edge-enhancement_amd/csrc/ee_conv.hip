@@ -302,6 +302,126 @@ EE_API int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float
 }
 
 // =====================================================================================================================
+// Forward of the stem convolution Conv2d(3, 64k, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113), round 2.
+// MIOpen's best solver (Winograd f3x2_stride2) takes 52 us un-profiled for [100,3,64,64] -> [100,64,32,32], the most expensive
+// single launch of a PGD iteration's forward pass.  Implicit GEMM on v_mfma_f32_32x32x2_f32:
+//   D[co][p] = sum_{(ci, ky, kx)} W[co][ci][ky][kx] * x[n, ci, 2 oy + ky - 3, 2 ox + kx - 3],     K = 3 * 7 * 8 (kx padded to 8, W = 0 there)
+// One MFMA step takes the taps (kx, kx + 1) of one (ci, ky) on the two lane halves: the B operand of lane (i, half) is the frame
+// element at column 2 i + kx + half - even and odd columns on disjoint LDS banks, one ds_read_b32 with an immediate offset per
+// MFMA and tile, no index arithmetic in the loop.  A workgroup (4 wavefronts = 2 channel halves x 2 row pairs) owns 64 output
+// channels x 4 output rows x 32 columns; its 13 x 72 x 3 input frame sits in LDS (zero outside the image) and the 84 A operands
+// of a lane stay in REGISTERS for both of its tiles (weights pass through LDS once, in their natural layout, 16-B global loads).
+// =====================================================================================================================
+namespace {
+
+constexpr int SF_ROWS = 4, SF_FH = 2 * SF_ROWS + 5, SF_FW = 72, SF_K = 147, SF_WS = 149, SF_STEPS = 3 * 7 * 4;
+
+__global__ __launch_bounds__(256, 3) void stem_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
+                                                               int K, int H, int W, int tiles_r, int tiles_c) {
+    __shared__ float fr[3 * SF_FH * SF_FW];
+    __shared__ __align__(16) float wn[64 * SF_WS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
+    const int mt = wave >> 1, nt = wave & 1;
+    const int OH = H / 2, OW = W / 2;
+    int t = static_cast<int>(blockIdx.x);
+    const int tc = t % tiles_c;
+    t /= tiles_c;
+    const int tr = t % tiles_r, n = t / tiles_r;
+    const int oy0 = tr * SF_ROWS, ox0 = tc * 32;
+    const int cb = static_cast<int>(blockIdx.y) * 64;
+    // ---- all global loads first (clamped addresses, masked afterwards) ----------------------------------------------------------
+    constexpr int WV4 = 64 * SF_K / 4, WPT = (WV4 + 255) / 256, FTOT = 3 * SF_FH * SF_FW, FPT = (FTOT + 255) / 256;
+    float4 wv[WPT];
+    const float4 *wsrc = reinterpret_cast<const float4 *>(w + static_cast<size_t>(cb) * SF_K);
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int e = threadIdx.x + j * 256;
+        wv[j] = wsrc[e < WV4 ? e : WV4 - 1];
+    }
+    float fv[FPT];
+    bool fok[FPT];
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        const int c = idx % SF_FW, q = idx / SF_FW;
+        const int r = q % SF_FH, ci = idx < FTOT ? q / SF_FH : 0;
+        const int iy = iy0 + r, ix = ix0 + c;
+        fok[j] = idx < FTOT && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        fv[j] = x[((static_cast<size_t>(n) * 3 + ci) * H + (fok[j] ? iy : 0)) * W + (fok[j] ? ix : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int e = threadIdx.x + j * 256;
+        if (e < WV4) {
+            const float v4[4] = {wv[j].x, wv[j].y, wv[j].z, wv[j].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = 4 * e + u, co = f / SF_K, k = f - co * SF_K;
+                wn[co * SF_WS + k] = v4[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < FPT; ++j)
+        if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;
+    __syncthreads();
+    // ---- this lane's 84 A operands: W[cb + mt*32 + i][ci][ky][2 kxp + kk], zero for the padded tap ---------------------------------
+    float a[SF_STEPS];
+    const float *wrow = wn + (mt * 32 + i) * SF_WS + kk;
+#pragma unroll
+    for (int s = 0; s < SF_STEPS; ++s) {
+        const int kxp = s & 3, cy = s >> 2;  // cy = ci * 7 + ky
+        const float v = wrow[cy * 7 + 2 * kxp];  // for (kxp 3, kk 1) this is the next row's first tap (or the pad column): finite, dropped
+        a[s] = (kxp == 3 && kk) ? 0.0f : v;
+    }
+#pragma unroll
+    for (int s = 0; s < SF_STEPS; ++s) asm volatile("" : "+v"(a[s]));  // keep them in registers: the compiler would re-read LDS per MFMA
+    // ---- two tiles (output rows 2 nt, 2 nt + 1 of the workgroup's four), 84 MFMAs each, interleaved ---------------------------------
+    f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+    const float *b0 = fr + (2 * (2 * nt)) * SF_FW + 2 * i + kk;  // frame row 2 r + ky, column 2 i + 2 kxp + kk
+    const float *b1 = b0 + 2 * SF_FW;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kxp = 0; kxp < 4; ++kxp) {
+                const int off = (ci * SF_FH + ky) * SF_FW + 2 * kxp;
+                const float av = a[(ci * 7 + ky) * 4 + kxp];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[off], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[off], acc1, 0, 0, 0);
+            }
+    // ---- store: lane (i, kk) holds column ox0 + i of rows acc_row(r, lane) ------------------------------------------------------------
+    const size_t plane = static_cast<size_t>(OH) * OW;
+    const int oy = oy0 + 2 * nt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = cb + mt * 32 + acc_row(r, lane);
+        float *o = y + (static_cast<size_t>(n) * K + co) * plane + static_cast<size_t>(oy) * OW + ox0 + i;
+        if (oy < OH) o[0] = acc0[r];
+        if (oy + 1 < OH) o[OW] = acc1[r];
+    }
+}
+
+}  // namespace
+
+EE_API int ee_stem7x7s2_fwd_f32(const float *x, const float *weight, float *y, int B, int K, int H, int W, void *stream) {
+    if (B < 0 || K < 1 || H < 2 || W < 2) return EE_ERR_SHAPE;
+    if ((H & 1) || (W & 1) || (W / 2) % 32 != 0 || K % 64 != 0) return EE_ERR_UNSUPPORTED;
+    if (B == 0) return EE_OK;
+    if (!x || !weight || !y) return EE_ERR_NULL;
+    if (reinterpret_cast<uintptr_t>(weight) & 15u) return EE_ERR_ALIGN;
+    const int OH = H / 2, OW = W / 2;
+    const int tiles_r = (OH + SF_ROWS - 1) / SF_ROWS, tiles_c = OW / 32;
+    const int64_t grid = static_cast<int64_t>(B) * tiles_r * tiles_c;
+    if (grid > 0x7fffffffLL || static_cast<int64_t>(B) * K * OH * OW > 0x7fffffffLL * 4LL) return EE_ERR_SHAPE;
+    EE_LAUNCH(stem_fwd_mfma_kernel, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(K / 64)), dim3(256), 0, as_stream(stream), x, weight, y,
+              K, H, W, tiles_r, tiles_c);
+    return launch_status();
+}
+
+// =====================================================================================================================
 // Conv2d(3x3, stride 1, padding 1, bias=False) of the residual blocks (Tiny_ImageNet/models_tinyimagenet/resnet.py:26-31),
 // forward and backward-data, as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32).
 //

@@ -1,6 +1,8 @@
 """torch.autograd bridges onto the HIP kernels (eeadv.ops).  Everything here requires ROCm tensors."""
 import weakref
 
+import os
+
 import torch
 
 from . import ops
@@ -161,6 +163,28 @@ class BnActFn(torch.autograd.Function):
         return dx, dres, (dg if want[2] else None), (db if want[3] else None), None, None, None, None, None, None
 
 
+class BnReluPoolFn(torch.autograd.Function):
+    """maxpool3s2(relu(batch_norm(x))) - the ResNet stem (resnet.py:113-117) - in one pass each way: the full-resolution activation and its
+    gradient never exist (ee_bn.hip: bn_pool_*)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training):
+        y, code, sm, si = ops.bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training)
+        ctx.save_for_backward(x, code, gamma, beta, sm, si, None if training else running_mean, None if training else running_var)
+        ctx.cfg = (eps, training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, code, gamma, beta, sm, si, rm, rv = ctx.saved_tensors
+        eps, training = ctx.cfg
+        want_params = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY
+        if not ctx.needs_input_grad[0] and not want_params:
+            return (None,) * 8
+        dx, dg, db = ops.bn_relu_pool_bwd(dy.contiguous(), code, x, gamma, beta, sm, si, rm, rv, eps, training, ctx.needs_input_grad[0], want_params)
+        return dx, (dg if ctx.needs_input_grad[1] and want_params else None), (db if ctx.needs_input_grad[2] and want_params else None), None, None, None, None, None
+
+
 class MaxPool3s2Fn(torch.autograd.Function):
     """MaxPool2d(3, stride 2, padding 1) with a one-byte argmax code (resnet.py:117; ee_pool.hip)."""
 
@@ -247,13 +271,18 @@ class Conv3x3S2Fn(torch.autograd.Function):
         return dx, dw, None, None
 
 
+_STEM_FWD = os.environ.get("EEADV_STEM_FWD", "1") == "1"  # 0: the stem's forward back on MIOpen (A/B)
+
+
 class StemConvFn(torch.autograd.Function):
-    """The stem Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (resnet.py:112-113): forward and weight gradient on MIOpen,
-    the gradient with respect to the image - what the attack loop is after - on ee_conv.hip."""
+    """The stem Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (resnet.py:112-113): the forward (maps whose width is a multiple
+    of 64) and the gradient with respect to the image - what the attack loop is after - on ee_conv.hip; the weight gradient on MIOpen."""
 
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        if _STEM_FWD and ops.stem7x7s2_fwd_supported(x, weight):
+            return ops.stem7x7s2_fwd(x, weight)
         return torch.ops.aten.convolution(x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1)
 
     @staticmethod

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime
-from .functional import BnActFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import BnActFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -74,6 +74,17 @@ _CONV3S2_MINOW = int(os.environ.get("EEADV_CONV3S2_MINOW", "8"))  # narrowest OU
 
 def _dense_f32(x):
     return x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+
+
+def stem_bn_pool(bn, pool, x):
+    """maxpool(relu(bn1(x))) of the ResNet stem (resnet.py:113-117): one fused pass each way when the shapes allow (ee_bn.hip, bn_pool_*),
+    the two separate kernels - or the stock modules - otherwise."""
+    if ("bn" not in _STOCK and "pool" not in _STOCK and "bnpool" not in _STOCK and type(bn) is BatchNorm2d and type(pool) is nn.MaxPool2d
+            and _dense_f32(x) and bn.affine and bn.track_running_stats and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1
+            and pool.dilation == 1 and not pool.ceil_mode and not pool.return_indices and ops.bn_relu_pool_supported(x)):
+        return BnReluPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.0 if bn.momentum is None else bn.momentum, bn.eps,
+                                  bn.training)
+    return stem_pool(pool, bn_act(bn, x))
 
 
 def stem_pool(pool, x):
@@ -140,8 +151,10 @@ def conv3(conv, x):
 
 
 def stem_conv(conv, x):
-    """conv1 of the ResNets (resnet.py:112): when x needs a gradient (the attack loop), its backward-data runs on ee_conv.hip."""
-    if ("stem" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and x.requires_grad and conv.in_channels == 3
+    """conv1 of the ResNets (resnet.py:112): forward on ee_conv.hip where the shape allows; when x needs a gradient (the attack loop),
+    its backward-data too."""
+    if ("stem" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.in_channels == 3
+            and (x.requires_grad or ops.stem7x7s2_fwd_supported(x, conv.weight))
             and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.bias is None and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and conv.weight.is_contiguous()):
         return StemConvFn.apply(x, conv.weight)
@@ -390,7 +403,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def body(self, x):
-        x = stem_pool(self.maxpool, bn_act(self.bn1, stem_conv(self.conv1, x)))
+        x = stem_bn_pool(self.bn1, self.maxpool, stem_conv(self.conv1, x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         _bump_bn_counters(self)
         return head(self.avgpool, self.fc, x)

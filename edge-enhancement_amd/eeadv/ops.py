@@ -572,6 +572,50 @@ def bn_act_bwd(dy, y, x, gamma, save_mean, save_invstd, running_mean, running_va
     return dx, dres, dg, db
 
 
+def bn_relu_pool_supported(x):
+    """relu(bn(x)) -> MaxPool2d(3, 2, 1) as one pass each way (the ResNet stem): shapes ee_bn_relu_pool_*_f32 take."""
+    return x.dim() == 4 and x.shape[0] > 0 and N.lib.ee_bn_relu_pool_workspace_floats(x.shape[0], x.shape[1], x.shape[2], x.shape[3]) > 0
+
+
+def _pool_workspace(x):
+    n = N.lib.ee_bn_relu_pool_workspace_floats(x.shape[0], x.shape[1], x.shape[2], x.shape[3])
+    return torch.empty(n, dtype=torch.float32, device=x.device)
+
+
+def bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training):
+    """maxpool3s2(relu(bn(x))) -> (y_pool, code uint8, save_mean, save_invstd) (resnet.py:113-117); the saves are None in eval mode."""
+    B, C, H, W = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+    code = torch.empty((B, C, OH, OW), dtype=torch.uint8, device=x.device)
+    sm = si = None
+    if training:
+        sm = torch.empty(C, dtype=torch.float32, device=x.device)
+        si = torch.empty(C, dtype=torch.float32, device=x.device)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    ws = _pool_workspace(x)
+    N.check(N.lib.ee_bn_relu_pool_fwd_f32(_chk(x, torch.float32, "x"), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
+                                          float(eps), 1 if training else 0, y.data_ptr(), code.data_ptr(), ptr(sm), ptr(si), ws.data_ptr(),
+                                          B, C, H, W, _stream()), "ee_bn_relu_pool_fwd_f32")
+    return y, code, sm, si
+
+
+def bn_relu_pool_bwd(dy_pool, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, training, want_dx=True,
+                     want_dparams=True):
+    """Backward of bn_relu_pool_fwd: (dx, dgamma, dbeta), None where not wanted."""
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x) if want_dx else None
+    dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
+    db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
+    ptr = lambda t: None if t is None else t.data_ptr()
+    ws = _pool_workspace(x)
+    N.check(N.lib.ee_bn_relu_pool_bwd_f32(_chk(dy_pool, torch.float32, "dy_pool", code.shape), _chk(code, torch.uint8, "code"),
+                                          _chk(x, torch.float32, "x"), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(running_mean),
+                                          ptr(running_var), float(eps), 1 if training else 0, ptr(dx), ptr(dg), ptr(db), ws.data_ptr(),
+                                          B, C, H, W, _stream()), "ee_bn_relu_pool_bwd_f32")
+    return dx, dg, db
+
+
 # ---- stem max-pool and classifier head -----------------------------------------------------------------------------------
 def maxpool3s2_fwd(x):
     """MaxPool2d(3, 2, 1) of x [B,C,H,W] -> (y, code uint8) (resnet.py:117)."""
@@ -662,6 +706,21 @@ def stem7x7s2_bwd_data(dy, weight, H, W):
                                             _chk(weight, torch.float32, "weight", (K, 3, 7, 7)), dx.data_ptr(), B, K, H, W, _stream()),
             "ee_stem7x7s2_bwd_data_f32")
     return dx
+
+
+def stem7x7s2_fwd_supported(x, weight):
+    return (x.dim() == 4 and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 64 == 0 and weight.shape[0] % 64 == 0
+            and tuple(weight.shape[1:]) == (3, 7, 7) and weight.data_ptr() % 16 == 0)
+
+
+def stem7x7s2_fwd(x, weight):
+    """Conv2d(3, K, 7, stride 2, padding 3) forward (resnet.py:112): x [B,3,H,W] -> [B,K,H/2,W/2] on the f32 matrix cores."""
+    B, _, H, W = x.shape
+    K = weight.shape[0]
+    y = torch.empty((B, K, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_stem7x7s2_fwd_f32(_chk(x, torch.float32, "x", (B, 3, H, W)), _chk(weight, torch.float32, "weight", (K, 3, 7, 7)),
+                                       y.data_ptr(), B, K, H, W, _stream()), "ee_stem7x7s2_fwd_f32")
+    return y
 
 
 def pool_linear_fwd(feat, weight, bias):

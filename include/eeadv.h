@@ -272,6 +272,21 @@ int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const flo
                       int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW,
                       void *stream);
 
+/* relu(batch_norm(x)) followed by MaxPool2d(3, stride 2, padding 1) - the ResNet stem (resnet.py:113-117 / :148-150) - without
+ * the full-resolution activation: forward x [B,C,H,W] -> y_pool [B,C,OH,OW] + one-byte argmax codes (OH = (H-1)/2+1); backward
+ * dy_pool + codes + x -> dx [B,C,H,W] (nullable), dgamma, dbeta [C] (nullable).  Values, codes and the pooled-gradient gather equal
+ * ee_bn_act_fwd_f32(relu=1) -> ee_maxpool3s2_fwd_f32 and their backwards bit for bit; the gradient sums run over a different
+ * partition (dgamma / dbeta / dx agree to rounding).  W % 4 == 0, H*W <= 16000 (else EE_ERR_UNSUPPORTED: use the two calls);
+ * workspace: ee_bn_relu_pool_workspace_floats(B, C, H, W) floats (0 = unsupported shape). */
+int ee_bn_relu_pool_workspace_floats(int B, int C, int H, int W);
+int ee_bn_relu_pool_fwd_f32(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                            float momentum, float eps, int training, float *y_pool, uint8_t *code, float *save_mean,
+                            float *save_invstd, float *workspace, int B, int C, int H, int W, void *stream);
+int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const uint8_t *code, const float *x, const float *gamma, const float *beta,
+                            const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
+                            float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
+                            int W, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The stem's MaxPool2d(3, stride 2, padding 1) (Tiny_ImageNet/models_tinyimagenet/resnet.py:117), bit-identical to ATen's
  * (first maximum wins, NaN always wins).  x [planes,H,W] -> y, code [planes,OH,OW], OH = (H-1)/2+1; code = 3*kh+kw of the
@@ -309,6 +324,9 @@ int ee_conv3x3s2_bwd_data_f32(const float *dy, const float *weight, float *dx, i
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.
  *   dy [B,K,H/2,W/2], weight [K,3,7,7] -> dx [B,3,H,W];  H, W even. */
 int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int K, int H, int W, void *stream);
+/* The same convolution forward (resnet.py:112-113 / :147): x [B,3,H,W], weight [K,3,7,7] -> y [B,K,H/2,W/2].
+ * H, W even, (W/2) % 32 == 0, K % 64 == 0 (else EE_ERR_UNSUPPORTED); weight 16-byte aligned. */
+int ee_stem7x7s2_fwd_f32(const float *x, const float *weight, float *y, int B, int K, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Classifier head: logits = fc(avgpool(feat).view(B,-1)) for a global average pool

@@ -480,6 +480,60 @@ def test_maxpool3s2_bit_identical_to_aten(ops, shape):
     assert_bitexact(g_got.cpu().numpy(), g_ref.cpu().numpy(), "maxpool bwd")
 
 
+@pytest.mark.parametrize("shape", [(100, 64, 32, 32), (70, 3, 6, 8), (3, 5, 7, 12), (2, 64, 112, 112), (130, 2, 1, 4)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_relu_pool_fused_equals_the_two_kernels(ops, shape, training):
+    """The ResNet stem's maxpool(relu(bn(x))) (resnet.py:113-117) in one pass each way (ee_bn.hip, bn_pool_*): pooled values, running
+    statistics and the gradient routing are bit-identical to BnActFn -> MaxPool3s2Fn (the same statistics, the same ReLU bits, ATen's
+    first-maximum rule), the gradient sums - taken over another partition - agree to rounding; and against torch's own ops."""
+    import torch.nn.functional as F
+    from eeadv.functional import BnActFn, BnReluPoolFn, MaxPool3s2Fn
+    g = torch.Generator(device="cpu").manual_seed(sum(shape) + training)
+    B, C = shape[:2]
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).to(DEV).requires_grad_(True)
+    w = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    if C > 1:
+        w[1] = -w[1]  # a negative scale: the pool's argmax is NOT the argmax of x there
+    w.requires_grad_(True)
+    b = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+    rm0, rv0 = torch.randn(C, generator=g).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    assert ops.bn_relu_pool_supported(x)
+    rm_a, rv_a = rm0.clone(), rv0.clone()
+    two = MaxPool3s2Fn.apply(BnActFn.apply(x, None, w, b, rm_a, rv_a, 0.1, 1e-5, training, True))
+    rm_b, rv_b = rm0.clone(), rv0.clone()
+    one = BnReluPoolFn.apply(x, w, b, rm_b, rv_b, 0.1, 1e-5, training)
+    from eeadv import _native as N
+    if not training or N.lib.ee_bn_workspace_floats(B, C, shape[2] * shape[3]) > 0:
+        # the unfused BatchNorm takes its statistics the same way (eval mode; or the split kernels, as for the stem at the reference batch)
+        assert torch.equal(one, two) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    else:  # it keeps the channel in registers there: same two-pass variance, another summation order
+        torch.testing.assert_close(one, two, rtol=1e-6, atol=2e-6)
+        torch.testing.assert_close(rm_b, rm_a, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(rv_b, rv_a, rtol=1e-6, atol=1e-7)
+    dy = torch.randn(two.shape, generator=g).to(DEV)
+    g2 = torch.autograd.grad(two, [x, w, b], dy)
+    g1 = torch.autograd.grad(one, [x, w, b], dy)
+    n = B * shape[2] * shape[3]
+    scale = max(1.0, float(n) ** 0.5)
+    for a, e, nm in zip(g1, g2, ["dx", "dgamma", "dbeta"]):
+        torch.testing.assert_close(a, e, rtol=2e-5, atol=2e-5 * (scale if nm != "dx" else 1.0), msg=lambda m: nm + ": " + m)
+    assert torch.equal(g1[0] == 0, g2[0] == 0) or training  # eval mode: dx = a * dz, zero exactly where the ReLU / the pool cut it
+    rm_c, rv_c = rm0.clone(), rv0.clone()
+    ref = F.max_pool2d(F.relu(F.batch_norm(x, rm_c, rv_c, w, b, training, 0.1, 1e-5)), 3, 2, 1)
+    torch.testing.assert_close(one, ref, rtol=1e-5, atol=2e-5)
+    for a, e, nm in zip(g1, torch.autograd.grad(ref, [x, w, b], dy), ["dx", "dgamma", "dbeta"]):
+        torch.testing.assert_close(a, e, rtol=2e-5, atol=2e-5 * (scale if nm != "dx" else 1.0), msg=lambda m: nm + " vs torch: " + m)
+    with EF_input_grad_only():
+        (gx,) = torch.autograd.grad(BnReluPoolFn.apply(x, w, b, rm0.clone(), rv0.clone(), 0.1, 1e-5, training), [x], dy)
+    assert torch.equal(gx, g1[0])
+    assert not ops.bn_relu_pool_supported(torch.empty(2, 3, 224, 224, device=DEV)) and not ops.bn_relu_pool_supported(torch.empty(2, 3, 8, 6, device=DEV))
+
+
+def EF_input_grad_only():
+    from eeadv.functional import input_grad_only
+    return input_grad_only()
+
+
 @pytest.mark.parametrize("B,C,HW,K", [(100, 512, (2, 2), 200), (3, 2048, (7, 7), 1000), (5, 7, (1, 1), 3), (2, 64, (3, 5), 10)])
 def test_pool_linear_head_matches_torch(ops, B, C, HW, K):
     import torch.nn.functional as F
@@ -567,6 +621,31 @@ def test_stem_conv_bwd_data_matches_aten(ops, B, K, H, W):
     (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
     torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)
+
+
+@pytest.mark.parametrize("B,K,H,W", [(100, 64, 64, 64), (3, 128, 10, 64), (2, 64, 6, 128), (1, 64, 2, 64), (5, 192, 64, 192)])
+def test_stem_conv_fwd_mfma_matches_aten(ops, B, K, H, W):
+    """The stem convolution forward (resnet.py:112) on the f32 matrix cores vs ATen: image borders on all four sides, output rows
+    that do not fill the 4-row tile (OH = 5, 3, 1), several column tiles and channel blocks; then through StemConvFn in a model-like
+    call (no input gradient: the update pass)."""
+    import torch.nn.functional as F
+    from eeadv.functional import StemConvFn
+    g = torch.Generator(device="cpu").manual_seed(B + K + H + W)
+    x = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    w = (torch.randn(K, 3, 7, 7, generator=g) / 12.0).to(DEV)
+    assert ops.stem7x7s2_fwd_supported(x, w)
+    ref = F.conv2d(x, w, None, 2, 3)
+    got = ops.stem7x7s2_fwd(x, w)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5)
+    assert float((got.double() - F.conv2d(x.double(), w.double(), None, 2, 3)).abs().max()) < 1e-5  # exact-f32 fma chains over K = 147
+    wp = w.clone().requires_grad_(True)
+    out = StemConvFn.apply(x, wp)
+    assert torch.equal(out, got)
+    dy = torch.randn(ref.shape, generator=g).to(DEV)
+    gw, = torch.autograd.grad(out, [wp], dy)
+    ew, = torch.autograd.grad(F.conv2d(x, wp, None, 2, 3), [wp], dy)
+    torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)
+    assert not ops.stem7x7s2_fwd_supported(torch.empty(1, 3, 224, 224, device=DEV), w)  # OW = 112: MIOpen keeps ImageNet's stem
 
 
 @pytest.mark.parametrize("B,Cin,Cout", [(100, 512, 512), (3, 5, 7), (1, 64, 32)])
