@@ -21,14 +21,20 @@ constexpr int HEAD_KCHUNK = 64;  // logits per workgroup: 4 wavefronts x 16, fou
 // wavefront produces 16 logits, 4 at a time so that 4 x C/64 independent loads are in flight per lane.
 __global__ __launch_bounds__(HEAD_NT) void pool_linear_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ w,
                                                                   const float *__restrict__ bias, float *__restrict__ pooled,
-                                                                  float *__restrict__ logits, int C, int HW, int K) {
-    __shared__ float p[HEAD_MAXC];
+                                                                  float *__restrict__ logits, int C, int HW, int K, int vec4) {
+    __shared__ __align__(16) float p[HEAD_MAXC];
     const int b = blockIdx.x;
     const float inv = 1.0f / static_cast<float>(HW);
     const float *f = feat + static_cast<size_t>(b) * C * HW;
+    const bool quad = HW == 4 && (reinterpret_cast<uintptr_t>(f) & 15u) == 0;  // a 2x2 map (ResNet-18 at 64x64 inputs): one 16-B load per channel, same summation order
     for (int c = threadIdx.x; c < C; c += HEAD_NT) {
         float s = 0.0f;
-        for (int i = 0; i < HW; ++i) s += f[static_cast<size_t>(c) * HW + i];
+        if (quad) {
+            const float4 q = reinterpret_cast<const float4 *>(f)[c];
+            s = ((q.x + q.y) + q.z) + q.w;
+        } else {
+            for (int i = 0; i < HW; ++i) s += f[static_cast<size_t>(c) * HW + i];
+        }
         s *= inv;
         p[c] = s;
         if (blockIdx.y == 0) pooled[static_cast<size_t>(b) * C + c] = s;
@@ -36,6 +42,47 @@ __global__ __launch_bounds__(HEAD_NT) void pool_linear_fwd_kernel(const float *_
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k_base = blockIdx.y * HEAD_KCHUNK + wave * 16;
+    if (vec4) {
+        // C % 4 == 0, 16-byte aligned rows: all 16 rows of the wavefront in flight as 16-B loads (ResNet-18: 2 per row and lane),
+        // one memory round trip for the whole product (the 4-rows-at-a-time loop below took four)
+        const int C4 = C / 4;
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int c0 = 0; c0 < C4; c0 += 128) {
+            float4 wv[16][2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = k_base + i < K ? k_base + i : K - 1;
+                const float4 *row = reinterpret_cast<const float4 *>(w + static_cast<size_t>(k) * C);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c4 = c0 + lane + 64 * u;
+                    wv[i][u] = row[c4 < C4 ? c4 : C4 - 1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c4 = c0 + lane + 64 * u;
+                if (c4 < C4) {
+                    const float4 pv = reinterpret_cast<const float4 *>(p)[c4];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        acc[i] = fmaf(pv.w, wv[i][u].w, fmaf(pv.z, wv[i][u].z, fmaf(pv.y, wv[i][u].y, fmaf(pv.x, wv[i][u].x, acc[i]))));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off);
+        }
+        float mine = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine = lane == i ? acc[i] : mine;
+        if (lane < 16 && k_base + lane < K) logits[static_cast<size_t>(b) * K + k_base + lane] = mine + (bias ? bias[k_base + lane] : 0.0f);
+        return;
+    }
 #pragma unroll 1
     for (int g = 0; g < 4; ++g) {
         const int k0 = k_base + g * 4;
@@ -99,7 +146,7 @@ EE_API int ee_pool_linear_fwd_f32(const float *feat, const float *weight, const 
     if (B == 0) return EE_OK;
     if (!feat || !weight || !pooled || !logits) return EE_ERR_NULL;
     EE_LAUNCH(pool_linear_fwd_kernel, dim3(static_cast<unsigned>(B), static_cast<unsigned>((K + HEAD_KCHUNK - 1) / HEAD_KCHUNK)), dim3(HEAD_NT), 0, as_stream(stream), feat, weight, bias, pooled, logits, C,
-              HW, K);
+              HW, K, (C % 4 == 0 && aligned16(weight)) ? 1 : 0);
     return launch_status();
 }
 
