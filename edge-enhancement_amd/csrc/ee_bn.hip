@@ -39,6 +39,10 @@ struct BnShape {
     int B, C, HW;
 };
 
+// the gradient may arrive in two pieces (the block output feeds the next block's convolution AND its identity branch; autograd
+// would add them in a separate launch): dy + dy2, the same fp32 add, on load
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
 // element e (0 .. B*HW) of channel c lives at ((b*C + c)*HW + p), b = e / HW, p = e % HW; VEC = 4 walks float4s (HW % 4 == 0)
 template <int NT, int VEC, class F>
 __device__ __forceinline__ void for_channel(const BnShape s, int c, F f) {
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(NT) void bn_fwd_kernel(const float *__restrict__ x,
 // backward.  dz = RELU ? dy * (y > 0) : dy  (threshold_backward); dres = dz (the residual branch's gradient);
 // training: dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat));  eval: dx = gamma*invstd_running * dz.
 template <int NT, int VEC, bool RELU>
-__global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
+__global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
+                                                    const float *__restrict__ x,
                                                     const float *__restrict__ gamma, const float *__restrict__ save_mean,
                                                     const float *__restrict__ save_invstd, const float *__restrict__ running_mean,
                                                     const float *__restrict__ running_var, float eps, int training, float *__restrict__ dx,
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy
     for_channel<NT, VEC>(s, c, [&](size_t o) {
         if (VEC == 4) {
             float4 g = *reinterpret_cast<const float4 *>(dy + o);
+            if (dy2) g = add4(g, *reinterpret_cast<const float4 *>(dy2 + o));
             if (RELU) {
                 const float4 yy = *reinterpret_cast<const float4 *>(y + o);
                 g.x = yy.x > 0.0f ? g.x : 0.0f;
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy
             sdz += (g.x + g.y) + (g.z + g.w);
             sdzx += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) + (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
         } else {
-            float g = dy[o];
+            float g = dy2 ? dy[o] + dy2[o] : dy[o];
             if (RELU) g = y[o] > 0.0f ? g : 0.0f;
             sdz += g;
             sdzx += g * ((x[o] - mean) * invstd);
@@ -166,6 +172,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy
     for_channel<NT, VEC>(s, c, [&](size_t o) {
         if (VEC == 4) {
             float4 g = *reinterpret_cast<const float4 *>(dy + o);
+            if (dy2) g = add4(g, *reinterpret_cast<const float4 *>(dy2 + o));
             if (RELU) {
                 const float4 yy = *reinterpret_cast<const float4 *>(y + o);
                 g.x = yy.x > 0.0f ? g.x : 0.0f;
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy
                 *reinterpret_cast<float4 *>(dx + o) = r;
             }
         } else {
-            float g = dy[o];
+            float g = dy2 ? dy[o] + dy2[o] : dy[o];
             if (RELU) g = y[o] > 0.0f ? g : 0.0f;
             if (dres) dres[o] = g;
             if (dx) dx[o] = w * ((g - m1) - ((x[o] - mean) * invstd) * m2);
@@ -272,7 +279,8 @@ __global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restri
 }
 
 template <int NT, int MAXV, bool RELU>
-__global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
+__global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
+                                                           const float *__restrict__ x,
                                                            const float *__restrict__ gamma, const float *__restrict__ save_mean,
                                                            const float *__restrict__ save_invstd, const float *__restrict__ running_mean,
                                                            const float *__restrict__ running_var, float eps, int training,
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
     const float mean = training ? save_mean[c] : running_mean[c];
     const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
     const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
+    const float4 *dy24 = reinterpret_cast<const float4 *>(dy2);
     float4 gv[MAXV], hv[MAXV];  // masked gradient dz and xhat
     unsigned off[MAXV];
     float sdz = 0.0f, sdzx = 0.0f;
@@ -299,6 +308,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
         gv[j] = dy4[off[j]];
         hv[j] = x4[off[j]];
         if (RELU) yv[j] = y4[off[j]];
+    }
+    if (dy24) {
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) gv[j] = add4(gv[j], dy24[off[j]]);
     }
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
@@ -353,14 +366,14 @@ void launch_fwd_cached(bool relu, bool has_res, hipStream_t st, const float *x, 
 }
 
 template <int NT, int MAXV>
-void launch_bwd_cached(bool relu, hipStream_t st, const float *dy, const float *y, const float *x, const float *gamma, const float *sm,
+void launch_bwd_cached(bool relu, hipStream_t st, const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *sm,
                        const float *si, const float *rm, const float *rv, float eps, int training, float *dx, float *dres, float *dgamma,
                        float *dbeta, BnShape s) {
     const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
     if (relu)
-        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, true>), grid, block, 0, st, dy, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, true>), grid, block, 0, st, dy, dy2, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
     else
-        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, false>), grid, block, 0, st, dy, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, false>), grid, block, 0, st, dy, dy2, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
 }
 
 // which cached variant holds a channel of `quads` float4s: 0 = none
@@ -418,6 +431,28 @@ __device__ __forceinline__ void for_slice(const BnShape s, int c, Slice sl, L lo
     }
 }
 
+// Chan's recombination of the S per-slice (sum, M2) partials of bn_split_stats_kernel, in slice order (as bn_split_apply_kernel).
+// The partials come through LDS in ONE parallel load: a loop of dependent global loads (S up to 64) cost 10 us per workgroup.
+__device__ __forceinline__ void combine_slices(const float *__restrict__ ws, int c, int S, int total, float n, float *sh, float &mean, float &var) {
+    for (int i = threadIdx.x; i < 2 * S; i += SPLIT_NT) sh[i] = ws[static_cast<size_t>(c) * S * 2 + i];
+    __syncthreads();
+    float sum = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < S; ++i) sum += sh[2 * i];
+    mean = sum / n;
+    float m2 = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < S; ++i) {
+        const Slice sl = my_slice(total, S, i);
+        const float cnt = 4.0f * static_cast<float>(sl.end - sl.begin);
+        if (cnt > 0.0f) {
+            const float d = sh[2 * i] / cnt - mean;
+            m2 += sh[2 * i + 1] + cnt * (d * d);
+        }
+    }
+    var = m2 / n;
+}
+
 // ws[(c*S + s)*2 + {0,1}] = (sum, M2 about the slice's own mean)
 __global__ __launch_bounds__(SPLIT_NT) void bn_split_stats_kernel(const float *__restrict__ x, float *__restrict__ ws, BnShape s, int S) {
     __shared__ float scratch[SPLIT_NT / 64];
@@ -451,20 +486,10 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_apply_kernel(const float *_
     const int total = s.B * (s.HW / 4);
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
     float mean, invstd;
-    if (training) {  // every lane recombines the S partials itself, in slice order: no LDS, identical in all workgroups
-        float sum = 0.0f;
-        for (int i = 0; i < S; ++i) sum += ws[(static_cast<size_t>(c) * S + i) * 2];
-        mean = sum / n;
-        float m2 = 0.0f;
-        for (int i = 0; i < S; ++i) {
-            const Slice sl = my_slice(total, S, i);
-            const float cnt = 4.0f * static_cast<float>(sl.end - sl.begin);
-            if (cnt > 0.0f) {
-                const float d = ws[(static_cast<size_t>(c) * S + i) * 2] / cnt - mean;
-                m2 += ws[(static_cast<size_t>(c) * S + i) * 2 + 1] + cnt * (d * d);
-            }
-        }
-        const float var = m2 / n;
+    if (training) {  // every lane recombines the S partials itself, in slice order: identical in all workgroups
+        __shared__ float parts[2 * SPLIT_MAX];
+        float var;
+        combine_slices(ws, c, S, total, n, parts, mean, var);
         invstd = 1.0f / sqrtf(var + eps);
         if (sl_i == 0 && threadIdx.x == 0) {
             save_mean[c] = mean;
@@ -503,9 +528,9 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_apply_kernel(const float *_
 struct BwdIn {
     float4 dy, y, x;
 };
-__device__ __forceinline__ BwdIn bwd_load(const float4 *dy4, const float4 *y4, const float4 *x4, size_t o, bool relu, bool want_x) {
+__device__ __forceinline__ BwdIn bwd_load(const float4 *dy4, const float4 *dy24, const float4 *y4, const float4 *x4, size_t o, bool relu, bool want_x) {
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    return BwdIn{dy4[o], relu ? y4[o] : z, want_x ? x4[o] : z};
+    return BwdIn{dy24 ? add4(dy4[o], dy24[o]) : dy4[o], relu ? y4[o] : z, want_x ? x4[o] : z};
 }
 __device__ __forceinline__ float4 masked_dz(const BwdIn &in, bool relu) {
     float4 g = in.dy;
@@ -520,7 +545,7 @@ __device__ __forceinline__ float4 masked_dz(const BwdIn &in, bool relu) {
 
 // ws[(c*S + s)*2 + {0,1}] = (sum dz, sum dz*xhat) of the slice
 template <bool RELU>
-__global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+__global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
                                                                         const float *__restrict__ x, const float *__restrict__ save_mean,
                                                                         const float *__restrict__ save_invstd,
                                                                         const float *__restrict__ running_mean,
@@ -532,7 +557,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const fl
     const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
     const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
     float sdz = 0.0f, sdzx = 0.0f;
-    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, y4, x4, o, RELU, true); }, [&](BwdIn in, size_t) {
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, reinterpret_cast<const float4 *>(dy2), y4, x4, o, RELU, true); }, [&](BwdIn in, size_t) {
         const float4 g = masked_dz(in, RELU);
         const float4 v = in.x;
         sdz += (g.x + g.y) + (g.z + g.w);
@@ -547,7 +572,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const fl
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+__global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
                                                                       const float *__restrict__ x, const float *__restrict__ gamma,
                                                                       const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
                                                                       const float *__restrict__ running_mean,
@@ -558,10 +583,14 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const floa
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
     const float mean = training ? save_mean[c] : running_mean[c];
     const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
+    __shared__ float parts[2 * SPLIT_MAX];
+    for (int i = threadIdx.x; i < 2 * S; i += SPLIT_NT) parts[i] = ws[static_cast<size_t>(c) * S * 2 + i];
+    __syncthreads();
     float sdz = 0.0f, sdzx = 0.0f;
+#pragma unroll 4
     for (int i = 0; i < S; ++i) {
-        sdz += ws[(static_cast<size_t>(c) * S + i) * 2];
-        sdzx += ws[(static_cast<size_t>(c) * S + i) * 2 + 1];
+        sdz += parts[2 * i];
+        sdzx += parts[2 * i + 1];
     }
     if (sl_i == 0 && threadIdx.x == 0) {
         if (dgamma) dgamma[c] = sdzx;
@@ -573,7 +602,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const floa
     const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
     float4 *dx4 = reinterpret_cast<float4 *>(dx), *dr4 = reinterpret_cast<float4 *>(dres);
     const bool want_x = dx != nullptr;
-    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, y4, x4, o, RELU, want_x); }, [&](BwdIn in, size_t o) {
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, reinterpret_cast<const float4 *>(dy2), y4, x4, o, RELU, want_x); }, [&](BwdIn in, size_t o) {
         const float4 g = masked_dz(in, RELU);
         if (dres) dr4[o] = g;
         if (dx) {
@@ -597,36 +626,20 @@ struct PoolShape {
     int B, C, H, W, OH, OW, IPW, G;  // IPW images per workgroup, G = ceil(B / IPW) groups
 };
 
-// Chan's recombination of the S per-slice (sum, M2) partials of bn_split_stats_kernel, in slice order (as bn_split_apply_kernel)
-__device__ __forceinline__ void combine_slices(const float *__restrict__ ws, int c, int S, int total, float n, float &mean, float &var) {
-    float sum = 0.0f;
-    for (int i = 0; i < S; ++i) sum += ws[(static_cast<size_t>(c) * S + i) * 2];
-    mean = sum / n;
-    float m2 = 0.0f;
-    for (int i = 0; i < S; ++i) {
-        const Slice sl = my_slice(total, S, i);
-        const float cnt = 4.0f * static_cast<float>(sl.end - sl.begin);
-        if (cnt > 0.0f) {
-            const float d = ws[(static_cast<size_t>(c) * S + i) * 2] / cnt - mean;
-            m2 += ws[(static_cast<size_t>(c) * S + i) * 2 + 1] + cnt * (d * d);
-        }
-    }
-    var = m2 / n;
-}
-
 __global__ __launch_bounds__(SPLIT_NT) void bn_pool_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                                const float *__restrict__ beta, float *running_mean, float *running_var,
                                                                float momentum, float eps, int training, float *__restrict__ yp,
                                                                uint8_t *__restrict__ code, float *__restrict__ save_mean,
                                                                float *__restrict__ save_invstd, const float *__restrict__ ws, PoolShape p, int S) {
     extern __shared__ __align__(16) float plane[];  // y = relu(bn(x)) of one image plane
+    __shared__ float parts[2 * SPLIT_MAX];
     const int c = blockIdx.x, g = blockIdx.y;
     const int HW = p.H * p.W, HWq = HW / 4, OHW = p.OH * p.OW;
     const float n = static_cast<float>(p.B) * static_cast<float>(HW);
     float mean, invstd;
     if (training) {
         float var;
-        combine_slices(ws, c, S, p.B * HWq, n, mean, var);
+        combine_slices(ws, c, S, p.B * HWq, n, parts, mean, var);
         invstd = 1.0f / sqrtf(var + eps);
         if (g == 0 && threadIdx.x == 0) {
             save_mean[c] = mean;
@@ -676,7 +689,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_pool_fwd_kernel(const float *__re
 
 // pass 1 (APPLY = false): ws[(c*G + g)*2 + {0,1}] = (sum dz, sum dz*xhat) of the group's images; pass 2 (APPLY = true): dx
 template <bool APPLY>
-__global__ __launch_bounds__(SPLIT_NT) void bn_pool_bwd_kernel(const float *__restrict__ dyp, const uint8_t *__restrict__ code,
+__global__ __launch_bounds__(SPLIT_NT) void bn_pool_bwd_kernel(const float *__restrict__ dyp, const float *__restrict__ dyp2, const uint8_t *__restrict__ code,
                                                                const float *__restrict__ x, const float *__restrict__ gamma,
                                                                const float *__restrict__ beta, const float *__restrict__ save_mean,
                                                                const float *__restrict__ save_invstd, const float *__restrict__ running_mean,
@@ -694,10 +707,14 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_pool_bwd_kernel(const float *__re
     const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
     float m1 = 0.0f, m2 = 0.0f;
     if (APPLY) {
+        __shared__ float parts[2 * SPLIT_MAX];  // the G partial sums, one parallel load (a loop of dependent global loads cost 8 us)
+        for (int i = threadIdx.x; i < 2 * p.G; i += SPLIT_NT) parts[i] = ws[static_cast<size_t>(c) * p.G * 2 + i];
+        __syncthreads();
         float sdz = 0.0f, sdzx = 0.0f;
+#pragma unroll 4
         for (int i = 0; i < p.G; ++i) {
-            sdz += ws[(static_cast<size_t>(c) * p.G + i) * 2];
-            sdzx += ws[(static_cast<size_t>(c) * p.G + i) * 2 + 1];
+            sdz += parts[2 * i];
+            sdzx += parts[2 * i + 1];
         }
         if (g == 0 && threadIdx.x == 0) {
             if (dgamma) dgamma[c] = sdzx;
@@ -713,7 +730,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_pool_bwd_kernel(const float *__re
     for (int b = g * p.IPW; b < b_end; ++b) {
         const size_t pl = static_cast<size_t>(b) * p.C + c;
         for (int o = threadIdx.x; o < OHW; o += SPLIT_NT) {
-            gp[o] = dyp[pl * OHW + o];
+            gp[o] = dyp2 ? dyp[pl * OHW + o] + dyp2[pl * OHW + o] : dyp[pl * OHW + o];
             cd[o] = code[pl * OHW + o];
         }
         __syncthreads();
@@ -797,13 +814,13 @@ void launch_fwd(bool relu, bool has_res, hipStream_t st, const float *x, const f
 }
 
 template <int NT, int VEC>
-void launch_bwd(bool relu, hipStream_t st, const float *dy, const float *y, const float *x, const float *gamma, const float *sm, const float *si,
+void launch_bwd(bool relu, hipStream_t st, const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *sm, const float *si,
                 const float *rm, const float *rv, float eps, int training, float *dx, float *dres, float *dgamma, float *dbeta, BnShape s) {
     const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
     if (relu)
-        EE_LAUNCH((bn_bwd_kernel<NT, VEC, true>), grid, block, 0, st, dy, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+        EE_LAUNCH((bn_bwd_kernel<NT, VEC, true>), grid, block, 0, st, dy, dy2, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
     else
-        EE_LAUNCH((bn_bwd_kernel<NT, VEC, false>), grid, block, 0, st, dy, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+        EE_LAUNCH((bn_bwd_kernel<NT, VEC, false>), grid, block, 0, st, dy, dy2, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
 }
 
 inline bool al16(const void *q) { return !q || aligned16(q); }
@@ -854,7 +871,7 @@ EE_API int ee_bn_act_fwd_f32(const float *x, const float *residual, const float 
     return launch_status();
 }
 
-EE_API int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
+EE_API int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *save_mean,
                              const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training, int relu,
                              float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW, void *stream) {
     if (B < 0 || C < 1 || HW < 1) return EE_ERR_SHAPE;
@@ -864,28 +881,35 @@ EE_API int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, co
     if (training && (!save_mean || !save_invstd)) return EE_ERR_NULL;
     if (!training && (!running_mean || !running_var)) return EE_ERR_NULL;
     const BnShape s{B, C, HW};
-    const bool vec = (HW % 4 == 0) && al16(dy) && al16(y) && al16(x) && al16(dx) && al16(dresidual);
+    const bool vec = (HW % 4 == 0) && al16(dy) && al16(dy2) && al16(y) && al16(x) && al16(dx) && al16(dresidual);
     const bool big = static_cast<int64_t>(B) * HW >= 16384;
     hipStream_t st = as_stream(stream);
     const int cv = vec ? cached_variant(static_cast<int64_t>(B) * (HW / 4), static_cast<int64_t>(B) * C * HW) : 0;
-    if (cv == 1) launch_bwd_cached<256, 2>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else if (cv == 2) launch_bwd_cached<256, 7>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else if (cv == 3) launch_bwd_cached<1024, 7>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    if (cv == 1) launch_bwd_cached<256, 2>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (cv == 2) launch_bwd_cached<256, 7>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (cv == 3) launch_bwd_cached<1024, 7>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     else if (vec && workspace && static_cast<int64_t>(B) * C * HW / 4 <= 0x7fffffffLL) {
         const int S = split_slices(static_cast<int64_t>(B) * (HW / 4));
         const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(S)), block(SPLIT_NT);
         if (relu) {
-            EE_LAUNCH((bn_split_bwd_partial_kernel<true>), grid, block, 0, st, dy, y, x, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
-            EE_LAUNCH((bn_split_bwd_apply_kernel<true>), grid, block, 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_partial_kernel<true>), grid, block, 0, st, dy, dy2, y, x, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_apply_kernel<true>), grid, block, 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
         } else {
-            EE_LAUNCH((bn_split_bwd_partial_kernel<false>), grid, block, 0, st, dy, y, x, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
-            EE_LAUNCH((bn_split_bwd_apply_kernel<false>), grid, block, 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_partial_kernel<false>), grid, block, 0, st, dy, dy2, y, x, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_apply_kernel<false>), grid, block, 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
         }
-    } else if (vec && big) launch_bwd<1024, 4>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else if (vec) launch_bwd<256, 4>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else if (big) launch_bwd<1024, 1>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else launch_bwd<256, 1>(relu != 0, st, dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    } else if (vec && big) launch_bwd<1024, 4>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (vec) launch_bwd<256, 4>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (big) launch_bwd<1024, 1>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else launch_bwd<256, 1>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     return launch_status();
+}
+
+EE_API int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
+                             const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training, int relu,
+                             float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW, void *stream) {
+    return ee_bn_act_bwd2_f32(dy, nullptr, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, relu, dx, dresidual, dgamma,
+                              dbeta, workspace, B, C, HW, stream);
 }
 
 // floats of workspace ee_bn_relu_pool_fwd/bwd_f32 want (statistics partials forward, gradient-sum partials backward); 0 = unsupported shape
@@ -915,7 +939,7 @@ EE_API int ee_bn_relu_pool_fwd_f32(const float *x, const float *gamma, const flo
     return launch_status();
 }
 
-EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const uint8_t *code, const float *x, const float *gamma, const float *beta,
+EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *gamma, const float *beta,
                                    const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
                                    float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
                                    int W, void *stream) {
@@ -930,9 +954,9 @@ EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const uint8_t *code, co
     hipStream_t st = as_stream(stream);
     const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(p.G)), block(SPLIT_NT);
     const size_t lds = (static_cast<size_t>(p.OH) * p.OW * 5 + 15) / 16 * 16;  // floats + bytes
-    EE_LAUNCH((bn_pool_bwd_kernel<false>), grid, block, lds, st, dy_pool, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
+    EE_LAUNCH((bn_pool_bwd_kernel<false>), grid, block, lds, st, dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
               training, dx, dgamma, dbeta, workspace, p);
-    EE_LAUNCH((bn_pool_bwd_kernel<true>), grid, block, lds, st, dy_pool, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
+    EE_LAUNCH((bn_pool_bwd_kernel<true>), grid, block, lds, st, dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
               training, dx, dgamma, dbeta, workspace, p);
     return launch_status();
 }

@@ -135,32 +135,48 @@ class AddSquareFn(torch.autograd.Function):
         return ops.add_square_bwd(g.contiguous(), x, ctx.eps, stripe, sq_sign, sq_pos, sq_size), None, None, None, None, None
 
 
+def _two_pieces(grads):
+    """(dy, dy2) of a forked output: either piece may be missing (its consumer needed no gradient)."""
+    g = [t.contiguous() for t in grads if t is not None]
+    return (g[0] if g else None), (g[1] if len(g) > 1 else None)
+
+
 class BnActFn(torch.autograd.Function):
-    """[relu]( batch_norm(x) [+ residual] ) in one launch each way (resnet.py:44-59 / :90-110; ee_bn.hip)."""
+    """[relu]( batch_norm(x) [+ residual] ) in one launch each way (resnet.py:44-59 / :90-110; ee_bn.hip).  `fork=True` returns the
+    output TWICE (two tensors over one buffer): a residual block's output feeds the next block's convolution and its identity branch,
+    autograd then hands the two gradients over separately and the backward kernel adds them on load - otherwise the engine sums them in
+    a launch of its own (8 per ResNet-18 pass)."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu, fork=False):
         y, sm, si = ops.bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu)
         ctx.save_for_backward(x, y if relu else None, gamma, sm, si, None if training else running_mean, None if training else running_var)
         ctx.cfg = (eps, training, relu, residual is not None)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, y.view_as(y)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *grads):
         x, y, gamma, sm, si, rm, rv = ctx.saved_tensors
         eps, training, relu, has_res = ctx.cfg
         want = list(ctx.needs_input_grad)
         if _INPUT_GRAD_ONLY:
             want[2] = want[3] = False
-        dy = dy.contiguous()
+        none = (None,) * 11
+        dy, dy2 = _two_pieces(grads)
+        if dy is None:
+            return none
         if not relu and not want[0] and not want[2] and not want[3]:
-            return None, (dy if has_res and want[1] else None), None, None, None, None, None, None, None, None
-        want_dres = has_res and want[1] and relu  # without the ReLU the residual's gradient IS dy: no copy needed
+            dres = None
+            if has_res and want[1]:
+                dres = dy if dy2 is None else dy + dy2
+            return (None, dres) + none[2:]
+        want_dres = has_res and want[1] and (relu or dy2 is not None)  # without the ReLU (and in one piece) the residual's gradient IS dy: no copy needed
         dx, dres, dg, db = ops.bn_act_bwd(dy, y, x, gamma, sm, si, rm, rv, eps, training, relu, want[0], want_dres,
-                                          want[2] or want[3])
-        if has_res and want[1] and not relu:
+                                          want[2] or want[3], dy2)
+        if has_res and want[1] and not want_dres:
             dres = dy
-        return dx, dres, (dg if want[2] else None), (db if want[3] else None), None, None, None, None, None, None
+        return (dx, dres, (dg if want[2] else None), (db if want[3] else None)) + none[4:]
 
 
 class BnReluPoolFn(torch.autograd.Function):
@@ -168,21 +184,23 @@ class BnReluPoolFn(torch.autograd.Function):
     gradient never exist (ee_bn.hip: bn_pool_*)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, fork=False):
         y, code, sm, si = ops.bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training)
         ctx.save_for_backward(x, code, gamma, beta, sm, si, None if training else running_mean, None if training else running_var)
         ctx.cfg = (eps, training)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, y.view_as(y)) if fork else y  # fork: see BnActFn
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *grads):
         x, code, gamma, beta, sm, si, rm, rv = ctx.saved_tensors
         eps, training = ctx.cfg
         want_params = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY
-        if not ctx.needs_input_grad[0] and not want_params:
-            return (None,) * 8
-        dx, dg, db = ops.bn_relu_pool_bwd(dy.contiguous(), code, x, gamma, beta, sm, si, rm, rv, eps, training, ctx.needs_input_grad[0], want_params)
-        return dx, (dg if ctx.needs_input_grad[1] and want_params else None), (db if ctx.needs_input_grad[2] and want_params else None), None, None, None, None, None
+        dy, dy2 = _two_pieces(grads)
+        if dy is None or (not ctx.needs_input_grad[0] and not want_params):
+            return (None,) * 9
+        dx, dg, db = ops.bn_relu_pool_bwd(dy, code, x, gamma, beta, sm, si, rm, rv, eps, training, ctx.needs_input_grad[0], want_params, dy2)
+        return (dx, (dg if ctx.needs_input_grad[1] and want_params else None), (db if ctx.needs_input_grad[2] and want_params else None)) + (None,) * 6
 
 
 class MaxPool3s2Fn(torch.autograd.Function):

@@ -40,18 +40,28 @@ class BatchNorm2d(nn.BatchNorm2d):
                             0.0 if self.momentum is None else self.momentum, self.eps)
 
 
-def bn_act(bn, x, residual=None, relu=True):
+def bn_act(bn, x, residual=None, relu=True, fork=False):
     """[relu]( bn(x) [+ residual] ): ONE HIP launch each way (ee_bn.hip) for our BatchNorm2d on dense NCHW fp32 ROCm
     tensors; the stock three-op sequence for anything else (SyncBatchNorm after convert_sync_batchnorm, channels_last,
-    CPU plumbing in the host tests)."""
+    CPU plumbing in the host tests).  fork=True: the fused path returns the output as a PAIR of tensors over one buffer, one per
+    consumer (functional.BnActFn); the stock path returns the plain tensor - callers take both (`_pair`)."""
     if ("bn" not in _STOCK and type(bn) is BatchNorm2d and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and bn.affine
             and bn.track_running_stats and (residual is None or (residual.is_contiguous() and residual.dtype == torch.float32))):
         return BnActFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                             0.0 if bn.momentum is None else bn.momentum, bn.eps, bn.training, relu)
+                             0.0 if bn.momentum is None else bn.momentum, bn.eps, bn.training, relu, fork and _FORK)
     out = bn(x)
     if residual is not None:
         out = out + residual
     return F.relu(out) if relu else out
+
+
+def _pair(x):
+    """(for the main branch, for the identity branch) of a block input: the two tensors of a forked output, or the tensor twice"""
+    return x if isinstance(x, tuple) else (x, x)
+
+
+# EEADV_FORK=0: block outputs as ONE tensor again (autograd adds the two consumers' gradients in a launch of its own): A/B switch
+_FORK = os.environ.get("EEADV_FORK", "1") == "1"
 
 
 # EEADV_STOCK_GLUE=bn,pool,head,conv,stem,dense,conv3 (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
@@ -76,14 +86,14 @@ def _dense_f32(x):
     return x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
 
 
-def stem_bn_pool(bn, pool, x):
+def stem_bn_pool(bn, pool, x, fork=False):
     """maxpool(relu(bn1(x))) of the ResNet stem (resnet.py:113-117): one fused pass each way when the shapes allow (ee_bn.hip, bn_pool_*),
     the two separate kernels - or the stock modules - otherwise."""
     if ("bn" not in _STOCK and "pool" not in _STOCK and "bnpool" not in _STOCK and type(bn) is BatchNorm2d and type(pool) is nn.MaxPool2d
             and _dense_f32(x) and bn.affine and bn.track_running_stats and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1
             and pool.dilation == 1 and not pool.ceil_mode and not pool.return_indices and ops.bn_relu_pool_supported(x)):
         return BnReluPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.0 if bn.momentum is None else bn.momentum, bn.eps,
-                                  bn.training)
+                                  bn.training, fork and _FORK)
     return stem_pool(pool, bn_act(bn, x))
 
 
@@ -334,9 +344,11 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out = bn_act(self.bn1, conv3(self.conv1, x))
-        return bn_act(self.bn2, conv3(self.conv2, out), shortcut(self, x))
+    def forward(self, x, fork=False):
+        """x: a tensor, or the two tensors of the previous block's forked output; fork: hand this block's output on the same way"""
+        xm, xs = _pair(x)
+        out = bn_act(self.bn1, conv3(self.conv1, xm))
+        return bn_act(self.bn2, conv3(self.conv2, out), shortcut(self, xs), fork=fork)
 
 
 class Bottleneck(nn.Module):
@@ -354,10 +366,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out = bn_act(self.bn1, self.conv1(x))
+    def forward(self, x, fork=False):
+        xm, xs = _pair(x)
+        out = bn_act(self.bn1, self.conv1(xm))
         out = bn_act(self.bn2, conv3(self.conv2, out))
-        return bn_act(self.bn3, self.conv3(out), shortcut(self, x))
+        return bn_act(self.bn3, self.conv3(out), shortcut(self, xs), fork=fork)
 
 
 class ResNet(nn.Module):
@@ -403,8 +416,11 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def body(self, x):
-        x = stem_bn_pool(self.bn1, self.maxpool, stem_conv(self.conv1, x))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        # every block output but the last feeds two consumers (the next block's convolution and its identity branch): forked outputs
+        x = stem_bn_pool(self.bn1, self.maxpool, stem_conv(self.conv1, x), fork=True)
+        blocks = [blk for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for blk in layer]
+        for i, blk in enumerate(blocks):
+            x = blk(x, fork=i + 1 < len(blocks))
         _bump_bn_counters(self)
         return head(self.avgpool, self.fc, x)
 

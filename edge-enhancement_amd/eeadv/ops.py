@@ -552,8 +552,9 @@ def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, ep
 
 
 def bn_act_bwd(dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, relu, want_dx=True,
-               want_dres=False, want_dparams=True):
-    """Backward of bn_act_fwd: returns (dx, dresidual, dgamma, dbeta), None where not wanted."""
+               want_dres=False, want_dparams=True, dy2=None):
+    """Backward of bn_act_fwd: returns (dx, dresidual, dgamma, dbeta), None where not wanted.  `dy2`: a second piece of the incoming
+    gradient (the output fed two consumers), added to dy on load."""
     B, C = x.shape[0], x.shape[1]
     HW = x[0, 0].numel() if B else 1
     pdy = _chk(dy, torch.float32, "dy", x.shape)
@@ -565,10 +566,11 @@ def bn_act_bwd(dy, y, x, gamma, save_mean, save_invstd, running_mean, running_va
     dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
     db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
     ptr = lambda t: None if t is None else t.data_ptr()
-    N.check(N.lib.ee_bn_act_bwd_f32(pdy, py, px, pg, ptr(save_mean), ptr(save_invstd), ptr(running_mean), ptr(running_var), float(eps),
-                                    1 if training else 0, 1 if relu else 0, ptr(dx), ptr(dres), ptr(dg), ptr(db),
-                                    _bn_workspace(x, B, C, HW), B, C, HW, _stream()),
-            "ee_bn_act_bwd_f32")
+    pdy2 = None if dy2 is None else _chk(dy2, torch.float32, "dy2", x.shape)
+    N.check(N.lib.ee_bn_act_bwd2_f32(pdy, pdy2, py, px, pg, ptr(save_mean), ptr(save_invstd), ptr(running_mean), ptr(running_var), float(eps),
+                                     1 if training else 0, 1 if relu else 0, ptr(dx), ptr(dres), ptr(dg), ptr(db),
+                                     _bn_workspace(x, B, C, HW), B, C, HW, _stream()),
+            "ee_bn_act_bwd2_f32")
     return dx, dres, dg, db
 
 
@@ -601,15 +603,16 @@ def bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, t
 
 
 def bn_relu_pool_bwd(dy_pool, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, training, want_dx=True,
-                     want_dparams=True):
-    """Backward of bn_relu_pool_fwd: (dx, dgamma, dbeta), None where not wanted."""
+                     want_dparams=True, dy_pool2=None):
+    """Backward of bn_relu_pool_fwd: (dx, dgamma, dbeta), None where not wanted; `dy_pool2` = a second piece of the gradient."""
     B, C, H, W = x.shape
     dx = torch.empty_like(x) if want_dx else None
     dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
     db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
     ptr = lambda t: None if t is None else t.data_ptr()
     ws = _pool_workspace(x)
-    N.check(N.lib.ee_bn_relu_pool_bwd_f32(_chk(dy_pool, torch.float32, "dy_pool", code.shape), _chk(code, torch.uint8, "code"),
+    p2 = None if dy_pool2 is None else _chk(dy_pool2, torch.float32, "dy_pool2", code.shape)
+    N.check(N.lib.ee_bn_relu_pool_bwd_f32(_chk(dy_pool, torch.float32, "dy_pool", code.shape), p2, _chk(code, torch.uint8, "code"),
                                           _chk(x, torch.float32, "x"), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(running_mean),
                                           ptr(running_var), float(eps), 1 if training else 0, ptr(dx), ptr(dg), ptr(db), ws.data_ptr(),
                                           B, C, H, W, _stream()), "ee_bn_relu_pool_bwd_f32")

@@ -271,10 +271,18 @@ int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const flo
                       const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training,
                       int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW,
                       void *stream);
+/* the same with the incoming gradient in two pieces, dy + dy2 (dy2 nullable): a residual block's output feeds the next block's
+ * convolution and its identity branch (resnet.py:44-59), and the two gradients are added here, on load, instead of in a launch of
+ * their own */
+int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *save_mean,
+                       const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training,
+                       int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW,
+                       void *stream);
 
 /* relu(batch_norm(x)) followed by MaxPool2d(3, stride 2, padding 1) - the ResNet stem (resnet.py:113-117 / :148-150) - without
  * the full-resolution activation: forward x [B,C,H,W] -> y_pool [B,C,OH,OW] + one-byte argmax codes (OH = (H-1)/2+1); backward
- * dy_pool + codes + x -> dx [B,C,H,W] (nullable), dgamma, dbeta [C] (nullable).  Values, codes and the pooled-gradient gather equal
+ * dy_pool (+ dy_pool2, nullable: the second piece of the gradient, see ee_bn_act_bwd2_f32) + codes + x -> dx [B,C,H,W] (nullable),
+ * dgamma, dbeta [C] (nullable).  Values, codes and the pooled-gradient gather equal
  * ee_bn_act_fwd_f32(relu=1) -> ee_maxpool3s2_fwd_f32 and their backwards bit for bit; the gradient sums run over a different
  * partition (dgamma / dbeta / dx agree to rounding).  W % 4 == 0, H*W <= 16000 (else EE_ERR_UNSUPPORTED: use the two calls);
  * workspace: ee_bn_relu_pool_workspace_floats(B, C, H, W) floats (0 = unsupported shape). */
@@ -282,7 +290,7 @@ int ee_bn_relu_pool_workspace_floats(int B, int C, int H, int W);
 int ee_bn_relu_pool_fwd_f32(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
                             float momentum, float eps, int training, float *y_pool, uint8_t *code, float *save_mean,
                             float *save_invstd, float *workspace, int B, int C, int H, int W, void *stream);
-int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const uint8_t *code, const float *x, const float *gamma, const float *beta,
+int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *gamma, const float *beta,
                             const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
                             float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
                             int W, void *stream);

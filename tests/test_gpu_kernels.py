@@ -441,6 +441,35 @@ def test_bn_act_matches_torch(ops, shape, relu, res, training):
         torch.testing.assert_close(a, e, rtol=2e-5, atol=tol, msg=lambda m: nm + ": " + m)
 
 
+@pytest.mark.parametrize("shape", [(100, 64, 16, 16), (100, 128, 8, 8), (100, 256, 4, 4), (100, 64, 32, 32), (7, 5, 3, 3), (3, 4, 1, 1)])
+@pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, True)])
+def test_bn_act_forked_output_adds_the_two_gradients_on_load(ops, shape, relu, res):
+    """BnActFn(fork=True) hands its output out twice (next block's convolution + identity branch, resnet.py:44-59); the two gradients
+    reach the backward kernel separately and are added on load (every kernel variant: cached <256,2> / <256,7> / <1024,7>, split, generic):
+    bit-identical to the unforked function fed with their sum (the same fp32 add autograd's own accumulation performs)."""
+    from eeadv.functional import BnActFn
+    g = torch.Generator(device="cpu").manual_seed(sum(shape) + relu + 2 * res)
+    C = shape[1]
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).to(DEV).requires_grad_(True)
+    r = torch.randn(shape, generator=g).to(DEV).requires_grad_(True) if res else None
+    w = (torch.rand(C, generator=g) + 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+    d1, d2 = torch.randn(shape, generator=g).to(DEV), torch.randn(shape, generator=g).to(DEV)
+    ins = [x, w, b] + ([r] if res else [])
+    stats = lambda: (torch.zeros(C, device=DEV), torch.ones(C, device=DEV))
+    one = BnActFn.apply(x, r, w, b, *stats(), 0.1, 1e-5, True, relu)
+    ref = torch.autograd.grad(one, ins, d1 + d2)
+    ya, yb = BnActFn.apply(x, r, w, b, *stats(), 0.1, 1e-5, True, relu, True)
+    assert ya.data_ptr() == yb.data_ptr() and torch.equal(ya, one)
+    got = torch.autograd.grad([ya, yb], ins, [d1, d2])
+    for a, e in zip(got, ref):
+        assert torch.equal(a, e)
+    # one consumer only: the other piece never arrives
+    ya, yb = BnActFn.apply(x, r, w, b, *stats(), 0.1, 1e-5, True, relu, True)
+    for a, e in zip(torch.autograd.grad([yb], ins, [d2]), torch.autograd.grad(BnActFn.apply(x, r, w, b, *stats(), 0.1, 1e-5, True, relu), ins, d2)):
+        assert torch.equal(a, e)
+
+
 def test_bn_act_only_input_grad_and_reproducible(ops):
     """The attack loop differentiates w.r.t. the input only (attacks.py:24): no parameter gradients are produced, and two
     runs give the same bits (fixed-order reductions)."""
@@ -526,6 +555,12 @@ def test_bn_relu_pool_fused_equals_the_two_kernels(ops, shape, training):
     with EF_input_grad_only():
         (gx,) = torch.autograd.grad(BnReluPoolFn.apply(x, w, b, rm0.clone(), rv0.clone(), 0.1, 1e-5, training), [x], dy)
     assert torch.equal(gx, g1[0])
+    # forked output (layer1.0's convolution + its identity branch): the two gradient pieces are added on load
+    ya, yb = BnReluPoolFn.apply(x, w, b, rm0.clone(), rv0.clone(), 0.1, 1e-5, training, True)
+    d2 = torch.randn(two.shape, generator=g).to(DEV)
+    for a, e in zip(torch.autograd.grad([ya, yb], [x, w, b], [dy, d2]),
+                    torch.autograd.grad(BnReluPoolFn.apply(x, w, b, rm0.clone(), rv0.clone(), 0.1, 1e-5, training), [x, w, b], dy + d2)):
+        assert torch.equal(a, e)
     assert not ops.bn_relu_pool_supported(torch.empty(2, 3, 224, 224, device=DEV)) and not ops.bn_relu_pool_supported(torch.empty(2, 3, 8, 6, device=DEV))
 
 
