@@ -16,7 +16,7 @@ os.environ["EEADV_GRAPH"] = "1"
 from eeadv import engine, trainer  # noqa: E402
 
 torch.backends.cudnn.benchmark = True
-cfg = bench.WORKLOADS["tiny_ee_at"] if hasattr(bench, "WORKLOADS") else None
+cfg = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "tiny_ee_at"]
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 model = bench.build_model(cfg).to(dev).train()
