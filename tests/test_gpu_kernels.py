@@ -534,7 +534,7 @@ def test_bn_relu_pool_fused_equals_the_two_kernels(ops, shape, training):
     from eeadv import _native as N
     if not training or N.lib.ee_bn_workspace_floats(B, C, shape[2] * shape[3]) > 0:
         # the unfused BatchNorm takes its statistics the same way (eval mode; or the split kernels, as for the stem at the reference batch)
-        assert torch.equal(one, two) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+        assert torch.equal(torch.nan_to_num(one, nan=-7.0), torch.nan_to_num(two, nan=-7.0)) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
     else:  # it keeps the channel in registers there: same two-pass variance, another summation order
         torch.testing.assert_close(one, two, rtol=1e-6, atol=2e-6)
         torch.testing.assert_close(rm_b, rm_a, rtol=1e-6, atol=1e-7)
@@ -545,23 +545,34 @@ def test_bn_relu_pool_fused_equals_the_two_kernels(ops, shape, training):
     n = B * shape[2] * shape[3]
     scale = max(1.0, float(n) ** 0.5)
     for a, e, nm in zip(g1, g2, ["dx", "dgamma", "dbeta"]):
-        torch.testing.assert_close(a, e, rtol=2e-5, atol=2e-5 * (scale if nm != "dx" else 1.0), msg=lambda m: nm + ": " + m)
+        torch.testing.assert_close(a, e, rtol=2e-5, atol=2e-5 * (scale if nm != "dx" else 1.0), equal_nan=True, msg=lambda m: nm + ": " + m)
     assert torch.equal(g1[0] == 0, g2[0] == 0) or training  # eval mode: dx = a * dz, zero exactly where the ReLU / the pool cut it
     rm_c, rv_c = rm0.clone(), rv0.clone()
     ref = F.max_pool2d(F.relu(F.batch_norm(x, rm_c, rv_c, w, b, training, 0.1, 1e-5)), 3, 2, 1)
-    torch.testing.assert_close(one, ref, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(one, ref, rtol=1e-5, atol=2e-5, equal_nan=True)
     for a, e, nm in zip(g1, torch.autograd.grad(ref, [x, w, b], dy), ["dx", "dgamma", "dbeta"]):
-        torch.testing.assert_close(a, e, rtol=2e-5, atol=2e-5 * (scale if nm != "dx" else 1.0), msg=lambda m: nm + " vs torch: " + m)
+        torch.testing.assert_close(a, e, rtol=2e-5, atol=2e-5 * (scale if nm != "dx" else 1.0), equal_nan=True, msg=lambda m: nm + " vs torch: " + m)
     with EF_input_grad_only():
         (gx,) = torch.autograd.grad(BnReluPoolFn.apply(x, w, b, rm0.clone(), rv0.clone(), 0.1, 1e-5, training), [x], dy)
-    assert torch.equal(gx, g1[0])
+    assert torch.equal(torch.nan_to_num(gx, nan=-7.0), torch.nan_to_num(g1[0], nan=-7.0))
     # forked output (layer1.0's convolution + its identity branch): the two gradient pieces are added on load
     ya, yb = BnReluPoolFn.apply(x, w, b, rm0.clone(), rv0.clone(), 0.1, 1e-5, training, True)
     d2 = torch.randn(two.shape, generator=g).to(DEV)
     for a, e in zip(torch.autograd.grad([ya, yb], [x, w, b], [dy, d2]),
                     torch.autograd.grad(BnReluPoolFn.apply(x, w, b, rm0.clone(), rv0.clone(), 0.1, 1e-5, training), [x, w, b], dy + d2)):
-        assert torch.equal(a, e)
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(e, nan=-7.0))
     assert not ops.bn_relu_pool_supported(torch.empty(2, 3, 224, 224, device=DEV)) and not ops.bn_relu_pool_supported(torch.empty(2, 3, 8, 6, device=DEV))
+    if not training and x.numel() > 50:
+        # eval mode (the statistics do not see x): a NaN wins its pooling windows and gets no gradient through the ReLU, +-inf pass -
+        # exactly as in the two separate kernels
+        xn = x.detach().clone()
+        xn.view(-1)[11], xn.view(-1)[-3], xn.view(-1)[5] = float("nan"), float("inf"), float("-inf")
+        xn.requires_grad_(True)
+        a = BnReluPoolFn.apply(xn, w, b, rm0.clone(), rv0.clone(), 0.1, 1e-5, False)
+        e = MaxPool3s2Fn.apply(BnActFn.apply(xn, None, w, b, rm0.clone(), rv0.clone(), 0.1, 1e-5, False, True))
+        assert bool(torch.isnan(a).any()) and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(e, nan=-7.0))
+        (ga,), (ge,) = torch.autograd.grad(a, [xn], dy), torch.autograd.grad(e, [xn], dy)
+        assert torch.equal(torch.nan_to_num(ga, nan=-7.0), torch.nan_to_num(ge, nan=-7.0))
 
 
 def EF_input_grad_only():
