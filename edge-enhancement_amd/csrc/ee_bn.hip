@@ -43,6 +43,24 @@ struct BnShape {
 // would add them in a separate launch): dy + dy2, the same fp32 add, on load
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// The ReLU mask of the backward is y > 0.  Without a residual branch y = relu((x - mean) * a + b0), so the mask can be recomputed
+// from x - which the backward reads anyway - with the forward's expression (the same bits) instead of reading y (one tensor less:
+// the layer-1 kernels run one workgroup per channel on 64 CUs and are bound by what a CU can pull).  MaskArgs.on selects it.
+struct MaskArgs {
+    int on;
+    float a, b0;  // invstd * gamma, beta
+};
+__device__ __forceinline__ float4 pre4(float4 v, float mean, const MaskArgs &m) {
+    return make_float4((v.x - mean) * m.a + m.b0, (v.y - mean) * m.a + m.b0, (v.z - mean) * m.a + m.b0, (v.w - mean) * m.a + m.b0);
+}
+__device__ __forceinline__ MaskArgs mask_args(const float *y, const float *gamma, const float *beta, float invstd, int c) {
+    MaskArgs m;
+    m.on = y == nullptr;
+    m.a = invstd * (gamma ? gamma[c] : 1.0f);
+    m.b0 = (beta && m.on) ? beta[c] : 0.0f;
+    return m;
+}
+
 // element e (0 .. B*HW) of channel c lives at ((b*C + c)*HW + p), b = e / HW, p = e % HW; VEC = 4 walks float4s (HW % 4 == 0)
 template <int NT, int VEC, class F>
 __device__ __forceinline__ void for_channel(const BnShape s, int c, F f) {
@@ -129,7 +147,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_kernel(const float *__restrict__ x,
 // training: dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat));  eval: dx = gamma*invstd_running * dz.
 template <int NT, int VEC, bool RELU>
 __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
-                                                    const float *__restrict__ x,
+                                                    const float *__restrict__ x, const float *__restrict__ beta,
                                                     const float *__restrict__ gamma, const float *__restrict__ save_mean,
                                                     const float *__restrict__ save_invstd, const float *__restrict__ running_mean,
                                                     const float *__restrict__ running_var, float eps, int training, float *__restrict__ dx,
@@ -139,26 +157,36 @@ __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
     const float mean = training ? save_mean[c] : running_mean[c];
     const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
+    const MaskArgs mk = mask_args(y, gamma, beta, invstd, c);
+    auto masked4 = [&](size_t o, float4 v) {
+        float4 g = *reinterpret_cast<const float4 *>(dy + o);
+        if (dy2) g = add4(g, *reinterpret_cast<const float4 *>(dy2 + o));
+        if (RELU) {
+            const float4 yy = mk.on ? pre4(v, mean, mk) : *reinterpret_cast<const float4 *>(y + o);
+            g.x = yy.x > 0.0f ? g.x : 0.0f;
+            g.y = yy.y > 0.0f ? g.y : 0.0f;
+            g.z = yy.z > 0.0f ? g.z : 0.0f;
+            g.w = yy.w > 0.0f ? g.w : 0.0f;
+        }
+        return g;
+    };
+    auto masked1 = [&](size_t o, float v) {
+        float g = dy2 ? dy[o] + dy2[o] : dy[o];
+        if (RELU) g = (mk.on ? (v - mean) * mk.a + mk.b0 : y[o]) > 0.0f ? g : 0.0f;
+        return g;
+    };
     float sdz = 0.0f, sdzx = 0.0f;
     for_channel<NT, VEC>(s, c, [&](size_t o) {
         if (VEC == 4) {
-            float4 g = *reinterpret_cast<const float4 *>(dy + o);
-            if (dy2) g = add4(g, *reinterpret_cast<const float4 *>(dy2 + o));
-            if (RELU) {
-                const float4 yy = *reinterpret_cast<const float4 *>(y + o);
-                g.x = yy.x > 0.0f ? g.x : 0.0f;
-                g.y = yy.y > 0.0f ? g.y : 0.0f;
-                g.z = yy.z > 0.0f ? g.z : 0.0f;
-                g.w = yy.w > 0.0f ? g.w : 0.0f;
-            }
             const float4 v = *reinterpret_cast<const float4 *>(x + o);
+            const float4 g = masked4(o, v);
             sdz += (g.x + g.y) + (g.z + g.w);
             sdzx += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) + (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
         } else {
-            float g = dy2 ? dy[o] + dy2[o] : dy[o];
-            if (RELU) g = y[o] > 0.0f ? g : 0.0f;
+            const float v = x[o];
+            const float g = masked1(o, v);
             sdz += g;
-            sdzx += g * ((x[o] - mean) * invstd);
+            sdzx += g * ((v - mean) * invstd);
         }
     });
     sdz = block_sum<NT>(sdz, scratch);
@@ -171,18 +199,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy
     const float m1 = training ? sdz / n : 0.0f, m2 = training ? sdzx / n : 0.0f;
     for_channel<NT, VEC>(s, c, [&](size_t o) {
         if (VEC == 4) {
-            float4 g = *reinterpret_cast<const float4 *>(dy + o);
-            if (dy2) g = add4(g, *reinterpret_cast<const float4 *>(dy2 + o));
-            if (RELU) {
-                const float4 yy = *reinterpret_cast<const float4 *>(y + o);
-                g.x = yy.x > 0.0f ? g.x : 0.0f;
-                g.y = yy.y > 0.0f ? g.y : 0.0f;
-                g.z = yy.z > 0.0f ? g.z : 0.0f;
-                g.w = yy.w > 0.0f ? g.w : 0.0f;
-            }
+            const float4 v = *reinterpret_cast<const float4 *>(x + o);
+            const float4 g = masked4(o, v);
             if (dres) *reinterpret_cast<float4 *>(dres + o) = g;
             if (dx) {
-                const float4 v = *reinterpret_cast<const float4 *>(x + o);
                 float4 r;
                 r.x = w * ((g.x - m1) - ((v.x - mean) * invstd) * m2);
                 r.y = w * ((g.y - m1) - ((v.y - mean) * invstd) * m2);
@@ -191,10 +211,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy
                 *reinterpret_cast<float4 *>(dx + o) = r;
             }
         } else {
-            float g = dy2 ? dy[o] + dy2[o] : dy[o];
-            if (RELU) g = y[o] > 0.0f ? g : 0.0f;
+            const float v = x[o];
+            const float g = masked1(o, v);
             if (dres) dres[o] = g;
-            if (dx) dx[o] = w * ((g - m1) - ((x[o] - mean) * invstd) * m2);
+            if (dx) dx[o] = w * ((g - m1) - ((v - mean) * invstd) * m2);
         }
     });
 }
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restri
 
 template <int NT, int MAXV, bool RELU>
 __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
-                                                           const float *__restrict__ x,
+                                                           const float *__restrict__ x, const float *__restrict__ beta,
                                                            const float *__restrict__ gamma, const float *__restrict__ save_mean,
                                                            const float *__restrict__ save_invstd, const float *__restrict__ running_mean,
                                                            const float *__restrict__ running_var, float eps, int training,
@@ -307,8 +327,9 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
         off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
         gv[j] = dy4[off[j]];
         hv[j] = x4[off[j]];
-        if (RELU) yv[j] = y4[off[j]];
+        if (RELU && y4) yv[j] = y4[off[j]];
     }
+    const MaskArgs mk = mask_args(y, gamma, beta, invstd, c);
     if (dy24) {
 #pragma unroll
         for (int j = 0; j < MAXV; ++j) gv[j] = add4(gv[j], dy24[off[j]]);
@@ -317,14 +338,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
     for (int j = 0; j < MAXV; ++j) {
         const bool in = static_cast<int>(threadIdx.x) + j * NT < total;
         float4 g = gv[j];
+        const float4 v = hv[j];
         if (RELU) {
-            const float4 yy = yv[j];
+            const float4 yy = mk.on ? pre4(v, mean, mk) : yv[j];
             g.x = yy.x > 0.0f ? g.x : 0.0f;
             g.y = yy.y > 0.0f ? g.y : 0.0f;
             g.z = yy.z > 0.0f ? g.z : 0.0f;
             g.w = yy.w > 0.0f ? g.w : 0.0f;
         }
-        const float4 v = hv[j];
         float4 h = make_float4((v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd);
         if (!in) g = h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         sdz += (g.x + g.y) + (g.z + g.w);
@@ -366,14 +387,14 @@ void launch_fwd_cached(bool relu, bool has_res, hipStream_t st, const float *x, 
 }
 
 template <int NT, int MAXV>
-void launch_bwd_cached(bool relu, hipStream_t st, const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *sm,
+void launch_bwd_cached(bool relu, hipStream_t st, const float *dy, const float *dy2, const float *y, const float *x, const float *beta, const float *gamma, const float *sm,
                        const float *si, const float *rm, const float *rv, float eps, int training, float *dx, float *dres, float *dgamma,
                        float *dbeta, BnShape s) {
     const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
     if (relu)
-        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, true>), grid, block, 0, st, dy, dy2, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, true>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
     else
-        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, false>), grid, block, 0, st, dy, dy2, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+        EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, false>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
 }
 
 // which cached variant holds a channel of `quads` float4s: 0 = none
@@ -528,9 +549,11 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_apply_kernel(const float *_
 struct BwdIn {
     float4 dy, y, x;
 };
-__device__ __forceinline__ BwdIn bwd_load(const float4 *dy4, const float4 *dy24, const float4 *y4, const float4 *x4, size_t o, bool relu, bool want_x) {
+__device__ __forceinline__ BwdIn bwd_load(const float4 *dy4, const float4 *dy24, const float4 *y4, const float4 *x4, size_t o, bool relu, bool want_x,
+                                          float mean, const MaskArgs &mk) {
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    return BwdIn{dy24 ? add4(dy4[o], dy24[o]) : dy4[o], relu ? y4[o] : z, want_x ? x4[o] : z};
+    const float4 xv = (want_x || (relu && mk.on)) ? x4[o] : z;
+    return BwdIn{dy24 ? add4(dy4[o], dy24[o]) : dy4[o], relu ? (mk.on ? pre4(xv, mean, mk) : y4[o]) : z, xv};
 }
 __device__ __forceinline__ float4 masked_dz(const BwdIn &in, bool relu) {
     float4 g = in.dy;
@@ -546,7 +569,8 @@ __device__ __forceinline__ float4 masked_dz(const BwdIn &in, bool relu) {
 // ws[(c*S + s)*2 + {0,1}] = (sum dz, sum dz*xhat) of the slice
 template <bool RELU>
 __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
-                                                                        const float *__restrict__ x, const float *__restrict__ save_mean,
+                                                                        const float *__restrict__ x, const float *__restrict__ gamma,
+                                                                        const float *__restrict__ beta, const float *__restrict__ save_mean,
                                                                         const float *__restrict__ save_invstd,
                                                                         const float *__restrict__ running_mean,
                                                                         const float *__restrict__ running_var, float eps, int training,
@@ -556,8 +580,9 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const fl
     const float mean = training ? save_mean[c] : running_mean[c];
     const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
     const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
+    const MaskArgs mk = mask_args(y, gamma, beta, invstd, c);
     float sdz = 0.0f, sdzx = 0.0f;
-    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, reinterpret_cast<const float4 *>(dy2), y4, x4, o, RELU, true); }, [&](BwdIn in, size_t) {
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, reinterpret_cast<const float4 *>(dy2), y4, x4, o, RELU, true, mean, mk); }, [&](BwdIn in, size_t) {
         const float4 g = masked_dz(in, RELU);
         const float4 v = in.x;
         sdz += (g.x + g.y) + (g.z + g.w);
@@ -573,7 +598,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const fl
 
 template <bool RELU>
 __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
-                                                                      const float *__restrict__ x, const float *__restrict__ gamma,
+                                                                      const float *__restrict__ x, const float *__restrict__ beta, const float *__restrict__ gamma,
                                                                       const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
                                                                       const float *__restrict__ running_mean,
                                                                       const float *__restrict__ running_var, float eps, int training,
@@ -602,7 +627,8 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const floa
     const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
     float4 *dx4 = reinterpret_cast<float4 *>(dx), *dr4 = reinterpret_cast<float4 *>(dres);
     const bool want_x = dx != nullptr;
-    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, reinterpret_cast<const float4 *>(dy2), y4, x4, o, RELU, want_x); }, [&](BwdIn in, size_t o) {
+    const MaskArgs mk = mask_args(y, gamma, beta, invstd, c);
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, reinterpret_cast<const float4 *>(dy2), y4, x4, o, RELU, want_x, mean, mk); }, [&](BwdIn in, size_t o) {
         const float4 g = masked_dz(in, RELU);
         if (dres) dr4[o] = g;
         if (dx) {
@@ -814,13 +840,13 @@ void launch_fwd(bool relu, bool has_res, hipStream_t st, const float *x, const f
 }
 
 template <int NT, int VEC>
-void launch_bwd(bool relu, hipStream_t st, const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *sm, const float *si,
+void launch_bwd(bool relu, hipStream_t st, const float *dy, const float *dy2, const float *y, const float *x, const float *beta, const float *gamma, const float *sm, const float *si,
                 const float *rm, const float *rv, float eps, int training, float *dx, float *dres, float *dgamma, float *dbeta, BnShape s) {
     const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
     if (relu)
-        EE_LAUNCH((bn_bwd_kernel<NT, VEC, true>), grid, block, 0, st, dy, dy2, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+        EE_LAUNCH((bn_bwd_kernel<NT, VEC, true>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
     else
-        EE_LAUNCH((bn_bwd_kernel<NT, VEC, false>), grid, block, 0, st, dy, dy2, y, x, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
+        EE_LAUNCH((bn_bwd_kernel<NT, VEC, false>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
 }
 
 inline bool al16(const void *q) { return !q || aligned16(q); }
@@ -871,13 +897,13 @@ EE_API int ee_bn_act_fwd_f32(const float *x, const float *residual, const float 
     return launch_status();
 }
 
-EE_API int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *save_mean,
+EE_API int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *beta, const float *save_mean,
                              const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training, int relu,
                              float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW, void *stream) {
     if (B < 0 || C < 1 || HW < 1) return EE_ERR_SHAPE;
     if (static_cast<int64_t>(B) * HW > 0x7fffffffLL) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
-    if (!dy || !x || (relu && !y)) return EE_ERR_NULL;
+    if (!dy || !x) return EE_ERR_NULL;  // y == NULL with relu: the mask is recomputed from x, gamma, beta (no residual branch: the caller's promise)
     if (training && (!save_mean || !save_invstd)) return EE_ERR_NULL;
     if (!training && (!running_mean || !running_var)) return EE_ERR_NULL;
     const BnShape s{B, C, HW};
@@ -885,30 +911,31 @@ EE_API int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y,
     const bool big = static_cast<int64_t>(B) * HW >= 16384;
     hipStream_t st = as_stream(stream);
     const int cv = vec ? cached_variant(static_cast<int64_t>(B) * (HW / 4), static_cast<int64_t>(B) * C * HW) : 0;
-    if (cv == 1) launch_bwd_cached<256, 2>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else if (cv == 2) launch_bwd_cached<256, 7>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else if (cv == 3) launch_bwd_cached<1024, 7>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    if (cv == 1) launch_bwd_cached<256, 2>(relu != 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (cv == 2) launch_bwd_cached<256, 7>(relu != 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (cv == 3) launch_bwd_cached<1024, 7>(relu != 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     else if (vec && workspace && static_cast<int64_t>(B) * C * HW / 4 <= 0x7fffffffLL) {
         const int S = split_slices(static_cast<int64_t>(B) * (HW / 4));
         const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(S)), block(SPLIT_NT);
         if (relu) {
-            EE_LAUNCH((bn_split_bwd_partial_kernel<true>), grid, block, 0, st, dy, dy2, y, x, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
-            EE_LAUNCH((bn_split_bwd_apply_kernel<true>), grid, block, 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_partial_kernel<true>), grid, block, 0, st, dy, dy2, y, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_apply_kernel<true>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
         } else {
-            EE_LAUNCH((bn_split_bwd_partial_kernel<false>), grid, block, 0, st, dy, dy2, y, x, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
-            EE_LAUNCH((bn_split_bwd_apply_kernel<false>), grid, block, 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_partial_kernel<false>), grid, block, 0, st, dy, dy2, y, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, training, workspace, s, S);
+            EE_LAUNCH((bn_split_bwd_apply_kernel<false>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, workspace, s, S);
         }
-    } else if (vec && big) launch_bwd<1024, 4>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else if (vec) launch_bwd<256, 4>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else if (big) launch_bwd<1024, 1>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
-    else launch_bwd<256, 1>(relu != 0, st, dy, dy2, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    } else if (vec && big) launch_bwd<1024, 4>(relu != 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (vec) launch_bwd<256, 4>(relu != 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else if (big) launch_bwd<1024, 1>(relu != 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
+    else launch_bwd<256, 1>(relu != 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dresidual, dgamma, dbeta, s);
     return launch_status();
 }
 
 EE_API int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
                              const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training, int relu,
                              float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW, void *stream) {
-    return ee_bn_act_bwd2_f32(dy, nullptr, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, relu, dx, dresidual, dgamma,
+    if (relu && !y) return EE_ERR_NULL;
+    return ee_bn_act_bwd2_f32(dy, nullptr, y, x, gamma, nullptr, save_mean, save_invstd, running_mean, running_var, eps, training, relu, dx, dresidual, dgamma,
                               dbeta, workspace, B, C, HW, stream);
 }
 

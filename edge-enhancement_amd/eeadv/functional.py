@@ -135,6 +135,9 @@ class AddSquareFn(torch.autograd.Function):
         return ops.add_square_bwd(g.contiguous(), x, ctx.eps, stripe, sq_sign, sq_pos, sq_size), None, None, None, None, None
 
 
+_MASK_FROM_X = os.environ.get("EEADV_BN_MASK_FROM_X", "1") == "1"  # 0: the BatchNorm backward reads y for its ReLU mask (A/B)
+
+
 def _two_pieces(grads):
     """(dy, dy2) of a forked output: either piece may be missing (its consumer needed no gradient)."""
     g = [t.contiguous() for t in grads if t is not None]
@@ -150,14 +153,17 @@ class BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu, fork=False):
         y, sm, si = ops.bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu)
-        ctx.save_for_backward(x, y if relu else None, gamma, sm, si, None if training else running_mean, None if training else running_var)
+        # the backward's ReLU mask is y > 0; without a residual it is recomputed from x (the forward's expression), and y is not kept for it
+        keep_y = relu and (residual is not None or not _MASK_FROM_X)
+        ctx.save_for_backward(x, y if keep_y else None, gamma, sm, si, None if training else running_mean, None if training else running_var,
+                              beta if relu and not keep_y else None)
         ctx.cfg = (eps, training, relu, residual is not None)
         ctx.set_materialize_grads(False)
         return (y, y.view_as(y)) if fork else y
 
     @staticmethod
     def backward(ctx, *grads):
-        x, y, gamma, sm, si, rm, rv = ctx.saved_tensors
+        x, y, gamma, sm, si, rm, rv, beta = ctx.saved_tensors
         eps, training, relu, has_res = ctx.cfg
         want = list(ctx.needs_input_grad)
         if _INPUT_GRAD_ONLY:
@@ -173,7 +179,7 @@ class BnActFn(torch.autograd.Function):
             return (None, dres) + none[2:]
         want_dres = has_res and want[1] and (relu or dy2 is not None)  # without the ReLU (and in one piece) the residual's gradient IS dy: no copy needed
         dx, dres, dg, db = ops.bn_act_bwd(dy, y, x, gamma, sm, si, rm, rv, eps, training, relu, want[0], want_dres,
-                                          want[2] or want[3], dy2)
+                                          want[2] or want[3], dy2, beta)
         if has_res and want[1] and not want_dres:
             dres = dy
         return (dx, dres, (dg if want[2] else None), (db if want[3] else None)) + none[4:]

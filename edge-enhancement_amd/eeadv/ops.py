@@ -552,9 +552,10 @@ def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, ep
 
 
 def bn_act_bwd(dy, y, x, gamma, save_mean, save_invstd, running_mean, running_var, eps, training, relu, want_dx=True,
-               want_dres=False, want_dparams=True, dy2=None):
+               want_dres=False, want_dparams=True, dy2=None, beta=None):
     """Backward of bn_act_fwd: returns (dx, dresidual, dgamma, dbeta), None where not wanted.  `dy2`: a second piece of the incoming
-    gradient (the output fed two consumers), added to dy on load."""
+    gradient (the output fed two consumers), added to dy on load.  y=None with relu (forward without residual only): the ReLU mask is
+    recomputed from x, gamma and `beta`."""
     B, C = x.shape[0], x.shape[1]
     HW = x[0, 0].numel() if B else 1
     pdy = _chk(dy, torch.float32, "dy", x.shape)
@@ -567,7 +568,7 @@ def bn_act_bwd(dy, y, x, gamma, save_mean, save_invstd, running_mean, running_va
     db = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
     ptr = lambda t: None if t is None else t.data_ptr()
     pdy2 = None if dy2 is None else _chk(dy2, torch.float32, "dy2", x.shape)
-    N.check(N.lib.ee_bn_act_bwd2_f32(pdy, pdy2, py, px, pg, ptr(save_mean), ptr(save_invstd), ptr(running_mean), ptr(running_var), float(eps),
+    N.check(N.lib.ee_bn_act_bwd2_f32(pdy, pdy2, py, px, pg, ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(running_mean), ptr(running_var), float(eps),
                                      1 if training else 0, 1 if relu else 0, ptr(dx), ptr(dres), ptr(dg), ptr(db),
                                      _bn_workspace(x, B, C, HW), B, C, HW, _stream()),
             "ee_bn_act_bwd2_f32")

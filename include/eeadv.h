@@ -271,10 +271,11 @@ int ee_bn_act_bwd_f32(const float *dy, const float *y, const float *x, const flo
                       const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training,
                       int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW,
                       void *stream);
-/* the same with the incoming gradient in two pieces, dy + dy2 (dy2 nullable): a residual block's output feeds the next block's
+/* the same with (1) the incoming gradient in two pieces, dy + dy2 (dy2 nullable): a residual block's output feeds the next block's
  * convolution and its identity branch (resnet.py:44-59), and the two gradients are added here, on load, instead of in a launch of
- * their own */
-int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *save_mean,
+ * their own; (2) y nullable when relu = 1 and the forward had NO residual: the ReLU mask is then recomputed from x, gamma and beta
+ * with the forward's expression (the same bits) - one tensor less to read */
+int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *beta, const float *save_mean,
                        const float *save_invstd, const float *running_mean, const float *running_var, float eps, int training,
                        int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW,
                        void *stream);

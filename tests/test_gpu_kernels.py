@@ -470,6 +470,35 @@ def test_bn_act_forked_output_adds_the_two_gradients_on_load(ops, shape, relu, r
         assert torch.equal(a, e)
 
 
+@pytest.mark.parametrize("shape", [(100, 64, 16, 16), (100, 128, 8, 8), (100, 256, 4, 4), (100, 64, 32, 32), (7, 5, 3, 3), (2, 3, 5, 7)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_backward_relu_mask_recomputed_from_x(ops, shape, training):
+    """Without a residual branch the backward's ReLU mask (y > 0) is recomputed from x, gamma, beta with the forward's expression
+    instead of reading y (ee_bn_act_bwd2_f32 with y = NULL): every kernel variant returns the same bits as with y, also where
+    the pre-activation is exactly 0, tiny, or NaN."""
+    g = torch.Generator(device="cpu").manual_seed(sum(shape) + training)
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    w = (torch.rand(C, generator=g) + 0.5)
+    w[0] = -w[0]
+    b = torch.randn(C, generator=g)
+    if C > 2:
+        b[2] = 0.0
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    if not training and x.numel() > 60:
+        x[0, 0].view(-1)[:3] = torch.tensor([float("nan"), float("inf"), float("-inf")])[:x[0, 0].numel()][:3] if x[0, 0].numel() >= 3 else x[0, 0].view(-1)[:3]
+        x[0, C - 1].view(-1)[0] = rm[C - 1]  # x - mean == 0 exactly: pre-activation = beta
+    x, w, b, rm, rv = (t.to(DEV) for t in (x, w, b, rm, rv))
+    y, sm, si = ops.bn_act_fwd(x, None, w, b, rm.clone(), rv.clone(), 0.1, 1e-5, training, True)
+    dy, dy2 = torch.randn(shape, generator=g).to(DEV), torch.randn(shape, generator=g).to(DEV)
+    for second in (None, dy2):
+        ref = ops.bn_act_bwd(dy, y, x, w, sm, si, rm, rv, 1e-5, training, True, True, False, True, second)
+        got = ops.bn_act_bwd(dy, None, x, w, sm, si, rm, rv, 1e-5, training, True, True, False, True, second, b)
+        for a, e in zip(got, ref):
+            if e is not None:
+                assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(e, nan=-7.0))
+
+
 def test_bn_act_only_input_grad_and_reproducible(ops):
     """The attack loop differentiates w.r.t. the input only (attacks.py:24): no parameter gradients are produced, and two
     runs give the same bits (fixed-order reductions)."""
