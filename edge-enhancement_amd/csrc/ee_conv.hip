@@ -317,7 +317,7 @@ namespace {
 constexpr int SF_ROWS = 4, SF_FH = 2 * SF_ROWS + 5, SF_FW = 72, SF_K = 147, SF_WS = 149, SF_STEPS = 3 * 7 * 4;
 
 __global__ __launch_bounds__(256, 3) void stem_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
-                                                               int K, int H, int W, int tiles_r, int tiles_c) {
+                                                               float *__restrict__ stats, int K, int H, int W, int tiles_r, int tiles_c) {
     __shared__ float fr[3 * SF_FH * SF_FW];
     __shared__ __align__(16) float wn[64 * SF_WS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
@@ -402,11 +402,65 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_mfma_kernel(const float *__re
         if (oy < OH) o[0] = acc0[r];
         if (oy + 1 < OH) o[OW] = acc1[r];
     }
+    // ---- optional: this workgroup's share of the BatchNorm statistics that follow the stem (resnet.py:113) - per output channel
+    // (sum, M2 about the tile's own mean, count) of its <= 4 x 32 values, so that bn1 does not have to read y twice for them:
+    // stats[(co * S + workgroup) * 3 + {0,1,2}], S = gridDim.x; merged by ee_bn.hip (bn_stats_finalize_kernel, Chan's update) -------
+    if (!stats) return;
+    // Through LDS, not through lane shuffles (a butterfly over 32 lanes for 2 x 16 registers is 160 dependent ds_bpermute: +13 us):
+    // the tile goes to LDS as [64 channels][4 rows x 32 columns] (channel stride 132: conflict-free), then four lanes per channel
+    // take 32 values each (two passes on registers: sum, then M2 about the tile mean) and meet through two quad exchanges.
+    constexpr int CS = 132;
+    __syncthreads();  // the weight rows in LDS are dead (every lane holds its A operands in registers): reuse them
+    float *ex = wn;
+    static_assert(64 * CS <= 64 * SF_WS, "the tile fits where the weights were");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float *e = ex + (mt * 32 + acc_row(r, lane)) * CS + (2 * nt) * 32 + i;
+        e[0] = acc0[r];
+        e[32] = acc1[r];
+    }
+    __syncthreads();
+    const int c = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int rows = OH - oy0 < SF_ROWS ? OH - oy0 : SF_ROWS;  // valid output rows of this tile (>= 1)
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = ex[c * CS + q + 4 * j];  // element q + 4j: row j / 8
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) sum += (j / 8 < rows) ? v[j] : 0.0f;
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    const float cnt = 32.0f * static_cast<float>(rows), mean = sum / cnt;
+    float m2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float d = v[j] - mean;
+        m2 += (j / 8 < rows) ? d * d : 0.0f;
+    }
+    m2 += __shfl_xor(m2, 1);
+    m2 += __shfl_xor(m2, 2);
+    if (q == 0) {
+        float *o = stats + (static_cast<size_t>(cb + c) * gridDim.x + blockIdx.x) * 3;
+        o[0] = sum;
+        o[1] = m2;
+        o[2] = cnt;
+    }
 }
 
 }  // namespace
 
+EE_API int ee_stem7x7s2_fwd_stats_floats(int B, int K, int H, int W) {
+    if (B < 1 || K < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || (W / 2) % 32 != 0 || K % 64 != 0) return 0;
+    const int64_t grid = static_cast<int64_t>(B) * ((H / 2 + SF_ROWS - 1) / SF_ROWS) * (W / 2 / 32);
+    if (grid * K * 3 > 0x7fffffffLL) return 0;
+    return static_cast<int>(grid * K * 3);
+}
+
 EE_API int ee_stem7x7s2_fwd_f32(const float *x, const float *weight, float *y, int B, int K, int H, int W, void *stream) {
+    return ee_stem7x7s2_fwd_stats_f32(x, weight, y, nullptr, B, K, H, W, stream);
+}
+
+EE_API int ee_stem7x7s2_fwd_stats_f32(const float *x, const float *weight, float *y, float *stats, int B, int K, int H, int W, void *stream) {
     if (B < 0 || K < 1 || H < 2 || W < 2) return EE_ERR_SHAPE;
     if ((H & 1) || (W & 1) || (W / 2) % 32 != 0 || K % 64 != 0) return EE_ERR_UNSUPPORTED;
     if (B == 0) return EE_OK;
@@ -417,7 +471,7 @@ EE_API int ee_stem7x7s2_fwd_f32(const float *x, const float *weight, float *y, i
     const int64_t grid = static_cast<int64_t>(B) * tiles_r * tiles_c;
     if (grid > 0x7fffffffLL || static_cast<int64_t>(B) * K * OH * OW > 0x7fffffffLL * 4LL) return EE_ERR_SHAPE;
     EE_LAUNCH(stem_fwd_mfma_kernel, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(K / 64)), dim3(256), 0, as_stream(stream), x, weight, y,
-              K, H, W, tiles_r, tiles_c);
+              stats, K, H, W, tiles_r, tiles_c);
     return launch_status();
 }
 

@@ -69,8 +69,8 @@ SIGNATURES = {
     "ee_bn_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_bn_act_bwd2_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_bn_relu_pool_workspace_floats": [c_i, c_i, c_i, c_i],
-    # x, gamma, beta, rm, rv, momentum, eps, training, y_pool, code, save_mean, save_invstd, workspace, B, C, H, W, stream
-    "ee_bn_relu_pool_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    # x, gamma, beta, rm, rv, momentum, eps, training, y_pool, code, save_mean, save_invstd, workspace, conv_stats, slices, B, C, H, W, stream
+    "ee_bn_relu_pool_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     # dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, rm, rv, eps, training, dx, dgamma, dbeta, workspace, B, C, H, W, stream
     "ee_bn_relu_pool_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_maxpool3s2_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -83,6 +83,8 @@ SIGNATURES = {
     "ee_conv3x3s2_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "ee_stem7x7s2_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_stem7x7s2_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "ee_stem7x7s2_fwd_stats_floats": [c_i, c_i, c_i, c_i],
+    "ee_stem7x7s2_fwd_stats_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_pool_linear_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_pool_linear_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_prof_enable": [c_i],

@@ -190,8 +190,10 @@ class BnReluPoolFn(torch.autograd.Function):
     gradient never exist (ee_bn.hip: bn_pool_*)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, fork=False):
-        y, code, sm, si = ops.bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training)
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, fork=False, conv_stats=None):
+        if conv_stats is not None and conv_stats.numel() == 0:
+            conv_stats = None
+        y, code, sm, si = ops.bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, conv_stats)
         ctx.save_for_backward(x, code, gamma, beta, sm, si, None if training else running_mean, None if training else running_var)
         ctx.cfg = (eps, training)
         ctx.set_materialize_grads(False)
@@ -204,9 +206,9 @@ class BnReluPoolFn(torch.autograd.Function):
         want_params = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY
         dy, dy2 = _two_pieces(grads)
         if dy is None or (not ctx.needs_input_grad[0] and not want_params):
-            return (None,) * 9
+            return (None,) * 10
         dx, dg, db = ops.bn_relu_pool_bwd(dy, code, x, gamma, beta, sm, si, rm, rv, eps, training, ctx.needs_input_grad[0], want_params, dy2)
-        return (dx, (dg if ctx.needs_input_grad[1] and want_params else None), (db if ctx.needs_input_grad[2] and want_params else None)) + (None,) * 6
+        return (dx, (dg if ctx.needs_input_grad[1] and want_params else None), (db if ctx.needs_input_grad[2] and want_params else None)) + (None,) * 7
 
 
 class MaxPool3s2Fn(torch.autograd.Function):
@@ -296,6 +298,7 @@ class Conv3x3S2Fn(torch.autograd.Function):
 
 
 _STEM_FWD = os.environ.get("EEADV_STEM_FWD", "1") == "1"  # 0: the stem's forward back on MIOpen (A/B)
+_STEM_STATS = os.environ.get("EEADV_STEM_STATS", "1") == "1"  # 0: bn1 takes its batch statistics in its own pass over the stem's output (A/B)
 
 
 class StemConvFn(torch.autograd.Function):
@@ -303,21 +306,33 @@ class StemConvFn(torch.autograd.Function):
     of 64) and the gradient with respect to the image - what the attack loop is after - on ee_conv.hip; the weight gradient on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
+        """want_stats: returns (y, stats) - stats = the per-workgroup moments of y for bn1 (ops.stem7x7s2_fwd), an EMPTY tensor when the
+        convolution ran on MIOpen (the BatchNorm then takes its statistics itself)."""
         ctx.save_for_backward(x, weight)
         if _STEM_FWD and ops.stem7x7s2_fwd_supported(x, weight):
-            return ops.stem7x7s2_fwd(x, weight)
-        return torch.ops.aten.convolution(x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1)
+            if want_stats and _STEM_STATS:
+                y, stats = ops.stem7x7s2_fwd(x, weight, True)
+                ctx.mark_non_differentiable(stats)
+                return y, stats
+            y = ops.stem7x7s2_fwd(x, weight)
+        else:
+            y = torch.ops.aten.convolution(x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1)
+        if want_stats:
+            stats = x.new_empty(0)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = ops.stem7x7s2_bwd_data(dy, weight, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
             dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return dx, dw
+        return dx, dw, None
 
 
 # ---- a 3x3 / stride 1 / padding 1 convolution on a 2x2 map is one dense product ----------------------------------------------

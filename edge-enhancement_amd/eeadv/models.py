@@ -86,14 +86,14 @@ def _dense_f32(x):
     return x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
 
 
-def stem_bn_pool(bn, pool, x, fork=False):
+def stem_bn_pool(bn, pool, x, fork=False, conv_stats=None):
     """maxpool(relu(bn1(x))) of the ResNet stem (resnet.py:113-117): one fused pass each way when the shapes allow (ee_bn.hip, bn_pool_*),
     the two separate kernels - or the stock modules - otherwise."""
     if ("bn" not in _STOCK and "pool" not in _STOCK and "bnpool" not in _STOCK and type(bn) is BatchNorm2d and type(pool) is nn.MaxPool2d
             and _dense_f32(x) and bn.affine and bn.track_running_stats and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1
             and pool.dilation == 1 and not pool.ceil_mode and not pool.return_indices and ops.bn_relu_pool_supported(x)):
         return BnReluPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.0 if bn.momentum is None else bn.momentum, bn.eps,
-                                  bn.training, fork and _FORK)
+                                  bn.training, fork and _FORK, conv_stats)
     return stem_pool(pool, bn_act(bn, x))
 
 
@@ -160,15 +160,15 @@ def conv3(conv, x):
     return conv(x)
 
 
-def stem_conv(conv, x):
+def stem_conv(conv, x, want_stats=False):
     """conv1 of the ResNets (resnet.py:112): forward on ee_conv.hip where the shape allows; when x needs a gradient (the attack loop),
     its backward-data too."""
     if ("stem" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.in_channels == 3
             and (x.requires_grad or ops.stem7x7s2_fwd_supported(x, conv.weight))
             and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.bias is None and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and conv.weight.is_contiguous()):
-        return StemConvFn.apply(x, conv.weight)
-    return conv(x)
+        return StemConvFn.apply(x, conv.weight, want_stats)
+    return (conv(x), None) if want_stats else conv(x)
 
 
 def _bump_bn_counters(model):
@@ -417,7 +417,8 @@ class ResNet(nn.Module):
 
     def body(self, x):
         # every block output but the last feeds two consumers (the next block's convolution and its identity branch): forked outputs
-        x = stem_bn_pool(self.bn1, self.maxpool, stem_conv(self.conv1, x), fork=True)
+        x, moments = stem_conv(self.conv1, x, want_stats=True)  # the convolution's epilogue collects bn1's batch statistics
+        x = stem_bn_pool(self.bn1, self.maxpool, x, fork=True, conv_stats=moments)
         blocks = [blk for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for blk in layer]
         for i, blk in enumerate(blocks):
             x = blk(x, fork=i + 1 < len(blocks))

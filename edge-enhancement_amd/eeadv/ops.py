@@ -585,8 +585,9 @@ def _pool_workspace(x):
     return torch.empty(n, dtype=torch.float32, device=x.device)
 
 
-def bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training):
-    """maxpool3s2(relu(bn(x))) -> (y_pool, code uint8, save_mean, save_invstd) (resnet.py:113-117); the saves are None in eval mode."""
+def bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, conv_stats=None):
+    """maxpool3s2(relu(bn(x))) -> (y_pool, code uint8, save_mean, save_invstd) (resnet.py:113-117); the saves are None in eval mode.
+    conv_stats [C,S,3]: the producing convolution's per-workgroup moments of x (stem7x7s2_fwd(want_stats=True)): no statistics pass over x."""
     B, C, H, W = x.shape
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
@@ -599,7 +600,8 @@ def bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, t
     ws = _pool_workspace(x)
     N.check(N.lib.ee_bn_relu_pool_fwd_f32(_chk(x, torch.float32, "x"), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
                                           float(eps), 1 if training else 0, y.data_ptr(), code.data_ptr(), ptr(sm), ptr(si), ws.data_ptr(),
-                                          B, C, H, W, _stream()), "ee_bn_relu_pool_fwd_f32")
+                                          None if conv_stats is None else _chk(conv_stats, torch.float32, "conv_stats"),
+                                          0 if conv_stats is None else conv_stats.shape[1], B, C, H, W, _stream()), "ee_bn_relu_pool_fwd_f32")
     return y, code, sm, si
 
 
@@ -717,14 +719,20 @@ def stem7x7s2_fwd_supported(x, weight):
             and tuple(weight.shape[1:]) == (3, 7, 7) and weight.data_ptr() % 16 == 0)
 
 
-def stem7x7s2_fwd(x, weight):
-    """Conv2d(3, K, 7, stride 2, padding 3) forward (resnet.py:112): x [B,3,H,W] -> [B,K,H/2,W/2] on the f32 matrix cores."""
+def stem7x7s2_fwd(x, weight, want_stats=False):
+    """Conv2d(3, K, 7, stride 2, padding 3) forward (resnet.py:112): x [B,3,H,W] -> [B,K,H/2,W/2] on the f32 matrix cores.
+    want_stats: also (y, stats [K,S,3]) - per channel and workgroup (sum, M2, count) of y for the BatchNorm that follows."""
     B, _, H, W = x.shape
     K = weight.shape[0]
     y = torch.empty((B, K, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    N.check(N.lib.ee_stem7x7s2_fwd_f32(_chk(x, torch.float32, "x", (B, 3, H, W)), _chk(weight, torch.float32, "weight", (K, 3, 7, 7)),
-                                       y.data_ptr(), B, K, H, W, _stream()), "ee_stem7x7s2_fwd_f32")
-    return y
+    stats = None
+    if want_stats:
+        n = N.lib.ee_stem7x7s2_fwd_stats_floats(B, K, H, W)
+        stats = torch.empty((K, n // (3 * K), 3), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_stem7x7s2_fwd_stats_f32(_chk(x, torch.float32, "x", (B, 3, H, W)), _chk(weight, torch.float32, "weight", (K, 3, 7, 7)),
+                                             y.data_ptr(), None if stats is None else stats.data_ptr(), B, K, H, W, _stream()),
+            "ee_stem7x7s2_fwd_stats_f32")
+    return (y, stats) if want_stats else y
 
 
 def pool_linear_fwd(feat, weight, bias):

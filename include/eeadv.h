@@ -286,11 +286,14 @@ int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y, const 
  * dgamma, dbeta [C] (nullable).  Values, codes and the pooled-gradient gather equal
  * ee_bn_act_fwd_f32(relu=1) -> ee_maxpool3s2_fwd_f32 and their backwards bit for bit; the gradient sums run over a different
  * partition (dgamma / dbeta / dx agree to rounding).  W % 4 == 0, H*W <= 16000 (else EE_ERR_UNSUPPORTED: use the two calls);
- * workspace: ee_bn_relu_pool_workspace_floats(B, C, H, W) floats (0 = unsupported shape). */
+ * workspace: ee_bn_relu_pool_workspace_floats(B, C, H, W) floats (0 = unsupported shape).  conv_stats (nullable): the producing
+ * convolution's per-workgroup moments [C][conv_stats_slices][3] (ee_stem7x7s2_fwd_stats_f32); training mode then merges those
+ * (Chan's update, fixed order) instead of reading x twice. */
 int ee_bn_relu_pool_workspace_floats(int B, int C, int H, int W);
 int ee_bn_relu_pool_fwd_f32(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
                             float momentum, float eps, int training, float *y_pool, uint8_t *code, float *save_mean,
-                            float *save_invstd, float *workspace, int B, int C, int H, int W, void *stream);
+                            float *save_invstd, float *workspace, const float *conv_stats, int conv_stats_slices, int B, int C, int H,
+                            int W, void *stream);
 int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *gamma, const float *beta,
                             const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
                             float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
@@ -336,6 +339,11 @@ int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float *dx, i
 /* The same convolution forward (resnet.py:112-113 / :147): x [B,3,H,W], weight [K,3,7,7] -> y [B,K,H/2,W/2].
  * H, W even, (W/2) % 32 == 0, K % 64 == 0 (else EE_ERR_UNSUPPORTED); weight 16-byte aligned. */
 int ee_stem7x7s2_fwd_f32(const float *x, const float *weight, float *y, int B, int K, int H, int W, void *stream);
+/* ... and, on the way, the statistics of y for the BatchNorm that follows it (resnet.py:113): stats [K][S][3] = per channel and
+ * workgroup (sum, M2 about the tile's own mean, count); ee_stem7x7s2_fwd_stats_floats = K*S*3 (0: unsupported shape).  Hand them to
+ * ee_bn_relu_pool_fwd_f32 (conv_stats, conv_stats_slices = S): it then needs no pass over y for its statistics. */
+int ee_stem7x7s2_fwd_stats_floats(int B, int K, int H, int W);
+int ee_stem7x7s2_fwd_stats_f32(const float *x, const float *weight, float *y, float *stats, int B, int K, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Classifier head: logits = fc(avgpool(feat).view(B,-1)) for a global average pool

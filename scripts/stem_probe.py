@@ -55,3 +55,6 @@ rows = [
 ]
 for name, fn in rows:
     print("%-50s %8.1f us" % (name, timeit(fn)), flush=True)
+print("%-50s %8.1f us" % ("stem conv fwd + BatchNorm moments in the epilogue", timeit(lambda: ops.stem7x7s2_fwd(img, w, True))), flush=True)
+_, st = ops.stem7x7s2_fwd(img, w, True)
+print("%-50s %8.1f us" % ("bn+relu+pool fwd, fused, moments from the conv", timeit(lambda: ops.bn_relu_pool_fwd(x, gamma, beta, rm, rv, 0.1, 1e-5, True, st))), flush=True)

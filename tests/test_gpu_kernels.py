@@ -721,6 +721,26 @@ def test_stem_conv_fwd_mfma_matches_aten(ops, B, K, H, W):
     ew, = torch.autograd.grad(F.conv2d(x, wp, None, 2, 3), [wp], dy)
     torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)
     assert not ops.stem7x7s2_fwd_supported(torch.empty(1, 3, 224, 224, device=DEV), w)  # OW = 112: MIOpen keeps ImageNet's stem
+    # the epilogue's per-workgroup moments of y (for bn1): same y, and merged they are the batch statistics of y
+    y2, st = ops.stem7x7s2_fwd(x, w, True)
+    assert torch.equal(y2, got) and st.shape[0] == K and st.shape[2] == 3
+    n = st[:, :, 2].double().sum(1)
+    mean = st[:, :, 0].double().sum(1) / n
+    tile_mean = st[:, :, 0].double() / st[:, :, 2].double().clamp_min(1)
+    m2 = (st[:, :, 1].double() + st[:, :, 2].double() * (tile_mean - mean[:, None]) ** 2).sum(1)
+    assert torch.all(n == B * (H // 2) * (W // 2))
+    ref64 = got.double().transpose(0, 1).reshape(K, -1)
+    torch.testing.assert_close(mean, ref64.mean(1), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(m2 / n, ref64.var(1, unbiased=False), rtol=1e-5, atol=1e-9)
+    if H * W // 4 <= 16000:
+        from eeadv.functional import BnReluPoolFn
+        gam, bet = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV)
+        outs = []
+        for cs in (None, st):
+            rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+            outs.append((BnReluPoolFn.apply(got, gam, bet, rm, rv, 0.1, 1e-5, True, False, cs), rm, rv))
+        for a, e in zip(outs[1], outs[0]):  # statistics merged from the convolution's tiles vs bn_split_stats_kernel's own two passes
+            torch.testing.assert_close(a, e, rtol=2e-6, atol=2e-6)
 
 
 @pytest.mark.parametrize("B,Cin,Cout", [(100, 512, 512), (3, 5, 7), (1, 64, 32)])
