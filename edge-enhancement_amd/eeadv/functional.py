@@ -345,19 +345,27 @@ _DENSE_W = {}  # id(weight) -> [weakref(weight), version, W2 buffer]
 _DENSE_IDX = {}
 
 
-def _rearranged(weight):
+def _rearranged(weight, kind="s1"):
+    """kind "s1": 3x3 / stride 1 / padding 1 on a 2x2 map -> [4 Cin, 4 Cout]; kind "s2": 3x3 / stride 2 / padding 1 from a 4x4 map to
+    a 2x2 map -> [16 Cin, 4 Cout] (tap ky = iy - 2 oy + 1, zero where it leaves the 3x3 window)."""
     co, ci = weight.shape[0], weight.shape[1]
-    idx = _DENSE_IDX.get(weight.device)
+    idx = _DENSE_IDX.get((weight.device, kind))
     if idx is None:
-        i = torch.arange(2, device=weight.device)
-        # k[iy, ix, oy, ox] = iy - oy + 1 (rows) / ix - ox + 1 (columns)
-        ky = (i.view(2, 1, 1, 1) - i.view(1, 1, 2, 1) + 1).expand(2, 2, 2, 2)
-        kx = (i.view(1, 2, 1, 1) - i.view(1, 1, 1, 2) + 1).expand(2, 2, 2, 2)
-        idx = _DENSE_IDX[weight.device] = (ky.contiguous(), kx.contiguous())
-    return weight.detach()[:, :, idx[0], idx[1]].permute(1, 2, 3, 0, 4, 5).reshape(4 * ci, 4 * co)
+        n_in, stride = (2, 1) if kind == "s1" else (4, 2)
+        i, o = torch.arange(n_in, device=weight.device), torch.arange(2, device=weight.device)
+        # k[iy, ix, oy, ox] = iy - stride * oy + 1 (rows) / ix - stride * ox + 1 (columns)
+        ky = (i.view(n_in, 1, 1, 1) - stride * o.view(1, 1, 2, 1) + 1).expand(n_in, n_in, 2, 2)
+        kx = (i.view(1, n_in, 1, 1) - stride * o.view(1, 1, 1, 2) + 1).expand(n_in, n_in, 2, 2)
+        ok = ((ky >= 0) & (ky <= 2) & (kx >= 0) & (kx <= 2))
+        idx = _DENSE_IDX[(weight.device, kind)] = (ky.clamp(0, 2).contiguous(), kx.clamp(0, 2).contiguous(),
+                                                   None if bool(ok.all()) else ok.to(weight.dtype).contiguous(), n_in * n_in)
+    g = weight.detach()[:, :, idx[0], idx[1]]  # [co, ci, iy, ix, oy, ox]
+    if idx[2] is not None:
+        g = g * idx[2]
+    return g.permute(1, 2, 3, 0, 4, 5).reshape(idx[3] * ci, 4 * co)
 
 
-def _dense_weight(weight):
+def _dense_weight(weight, kind="s1"):
     ent = _DENSE_W.get(id(weight))
     if ent is not None and ent[0]() is not weight:
         ent = None
@@ -368,9 +376,9 @@ def _dense_weight(weight):
     if ent is None or ent[1] != weight._version:
         with torch.no_grad():
             if ent is None:
-                ent = _DENSE_W[id(weight)] = [weakref.ref(weight), weight._version, _rearranged(weight).contiguous()]
+                ent = _DENSE_W[id(weight)] = [weakref.ref(weight), weight._version, _rearranged(weight, kind).contiguous(), kind]
             else:
-                ent[2].copy_(_rearranged(weight))
+                ent[2].copy_(_rearranged(weight, kind))
                 ent[1] = weight._version
     return ent[2]
 
@@ -387,7 +395,7 @@ def rebuild_dense_weights(model=None):
             if w is None:
                 del _DENSE_W[key]
             elif own is None or key in own:
-                _DENSE_W[key][2].copy_(_rearranged(w))
+                _DENSE_W[key][2].copy_(_rearranged(w, _DENSE_W[key][3]))
                 _DENSE_W[key][1] = w._version
 
 
@@ -399,7 +407,31 @@ def refresh_dense_weights():
         if w is None:
             del _DENSE_W[key]
         elif _DENSE_W[key][1] != w._version:
-            _dense_weight(w)
+            _dense_weight(w, _DENSE_W[key][3])
+
+
+class Conv3x3S2Map4Fn(torch.autograd.Function):
+    """Conv2d(Cin, Cout, 3, stride 2, padding 1, bias=False) from a 4x4 map to a 2x2 map (layer4.0.conv1 at 64x64 inputs, resnet.py:26-31):
+    the BACKWARD-DATA as one dense product [B, 4 Cout] x [4 Cout, 16 Cin] (22 us on the BLAS against 39 us for MIOpen's NHWC implicit
+    GEMM + its three layout transposes + zero fill, un-profiled; 9/16 of the matrix are structural zeros); forward (27 us either way)
+    and weight gradient stay on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _dense_weight(weight, "s2")  # created / refreshed outside any capture; the backward only reads it
+        ctx.save_for_backward(x, weight)
+        return torch.ops.aten.convolution(x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        B = dy.shape[0]
+        dx = torch.mm(dy.reshape(B, -1), _dense_weight(weight, "s2").t()).view_as(x) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw
 
 
 class Conv3x3Map2Fn(torch.autograd.Function):

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime
-from .functional import BnActFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import BnActFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -78,6 +78,9 @@ _CONV3_EAGER = os.environ.get("EEADV_CONV3_EAGER", "0") == "1"  # use the MFMA 3
 # bench.py's probe iterations (engine.PROBE_ITERS) run outside the captured graph so that the library's event hooks can time
 # their kernels: engine sets this around them, and the probe then launches the same convolution kernels the graph replays
 PROBE_MFMA_CONV = False
+# layer4.0.conv1's backward-data as a dense [B, 4 Cout] x [4 Cout, 16 Cin] product: 22 us against 39 in isolation, but inside the step its
+# 33.6 MB matrix comes from HBM every pass and the gain drowns in the noise (6220 vs 6211 img/s): opt-in
+_DENSE_S2 = os.environ.get("EEADV_DENSE_S2", "0") == "1"
 _CONV3S2_BWD_MINOW = int(os.environ.get("EEADV_CONV3S2_BWD_MINOW", "8"))  # its backward-data kernel: 29 us vs 36 on layer2.0 un-profiled, +0.5 % end to end (35 / 69 us vs 34 / 39 at 4 / 2: not there)
 _CONV3S2_MINOW = int(os.environ.get("EEADV_CONV3S2_MINOW", "8"))  # narrowest OUTPUT map the stride-2 MFMA convolution takes (24 us vs 50 at 8; no gain at 4)
 
@@ -142,6 +145,10 @@ def conv3(conv, x):
     # Function + ctypes launch + a separate ATen call for the weight gradient against one ATen call): they pay where the
     # host cost vanishes, i.e. while a HIP graph is being captured, and lose in eager, host-bound passes (TRADES / ALP
     # updates: 4.2 k -> 4.9 k img/s with this rule).
+    if (_DENSE_S2 and "dense" not in _STOCK and x.shape[2] == 4 and x.shape[3] == 4 and type(conv) is nn.Conv2d and _dense_f32(x)
+            and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels * conv.out_channels <= 1 << 18):
+        return Conv3x3S2Map4Fn.apply(x, conv.weight)  # layer4.0.conv1 at 64x64 inputs: backward-data as one dense product (opt-in)
     if not (_CONV3_EAGER or PROBE_MFMA_CONV or torch.cuda.is_current_stream_capturing()):
         return conv(x)
     if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)

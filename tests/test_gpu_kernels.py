@@ -743,6 +743,31 @@ def test_stem_conv_fwd_mfma_matches_aten(ops, B, K, H, W):
             torch.testing.assert_close(a, e, rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("B,Cin,Cout", [(100, 256, 512), (3, 5, 7), (2, 64, 32)])
+def test_conv3x3s2_from_4x4_map_backward_as_dense_product(ops, B, Cin, Cout):
+    """Conv2d(3x3, stride 2, padding 1) from a 4x4 to a 2x2 map (layer4.0.conv1 at 64x64 inputs): backward-data as one dense product
+    vs ATen, the rearranged [16 Cin, 4 Cout] matrix follows in-place weight updates, forward and weight gradient are ATen's own."""
+    import torch.nn.functional as F
+    from eeadv import functional as EF
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + 1)
+    x = torch.randn(B, Cin, 4, 4, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
+    dy = torch.randn(B, Cout, 2, 2, generator=g).to(DEV)
+    for round_ in range(2):
+        ref = F.conv2d(x, w, None, 2, 1)
+        got = EF.Conv3x3S2Map4Fn.apply(x, w)
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+        (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
+        torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (4 * B) ** 0.5)
+        w2 = EF._dense_weight(w, "s2")
+        assert w2.shape == (16 * Cin, 4 * Cout) and float((w2 != 0).float().mean()) <= 9 / 16 + 1e-6
+        ptr = w2.data_ptr()
+        with torch.no_grad():
+            w.mul_(1.5)
+        assert EF._dense_weight(w, "s2").data_ptr() == ptr  # same buffer, new contents
+
+
 @pytest.mark.parametrize("B,Cin,Cout", [(100, 512, 512), (3, 5, 7), (1, 64, 32)])
 def test_conv3x3_on_2x2_map_as_dense_product(ops, B, Cin, Cout):
     """Conv2d(3x3, stride 1, padding 1) on a 2x2 map (ResNet layer4 at 64x64 inputs) as one GEMM vs ATen, and the rearranged
