@@ -1,0 +1,316 @@
+// ee_net2.hip - the convolutional half of the MNIST classifier Net_2 (MNIST/models_mnist/Net2.py:13-16), forward and input gradient:
+//     x = relu(max_pool2d(conv1(x), 2))                         conv1 = Conv2d(1, 32, 5)      [B,1,28,28]  -> [B,32,12,12]
+//     x = relu(max_pool2d(conv2_drop(conv2(x)), 2))             conv2 = Conv2d(32, 64, 5)     [B,32,12,12] -> [B,64,4,4]
+// At the reference batch (50 images) one PGD iteration of the MNIST configs spends 256 us in 35 launches of ~5 us - convolutions of
+// 0.02 / 0.16 GFLOP through MIOpen (Winograd + NHWC implicit GEMM with three layout transposes and a zero fill each), bias adds, pools,
+// ReLUs, dropout multiplies and their backward twins - around a 15 us hand-written front end.  Here each half is ONE launch each way:
+// convolution, bias, dropout scale, 2x2 pool (ATen's scan: first maximum wins, a NaN always wins) and ReLU fused, the pooled map and a
+// 2-bit argmax code the only things written; the backward gathers through the codes, applies ATen's threshold rule (the gradient passes
+// unless the output is <= 0, so a NaN output passes it) and runs the transposed convolution.  Exact-f32 fma chains in a fixed order;
+// parity is "logits within 1e-4" through the model tests plus per-kernel tests against ATen.  Only the attack loop (input gradient)
+// runs here: a pass that needs parameter gradients recomputes the stock sequence (functional.Net2ConvFn).
+//
+// CNN-body glue, not a row of SURVEY.md section 8.
+#include "ee_common.hpp"
+
+#include <math.h>
+
+namespace {
+
+using namespace ee;
+
+constexpr int N2_NT = 256;
+constexpr int N2_H0 = 28, N2_C1 = 32, N2_H1 = 12, N2_C2 = 64, N2_H2 = 4;
+
+__device__ __forceinline__ float relu_keep_nan(float v) { return v > 0.0f ? v : (v != v ? v : 0.0f); }
+
+// max over a 2x2 window in ATen's order (0,0) (0,1) (1,0) (1,1); code = index of the winner
+__device__ __forceinline__ float pool4(const float v[4], int &code) {
+    float best = -INFINITY;
+    code = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (v[k] > best || v[k] != v[k]) {
+            best = v[k];
+            code = k;
+        }
+    return best;
+}
+
+// ---- conv1 + bias -> pool -> relu.  grid (B, 4): 8 output channels of one image per workgroup ---------------------------------------
+__global__ __launch_bounds__(N2_NT) void net2_conv1_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                               float *__restrict__ a1, uint8_t *__restrict__ code1) {
+    __shared__ __align__(16) float xs[N2_H0 * N2_H0];
+    __shared__ float ws[8 * 25];
+    __shared__ float bs[8];
+    const int b = blockIdx.x, c0 = blockIdx.y * 8;
+    if (threadIdx.x < N2_H0 * N2_H0 / 4)
+        reinterpret_cast<float4 *>(xs)[threadIdx.x] = reinterpret_cast<const float4 *>(x + static_cast<size_t>(b) * N2_H0 * N2_H0)[threadIdx.x];
+    if (threadIdx.x < 200) ws[threadIdx.x] = w[c0 * 25 + threadIdx.x];
+    if (threadIdx.x < 8) bs[threadIdx.x] = bias ? bias[c0 + threadIdx.x] : 0.0f;
+    __syncthreads();
+    for (int o = threadIdx.x; o < 8 * N2_H1 * N2_H1; o += N2_NT) {
+        const int c = o / (N2_H1 * N2_H1), r = o - c * (N2_H1 * N2_H1);
+        const int py = r / N2_H1, px = r - py * N2_H1;
+        float patch[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float2 *row = reinterpret_cast<const float2 *>(xs + (2 * py + i) * N2_H0 + 2 * px);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float2 t = row[j];
+                patch[i][2 * j] = t.x;
+                patch[i][2 * j + 1] = t.y;
+            }
+        }
+        float v[4] = {bs[c], bs[c], bs[c], bs[c]};
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const float wv = ws[c * 25 + ky * 5 + kx];
+                v[0] = fmaf(wv, patch[ky][kx], v[0]);
+                v[1] = fmaf(wv, patch[ky][kx + 1], v[1]);
+                v[2] = fmaf(wv, patch[ky + 1][kx], v[2]);
+                v[3] = fmaf(wv, patch[ky + 1][kx + 1], v[3]);
+            }
+        int code;
+        const float best = pool4(v, code);
+        const size_t dst = (static_cast<size_t>(b) * N2_C1 + c0 + c) * (N2_H1 * N2_H1) + r;
+        a1[dst] = relu_keep_nan(best);
+        code1[dst] = static_cast<uint8_t>(code);
+    }
+}
+
+// ---- conv2 + bias -> dropout scale -> pool -> relu.  grid (B, 8): 8 output channels per workgroup; the 32 input channels are split
+// over the two halves of the workgroup (threads 0-127 / 128-255), partial sums meet in LDS and are added in that order ----------------
+constexpr int N2_WP = 28;  // weights of one (co, ci) padded 25 -> 28: 16-byte rows
+__global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__restrict__ a1, const float *__restrict__ w, const float *__restrict__ bias,
+                                                               const float *__restrict__ drop, float *__restrict__ a2, uint8_t *__restrict__ code2) {
+    __shared__ __align__(16) float as[N2_C1 * N2_H1 * N2_H1];      // 18 KB
+    __shared__ __align__(16) float ws[8 * N2_C1 * N2_WP];          // 28 KB
+    __shared__ float part[128 * 4];
+    const int b = blockIdx.x, c0 = blockIdx.y * 8;
+    const float4 *src = reinterpret_cast<const float4 *>(a1 + static_cast<size_t>(b) * N2_C1 * N2_H1 * N2_H1);
+    for (int i = threadIdx.x; i < N2_C1 * N2_H1 * N2_H1 / 4; i += N2_NT) reinterpret_cast<float4 *>(as)[i] = src[i];
+    for (int i = threadIdx.x; i < 8 * N2_C1 * 25; i += N2_NT) {  // w[c0 + co][ci][25] is one contiguous block of 8 * 32 * 25 floats
+        const int pair = i / 25, k = i - pair * 25;
+        ws[pair * N2_WP + k] = w[static_cast<size_t>(c0) * N2_C1 * 25 + i];
+    }
+    __syncthreads();
+    const int half = threadIdx.x >> 7, idx = threadIdx.x & 127;
+    const int co = idx >> 4, p = idx & 15, py = p >> 2, px = p & 3;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 2
+    for (int cc = 0; cc < 16; ++cc) {
+        const int ci = half * 16 + cc;
+        float patch[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float2 *row = reinterpret_cast<const float2 *>(as + ci * (N2_H1 * N2_H1) + (2 * py + i) * N2_H1 + 2 * px);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float2 t = row[j];
+                patch[i][2 * j] = t.x;
+                patch[i][2 * j + 1] = t.y;
+            }
+        }
+        float wv[N2_WP];
+        const float4 *wr = reinterpret_cast<const float4 *>(ws + (co * N2_C1 + ci) * N2_WP);
+#pragma unroll
+        for (int j = 0; j < N2_WP / 4; ++j) {
+            const float4 t = wr[j];
+            wv[4 * j] = t.x; wv[4 * j + 1] = t.y; wv[4 * j + 2] = t.z; wv[4 * j + 3] = t.w;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const float t = wv[ky * 5 + kx];
+                v[0] = fmaf(t, patch[ky][kx], v[0]);
+                v[1] = fmaf(t, patch[ky][kx + 1], v[1]);
+                v[2] = fmaf(t, patch[ky + 1][kx], v[2]);
+                v[3] = fmaf(t, patch[ky + 1][kx + 1], v[3]);
+            }
+    }
+    if (half == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[idx * 4 + k] = v[k];
+    }
+    __syncthreads();
+    if (half == 0) {
+        const float bv = bias ? bias[c0 + co] : 0.0f;
+        const float dm = drop ? drop[static_cast<size_t>(b) * N2_C2 + c0 + co] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float s = (v[k] + part[idx * 4 + k]) + bv;
+            v[k] = drop ? s * dm : s;
+        }
+        int code;
+        const float best = pool4(v, code);
+        const size_t dst = (static_cast<size_t>(b) * N2_C2 + c0 + co) * (N2_H2 * N2_H2) + p;
+        a2[dst] = relu_keep_nan(best);
+        code2[dst] = static_cast<uint8_t>(code);
+    }
+}
+
+// ---- backward of the second half: d a2 -> d a1.  G[co][8][8] = the un-pooled gradient (threshold rule, argmax position, dropout scale),
+// then the transposed convolution d a1[ci][y][x] = sum_co sum_{ky,kx} G[co][y - ky][x - kx] * w[co][ci][ky][kx].
+// grid (B, 8): 4 input channels per workgroup; a thread owns one row y of one channel for a quarter of the output channels in flight
+// (192 threads work; 32 output channels at a time in LDS), the four partial rows meet in LDS and are added in quarter order --------
+constexpr int N2_GW = 16;  // G rows padded 8 -> 16 columns (4 zeros either side), 4 zero rows above and below: [co][16][16]
+__global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__restrict__ da2, const float *__restrict__ a2, const uint8_t *__restrict__ code2,
+                                                               const float *__restrict__ drop, const float *__restrict__ w, float *__restrict__ da1) {
+    __shared__ __align__(16) float G[32 * N2_GW * N2_GW];      // 32 KB
+    __shared__ __align__(16) float ws[N2_C2 * 4 * N2_WP];      // w[co][ci0 .. ci0+3][25 -> 28]: 28 KB
+    const int b = blockIdx.x, ci0 = blockIdx.y * 4;
+    for (int i = threadIdx.x; i < N2_C2 * 4 * 25; i += N2_NT) {
+        const int co = i / 100, rem = i - co * 100, cl = rem / 25, k = rem - cl * 25;
+        ws[(co * 4 + cl) * N2_WP + k] = w[(static_cast<size_t>(co) * N2_C1 + ci0 + cl) * 25 + k];
+    }
+    float acc[N2_H1];
+#pragma unroll
+    for (int xx = 0; xx < N2_H1; ++xx) acc[xx] = 0.0f;
+    const int q = threadIdx.x / 48, rem = threadIdx.x - q * 48, cl = rem / N2_H1, y = rem - cl * N2_H1;  // threads 0..191: (quarter, channel, row)
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();  // the previous half's rows have been read (and, first time round, nothing is pending)
+        for (int i = threadIdx.x; i < 32 * N2_GW * N2_GW / 4; i += N2_NT) reinterpret_cast<float4 *>(G)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * 16; i += N2_NT) {
+            const int cc = i >> 4, p = i & 15, wy = p >> 2, wx = p & 3, co = 32 * h + cc;
+            const size_t src = (static_cast<size_t>(b) * N2_C2 + co) * 16 + p;
+            float g = da2[src];
+            if (a2[src] <= 0.0f) g = 0.0f;  // ATen's threshold_backward: the gradient passes unless the output is <= 0
+            if (drop) g *= drop[static_cast<size_t>(b) * N2_C2 + co];
+            const int cd = code2[src];
+            G[cc * (N2_GW * N2_GW) + (4 + 2 * wy + (cd >> 1)) * N2_GW + 4 + 2 * wx + (cd & 1)] = g;
+        }
+        __syncthreads();
+        if (threadIdx.x < 192) {
+            for (int cc = 0; cc < 8; ++cc) {
+                const int gl = q * 8 + cc, co = 32 * h + gl;
+                float wv[N2_WP];
+                const float4 *wr = reinterpret_cast<const float4 *>(ws + (co * 4 + cl) * N2_WP);
+#pragma unroll
+                for (int j = 0; j < N2_WP / 4; ++j) {
+                    const float4 t = wr[j];
+                    wv[4 * j] = t.x; wv[4 * j + 1] = t.y; wv[4 * j + 2] = t.z; wv[4 * j + 3] = t.w;
+                }
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    // G row y - ky of the 8x8 map = padded row 4 + y - ky; its padded columns 0 .. 15 cover x - kx for x in 0..11, kx in 0..4
+                    const float4 *gr = reinterpret_cast<const float4 *>(G + gl * (N2_GW * N2_GW) + (4 + y - ky) * N2_GW);
+                    float row[N2_GW];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 t = gr[j];
+                        row[4 * j] = t.x; row[4 * j + 1] = t.y; row[4 * j + 2] = t.z; row[4 * j + 3] = t.w;
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const float t = wv[ky * 5 + kx];
+#pragma unroll
+                        for (int xx = 0; xx < N2_H1; ++xx) acc[xx] = fmaf(t, row[4 + xx - kx], acc[xx]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();  // G is dead: the partial rows of quarters 1-3 go there
+    float *part = G;
+    if (threadIdx.x < 192 && q > 0) {
+#pragma unroll
+        for (int xx = 0; xx < N2_H1; ++xx) part[((q - 1) * 48 + rem) * N2_H1 + xx] = acc[xx];
+    }
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        float *dst = da1 + ((static_cast<size_t>(b) * N2_C1 + ci0 + cl) * N2_H1 + y) * N2_H1;
+#pragma unroll
+        for (int xx = 0; xx < N2_H1; ++xx)
+            dst[xx] = ((acc[xx] + part[(0 * 48 + rem) * N2_H1 + xx]) + part[(1 * 48 + rem) * N2_H1 + xx]) + part[(2 * 48 + rem) * N2_H1 + xx];
+    }
+}
+
+// ---- backward of the first half: d a1 -> d x.  G1[c][24][24] un-pooled (threshold rule, argmax), d x[y][x] = sum_c sum_k G1[c][y-ky][x-kx] w1[c][ky][kx].
+// grid (B, 2): 14 rows of one image per workgroup; a thread owns 4 neighbouring pixels of a row for half of the channels in flight (8 at
+// a time in LDS, zero-padded frame [c][18][32]); the two halves meet in LDS -------------------------------------------------------------
+__global__ __launch_bounds__(N2_NT) void net2_conv1_bwd_kernel(const float *__restrict__ da1, const float *__restrict__ a1, const uint8_t *__restrict__ code1,
+                                                               const float *__restrict__ w, float *__restrict__ dx) {
+    constexpr int ROWS = 14, FR = ROWS + 4, FW = 32;
+    __shared__ __align__(16) float G[8 * FR * FW];  // 18 KB: [c][4 + (y - y0) - ky][4 + x - kx]
+    __shared__ float ws[N2_C1 * 25];
+    __shared__ __align__(16) float part[98 * 4];
+    const int b = blockIdx.x, y0 = blockIdx.y * ROWS;
+    for (int i = threadIdx.x; i < N2_C1 * 25; i += N2_NT) ws[i] = w[i];
+    const int hc = threadIdx.x / 98, quad = threadIdx.x - hc * 98, ry = quad / 7, x0 = 4 * (quad - ry * 7);  // threads 0..195
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c0 = 0; c0 < N2_C1; c0 += 8) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * FR * FW / 4; i += N2_NT) reinterpret_cast<float4 *>(G)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * N2_H1 * N2_H1; i += N2_NT) {
+            const int c = i / (N2_H1 * N2_H1), r = i - c * (N2_H1 * N2_H1), py = r / N2_H1, px = r - py * N2_H1;
+            const size_t src = (static_cast<size_t>(b) * N2_C1 + c0 + c) * (N2_H1 * N2_H1) + r;
+            const int cd = code1[src];
+            const int lr = 2 * py + (cd >> 1) - y0 + 4;  // frame row of the un-pooled position
+            if (lr >= 0 && lr < FR) {
+                float g = da1[src];
+                if (a1[src] <= 0.0f) g = 0.0f;
+                G[(c * FR + lr) * FW + 4 + 2 * px + (cd & 1)] = g;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 196) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = hc * 4 + cc;
+                const float *wc = ws + (c0 + c) * 25;
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    const float4 *gr = reinterpret_cast<const float4 *>(G + (c * FR + 4 + ry - ky) * FW + x0);
+                    const float4 t0 = gr[0], t1 = gr[1];  // frame columns x0 .. x0 + 7 = pixels x0 - 4 .. x0 + 3
+                    const float row[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const float t = wc[ky * 5 + kx];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k] = fmaf(t, row[4 + k - kx], acc[k]);
+                    }
+                }
+            }
+        }
+    }
+    if (threadIdx.x >= 98 && threadIdx.x < 196) reinterpret_cast<float4 *>(part)[quad] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (threadIdx.x < 98) {
+        const float4 o = reinterpret_cast<const float4 *>(part)[quad];
+        *reinterpret_cast<float4 *>(dx + (static_cast<size_t>(b) * N2_H0 + y0 + ry) * N2_H0 + x0) =
+            make_float4(acc[0] + o.x, acc[1] + o.y, acc[2] + o.z, acc[3] + o.w);
+    }
+}
+
+}  // namespace
+
+EE_API int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *drop, float *a1,
+                                uint8_t *code1, float *a2, uint8_t *code2, int B, void *stream) {
+    if (B < 0) return EE_ERR_SHAPE;
+    if (B == 0) return EE_OK;
+    if (!x || !w1 || !w2 || !a1 || !code1 || !a2 || !code2) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(a1)) return EE_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    EE_LAUNCH(net2_conv1_fwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, x, w1, b1, a1, code1);
+    EE_LAUNCH(net2_conv2_fwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, a1, w2, b2, drop, a2, code2);
+    return launch_status();
+}
+
+EE_API int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t *code2, const float *drop, const float *w2, const float *a1,
+                                const uint8_t *code1, const float *w1, float *da1, float *dx, int B, void *stream) {
+    if (B < 0) return EE_ERR_SHAPE;
+    if (B == 0) return EE_OK;
+    if (!da2 || !a2 || !code2 || !w2 || !a1 || !code1 || !w1 || !da1 || !dx) return EE_ERR_NULL;
+    if (!aligned16(dx)) return EE_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    EE_LAUNCH(net2_conv2_bwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, da2, a2, code2, drop, w2, da1);
+    EE_LAUNCH(net2_conv1_bwd_kernel, dim3(static_cast<unsigned>(B), 2), dim3(N2_NT), 0, st, da1, a1, code1, w1, dx);
+    return launch_status();
+}

@@ -457,6 +457,38 @@ class Conv3x3Map2Fn(torch.autograd.Function):
         return dx, dw
 
 
+class Net2ConvFn(torch.autograd.Function):
+    """relu(max_pool2d(conv2_drop(conv2(relu(max_pool2d(conv1(x), 2)))), 2)) of Net_2 (MNIST/models_mnist/Net2.py:13-14) in two launches
+    each way (ee_net2.hip).  The kernels give the gradient w.r.t. the image - what the attack loop asks for, 40 times per training step;
+    a backward that needs PARAMETER gradients (the update, once per step) recomputes the stock sequence with the same dropout mask and lets
+    ATen differentiate it."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, drop):
+        a2, saved = ops.net2_conv_fwd(x, w1, b1, w2, b2, drop)
+        ctx.save_for_backward(x, w1, b1, w2, b2, drop, a2, *saved)
+        return a2
+
+    @staticmethod
+    def backward(ctx, da2):
+        x, w1, b1, w2, b2, drop, a2, a1, c1, c2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        if any(need[1:5]) and not _INPUT_GRAD_ONLY:
+            import torch.nn.functional as F
+            with torch.enable_grad():
+                xx = x.detach().requires_grad_(need[0])
+                h = F.relu(F.max_pool2d(F.conv2d(xx, w1, b1), 2))
+                h = F.conv2d(h, w2, b2)
+                if drop is not None:
+                    h = h * drop.view(drop.shape[0], drop.shape[1], 1, 1)
+                h = F.relu(F.max_pool2d(h, 2))
+                wanted = [t for t, n in zip((xx, w1, b1, w2, b2), need[:5]) if n and t is not None]
+                got = iter(torch.autograd.grad(h, wanted, da2))
+            return tuple(next(got) if (n and t is not None) else None for t, n in zip((xx, w1, b1, w2, b2), need[:5])) + (None,)
+        dx = ops.net2_conv_bwd(da2.contiguous(), a2, (a1, c1, c2), w1, w2, drop) if need[0] else None
+        return dx, None, None, None, None, None
+
+
 class PoolLinearFn(torch.autograd.Function):
     """fc(global_avgpool(feat).view(B, -1)) in one launch each way (resnet.py:157-160; ee_head.hip).  The weight and
     bias gradients (once per training step) are two BLAS calls on the saved pooled features."""

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime
-from .functional import BnActFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import Net2ConvFn, BnActFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -295,8 +295,19 @@ class Net_2(nn.Module):
         self.fc2 = nn.Linear(1024, 10)
 
     def body(self, x):
-        x = F.relu(F.max_pool2d(self.conv1(x), 2))
-        x = F.relu(F.max_pool2d(self.conv2_drop(self.conv2(x)), 2))
+        if ("net2" not in _STOCK and _dense_f32(x) and type(self.conv1) is nn.Conv2d and type(self.conv2) is nn.Conv2d
+                and ops.net2_conv_supported(x, self.conv1.weight, self.conv2.weight) and self.conv1.weight.is_contiguous()
+                and self.conv2.weight.is_contiguous()):
+            # both convolution + pool + ReLU halves as one launch each (ee_net2.hip); Dropout2d's per-(image, channel) mask is drawn here
+            # with the calls F.dropout2d makes (bernoulli_(1 - p), div_(1 - p)), so the generator advances as in the stock sequence
+            drop = None
+            if self.training and self.conv2_drop.p > 0:
+                keep = 1.0 - self.conv2_drop.p
+                drop = torch.empty((x.shape[0], 64), dtype=x.dtype, device=x.device).bernoulli_(keep).div_(keep)
+            x = Net2ConvFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, drop)
+        else:
+            x = F.relu(F.max_pool2d(self.conv1(x), 2))
+            x = F.relu(F.max_pool2d(self.conv2_drop(self.conv2(x)), 2))
         x = x.view(-1, 4 * 4 * 64)
         return self.fc2(F.relu(self.fc1(x)))
 

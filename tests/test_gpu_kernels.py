@@ -865,3 +865,83 @@ def test_frontend_bwd_from_saved_responses_is_bit_identical(ops, shape):
     assert_bitexact(s_edge.cpu().numpy(), r_edge.cpu().numpy(), "g_edge")
     if shape[2] >= 16:
         assert int(torch.isnan(s_edge).sum()) > 0
+
+
+# ---- Net_2's convolutional half (MNIST/models_mnist/Net2.py:13-14) as two launches each way (ee_net2.hip) ----------------------------
+@pytest.mark.parametrize("B,with_drop", [(50, False), (50, True), (3, True), (1, False)])
+def test_net2_conv_half_matches_aten(ops, B, with_drop):
+    """relu(max_pool2d(drop * conv2(relu(max_pool2d(conv1(x), 2))), 2)): values within 1e-5 of ATen's sequence, the input gradient within
+    1e-5 of autograd's (the same pool winners and ReLU masks - compared on inputs without ties), parameter gradients through the
+    recomputing branch, NaN / inf inputs keep ATen's footprint."""
+    import torch.nn.functional as F
+    from eeadv.functional import Net2ConvFn
+    g = torch.Generator(device="cpu").manual_seed(B + 7 * with_drop)
+    x = torch.rand(B, 1, 28, 28, generator=g).to(DEV).requires_grad_(True)
+    w1 = (torch.randn(32, 1, 5, 5, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    b1 = (torch.randn(32, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    w2 = (torch.randn(64, 32, 5, 5, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b2 = (torch.randn(64, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    drop = (torch.rand(B, 64, generator=g) < 0.5).float().mul(2.0).to(DEV) if with_drop else None
+    assert ops.net2_conv_supported(x, w1, w2)
+
+    def stock(xx):
+        h = F.relu(F.max_pool2d(F.conv2d(xx, w1, b1), 2))
+        h = F.conv2d(h, w2, b2)
+        if drop is not None:
+            h = h * drop.view(B, 64, 1, 1)
+        return F.relu(F.max_pool2d(h, 2))
+
+    ref = stock(x)
+    got = Net2ConvFn.apply(x, w1, b1, w2, b2, drop)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(got == 0, ref == 0)
+    dy = torch.randn(ref.shape, generator=g).to(DEV)
+    from eeadv.functional import input_grad_only
+    with input_grad_only():  # the attack loop: the HIP backward
+        (gx,) = torch.autograd.grad(got, [x], dy, retain_graph=True)
+    (ex,) = torch.autograd.grad(ref, [x], dy, retain_graph=True)
+    torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-5 * float(ex.abs().max()))
+    # the update: parameter gradients (and x's) through the recomputing branch
+    for a, e in zip(torch.autograd.grad(got, [x, w1, b1, w2, b2], dy), torch.autograd.grad(ref, [x, w1, b1, w2, b2], dy)):
+        torch.testing.assert_close(a, e, rtol=1e-4, atol=1e-5 * float(e.abs().max()))
+    # NaN / inf in the image: the NaN footprint of a direct convolution (float64 on the host - MIOpen's Winograd spreads a NaN over its
+    # whole transform tile and turns inf - inf into NaN, so the stock GPU sequence is no yardstick here), forward and backward
+    xn = x.detach().clone()
+    xn[0, 0, 5, 7], xn[B - 1, 0, 20, 3] = float("nan"), float("inf")
+    xn.requires_grad_(True)
+    gotn = Net2ConvFn.apply(xn, w1, b1, w2, b2, drop)
+    with input_grad_only():
+        (gn,) = torch.autograd.grad(gotn, [xn], dy)
+    xc = xn.detach().double().cpu().requires_grad_(True)
+    pc = [t.detach().double().cpu() for t in (w1, b1, w2, b2)]
+    hc = F.relu(F.max_pool2d(F.conv2d(xc, pc[0], pc[1]), 2))
+    hc = F.conv2d(hc, pc[2], pc[3])
+    if drop is not None:
+        hc = hc * drop.double().cpu().view(B, 64, 1, 1)
+    hc = F.relu(F.max_pool2d(hc, 2))
+    (gc,) = torch.autograd.grad(hc, [xc], dy.double().cpu())
+    assert bool(torch.isnan(gotn).any()) and torch.equal(torch.isnan(gotn).cpu(), torch.isnan(hc))
+    assert torch.equal(torch.isnan(gn).cpu(), torch.isnan(gc))
+
+
+def test_net2_model_uses_the_fused_half_and_draws_the_stock_dropout_mask(ops):
+    """Net_2.body in train mode: Dropout2d's mask is drawn with the calls F.dropout2d makes, so under the same seed the fused path and the
+    stock sequence see the same mask (logits within 1e-4) and leave the generator in the same state."""
+    import torch.nn.functional as F
+    from eeadv.models import Net_2
+    torch.manual_seed(3)
+    net = Net_2().to(DEV).train()
+    x = torch.rand(50, 1, 28, 28, device=DEV)
+    torch.manual_seed(11)
+    got = net.body(x)
+    after_a = torch.cuda.get_rng_state(0)
+    torch.manual_seed(11)
+    h = F.relu(F.max_pool2d(net.conv1(x), 2))
+    h = F.relu(F.max_pool2d(net.conv2_drop(net.conv2(h)), 2))
+    ref = net.fc2(F.relu(net.fc1(h.view(-1, 1024))))
+    after_b = torch.cuda.get_rng_state(0)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    assert torch.equal(after_a, after_b)
+    net.eval()
+    torch.testing.assert_close(net.body(x), net.fc2(F.relu(net.fc1(F.relu(F.max_pool2d(net.conv2(F.relu(F.max_pool2d(net.conv1(x), 2))), 2)).view(-1, 1024)))),
+                               rtol=1e-4, atol=1e-4)
