@@ -88,14 +88,15 @@ constexpr int N2_WP = 28;  // weights of one (co, ci) padded 25 -> 28: 16-byte r
 __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__restrict__ a1, const float *__restrict__ w, const float *__restrict__ bias,
                                                                const float *__restrict__ drop, float *__restrict__ a2, uint8_t *__restrict__ code2) {
     __shared__ __align__(16) float as[N2_C1 * N2_H1 * N2_H1];      // 18 KB
-    __shared__ __align__(16) float ws[8 * N2_C1 * N2_WP];          // 28 KB
+    constexpr int CS = N2_C1 * N2_WP + 4;  // per-channel stride: the 8 channels of a wavefront on disjoint banks (32 * 28 floats apart they collide 8-fold)
+    __shared__ __align__(16) float ws[8 * CS];                     // 28 KB
     __shared__ float part[128 * 4];
     const int b = blockIdx.x, c0 = blockIdx.y * 8;
     const float4 *src = reinterpret_cast<const float4 *>(a1 + static_cast<size_t>(b) * N2_C1 * N2_H1 * N2_H1);
     for (int i = threadIdx.x; i < N2_C1 * N2_H1 * N2_H1 / 4; i += N2_NT) reinterpret_cast<float4 *>(as)[i] = src[i];
     for (int i = threadIdx.x; i < 8 * N2_C1 * 25; i += N2_NT) {  // w[c0 + co][ci][25] is one contiguous block of 8 * 32 * 25 floats
         const int pair = i / 25, k = i - pair * 25;
-        ws[pair * N2_WP + k] = w[static_cast<size_t>(c0) * N2_C1 * 25 + i];
+        ws[(pair >> 5) * CS + (pair & 31) * N2_WP + k] = w[static_cast<size_t>(c0) * N2_C1 * 25 + i];
     }
     __syncthreads();
     const int half = threadIdx.x >> 7, idx = threadIdx.x & 127;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__re
             }
         }
         float wv[N2_WP];
-        const float4 *wr = reinterpret_cast<const float4 *>(ws + (co * N2_C1 + ci) * N2_WP);
+        const float4 *wr = reinterpret_cast<const float4 *>(ws + co * CS + ci * N2_WP);
 #pragma unroll
         for (int j = 0; j < N2_WP / 4; ++j) {
             const float4 t = wr[j];
@@ -158,10 +159,11 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__re
 // then the transposed convolution d a1[ci][y][x] = sum_co sum_{ky,kx} G[co][y - ky][x - kx] * w[co][ci][ky][kx].
 // grid (B, 8): 4 input channels per workgroup; a thread owns one row y of one channel for a quarter of the output channels in flight
 // (192 threads work; 32 output channels at a time in LDS), the four partial rows meet in LDS and are added in quarter order --------
-constexpr int N2_GW = 16;  // G rows padded 8 -> 16 columns (4 zeros either side), 4 zero rows above and below: [co][16][16]
+constexpr int N2_GW = 20;  // G rows: 8 -> 16 columns (4 zeros either side) + 4 of padding (a wavefront's 12 rows on disjoint banks); 16 rows: [co][16][20]
 __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__restrict__ da2, const float *__restrict__ a2, const uint8_t *__restrict__ code2,
                                                                const float *__restrict__ drop, const float *__restrict__ w, float *__restrict__ da1) {
-    __shared__ __align__(16) float G[32 * N2_GW * N2_GW];      // 32 KB
+    constexpr int GP = 16 * N2_GW;                             // one channel's frame
+    __shared__ __align__(16) float G[32 * GP];                 // 40 KB
     __shared__ __align__(16) float ws[N2_C2 * 4 * N2_WP];      // w[co][ci0 .. ci0+3][25 -> 28]: 28 KB
     const int b = blockIdx.x, ci0 = blockIdx.y * 4;
     for (int i = threadIdx.x; i < N2_C2 * 4 * 25; i += N2_NT) {
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__re
     const int q = threadIdx.x / 48, rem = threadIdx.x - q * 48, cl = rem / N2_H1, y = rem - cl * N2_H1;  // threads 0..191: (quarter, channel, row)
     for (int h = 0; h < 2; ++h) {
         __syncthreads();  // the previous half's rows have been read (and, first time round, nothing is pending)
-        for (int i = threadIdx.x; i < 32 * N2_GW * N2_GW / 4; i += N2_NT) reinterpret_cast<float4 *>(G)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int i = threadIdx.x; i < 32 * GP / 4; i += N2_NT) reinterpret_cast<float4 *>(G)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         __syncthreads();
         for (int i = threadIdx.x; i < 32 * 16; i += N2_NT) {
             const int cc = i >> 4, p = i & 15, wy = p >> 2, wx = p & 3, co = 32 * h + cc;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__re
             if (a2[src] <= 0.0f) g = 0.0f;  // ATen's threshold_backward: the gradient passes unless the output is <= 0
             if (drop) g *= drop[static_cast<size_t>(b) * N2_C2 + co];
             const int cd = code2[src];
-            G[cc * (N2_GW * N2_GW) + (4 + 2 * wy + (cd >> 1)) * N2_GW + 4 + 2 * wx + (cd & 1)] = g;
+            G[cc * GP + (4 + 2 * wy + (cd >> 1)) * N2_GW + 4 + 2 * wx + (cd & 1)] = g;
         }
         __syncthreads();
         if (threadIdx.x < 192) {
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__re
 #pragma unroll
                 for (int ky = 0; ky < 5; ++ky) {
                     // G row y - ky of the 8x8 map = padded row 4 + y - ky; its padded columns 0 .. 15 cover x - kx for x in 0..11, kx in 0..4
-                    const float4 *gr = reinterpret_cast<const float4 *>(G + gl * (N2_GW * N2_GW) + (4 + y - ky) * N2_GW);
-                    float row[N2_GW];
+                    const float4 *gr = reinterpret_cast<const float4 *>(G + gl * GP + (4 + y - ky) * N2_GW);
+                    float row[16];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float4 t = gr[j];
@@ -232,17 +234,17 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__re
 }
 
 // ---- backward of the first half: d a1 -> d x.  G1[c][24][24] un-pooled (threshold rule, argmax), d x[y][x] = sum_c sum_k G1[c][y-ky][x-kx] w1[c][ky][kx].
-// grid (B, 2): 14 rows of one image per workgroup; a thread owns 4 neighbouring pixels of a row for half of the channels in flight (8 at
-// a time in LDS, zero-padded frame [c][18][32]); the two halves meet in LDS -------------------------------------------------------------
+// grid (B, 4): 7 rows of one image per workgroup; a thread owns 4 neighbouring pixels of a row for a quarter of the channels in flight
+// (8 at a time in LDS, zero-padded frame [c][11][36]); the four quarters meet in LDS and are added in quarter order ----------------------
 __global__ __launch_bounds__(N2_NT) void net2_conv1_bwd_kernel(const float *__restrict__ da1, const float *__restrict__ a1, const uint8_t *__restrict__ code1,
                                                                const float *__restrict__ w, float *__restrict__ dx) {
-    constexpr int ROWS = 14, FR = ROWS + 4, FW = 32;
-    __shared__ __align__(16) float G[8 * FR * FW];  // 18 KB: [c][4 + (y - y0) - ky][4 + x - kx]
+    constexpr int ROWS = 7, FR = ROWS + 4, FW = 36, NQ = ROWS * 7;  // 49 pixel quads
+    __shared__ __align__(16) float G[8 * FR * FW];  // 12.4 KB: [c][4 + (y - y0) - ky][4 + x - kx]
     __shared__ float ws[N2_C1 * 25];
-    __shared__ __align__(16) float part[98 * 4];
+    __shared__ __align__(16) float part[3 * NQ * 4];
     const int b = blockIdx.x, y0 = blockIdx.y * ROWS;
     for (int i = threadIdx.x; i < N2_C1 * 25; i += N2_NT) ws[i] = w[i];
-    const int hc = threadIdx.x / 98, quad = threadIdx.x - hc * 98, ry = quad / 7, x0 = 4 * (quad - ry * 7);  // threads 0..195
+    const int hc = threadIdx.x / NQ, quad = threadIdx.x - hc * NQ, ry = quad / 7, x0 = 4 * (quad - ry * 7);  // threads 0..195: (channel quarter, quad)
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int c0 = 0; c0 < N2_C1; c0 += 8) {
         __syncthreads();
@@ -260,10 +262,10 @@ __global__ __launch_bounds__(N2_NT) void net2_conv1_bwd_kernel(const float *__re
             }
         }
         __syncthreads();
-        if (threadIdx.x < 196) {
+        if (threadIdx.x < 4 * NQ) {
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = hc * 4 + cc;
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = hc * 2 + cc;
                 const float *wc = ws + (c0 + c) * 25;
 #pragma unroll
                 for (int ky = 0; ky < 5; ++ky) {
@@ -280,12 +282,13 @@ __global__ __launch_bounds__(N2_NT) void net2_conv1_bwd_kernel(const float *__re
             }
         }
     }
-    if (threadIdx.x >= 98 && threadIdx.x < 196) reinterpret_cast<float4 *>(part)[quad] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (threadIdx.x >= NQ && threadIdx.x < 4 * NQ) reinterpret_cast<float4 *>(part)[(hc - 1) * NQ + quad] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     __syncthreads();
-    if (threadIdx.x < 98) {
-        const float4 o = reinterpret_cast<const float4 *>(part)[quad];
+    if (threadIdx.x < NQ) {
+        const float4 *pp = reinterpret_cast<const float4 *>(part);
+        const float4 o1 = pp[quad], o2 = pp[NQ + quad], o3 = pp[2 * NQ + quad];
         *reinterpret_cast<float4 *>(dx + (static_cast<size_t>(b) * N2_H0 + y0 + ry) * N2_H0 + x0) =
-            make_float4(acc[0] + o.x, acc[1] + o.y, acc[2] + o.z, acc[3] + o.w);
+            make_float4(((acc[0] + o1.x) + o2.x) + o3.x, ((acc[1] + o1.y) + o2.y) + o3.y, ((acc[2] + o1.z) + o2.z) + o3.z, ((acc[3] + o1.w) + o2.w) + o3.w);
     }
 }
 
@@ -311,6 +314,6 @@ EE_API int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t
     if (!aligned16(dx)) return EE_ERR_ALIGN;
     hipStream_t st = as_stream(stream);
     EE_LAUNCH(net2_conv2_bwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, da2, a2, code2, drop, w2, da1);
-    EE_LAUNCH(net2_conv1_bwd_kernel, dim3(static_cast<unsigned>(B), 2), dim3(N2_NT), 0, st, da1, a1, code1, w1, dx);
+    EE_LAUNCH(net2_conv1_bwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, da1, a1, code1, w1, dx);
     return launch_status();
 }
