@@ -86,7 +86,8 @@ __global__ __launch_bounds__(N2_NT) void net2_conv1_fwd_kernel(const float *__re
 // over the two halves of the workgroup (threads 0-127 / 128-255), partial sums meet in LDS and are added in that order ----------------
 constexpr int N2_WP = 28;  // weights of one (co, ci) padded 25 -> 28: 16-byte rows
 __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__restrict__ a1, const float *__restrict__ w, const float *__restrict__ bias,
-                                                               const float *__restrict__ drop, float *__restrict__ a2, uint8_t *__restrict__ code2) {
+                                                               const float *__restrict__ drop, float keep, float *__restrict__ a2,
+                                                               uint8_t *__restrict__ code2) {
     __shared__ __align__(16) float as[N2_C1 * N2_H1 * N2_H1];      // 18 KB
     constexpr int CS = N2_C1 * N2_WP + 4;  // per-channel stride: the 8 channels of a wavefront on disjoint banks (32 * 28 floats apart they collide 8-fold)
     __shared__ __align__(16) float ws[8 * CS];                     // 28 KB
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__re
     __syncthreads();
     if (half == 0) {
         const float bv = bias ? bias[c0 + co] : 0.0f;
-        const float dm = drop ? drop[static_cast<size_t>(b) * N2_C2 + c0 + co] : 1.0f;
+        const float dm = drop ? drop[static_cast<size_t>(b) * N2_C2 + c0 + co] / keep : 1.0f;  // Bernoulli(keep) draw (0 / 1) -> 0 or 1 / keep, as noise.div_(keep)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float s = (v[k] + part[idx * 4 + k]) + bv;
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__re
 // (192 threads work; 32 output channels at a time in LDS), the four partial rows meet in LDS and are added in quarter order --------
 constexpr int N2_GW = 20;  // G rows: 8 -> 16 columns (4 zeros either side) + 4 of padding (a wavefront's 12 rows on disjoint banks); 16 rows: [co][16][20]
 __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__restrict__ da2, const float *__restrict__ a2, const uint8_t *__restrict__ code2,
-                                                               const float *__restrict__ drop, const float *__restrict__ w, float *__restrict__ da1) {
+                                                               const float *__restrict__ drop, float keep, const float *__restrict__ w,
+                                                               float *__restrict__ da1) {
     constexpr int GP = 16 * N2_GW;                             // one channel's frame
     __shared__ __align__(16) float G[32 * GP];                 // 40 KB
     __shared__ __align__(16) float ws[N2_C2 * 4 * N2_WP];      // w[co][ci0 .. ci0+3][25 -> 28]: 28 KB
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__re
             const size_t src = (static_cast<size_t>(b) * N2_C2 + co) * 16 + p;
             float g = da2[src];
             if (a2[src] <= 0.0f) g = 0.0f;  // ATen's threshold_backward: the gradient passes unless the output is <= 0
-            if (drop) g *= drop[static_cast<size_t>(b) * N2_C2 + co];
+            if (drop) g *= drop[static_cast<size_t>(b) * N2_C2 + co] / keep;
             const int cd = code2[src];
             G[cc * GP + (4 + 2 * wy + (cd >> 1)) * N2_GW + 4 + 2 * wx + (cd & 1)] = g;
         }
@@ -294,26 +296,27 @@ __global__ __launch_bounds__(N2_NT) void net2_conv1_bwd_kernel(const float *__re
 
 }  // namespace
 
-EE_API int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *drop, float *a1,
-                                uint8_t *code1, float *a2, uint8_t *code2, int B, void *stream) {
+EE_API int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *drop, float keep,
+                                float *a1, uint8_t *code1, float *a2, uint8_t *code2, int B, void *stream) {
     if (B < 0) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
     if (!x || !w1 || !w2 || !a1 || !code1 || !a2 || !code2) return EE_ERR_NULL;
+    if (drop && !(keep > 0.0f)) return EE_ERR_SHAPE;
     if (!aligned16(x) || !aligned16(a1)) return EE_ERR_ALIGN;
     hipStream_t st = as_stream(stream);
     EE_LAUNCH(net2_conv1_fwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, x, w1, b1, a1, code1);
-    EE_LAUNCH(net2_conv2_fwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, a1, w2, b2, drop, a2, code2);
+    EE_LAUNCH(net2_conv2_fwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, a1, w2, b2, drop, keep, a2, code2);
     return launch_status();
 }
 
-EE_API int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t *code2, const float *drop, const float *w2, const float *a1,
-                                const uint8_t *code1, const float *w1, float *da1, float *dx, int B, void *stream) {
+EE_API int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t *code2, const float *drop, float keep, const float *w2,
+                                const float *a1, const uint8_t *code1, const float *w1, float *da1, float *dx, int B, void *stream) {
     if (B < 0) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
     if (!da2 || !a2 || !code2 || !w2 || !a1 || !code1 || !w1 || !da1 || !dx) return EE_ERR_NULL;
     if (!aligned16(dx)) return EE_ERR_ALIGN;
     hipStream_t st = as_stream(stream);
-    EE_LAUNCH(net2_conv2_bwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, da2, a2, code2, drop, w2, da1);
+    EE_LAUNCH(net2_conv2_bwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, da2, a2, code2, drop, keep, w2, da1);
     EE_LAUNCH(net2_conv1_bwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, da1, a1, code1, w1, dx);
     return launch_status();
 }

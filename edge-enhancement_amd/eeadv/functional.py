@@ -464,9 +464,11 @@ class Net2ConvFn(torch.autograd.Function):
     ATen differentiate it."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, drop):
-        a2, saved = ops.net2_conv_fwd(x, w1, b1, w2, b2, drop)
+    def forward(ctx, x, w1, b1, w2, b2, drop, keep=1.0):
+        """drop: the Bernoulli(keep) draw [B,64] of Dropout2d (0 / 1), or None; scaled by 1 / keep inside the kernels"""
+        a2, saved = ops.net2_conv_fwd(x, w1, b1, w2, b2, drop, keep)
         ctx.save_for_backward(x, w1, b1, w2, b2, drop, a2, *saved)
+        ctx.keep = keep
         return a2
 
     @staticmethod
@@ -480,13 +482,13 @@ class Net2ConvFn(torch.autograd.Function):
                 h = F.relu(F.max_pool2d(F.conv2d(xx, w1, b1), 2))
                 h = F.conv2d(h, w2, b2)
                 if drop is not None:
-                    h = h * drop.view(drop.shape[0], drop.shape[1], 1, 1)
+                    h = h * drop.div(ctx.keep).view(drop.shape[0], drop.shape[1], 1, 1)
                 h = F.relu(F.max_pool2d(h, 2))
                 wanted = [t for t, n in zip((xx, w1, b1, w2, b2), need[:5]) if n and t is not None]
                 got = iter(torch.autograd.grad(h, wanted, da2))
-            return tuple(next(got) if (n and t is not None) else None for t, n in zip((xx, w1, b1, w2, b2), need[:5])) + (None,)
-        dx = ops.net2_conv_bwd(da2.contiguous(), a2, (a1, c1, c2), w1, w2, drop) if need[0] else None
-        return dx, None, None, None, None, None
+            return tuple(next(got) if (n and t is not None) else None for t, n in zip((xx, w1, b1, w2, b2), need[:5])) + (None, None)
+        dx = ops.net2_conv_bwd(da2.contiguous(), a2, (a1, c1, c2), w1, w2, drop, ctx.keep) if need[0] else None
+        return dx, None, None, None, None, None, None
 
 
 class PoolLinearFn(torch.autograd.Function):

@@ -299,12 +299,13 @@ class Net_2(nn.Module):
                 and ops.net2_conv_supported(x, self.conv1.weight, self.conv2.weight) and self.conv1.weight.is_contiguous()
                 and self.conv2.weight.is_contiguous()):
             # both convolution + pool + ReLU halves as one launch each (ee_net2.hip); Dropout2d's per-(image, channel) mask is drawn here
-            # with the calls F.dropout2d makes (bernoulli_(1 - p), div_(1 - p)), so the generator advances as in the stock sequence
-            drop = None
+            # with the call F.dropout2d makes (noise.bernoulli_(1 - p)), so the generator advances as in the stock sequence; its
+            # noise.div_(1 - p) happens inside the kernels
+            drop, keep = None, 1.0
             if self.training and self.conv2_drop.p > 0:
                 keep = 1.0 - self.conv2_drop.p
-                drop = torch.empty((x.shape[0], 64), dtype=x.dtype, device=x.device).bernoulli_(keep).div_(keep)
-            x = Net2ConvFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, drop)
+                drop = torch.empty((x.shape[0], 64), dtype=x.dtype, device=x.device).bernoulli_(keep)
+            x = Net2ConvFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, drop, keep)
         else:
             x = F.relu(F.max_pool2d(self.conv1(x), 2))
             x = F.relu(F.max_pool2d(self.conv2_drop(self.conv2(x)), 2))

@@ -767,9 +767,10 @@ def net2_conv_supported(x, w1, w2):
             and x.data_ptr() % 16 == 0)
 
 
-def net2_conv_fwd(x, w1, b1, w2, b2, drop=None):
+def net2_conv_fwd(x, w1, b1, w2, b2, drop=None, keep=1.0):
     """a2 = relu(max_pool2d(drop * conv2(relu(max_pool2d(conv1(x), 2))), 2)) (MNIST/models_mnist/Net2.py:13-14), two launches.
-    Returns (a2 [B,64,4,4], saved) - `saved` = (a1, code1, code2) for net2_conv_bwd.  drop: Dropout2d's [B,64] scale (0 or 1/(1-p)) or None."""
+    Returns (a2 [B,64,4,4], saved) - `saved` = (a1, code1, code2) for net2_conv_bwd.  drop: Dropout2d's [B,64] Bernoulli(keep) draw (0 / 1) or None; the kernels scale by
+    drop / keep (what noise.div_(1 - p) does)."""
     B = x.shape[0]
     dev = x.device
     a1 = torch.empty((B, 32, 12, 12), dtype=torch.float32, device=dev)
@@ -780,19 +781,19 @@ def net2_conv_fwd(x, w1, b1, w2, b2, drop=None):
     N.check(N.lib.ee_net2_conv_fwd_f32(_chk(x, torch.float32, "x", (B, 1, 28, 28)), _chk(w1, torch.float32, "w1", (32, 1, 5, 5)),
                                        None if b1 is None else _chk(b1, torch.float32, "b1", (32,)), _chk(w2, torch.float32, "w2", (64, 32, 5, 5)),
                                        None if b2 is None else _chk(b2, torch.float32, "b2", (64,)),
-                                       None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)), ptr(a1), ptr(c1), ptr(a2), ptr(c2), B,
-                                       _stream()), "ee_net2_conv_fwd_f32")
+                                       None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)), float(keep), ptr(a1), ptr(c1), ptr(a2),
+                                       ptr(c2), B, _stream()), "ee_net2_conv_fwd_f32")
     return a2, (a1, c1, c2)
 
 
-def net2_conv_bwd(da2, a2, saved, w1, w2, drop=None):
+def net2_conv_bwd(da2, a2, saved, w1, w2, drop=None, keep=1.0):
     """d loss / d x [B,1,28,28] of net2_conv_fwd (input gradient only), two launches."""
     a1, c1, c2 = saved
     B = a2.shape[0]
     da1 = torch.empty_like(a1)
     dx = torch.empty((B, 1, 28, 28), dtype=torch.float32, device=a2.device)
     N.check(N.lib.ee_net2_conv_bwd_f32(_chk(da2, torch.float32, "da2", (B, 64, 4, 4)), _chk(a2, torch.float32, "a2"), _chk(c2, torch.uint8, "code2"),
-                                       None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)), _chk(w2, torch.float32, "w2"),
+                                       None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)), float(keep), _chk(w2, torch.float32, "w2"),
                                        _chk(a1, torch.float32, "a1"), _chk(c1, torch.uint8, "code1"), _chk(w1, torch.float32, "w1"),
                                        da1.data_ptr(), dx.data_ptr(), B, _stream()), "ee_net2_conv_bwd_f32")
     return dx

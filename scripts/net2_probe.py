@@ -37,8 +37,9 @@ def timeit(fn, iters=30, reps=3):
 x = torch.rand(B, 1, 28, 28, device=dev)
 w1, b1 = torch.randn(32, 1, 5, 5, device=dev) * 0.2, torch.randn(32, device=dev) * 0.1
 w2, b2 = torch.randn(64, 32, 5, 5, device=dev) * 0.05, torch.randn(64, device=dev) * 0.1
-drop = (torch.rand(B, 64, device=dev) < 0.5).float() * 2
-a2, saved = ops.net2_conv_fwd(x, w1, b1, w2, b2, drop)
+draw = (torch.rand(B, 64, device=dev) < 0.5).float()
+drop = draw * 2
+a2, saved = ops.net2_conv_fwd(x, w1, b1, w2, b2, draw, 0.5)
 da2 = torch.randn_like(a2)
 
 
@@ -56,7 +57,7 @@ def stock_both():
     return torch.autograd.grad(h, [xr], da2)
 
 
-print("%-44s %8.1f us" % ("fused forward (2 launches)", timeit(lambda: ops.net2_conv_fwd(x, w1, b1, w2, b2, drop))))
-print("%-44s %8.1f us" % ("fused backward (2 launches)", timeit(lambda: ops.net2_conv_bwd(da2, a2, saved, w1, w2, drop))))
+print("%-44s %8.1f us" % ("fused forward (2 launches)", timeit(lambda: ops.net2_conv_fwd(x, w1, b1, w2, b2, draw, 0.5))))
+print("%-44s %8.1f us" % ("fused backward (2 launches)", timeit(lambda: ops.net2_conv_bwd(da2, a2, saved, w1, w2, draw, 0.5))))
 print("%-44s %8.1f us" % ("stock forward", timeit(stock_fwd)))
 print("%-44s %8.1f us" % ("stock forward + backward", timeit(stock_both)))

@@ -881,7 +881,9 @@ def test_net2_conv_half_matches_aten(ops, B, with_drop):
     b1 = (torch.randn(32, generator=g) * 0.1).to(DEV).requires_grad_(True)
     w2 = (torch.randn(64, 32, 5, 5, generator=g) * 0.05).to(DEV).requires_grad_(True)
     b2 = (torch.randn(64, generator=g) * 0.1).to(DEV).requires_grad_(True)
-    drop = (torch.rand(B, 64, generator=g) < 0.5).float().mul(2.0).to(DEV) if with_drop else None
+    keep = 0.7 if B == 3 else 0.5
+    draw = (torch.rand(B, 64, generator=g) < keep).float().to(DEV) if with_drop else None  # Bernoulli(keep): 0 / 1
+    drop = draw.div(keep) if with_drop else None                                           # what the stock sequence multiplies by
     assert ops.net2_conv_supported(x, w1, w2)
 
     def stock(xx):
@@ -892,7 +894,7 @@ def test_net2_conv_half_matches_aten(ops, B, with_drop):
         return F.relu(F.max_pool2d(h, 2))
 
     ref = stock(x)
-    got = Net2ConvFn.apply(x, w1, b1, w2, b2, drop)
+    got = Net2ConvFn.apply(x, w1, b1, w2, b2, draw, keep)
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
     assert torch.equal(got == 0, ref == 0)
     dy = torch.randn(ref.shape, generator=g).to(DEV)
@@ -909,7 +911,7 @@ def test_net2_conv_half_matches_aten(ops, B, with_drop):
     xn = x.detach().clone()
     xn[0, 0, 5, 7], xn[B - 1, 0, 20, 3] = float("nan"), float("inf")
     xn.requires_grad_(True)
-    gotn = Net2ConvFn.apply(xn, w1, b1, w2, b2, drop)
+    gotn = Net2ConvFn.apply(xn, w1, b1, w2, b2, draw, keep)
     with input_grad_only():
         (gn,) = torch.autograd.grad(gotn, [xn], dy)
     xc = xn.detach().double().cpu().requires_grad_(True)
