@@ -5,6 +5,7 @@ train_batch follows Tiny_ImageNet/experiments_tinyimagenet.py:245-306 (MNIST twi
 zero_grad / backward / optimizer.step.  Everything stays on the device; nothing calls .item() here (the
 reference syncs every batch at :299 - the drivers sync only when they print).
 """
+import os
 import weakref
 
 import torch
@@ -161,6 +162,75 @@ class _GraphedUpdate:
         return self.loss.clone(), self.output.clone()
 
 
+class _GraphedPredsUpdate:
+    """TRADES / ALP / tarALP (experiments_tinyimagenet.py:250-262, :286-291): the step is  preds = model(input)  ->  attack  ->
+    output = model(data_adv); loss = criterion.loss(model, preds, ...); zero_grad; backward; step  - and `preds` stays attached across
+    the attack (the backward runs through that first forward too).  The attack cannot be part of a capture (it is a graph of its
+    own and draws its random start eagerly), so the step is TWO captured graphs around it that share one memory pool: the first forward
+    (its saved activations stay where the second graph's backward reads them), and everything after the attack.  Eager, these were ~1200
+    launches from Python per step behind a replayed attack - 9 ms of host time against 18 ms on the device, close enough for the
+    device to wait on the host between small kernels."""
+
+    def __init__(self, model, criterion, optimizer, args, input, target, device):
+        self.model, self.criterion, self.optimizer = weakref.ref(model), criterion, weakref.ref(optimizer)
+        self.args, self.device = args, device
+        self.x, self.y, self.adv = torch.empty_like(input), torch.empty_like(target), torch.empty_like(input)
+        self.g1 = self.g2 = None
+        self.eager_left = EAGER_UPDATES_BEFORE_CAPTURE
+
+    def _attack(self, preds):
+        model, m = self.model(), self.args.method_name
+        if m == 'TRADES':
+            return self.criterion.PGD_Linf(model, self.x, preds)
+        if m == 'ALP':
+            return self.criterion.PGD_Linf(model, self.x, self.y)
+        return self.criterion.tarPGD_Linf(model, self.x, self.y, self.device)
+
+    def _after_attack(self, preds):
+        model, optimizer = self.model(), self.optimizer()
+        output = model(self.adv)
+        if self.args.method_name == 'TRADES':
+            loss = self.criterion.loss(model, preds, self.adv, self.y, optimizer)
+        else:
+            loss = self.criterion.loss(model, preds, output, self.y, optimizer)
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        optimizer.step()
+        if torch.cuda.is_current_stream_capturing():
+            from eeadv.functional import rebuild_dense_weights
+            rebuild_dense_weights(model)
+        return loss.detach(), output.detach()
+
+    def __call__(self, input, target):
+        model = self.model()
+        self.x.copy_(input)
+        self.y.copy_(target)
+        if self.eager_left > 0:
+            self.eager_left -= 1
+            preds = model(self.x)
+            self.adv.copy_(self._attack(preds))
+            return self._after_attack(preds)
+        from eeadv.functional import refresh_dense_weights
+        refresh_dense_weights()
+        if self.g1 is None:
+            if not model.training:
+                raise RuntimeError("TRADES / ALP step: the model must be in train mode when the step starts (the .loss() methods leave it there)")
+            torch.cuda.synchronize()
+            self.g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g1, capture_error_mode=runtime.capture_mode()):
+                self.preds = model(self.x)
+            self.adv.copy_(self._attack(self.preds))  # leaves the model in eval mode, as in the eager step: the second capture starts there
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode=runtime.capture_mode()):
+                self.loss, self.output = self._after_attack(self.preds)
+            # the captures recorded the kernels without running them: run the step they stand for
+        self.g1.replay()
+        self.adv.copy_(self._attack(self.preds))
+        self.g2.replay()
+        model.train()  # where criterion.loss() leaves it
+        return self.loss.clone(), self.output.clone()
+
+
 class PhaseEvents:
     """Per-rank device time of the phases of a data-parallel training step (bench.py, N > 1): HIP events on the current stream at
     the phase boundaries, read after the timed region."""
@@ -198,6 +268,16 @@ def _graphable_update(model, criterion, optimizer, args, data_adv):
             and args.method_name not in ('ALP', 'tarALP', 'TRADES', 'AVmixup', 'tarAVmixup'))
 
 
+def _graphable_preds_update(model, criterion, optimizer, args, input, sync):
+    from eeadv import engine
+    return (engine.graphs_enabled() and input.is_cuda and sync is None and type(optimizer) is torch.optim.SGD and model.training
+            and not isinstance(model, (nn.parallel.DistributedDataParallel, nn.DataParallel)) and _GRAPH_PREDS
+            and args.method_name in ('TRADES', 'ALP', 'tarALP'))
+
+
+_GRAPH_PREDS = os.environ.get("EEADV_GRAPH_TRADES", "1") == "1"  # 0: the TRADES / ALP step around the attack stays eager (A/B)
+
+
 def backward_and_step(loss, optimizer, sync=None):
     """zero_grad / backward / step of the drivers (experiments_tinyimagenet.py:304-306), with the gradient all-reduce of a
     data-parallel run in between when `sync` (ddp.FlatGradSync) is given."""
@@ -216,6 +296,18 @@ def backward_and_step(loss, optimizer, sync=None):
 def train_batch(model, criterion, optimizer, args, input, target, device, avmixup=None, sync=None):
     """One optimisation step; returns (loss, output) detached, both still on the device.  sync: ddp.FlatGradSync of a
     data-parallel run (the model is then NOT wrapped in DistributedDataParallel)."""
+    if _graphable_preds_update(model, criterion, optimizer, args, input, sync):
+        owner = (id(model), id(optimizer))
+        sig = _sgd_signature(optimizer)
+        slot = _UPDATES.get(owner)
+        if slot is None or slot[0] != sig or slot[1]() is not model or slot[2]() is not optimizer:
+            slot = (sig, weakref.ref(model), weakref.ref(optimizer), {})
+            _UPDATES[owner] = slot
+        key = ("preds", args.method_name, tuple(input.shape), tuple(target.shape), target.dtype, input.device.index)
+        update = slot[3].get(key)
+        if update is None:
+            update = slot[3][key] = _GraphedPredsUpdate(model, criterion, optimizer, args, input, target, device)
+        return update(input.detach(), target)
     data_adv, preds, new_target = attack_for_training(model, criterion, args, input, target, device, avmixup)
     if PHASE_EVENTS is not None:
         PHASE_EVENTS.mark("attack")
