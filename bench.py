@@ -448,8 +448,9 @@ def main():
                 "rank0_phase_ms": phases, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": probe_iters, "probe_every": a.probe_every,
                 "device": (N.lib.ee_device_name() or b"?").decode()},
             "roofline": roofline, "roofline_front_end": roofline_hbm, "kernels": kernels, "final_loss": round(loss_val, 5),
-            "note": "throughput is bounded by the CNN convolutions (MIOpen fp32), not by the hand-written kernels; "
-                    "reference log (unrecorded GPU): ~143 img/s for this config (BASELINE.md)",
+            "note": "throughput is bounded by the classifier's fp32 convolutions (hand-written MFMA kernels + MIOpen) and BatchNorm launches, "
+                    "not by the front-end / update / loss kernels (3 % of an iteration); reference log (unrecorded GPU): ~143 img/s for "
+                    "this config (BASELINE.md)",
         }
         if world == 1 and a.large_batch:
             out["kernels_large_batch"] = large_batch_kernels(cfg, dev)
