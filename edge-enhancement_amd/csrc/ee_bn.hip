@@ -372,6 +372,164 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
         }
 }
 
+// ---- a residual block with a down-sampling shortcut ends in TWO BatchNorms: relu(bn2(conv2 out) + bn_ds(conv1x1 out)) (resnet.py:54-59,
+// :137-142).  Both are per-channel, so one workgroup does both for its channel - one launch each way instead of two (at these sizes
+// a BatchNorm launch is 5-6 us of launch floor).  Same statistics, same expressions, same order as bn_fwd/bwd_cached_kernel run one
+// after the other: bit-identical results. ---------------------------------------------------------------------------------------------
+struct BnParams {
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    float momentum, eps;
+    float *save_mean, *save_invstd;
+};
+
+template <int NT, int MAXV>
+__device__ __forceinline__ void cached_stats(const float4 (&xv)[MAXV], int total, float n, const BnParams &p, int training, int c, float *scratch,
+                                             float &mean, float &invstd) {
+    if (training) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) acc += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);  // lanes past the end hold zeros
+        mean = block_sum<NT>(acc, scratch) / n;
+        float var = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j)
+            if (static_cast<int>(threadIdx.x) + j * NT < total) {
+                const float a = xv[j].x - mean, b = xv[j].y - mean, cc = xv[j].z - mean, d = xv[j].w - mean;
+                var += (a * a + b * b) + (cc * cc + d * d);
+            }
+        var = block_sum<NT>(var, scratch) / n;
+        invstd = 1.0f / sqrtf(var + p.eps);
+        if (threadIdx.x == 0) {
+            p.save_mean[c] = mean;
+            p.save_invstd[c] = invstd;
+            if (p.running_mean) {
+                const float unbiased = (n > 1.0f) ? var * (n / (n - 1.0f)) : var;
+                p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+                p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * unbiased;
+            }
+        }
+    } else {
+        mean = p.running_mean[c];
+        invstd = 1.0f / sqrtf(p.running_var[c] + p.eps);
+    }
+}
+
+// y = relu( bn_a(xa) + bn_b(xb) ): bn_b first (it is the `residual` of the unfused call), then bn_a with the residual added
+template <int NT, int MAXV>
+__global__ __launch_bounds__(NT) void bn_dual_fwd_cached_kernel(const float *__restrict__ xa, const float *__restrict__ xb, BnParams pa, BnParams pb,
+                                                                int training, float *__restrict__ y, BnShape s) {
+    __shared__ float scratch[NT / 64];
+    const int c = blockIdx.x;
+    const int per = s.HW / 4, total = s.B * per;
+    const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
+    const float4 *a4 = reinterpret_cast<const float4 *>(xa), *b4 = reinterpret_cast<const float4 *>(xb);
+    float4 av[MAXV], bv[MAXV];
+    unsigned off[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int e0 = threadIdx.x + j * NT;
+        const int e = e0 < total ? e0 : total - 1;
+        const int b = e / per, q = e - b * per;
+        off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
+        av[j] = a4[off[j]];
+        bv[j] = b4[off[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+        if (static_cast<int>(threadIdx.x) + j * NT >= total) av[j] = bv[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float mean_b, inv_b, mean_a, inv_a;
+    cached_stats<NT, MAXV>(bv, total, n, pb, training, c, scratch, mean_b, inv_b);
+    cached_stats<NT, MAXV>(av, total, n, pa, training, c, scratch, mean_a, inv_a);
+    const float sb = inv_b * (pb.gamma ? pb.gamma[c] : 1.0f), tb = pb.beta ? pb.beta[c] : 0.0f;
+    const float sa = inv_a * (pa.gamma ? pa.gamma[c] : 1.0f), ta = pa.beta ? pa.beta[c] : 0.0f;
+    float4 *y4 = reinterpret_cast<float4 *>(y);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+        if (static_cast<int>(threadIdx.x) + j * NT < total) {
+            const float4 u = bv[j], v = av[j];
+            const float4 q = make_float4((u.x - mean_b) * sb + tb, (u.y - mean_b) * sb + tb, (u.z - mean_b) * sb + tb, (u.w - mean_b) * sb + tb);
+            float4 r = make_float4((v.x - mean_a) * sa + ta, (v.y - mean_a) * sa + ta, (v.z - mean_a) * sa + ta, (v.w - mean_a) * sa + ta);
+            r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+            y4[off[j]] = make_float4(relu_nan(r.x), relu_nan(r.y), relu_nan(r.z), relu_nan(r.w));
+        }
+}
+
+// dz = (y > 0) * (dy + dy2); bn_a's backward on dz -> dxa, then bn_b's (no ReLU of its own) on the same dz -> dxb
+template <int NT, int MAXV>
+__global__ __launch_bounds__(NT) void bn_dual_bwd_cached_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
+                                                                const float *__restrict__ xa, const float *__restrict__ xb, BnParams pa, BnParams pb,
+                                                                int training, float *__restrict__ dxa, float *__restrict__ dxb,
+                                                                float *__restrict__ dgamma_a, float *__restrict__ dbeta_a,
+                                                                float *__restrict__ dgamma_b, float *__restrict__ dbeta_b, BnShape s) {
+    __shared__ float scratch[NT / 64];
+    const int c = blockIdx.x;
+    const int per = s.HW / 4, total = s.B * per;
+    const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
+    const float mean_a = training ? pa.save_mean[c] : pa.running_mean[c], mean_b = training ? pb.save_mean[c] : pb.running_mean[c];
+    const float inv_a = training ? pa.save_invstd[c] : 1.0f / sqrtf(pa.running_var[c] + pa.eps);
+    const float inv_b = training ? pb.save_invstd[c] : 1.0f / sqrtf(pb.running_var[c] + pb.eps);
+    const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *dy24 = reinterpret_cast<const float4 *>(dy2), *y4 = reinterpret_cast<const float4 *>(y);
+    const float4 *a4 = reinterpret_cast<const float4 *>(xa), *b4 = reinterpret_cast<const float4 *>(xb);
+    float4 gv[MAXV], ha[MAXV], hb[MAXV], yv[MAXV];
+    unsigned off[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int e0 = threadIdx.x + j * NT;
+        const int e = e0 < total ? e0 : total - 1;
+        const int b = e / per, q = e - b * per;
+        off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
+        gv[j] = dy4[off[j]];
+        ha[j] = a4[off[j]];
+        hb[j] = b4[off[j]];
+        yv[j] = y4[off[j]];
+    }
+    if (dy24) {
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) gv[j] = add4(gv[j], dy24[off[j]]);
+    }
+    float sdz = 0.0f, sa = 0.0f, sb = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const bool in = static_cast<int>(threadIdx.x) + j * NT < total;
+        float4 g = gv[j];
+        const float4 yy = yv[j];
+        g.x = yy.x > 0.0f ? g.x : 0.0f;
+        g.y = yy.y > 0.0f ? g.y : 0.0f;
+        g.z = yy.z > 0.0f ? g.z : 0.0f;
+        g.w = yy.w > 0.0f ? g.w : 0.0f;
+        const float4 va = ha[j], vb = hb[j];
+        float4 xa_ = make_float4((va.x - mean_a) * inv_a, (va.y - mean_a) * inv_a, (va.z - mean_a) * inv_a, (va.w - mean_a) * inv_a);
+        float4 xb_ = make_float4((vb.x - mean_b) * inv_b, (vb.y - mean_b) * inv_b, (vb.z - mean_b) * inv_b, (vb.w - mean_b) * inv_b);
+        if (!in) g = xa_ = xb_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        sdz += (g.x + g.y) + (g.z + g.w);
+        sa += (g.x * xa_.x + g.y * xa_.y) + (g.z * xa_.z + g.w * xa_.w);
+        sb += (g.x * xb_.x + g.y * xb_.y) + (g.z * xb_.z + g.w * xb_.w);
+        gv[j] = g;
+        ha[j] = xa_;
+        hb[j] = xb_;
+    }
+    sdz = block_sum<NT>(sdz, scratch);
+    sa = block_sum<NT>(sa, scratch);
+    sb = block_sum<NT>(sb, scratch);
+    if (threadIdx.x == 0) {
+        if (dgamma_a) dgamma_a[c] = sa;
+        if (dbeta_a) dbeta_a[c] = sdz;
+        if (dgamma_b) dgamma_b[c] = sb;
+        if (dbeta_b) dbeta_b[c] = sdz;
+    }
+    const float wa = (pa.gamma ? pa.gamma[c] : 1.0f) * inv_a, wb = (pb.gamma ? pb.gamma[c] : 1.0f) * inv_b;
+    const float m1 = training ? sdz / n : 0.0f, ma = training ? sa / n : 0.0f, mb = training ? sb / n : 0.0f;
+    float4 *da4 = reinterpret_cast<float4 *>(dxa), *db4 = reinterpret_cast<float4 *>(dxb);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+        if (static_cast<int>(threadIdx.x) + j * NT < total) {
+            const float4 g = gv[j], p = ha[j], q = hb[j];
+            if (dxa) da4[off[j]] = make_float4(wa * ((g.x - m1) - p.x * ma), wa * ((g.y - m1) - p.y * ma), wa * ((g.z - m1) - p.z * ma), wa * ((g.w - m1) - p.w * ma));
+            if (dxb) db4[off[j]] = make_float4(wb * ((g.x - m1) - q.x * mb), wb * ((g.y - m1) - q.y * mb), wb * ((g.z - m1) - q.z * mb), wb * ((g.w - m1) - q.w * mb));
+        }
+}
+
 template <int NT, int MAXV>
 void launch_fwd_cached(bool relu, bool has_res, hipStream_t st, const float *x, const float *res, const float *gamma, const float *beta, float *rm,
                        float *rv, float momentum, float eps, int training, float *y, float *sm, float *si, BnShape s) {
@@ -1042,6 +1200,62 @@ EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, 
               training, dx, dgamma, dbeta, workspace, p);
     EE_LAUNCH((bn_pool_bwd_kernel<true>), grid, block, lds, st, dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
               training, dx, dgamma, dbeta, workspace, p);
+    return launch_status();
+}
+
+// 1 when relu(bn_a(xa) + bn_b(xb)) runs as one launch each way (the register-cached variants with 256-lane workgroups), else 0
+EE_API int ee_bn_dual_supported(int B, int C, int HW) {
+    if (B < 1 || C < 1 || HW < 1 || HW % 4) return 0;
+    const int cv = cached_variant(static_cast<int64_t>(B) * (HW / 4), static_cast<int64_t>(B) * C * HW);
+    return (cv == 1 || cv == 2) ? 1 : 0;
+}
+
+EE_API int ee_bn_dual_fwd_f32(const float *xa, const float *xb, const float *gamma_a, const float *beta_a, float *running_mean_a, float *running_var_a,
+                              float momentum_a, float eps_a, float *save_mean_a, float *save_invstd_a, const float *gamma_b, const float *beta_b,
+                              float *running_mean_b, float *running_var_b, float momentum_b, float eps_b, float *save_mean_b, float *save_invstd_b,
+                              int training, float *y, int B, int C, int HW, void *stream) {
+    if (B < 0 || C < 1 || HW < 1) return EE_ERR_SHAPE;
+    if (B == 0) return EE_OK;
+    if (!ee_bn_dual_supported(B, C, HW)) return EE_ERR_UNSUPPORTED;
+    if (!xa || !xb || !y) return EE_ERR_NULL;
+    if (training && (!save_mean_a || !save_invstd_a || !save_mean_b || !save_invstd_b)) return EE_ERR_NULL;
+    if (!training && (!running_mean_a || !running_var_a || !running_mean_b || !running_var_b)) return EE_ERR_NULL;
+    if (!aligned16(xa) || !aligned16(xb) || !aligned16(y)) return EE_ERR_ALIGN;
+    const BnShape s{B, C, HW};
+    const BnParams pa{gamma_a, beta_a, running_mean_a, running_var_a, momentum_a, eps_a, save_mean_a, save_invstd_a};
+    const BnParams pb{gamma_b, beta_b, running_mean_b, running_var_b, momentum_b, eps_b, save_mean_b, save_invstd_b};
+    const dim3 grid(static_cast<unsigned>(C)), block(256);
+    if (cached_variant(static_cast<int64_t>(B) * (HW / 4), static_cast<int64_t>(B) * C * HW) == 1)
+        EE_LAUNCH((bn_dual_fwd_cached_kernel<256, 2>), grid, block, 0, as_stream(stream), xa, xb, pa, pb, training, y, s);
+    else
+        EE_LAUNCH((bn_dual_fwd_cached_kernel<256, 7>), grid, block, 0, as_stream(stream), xa, xb, pa, pb, training, y, s);
+    return launch_status();
+}
+
+EE_API int ee_bn_dual_bwd_f32(const float *dy, const float *dy2, const float *y, const float *xa, const float *xb, const float *gamma_a,
+                              const float *save_mean_a, const float *save_invstd_a, const float *running_mean_a, const float *running_var_a,
+                              float eps_a, const float *gamma_b, const float *save_mean_b, const float *save_invstd_b,
+                              const float *running_mean_b, const float *running_var_b, float eps_b, int training, float *dxa, float *dxb,
+                              float *dgamma_a, float *dbeta_a, float *dgamma_b, float *dbeta_b, int B, int C, int HW, void *stream) {
+    if (B < 0 || C < 1 || HW < 1) return EE_ERR_SHAPE;
+    if (B == 0) return EE_OK;
+    if (!ee_bn_dual_supported(B, C, HW)) return EE_ERR_UNSUPPORTED;
+    if (!dy || !y || !xa || !xb) return EE_ERR_NULL;
+    if (training && (!save_mean_a || !save_invstd_a || !save_mean_b || !save_invstd_b)) return EE_ERR_NULL;
+    if (!training && (!running_mean_a || !running_var_a || !running_mean_b || !running_var_b)) return EE_ERR_NULL;
+    if (!aligned16(dy) || !al16(dy2) || !aligned16(y) || !aligned16(xa) || !aligned16(xb) || !al16(dxa) || !al16(dxb)) return EE_ERR_ALIGN;
+    const BnShape s{B, C, HW};
+    const BnParams pa{gamma_a, nullptr, const_cast<float *>(running_mean_a), const_cast<float *>(running_var_a), 0.0f, eps_a, const_cast<float *>(save_mean_a),
+                      const_cast<float *>(save_invstd_a)};
+    const BnParams pb{gamma_b, nullptr, const_cast<float *>(running_mean_b), const_cast<float *>(running_var_b), 0.0f, eps_b, const_cast<float *>(save_mean_b),
+                      const_cast<float *>(save_invstd_b)};
+    const dim3 grid(static_cast<unsigned>(C)), block(256);
+    if (cached_variant(static_cast<int64_t>(B) * (HW / 4), static_cast<int64_t>(B) * C * HW) == 1)
+        EE_LAUNCH((bn_dual_bwd_cached_kernel<256, 2>), grid, block, 0, as_stream(stream), dy, dy2, y, xa, xb, pa, pb, training, dxa, dxb, dgamma_a, dbeta_a,
+                  dgamma_b, dbeta_b, s);
+    else
+        EE_LAUNCH((bn_dual_bwd_cached_kernel<256, 7>), grid, block, 0, as_stream(stream), dy, dy2, y, xa, xb, pa, pb, training, dxa, dxb, dgamma_a, dbeta_a,
+                  dgamma_b, dbeta_b, s);
     return launch_status();
 }
 

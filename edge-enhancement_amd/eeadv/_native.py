@@ -68,6 +68,10 @@ SIGNATURES = {
     "ee_bn_act_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_bn_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_bn_act_bwd2_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "ee_bn_dual_supported": [c_i, c_i, c_i],
+    "ee_bn_dual_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p],
+    "ee_bn_dual_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p,
+                           c_i, c_i, c_i, c_p],
     "ee_bn_relu_pool_workspace_floats": [c_i, c_i, c_i, c_i],
     # x, gamma, beta, rm, rv, momentum, eps, training, y_pool, code, save_mean, save_invstd, workspace, conv_stats, slices, B, C, H, W, stream
     "ee_bn_relu_pool_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],

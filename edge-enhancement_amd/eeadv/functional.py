@@ -185,6 +185,35 @@ class BnActFn(torch.autograd.Function):
         return (dx, dres, (dg if want[2] else None), (db if want[3] else None)) + none[4:]
 
 
+class BnDualFn(torch.autograd.Function):
+    """relu(bn_a(xa) + bn_b(xb)): the end of a residual block with a down-sampling shortcut (resnet.py:54-59, :137-142) - the block's
+    second BatchNorm and the shortcut's in ONE launch each way (ee_bn.hip, bn_dual_*), bit-identical to the two BnActFn calls.
+    fork: see BnActFn."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, ga, ba, rma, rva, mom_a, eps_a, gb, bb, rmb, rvb, mom_b, eps_b, training, fork=False):
+        y, saves = ops.bn_dual_fwd(xa, xb, (ga, ba, rma, rva, mom_a, eps_a), (gb, bb, rmb, rvb, mom_b, eps_b), training)
+        ctx.save_for_backward(xa, xb, y, ga, gb, *saves, *((None,) * 4 if training else (rma, rva, rmb, rvb)))
+        ctx.cfg = (eps_a, eps_b, training)
+        ctx.set_materialize_grads(False)
+        return (y, y.view_as(y)) if fork else y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xa, xb, y, ga, gb, sma, sia, smb, sib, rma, rva, rmb, rvb = ctx.saved_tensors
+        eps_a, eps_b, training = ctx.cfg
+        need = ctx.needs_input_grad
+        none = (None,) * 16
+        dy, dy2 = _two_pieces(grads)
+        want_params = (need[2] or need[3] or need[8] or need[9]) and not _INPUT_GRAD_ONLY
+        if dy is None or not (need[0] or need[1] or want_params):
+            return none
+        dxa, dxb, dga, dba, dgb, dbb = ops.bn_dual_bwd(dy, dy2, y, xa, xb, ga, gb, (sma, sia, smb, sib), rma, rva, rmb, rvb, eps_a, eps_b, training,
+                                                       need[0], need[1], want_params)
+        keep = lambda t, i: t if (need[i] and want_params) else None
+        return (dxa, dxb, keep(dga, 2), keep(dba, 3), None, None, None, None, keep(dgb, 8), keep(dbb, 9)) + none[10:]
+
+
 class BnReluPoolFn(torch.autograd.Function):
     """maxpool3s2(relu(batch_norm(x))) - the ResNet stem (resnet.py:113-117) - in one pass each way: the full-resolution activation and its
     gradient never exist (ee_bn.hip: bn_pool_*)."""

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime
-from .functional import Net2ConvFn, BnActFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -118,6 +118,26 @@ def head(avgpool, fc, x):
         return PoolLinearFn.apply(x, fc.weight, fc.bias)
     x = avgpool(x)
     return fc(x.view(x.size(0), -1))
+
+
+def block_tail(block, bn, out, x, fork):
+    """relu(bn(out) + shortcut(x)) - the last line of a residual block (resnet.py:54-59 / :105-110).  With a down-sampling shortcut whose
+    1x1 convolution runs on ee_conv.hip, its BatchNorm and the block's last one are ONE launch each way (functional.BnDualFn)."""
+    ds = block.downsample
+    if ("bn" not in _STOCK and "bndual" not in _STOCK and ds is not None and isinstance(ds, nn.Sequential) and len(ds) == 2 and type(ds[0]) is nn.Conv2d
+            and type(ds[1]) is BatchNorm2d and type(bn) is BatchNorm2d and _dense_f32(x) and _dense_f32(out) and bn.affine and ds[1].affine
+            and bn.track_running_stats and ds[1].track_running_stats and bn.training == ds[1].training and ops.bn_dual_supported(out)):
+        cv = ds[0]
+        if ("conv" not in _STOCK and cv.kernel_size == (1, 1) and cv.stride == (2, 2) and cv.padding == (0, 0) and cv.bias is None and cv.groups == 1
+                and cv.in_channels % 2 == 0 and cv.out_channels % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                and cv.weight.is_contiguous()):
+            sc = Conv1x1S2Fn.apply(x, cv.weight)
+            if sc.shape == out.shape:
+                b2 = ds[1]
+                return BnDualFn.apply(out, sc, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.0 if bn.momentum is None else bn.momentum, bn.eps,
+                                      b2.weight, b2.bias, b2.running_mean, b2.running_var, 0.0 if b2.momentum is None else b2.momentum, b2.eps,
+                                      bn.training, fork and _FORK)
+    return bn_act(bn, out, shortcut(block, x), fork=fork)
 
 
 def shortcut(block, x):
@@ -367,7 +387,7 @@ class BasicBlock(nn.Module):
         """x: a tensor, or the two tensors of the previous block's forked output; fork: hand this block's output on the same way"""
         xm, xs = _pair(x)
         out = bn_act(self.bn1, conv3(self.conv1, xm))
-        return bn_act(self.bn2, conv3(self.conv2, out), shortcut(self, xs), fork=fork)
+        return block_tail(self, self.bn2, conv3(self.conv2, out), xs, fork)
 
 
 class Bottleneck(nn.Module):
@@ -389,7 +409,7 @@ class Bottleneck(nn.Module):
         xm, xs = _pair(x)
         out = bn_act(self.bn1, self.conv1(xm))
         out = bn_act(self.bn2, conv3(self.conv2, out))
-        return bn_act(self.bn3, self.conv3(out), shortcut(self, xs), fork=fork)
+        return block_tail(self, self.bn3, self.conv3(out), xs, fork)
 
 
 class ResNet(nn.Module):

@@ -575,6 +575,44 @@ def bn_act_bwd(dy, y, x, gamma, save_mean, save_invstd, running_mean, running_va
     return dx, dres, dg, db
 
 
+def bn_dual_supported(x):
+    return x.dim() == 4 and x.shape[0] > 0 and N.lib.ee_bn_dual_supported(x.shape[0], x.shape[1], x[0, 0].numel()) == 1
+
+
+def bn_dual_fwd(xa, xb, bna, bnb, training):
+    """y = relu(bn_a(xa) + bn_b(xb)) in one launch (the end of a residual block with a down-sampling shortcut, resnet.py:54-59).
+    bna / bnb = (gamma, beta, running_mean, running_var, momentum, eps).  Returns (y, (sm_a, si_a, sm_b, si_b)) - Nones in eval mode."""
+    B, C = xa.shape[0], xa.shape[1]
+    HW = xa[0, 0].numel()
+    y = torch.empty_like(xa)
+    saves = [None] * 4
+    if training:
+        saves = [torch.empty(C, dtype=torch.float32, device=xa.device) for _ in range(4)]
+    ptr = lambda t: None if t is None else t.data_ptr()
+    ga, ba, rma, rva, ma, ea = bna
+    gb, bb, rmb, rvb, mb, eb = bnb
+    N.check(N.lib.ee_bn_dual_fwd_f32(_chk(xa, torch.float32, "xa"), _chk(xb, torch.float32, "xb", xa.shape), ptr(ga), ptr(ba), ptr(rma), ptr(rva),
+                                     float(ma), float(ea), ptr(saves[0]), ptr(saves[1]), ptr(gb), ptr(bb), ptr(rmb), ptr(rvb), float(mb), float(eb),
+                                     ptr(saves[2]), ptr(saves[3]), 1 if training else 0, y.data_ptr(), B, C, HW, _stream()), "ee_bn_dual_fwd_f32")
+    return y, tuple(saves)
+
+
+def bn_dual_bwd(dy, dy2, y, xa, xb, ga, gb, saves, rma, rva, rmb, rvb, ea, eb, training, want_dxa=True, want_dxb=True, want_dparams=True):
+    """Backward of bn_dual_fwd: (dxa, dxb, dgamma_a, dbeta_a, dgamma_b, dbeta_b), None where not wanted."""
+    B, C = xa.shape[0], xa.shape[1]
+    HW = xa[0, 0].numel()
+    dxa = torch.empty_like(xa) if want_dxa else None
+    dxb = torch.empty_like(xb) if want_dxb else None
+    dp = [torch.empty(C, dtype=torch.float32, device=xa.device) if want_dparams else None for _ in range(4)]
+    ptr = lambda t: None if t is None else t.data_ptr()
+    N.check(N.lib.ee_bn_dual_bwd_f32(_chk(dy, torch.float32, "dy", xa.shape), None if dy2 is None else _chk(dy2, torch.float32, "dy2", xa.shape),
+                                     _chk(y, torch.float32, "y", xa.shape), _chk(xa, torch.float32, "xa"), _chk(xb, torch.float32, "xb"), ptr(ga),
+                                     ptr(saves[0]), ptr(saves[1]), ptr(rma), ptr(rva), float(ea), ptr(gb), ptr(saves[2]), ptr(saves[3]), ptr(rmb),
+                                     ptr(rvb), float(eb), 1 if training else 0, ptr(dxa), ptr(dxb), ptr(dp[0]), ptr(dp[1]), ptr(dp[2]), ptr(dp[3]),
+                                     B, C, HW, _stream()), "ee_bn_dual_bwd_f32")
+    return (dxa, dxb) + tuple(dp)
+
+
 def bn_relu_pool_supported(x):
     """relu(bn(x)) -> MaxPool2d(3, 2, 1) as one pass each way (the ResNet stem): shapes ee_bn_relu_pool_*_f32 take."""
     return x.dim() == 4 and x.shape[0] > 0 and N.lib.ee_bn_relu_pool_workspace_floats(x.shape[0], x.shape[1], x.shape[2], x.shape[3]) > 0

@@ -280,6 +280,22 @@ int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y, const 
                        int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW,
                        void *stream);
 
+/* The end of a residual block with a down-sampling shortcut (resnet.py:54-59 with :137-142): y = relu(bn_a(xa) + bn_b(xb)), bn_a = the
+ * block's second BatchNorm on its convolution's output, bn_b = the shortcut's BatchNorm on the 1x1 convolution's output - both per
+ * channel, so ONE launch each way instead of two; results bit-identical to ee_bn_act_fwd_f32(xb, relu=0) -> ee_bn_act_fwd_f32(xa,
+ * residual, relu=1) and their backwards.  ee_bn_dual_supported: 1 for the shapes it takes (one 256-lane workgroup holds a channel in
+ * registers), else use the two calls.  Backward: dy (+ dy2, nullable second piece) -> dxa, dxb (nullable), dgamma / dbeta (nullable). */
+int ee_bn_dual_supported(int B, int C, int HW);
+int ee_bn_dual_fwd_f32(const float *xa, const float *xb, const float *gamma_a, const float *beta_a, float *running_mean_a, float *running_var_a,
+                       float momentum_a, float eps_a, float *save_mean_a, float *save_invstd_a, const float *gamma_b, const float *beta_b,
+                       float *running_mean_b, float *running_var_b, float momentum_b, float eps_b, float *save_mean_b, float *save_invstd_b,
+                       int training, float *y, int B, int C, int HW, void *stream);
+int ee_bn_dual_bwd_f32(const float *dy, const float *dy2, const float *y, const float *xa, const float *xb, const float *gamma_a,
+                       const float *save_mean_a, const float *save_invstd_a, const float *running_mean_a, const float *running_var_a,
+                       float eps_a, const float *gamma_b, const float *save_mean_b, const float *save_invstd_b,
+                       const float *running_mean_b, const float *running_var_b, float eps_b, int training, float *dxa, float *dxb,
+                       float *dgamma_a, float *dbeta_a, float *dgamma_b, float *dbeta_b, int B, int C, int HW, void *stream);
+
 /* relu(batch_norm(x)) followed by MaxPool2d(3, stride 2, padding 1) - the ResNet stem (resnet.py:113-117 / :148-150) - without
  * the full-resolution activation: forward x [B,C,H,W] -> y_pool [B,C,OH,OW] + one-byte argmax codes (OH = (H-1)/2+1); backward
  * dy_pool (+ dy_pool2, nullable: the second piece of the gradient, see ee_bn_act_bwd2_f32) + codes + x -> dx [B,C,H,W] (nullable),

@@ -499,6 +499,39 @@ def test_bn_act_backward_relu_mask_recomputed_from_x(ops, shape, training):
                 assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(e, nan=-7.0))
 
 
+@pytest.mark.parametrize("shape", [(100, 128, 8, 8), (100, 256, 4, 4), (100, 512, 2, 2), (3, 6, 2, 2), (9, 4, 4, 8)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_dual_equals_the_two_batchnorm_calls(ops, shape, training):
+    """relu(bn2(conv2 out) + bn_ds(conv1x1 out)) - the end of a block with a down-sampling shortcut (resnet.py:54-59, :137-142) - in one
+    launch each way: output, running statistics and every gradient bit-identical to BnActFn(xb, relu=False) -> BnActFn(xa, residual,
+    relu=True), one gradient piece or two (forked output)."""
+    from eeadv.functional import BnActFn, BnDualFn
+    g = torch.Generator(device="cpu").manual_seed(sum(shape) + training)
+    C = shape[1]
+    assert ops.bn_dual_supported(torch.empty(shape, device=DEV))
+    mk = lambda: (torch.randn(shape, generator=g) * 2 + 0.5).to(DEV).requires_grad_(True)
+    xa, xb = mk(), mk()
+    pr = lambda: ((torch.rand(C, generator=g) + 0.5).to(DEV).requires_grad_(True), torch.randn(C, generator=g).to(DEV).requires_grad_(True))
+    (ga, ba), (gb, bb) = pr(), pr()
+    st0 = [torch.randn(C, generator=g).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)]
+    ins = [xa, xb, ga, ba, gb, bb]
+    d1, d2 = torch.randn(shape, generator=g).to(DEV), torch.randn(shape, generator=g).to(DEV)
+    s_two = [t.clone() for t in st0]
+    res = BnActFn.apply(xb, None, gb, bb, s_two[2], s_two[3], 0.1, 1e-5, training, False)
+    two = BnActFn.apply(xa, res, ga, ba, s_two[0], s_two[1], 0.2, 2e-5, training, True)
+    s_one = [t.clone() for t in st0]
+    one = BnDualFn.apply(xa, xb, ga, ba, s_one[0], s_one[1], 0.2, 2e-5, gb, bb, s_one[2], s_one[3], 0.1, 1e-5, training)
+    assert torch.equal(one, two)
+    for a, e in zip(s_one, s_two):
+        assert torch.equal(a, e)
+    for a, e in zip(torch.autograd.grad(one, ins, d1, retain_graph=True), torch.autograd.grad(two, ins, d1, retain_graph=True)):
+        assert torch.equal(a, e)
+    ya, yb = BnDualFn.apply(xa, xb, ga, ba, st0[0].clone(), st0[1].clone(), 0.2, 2e-5, gb, bb, st0[2].clone(), st0[3].clone(), 0.1, 1e-5, training, True)
+    for a, e in zip(torch.autograd.grad([ya, yb], ins, [d1, d2]), torch.autograd.grad(two, ins, d1 + d2)):
+        assert torch.equal(a, e)
+    assert not ops.bn_dual_supported(torch.empty(100, 64, 32, 32, device=DEV))  # the stem's size: split kernels, two calls
+
+
 def test_bn_act_only_input_grad_and_reproducible(ops):
     """The attack loop differentiates w.r.t. the input only (attacks.py:24): no parameter gradients are produced, and two
     runs give the same bits (fixed-order reductions)."""
