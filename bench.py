@@ -301,7 +301,7 @@ def main():
     model = build_model(cfg).to(dev).train()
     if a.channels_last:
         model = model.to(memory_format=torch.channels_last)
-    optimizer = torch.optim.SGD(model.parameters(), lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"])
+    optimizer = trainer.make_sgd(model.parameters(), lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"])
     from eeadv import ddp
     # N > 1: one flat gradient buffer all-reduced over RCCL between the two captured halves of the update (eeadv.ddp.FlatGradSync);
     # the attack needs no collective at all.  The model is not wrapped: DistributedDataParallel's reducer needs an eager backward

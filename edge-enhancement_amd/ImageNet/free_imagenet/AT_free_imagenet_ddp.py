@@ -173,7 +173,7 @@ def main(argv=None, parser=None, build=build_model, dirs_of=output_dirs, eval_at
     sync = ddp.FlatGradSync(model) if ddp.world() > 1 else None
     net = model
     criterion = trainer.Criterion()
-    optimizer = torch.optim.SGD(net.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    optimizer = trainer.make_sgd(net.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
     if ddp.rank() == 0:
         print('arch:{},bs:{},lr:{},wd:{},momentum:{},epochs:{}'.format(args.arch, args.batch_size, args.lr, args.weight_decay, args.momentum, args.epochs))
         print('clip-eps:{},fgsm-step:{},n-repeats:{},world:{}'.format(int(round(args.clip_eps * 255)), int(round(args.fgsm_step * 255)),

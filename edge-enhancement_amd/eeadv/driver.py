@@ -245,7 +245,7 @@ def run(spec, build_model, argv=None):
     if use_cuda:
         torch.backends.cudnn.benchmark = False  # experiments_tinyimagenet.py:111-112
         torch.backends.cudnn.deterministic = True
-    optimizer = optim.SGD(net.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    optimizer = trainer.make_sgd(net.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
     criterion = trainer.make_criterion(args)
     best_prec1 = 0.0
     if args.resume:
