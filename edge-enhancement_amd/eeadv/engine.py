@@ -126,9 +126,11 @@ class _GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         self.load(x_init, x0, payload)
         self.graph = torch.cuda.CUDAGraph()
+        from .models import deferred_bn_counters
         with torch.cuda.graph(self.graph, capture_error_mode=runtime.capture_mode()):
-            for _ in range(self.iters):
-                self._body(model)
+            with deferred_bn_counters():  # the BatchNorm counters of the `iters` forwards: one launch at the end of the graph
+                for _ in range(self.iters):
+                    self._body(model)
 
     def load(self, x_init, x0, payload):
         with torch.no_grad():

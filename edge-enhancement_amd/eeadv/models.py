@@ -198,15 +198,35 @@ def stem_conv(conv, x, want_stats=False):
     return (conv(x), None) if want_stats else conv(x)
 
 
-def _bump_bn_counters(model):
-    if not model.training:
+class deferred_bn_counters:
+    """Inside this context the per-forward `num_batches_tracked += 1` of the ResNets is only COUNTED; leaving it adds the total in one
+    multi-tensor launch per model.  engine wraps the capture of a multi-iteration attack graph in it: one 5 us launch per replay instead
+    of one per iteration (nothing reads the counters in between: momentum is never None in these models)."""
+    active = None
+
+    def __enter__(self):
+        self._prev, deferred_bn_counters.active = deferred_bn_counters.active, {}
+        return self
+
+    def __exit__(self, *exc):
+        pending, deferred_bn_counters.active = deferred_bn_counters.active, self._prev
+        for model, n in pending.values():
+            _bump_bn_counters(model, n)
+
+
+def _bump_bn_counters(model, n=1):
+    if not model.training and n == 1:
+        return
+    if deferred_bn_counters.active is not None and model.training:
+        ent = deferred_bn_counters.active.setdefault(id(model), [model, 0])
+        ent[1] += n
         return
     counters = getattr(model, "_bn_counters", None)
     if counters is None or (counters and counters[0].device != next(model.parameters()).device):
         counters = [m.num_batches_tracked for m in model.modules() if isinstance(m, BatchNorm2d) and m.num_batches_tracked is not None]
         model._bn_counters = counters
     if counters:
-        torch._foreach_add_(counters, 1)
+        torch._foreach_add_(counters, n)
 
 
 class _EEFrontMixin:
