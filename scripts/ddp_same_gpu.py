@@ -40,7 +40,7 @@ def main():
                            type_canny="CannyFilter_step125_1", epsilon=0.05, n_queries=1).to(dev).train()
     sync = ddp.FlatGradSync(model)  # broadcasts rank 0's weights (the ranks were seeded differently)
     net = model
-    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=2e-4)
+    opt = trainer.make_sgd(net.parameters(), lr=0.05, momentum=0.9, weight_decay=2e-4)  # what bench.py and the drivers build (torch's fused SGD)
     args = Args(method_name="EE_BPDA3_AT_square", random=True, epsilon=16 / 255, num_steps_1=4, step_size_1=2 / 255, num_classes=200)
     crit = trainer.make_criterion(args)
     trainer.PHASE_EVENTS = trainer.PhaseEvents()
