@@ -1,0 +1,185 @@
+// ee_wino.hip - Conv2d(3x3, stride 1, padding 1, bias=False) on 8x8 maps (ResNet-18 layer2 at 64x64 inputs, resnet.py:26-31) as
+// Winograd F(2x2, 3x3) around the f32 matrix cores.
+//
+// Why: the direct implicit-GEMM kernels of ee_conv.hip sit at the matrix pipe's effective rate for these occupancies;
+// on the 128-channel 8x8 layers they only tie MIOpen's Winograd (31.9 vs 29.4 us for 1.9 GFLOP), which does 2.25x fewer multiplies on the
+// vector ALUs.  Here the 16 element-wise products of the transform domain are 16 small GEMMs on v_mfma_f32_16x16x4_f32:
+//     V = B^T d B  (4x4 input patch d of tile t, channel ci)        U = G g G^T  (3x3 filter g of (co, ci); precomputed, `u`)
+//     M_xi[co][t] = sum_ci U_xi[co][ci] * V_xi[ci][t]   xi = 0..15     Y = A^T M A  (2x2 outputs of tile t, channel co)
+// An 8x8 map is 4x4 = 16 tiles - exactly the N of one MFMA - so a workgroup owns ONE image x 32 result channels: per 16-channel round
+// it stages the input patch plane (zero ring) and the U slice [16 xi][16 ci][32 co] in LDS, every lane transforms one (ci, tile) patch
+// into V, and each of the 4 wavefronts multiplies its four xi (2 channel tiles x 4 k-steps = 32 MFMAs); the next round's global loads
+// travel meanwhile.  The accumulators meet in LDS for the output transform.  Backward-data is the same kernel on U built from the
+// flipped, transposed filter.  Exact f32 products; the transforms add a few 1e-7 of relative error (as MIOpen's solver does).
+//
+// CNN-body glue, not a row of SURVEY.md section 8.
+#include "ee_common.hpp"
+
+namespace {
+
+using namespace ee;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WN_NT = 256, WN_CK = 16, WN_CO = 32;
+constexpr int WN_CP = 48;                      // U row stride in LDS: the four k of a wavefront on disjoint banks (32 + 16)
+constexpr int WN_US = WN_CK * WN_CP;           // one xi's [16 ci][48]
+constexpr int WN_XW = 12, WN_XP = 10 * WN_XW;  // input plane 10 x 10 (zero ring) in a 10 x 12 frame
+
+struct WinoDims {
+    int B, KC, RC;  // reduction channels (input channels forward), result channels
+};
+
+// x [B][KC][8][8], u [16][KC][RC] (transformed filters), y [B][RC][8][8].  grid (B, RC / 32).
+__global__ __launch_bounds__(WN_NT) void wino3x3_map8_kernel(const float *__restrict__ x, const float *__restrict__ u, float *__restrict__ y, WinoDims d) {
+    __shared__ __align__(16) float us[16 * WN_US];          // 48 KB; after the rounds: M [16 xi][32 co][16 tiles] (32 KB)
+    __shared__ __align__(16) float vs[16 * WN_CK * 16];     // 16 KB: [xi][ci][tile]
+    __shared__ __align__(16) float xs[WN_CK * WN_XP];       // 7.5 KB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, co0 = blockIdx.y * WN_CO;
+    const int l15 = lane & 15, lq = lane >> 4;
+    // zero ring of the input frames, once (the interior is rewritten every round)
+    for (int i = threadIdx.x; i < WN_CK * WN_XP; i += WN_NT) xs[i] = 0.0f;
+    // staging roles: U slice = 16 xi x 16 ci rows of 32 floats -> 8 lanes (16 B each) per row, 8 rows per thread; x chunk = 16 ci x 64 px -> one float4
+    const int urow0 = threadIdx.x >> 3, uq = threadIdx.x & 7;
+    // The prefetch registers are eight NAMED float4s and the loads straight-line code: as an array (under a lambda, or in a loop the
+    // compiler would not unroll) they lived in scratch memory - a store and a load through the memory pipe per round.
+    const int ci_s = urow0 & 15, xi_s = urow0 >> 4;  // rows urow0 + 32 j: ci = urow0 & 15 for every j, xi = (urow0 >> 4) + 2 j
+    const float *ubase = u + (static_cast<size_t>(xi_s) * d.KC + ci_s) * d.RC + co0 + 4 * uq;
+    const size_t uxi2 = 2 * static_cast<size_t>(d.KC) * d.RC;  // two xi further
+    const float *xsrc = x + (static_cast<size_t>(b) * d.KC + (threadIdx.x >> 4)) * 64 + 4 * (threadIdx.x & 15);
+    const size_t ustep = static_cast<size_t>(WN_CK) * d.RC, xstep = static_cast<size_t>(WN_CK) * 64;
+    float4 u0, u1, u2, u3, u4, u5, u6, u7, xpre;
+#define WN_PREFETCH(round_)                                                                  \
+    do {                                                                                     \
+        const float *up_ = ubase + (round_) * ustep;                                         \
+        u0 = *reinterpret_cast<const float4 *>(up_);                                         \
+        u1 = *reinterpret_cast<const float4 *>(up_ + uxi2);                                  \
+        u2 = *reinterpret_cast<const float4 *>(up_ + 2 * uxi2);                              \
+        u3 = *reinterpret_cast<const float4 *>(up_ + 3 * uxi2);                              \
+        u4 = *reinterpret_cast<const float4 *>(up_ + 4 * uxi2);                              \
+        u5 = *reinterpret_cast<const float4 *>(up_ + 5 * uxi2);                              \
+        u6 = *reinterpret_cast<const float4 *>(up_ + 6 * uxi2);                              \
+        u7 = *reinterpret_cast<const float4 *>(up_ + 7 * uxi2);                              \
+        xpre = *reinterpret_cast<const float4 *>(xsrc + (round_) * xstep);                   \
+    } while (0)
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[a][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int rounds = d.KC / WN_CK;
+    WN_PREFETCH(0);
+    for (int round = 0; round < rounds; ++round) {
+        __syncthreads();  // the previous round's MFMAs have read us / vs; (first round: the zero ring is written)
+        {
+            float *ud = us + xi_s * WN_US + ci_s * WN_CP + 4 * uq;  // row urow0 + 32 j -> xi = xi_s + 2 j
+            *reinterpret_cast<float4 *>(ud) = u0;
+            *reinterpret_cast<float4 *>(ud + 2 * WN_US) = u1;
+            *reinterpret_cast<float4 *>(ud + 4 * WN_US) = u2;
+            *reinterpret_cast<float4 *>(ud + 6 * WN_US) = u3;
+            *reinterpret_cast<float4 *>(ud + 8 * WN_US) = u4;
+            *reinterpret_cast<float4 *>(ud + 10 * WN_US) = u5;
+            *reinterpret_cast<float4 *>(ud + 12 * WN_US) = u6;
+            *reinterpret_cast<float4 *>(ud + 14 * WN_US) = u7;
+        }
+        {
+            const int ci = threadIdx.x >> 4, q = threadIdx.x & 15, r = q >> 1, c4 = 4 * (q & 1);
+            float *dst = xs + ci * WN_XP + (1 + r) * WN_XW + 1 + c4;
+            dst[0] = xpre.x; dst[1] = xpre.y; dst[2] = xpre.z; dst[3] = xpre.w;
+        }
+        __syncthreads();
+        {
+            const int nr = round + 1 < rounds ? round + 1 : round;  // always issued (the last round re-reads its own slice): a load under a
+            WN_PREFETCH(nr);                                          // condition kept the register array in scratch memory
+        }
+        // ---- V = B^T d B: lane = (ci, tile) ------------------------------------------------------------------------------------------
+        {
+            const int ci = threadIdx.x >> 4, t = threadIdx.x & 15, ty = t >> 2, tx = t & 3;
+            const float *p = xs + ci * WN_XP + (2 * ty) * WN_XW + 2 * tx;  // patch rows 2ty-1 .. 2ty+2 of the image = frame rows 2ty .. 2ty+3
+            float dd[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dd[i][j] = p[i * WN_XW + j];
+            float tt[4][4];  // B^T d
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tt[0][j] = dd[0][j] - dd[2][j];
+                tt[1][j] = dd[1][j] + dd[2][j];
+                tt[2][j] = dd[2][j] - dd[1][j];
+                tt[3][j] = dd[1][j] - dd[3][j];
+            }
+            float *vp = vs + ci * 16 + t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vp[(4 * i + 0) * (WN_CK * 16)] = tt[i][0] - tt[i][2];
+                vp[(4 * i + 1) * (WN_CK * 16)] = tt[i][1] + tt[i][2];
+                vp[(4 * i + 2) * (WN_CK * 16)] = tt[i][2] - tt[i][1];
+                vp[(4 * i + 3) * (WN_CK * 16)] = tt[i][1] - tt[i][3];
+            }
+        }
+        __syncthreads();
+        // ---- M_xi += U_xi V_xi for this wavefront's four xi: A[m = l15][k = lq] = U[xi][ci = 4 kq + lq][co], B[k = lq][n = l15] = V[xi][ci][tile] ----
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int xi = 4 * wave + a;
+            const float *up = us + xi * WN_US + lq * WN_CP + l15;
+            const float *vp = vs + xi * (WN_CK * 16) + lq * 16 + l15;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const float bv = vp[kq * 4 * 16];
+                const float a0 = up[kq * 4 * WN_CP], a1 = up[kq * 4 * WN_CP + 16];
+                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[a][1], 0, 0, 0);
+            }
+        }
+    }
+    // ---- output transform Y = A^T M A.  D[row = 4 lq + reg][col = l15] -> ms[xi][co][tile] ------------------------------------------------
+    __syncthreads();
+    float *ms = us;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ms[((4 * wave + a) * WN_CO + 16 * m + 4 * lq + r) * 16 + l15] = acc[a][m][r];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = threadIdx.x + k * WN_NT;  // (co, tile)
+        const int co = idx >> 4, t = idx & 15, ty = t >> 2, tx = t & 3;
+        float mm[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm[i][j] = ms[((4 * i + j) * WN_CO + co) * 16 + t];
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t0[j] = (mm[0][j] + mm[1][j]) + mm[2][j];
+            t1[j] = (mm[1][j] - mm[2][j]) - mm[3][j];
+        }
+        float *o = y + ((static_cast<size_t>(b) * d.RC + co0 + co) * 8 + 2 * ty) * 8 + 2 * tx;
+        *reinterpret_cast<float2 *>(o) = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]);
+        *reinterpret_cast<float2 *>(o + 8) = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
+    }
+}
+
+#undef WN_PREFETCH
+
+}  // namespace
+
+// y = conv3x3(x) for 8x8 maps with the filters given in the transform domain: u [16][KC][RC], u[4i+j][k][r] = (G g G^T)[i][j] of the
+// (r, k) filter pair the product needs (forward: g = w[r][k]; backward-data: g = w[k][r] rotated by 180 degrees).
+EE_API int ee_wino3x3_map8_f32(const float *x, const float *u, float *y, int B, int KC, int RC, void *stream) {
+    if (B < 0 || KC < 1 || RC < 1) return EE_ERR_SHAPE;
+    if (KC % WN_CK != 0 || RC % WN_CO != 0) return EE_ERR_UNSUPPORTED;
+    if (B == 0) return EE_OK;
+    if (!x || !u || !y) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(u) || !aligned16(y)) return EE_ERR_ALIGN;
+    if (static_cast<int64_t>(B) * (KC > RC ? KC : RC) * 64 > 0x7fffffffLL) return EE_ERR_SHAPE;
+    EE_LAUNCH(wino3x3_map8_kernel, dim3(static_cast<unsigned>(B), static_cast<unsigned>(RC / WN_CO)), dim3(WN_NT), 0, as_stream(stream), x, u, y,
+              WinoDims{B, KC, RC});
+    return launch_status();
+}

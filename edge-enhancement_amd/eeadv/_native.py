@@ -77,6 +77,7 @@ SIGNATURES = {
     "ee_bn_relu_pool_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     # dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, rm, rv, eps, training, dx, dgamma, dbeta, workspace, B, C, H, W, stream
     "ee_bn_relu_pool_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "ee_wino3x3_map8_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_net2_conv_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],
     "ee_net2_conv_bwd_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "ee_maxpool3s2_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],

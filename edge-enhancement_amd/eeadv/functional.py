@@ -378,6 +378,17 @@ def _rearranged(weight, kind="s1"):
     """kind "s1": 3x3 / stride 1 / padding 1 on a 2x2 map -> [4 Cin, 4 Cout]; kind "s2": 3x3 / stride 2 / padding 1 from a 4x4 map to
     a 2x2 map -> [16 Cin, 4 Cout] (tap ky = iy - 2 oy + 1, zero where it leaves the 3x3 window)."""
     co, ci = weight.shape[0], weight.shape[1]
+    if kind in ("wino_f", "wino_b"):
+        # Winograd F(2x2, 3x3) filter transform U = G g G^T, laid out [16][KC][RC] for ee_wino.hip: forward g = w[r][k] (k = input channel),
+        # backward-data g = w[k][r] rotated by 180 degrees (k = output channel)
+        G = _DENSE_IDX.get((weight.device, "G"))
+        if G is None:
+            G = _DENSE_IDX[(weight.device, "G")] = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+                                                                 dtype=weight.dtype, device=weight.device)
+        w = weight.detach()
+        if kind == "wino_f":
+            return torch.einsum("ia,jb,rkab->ijkr", G, G, w).reshape(16, ci, co)
+        return torch.einsum("ia,jb,krab->ijkr", G, G, w.flip(2, 3)).reshape(16, co, ci)
     idx = _DENSE_IDX.get((weight.device, kind))
     if idx is None:
         n_in, stride = (2, 1) if kind == "s1" else (4, 2)
@@ -395,7 +406,7 @@ def _rearranged(weight, kind="s1"):
 
 
 def _dense_weight(weight, kind="s1"):
-    ent = _DENSE_W.get(id(weight))
+    ent = _DENSE_W.get((id(weight), kind))
     if ent is not None and ent[0]() is not weight:
         ent = None
     if torch.cuda.is_current_stream_capturing():
@@ -405,7 +416,7 @@ def _dense_weight(weight, kind="s1"):
     if ent is None or ent[1] != weight._version:
         with torch.no_grad():
             if ent is None:
-                ent = _DENSE_W[id(weight)] = [weakref.ref(weight), weight._version, _rearranged(weight, kind).contiguous(), kind]
+                ent = _DENSE_W[(id(weight), kind)] = [weakref.ref(weight), weight._version, _rearranged(weight, kind).contiguous(), kind]
             else:
                 ent[2].copy_(_rearranged(weight, kind))
                 ent[1] = weight._version
@@ -423,7 +434,7 @@ def rebuild_dense_weights(model=None):
             w = _DENSE_W[key][0]()
             if w is None:
                 del _DENSE_W[key]
-            elif own is None or key in own:
+            elif own is None or key[0] in own:
                 _DENSE_W[key][2].copy_(_rearranged(w, _DENSE_W[key][3]))
                 _DENSE_W[key][1] = w._version
 
@@ -437,6 +448,29 @@ def refresh_dense_weights():
             del _DENSE_W[key]
         elif _DENSE_W[key][1] != w._version:
             _dense_weight(w, _DENSE_W[key][3])
+
+
+class Conv3x3WinoFn(torch.autograd.Function):
+    """Conv2d(3x3, stride 1, padding 1, bias=False) on 8x8 maps (ResNet-18 layer2 at 64x64 inputs, resnet.py:26-31): forward and
+    backward-data as Winograd F(2x2, 3x3) around the f32 matrix cores (ee_wino.hip); the transformed filters follow the weight's version
+    counter like the dense matrices above (rebuilt inside a captured optimiser step); weight gradient on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        u = _dense_weight(weight, "wino_f")
+        _dense_weight(weight, "wino_b")  # created outside any capture; the backward only reads it
+        ctx.save_for_backward(x, weight)
+        return ops.wino3x3_map8(x, u)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.wino3x3_map8(dy, _dense_weight(weight, "wino_b")) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw
 
 
 class Conv3x3S2Map4Fn(torch.autograd.Function):

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime
-from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -169,6 +169,11 @@ def conv3(conv, x):
             and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels * conv.out_channels <= 1 << 18):
         return Conv3x3S2Map4Fn.apply(x, conv.weight)  # layer4.0.conv1 at 64x64 inputs: backward-data as one dense product (opt-in)
+    if ("conv3" not in _STOCK and "wino" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and x.shape[2] == 8 and x.shape[3] == 8
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
+            and conv.weight.is_contiguous()):
+        return Conv3x3WinoFn.apply(x, conv.weight)  # 8x8 maps (layer2): Winograd F(2x2,3x3) on the matrix cores, 21 us against MIOpen's 29.4 - eager passes included
     if not (_CONV3_EAGER or PROBE_MFMA_CONV or torch.cuda.is_current_stream_capturing()):
         return conv(x)
     if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)

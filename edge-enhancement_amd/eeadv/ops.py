@@ -721,6 +721,16 @@ def conv3x3s1_bwd_data(dy, weight):
     return dx
 
 
+def wino3x3_map8(x, u):
+    """3x3 / stride 1 / padding 1 convolution of 8x8 maps, filters in the Winograd domain: x [B,KC,8,8], u [16,KC,RC] -> [B,RC,8,8]."""
+    B, KC = x.shape[0], x.shape[1]
+    RC = u.shape[2]
+    y = torch.empty((B, RC, 8, 8), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_wino3x3_map8_f32(_chk(x, torch.float32, "x", (B, KC, 8, 8)), _chk(u, torch.float32, "u", (16, KC, RC)), y.data_ptr(), B, KC, RC,
+                                      _stream()), "ee_wino3x3_map8_f32")
+    return y
+
+
 def conv3x3s2_fwd(x, weight):
     """Conv2d(Cin, Cout, 3, stride 2, padding 1, bias=False) forward on ee_conv.hip's implicit GEMM."""
     B, Cin, H, W = x.shape

@@ -348,6 +348,12 @@ int ee_conv3x3s2_fwd_f32(const float *x, const float *weight, float *y, int B, i
 int ee_conv3x3s2_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W,
                               void *stream);
 
+/* Conv2d(3x3, stride 1, padding 1, bias=False) on 8x8 maps as Winograd F(2x2, 3x3) around the f32 matrix cores (ResNet-18 layer2 at
+ * 64x64 inputs, resnet.py:26-31): x [B,KC,8,8], u [16][KC][RC] = the filters in the transform domain, u[4i+j][k][r] = (G g G^T)[i][j] with
+ * g = weight[r][k] (forward: KC = Cin, RC = Cout) or g = weight[k][r] rotated by 180 degrees (backward-data: KC = Cout, RC = Cin;
+ * x = dy) -> y [B,RC,8,8].  KC % 16 == 0, RC % 32 == 0 (else EE_ERR_UNSUPPORTED). */
+int ee_wino3x3_map8_f32(const float *x, const float *u, float *y, int B, int KC, int RC, void *stream);
+
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.
  *   dy [B,K,H/2,W/2], weight [K,3,7,7] -> dx [B,3,H,W];  H, W even. */

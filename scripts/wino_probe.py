@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Un-profiled cost of the 3x3 convolution on 128-channel 8x8 maps (ResNet-18 layer2, B = 100): MIOpen (Winograd on the vector ALUs), the
+direct MFMA kernel of ee_conv.hip, Winograd F(2x2,3x3) on the matrix cores (ee_wino.hip); graph-replayed back-to-back launches."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "edge-enhancement_amd"))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from eeadv import functional as EF, ops  # noqa: E402
+
+torch.backends.cudnn.benchmark = True
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+dev = "cuda:0"
+
+
+def timeit(fn, iters=30, reps=3):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return 1e3 * a.elapsed_time(b) / (iters * reps)
+
+
+for c in (128, 64, 256):
+    x = torch.randn(B, c, 8, 8, device=dev)
+    w = torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5)
+    u = EF._rearranged(w, "wino_f").contiguous()
+    print("%3d ch 8x8:  MIOpen %6.1f us   direct MFMA %6.1f us   Winograd MFMA %6.1f us" % (
+        c, timeit(lambda: F.conv2d(x, w, None, 1, 1)), timeit(lambda: ops.conv3x3s1_fwd(x, w)), timeit(lambda: ops.wino3x3_map8(x, u))), flush=True)

@@ -818,11 +818,11 @@ def test_conv3x3_on_2x2_map_as_dense_product(ops, B, Cin, Cout):
         (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
         torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-3)
-        ptr = EF._DENSE_W[id(w)][2].data_ptr()
+        ptr = EF._DENSE_W[(id(w), "s1")][2].data_ptr()
         with torch.no_grad():
             w.mul_(0.5).add_(0.01)  # an optimiser step: the next forward must see it
         if round_ == 1:
-            assert EF._DENSE_W[id(w)][2].data_ptr() == ptr
+            assert EF._DENSE_W[(id(w), "s1")][2].data_ptr() == ptr
     # a captured forward reads the buffer refreshed by refresh_dense_weights()
     with torch.no_grad():
         xs = x.detach()
@@ -980,3 +980,31 @@ def test_net2_model_uses_the_fused_half_and_draws_the_stock_dropout_mask(ops):
     net.eval()
     torch.testing.assert_close(net.body(x), net.fc2(F.relu(net.fc1(F.relu(F.max_pool2d(net.conv2(F.relu(F.max_pool2d(net.conv1(x), 2))), 2)).view(-1, 1024)))),
                                rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,Cin,Cout", [(100, 128, 128), (3, 32, 32), (2, 64, 96), (1, 128, 64)])
+def test_conv3x3_winograd_on_8x8_maps_matches_aten(ops, B, Cin, Cout):
+    """Conv2d(3x3, stride 1, padding 1) on 8x8 maps as Winograd F(2x2, 3x3) on the f32 matrix cores (ee_wino.hip): forward and input
+    gradient against float64 direct convolution (error of the order of MIOpen's own Winograd solver) and against ATen; the transformed
+    filters follow in-place weight updates."""
+    import torch.nn.functional as F
+    from eeadv import functional as EF
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout)
+    x = torch.randn(B, Cin, 8, 8, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
+    dy = torch.randn(B, Cout, 8, 8, generator=g).to(DEV)
+    for round_ in range(2):
+        ref = F.conv2d(x, w, None, 1, 1)
+        got = EF.Conv3x3WinoFn.apply(x, w)
+        x64, w64 = x.detach().double().requires_grad_(True), w.detach().double()
+        ref64 = F.conv2d(x64, w64, None, 1, 1)
+        scale = float(ref64.abs().max())
+        assert float((got.double() - ref64).abs().max()) < 2e-6 * scale
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+        (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
+        (e64,) = torch.autograd.grad(ref64, [x64], dy.double())
+        assert float((gx.double() - e64).abs().max()) < 2e-6 * float(e64.abs().max())
+        torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (64 * B) ** 0.5)
+        with torch.no_grad():
+            w.mul_(1.25)
