@@ -381,7 +381,10 @@ def main():
         # matrix-core families (the residual blocks' 3x3 convolutions, ee_conv.hip): the library sums the floating-point
         # operations its timed launches declared (2 * 9 * Cin * Cout * B * H * W each), so mixed shapes average correctly
         mfma_fams = {"ee_conv3x3s1_fwd": N.K_CONV3_FWD, "ee_conv3x3s1_bwd_data": N.K_CONV3_BWD,
-                     "ee_conv3x3s1_pipe_fwd": N.K_CONV3P_FWD, "ee_conv3x3s1_pipe_bwd_data": N.K_CONV3P_BWD}
+                     "ee_conv3x3s1_pipe_fwd": N.K_CONV3P_FWD, "ee_conv3x3s1_pipe_bwd_data": N.K_CONV3P_BWD, "ee_wino3x3": N.K_WINO}
+        # Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile where the convolution has 36: `flops` stays the convolution's
+        # algorithmic count, `executed_flops` = 4/9 of it is what the matrix cores actually do
+        executed_share = {"ee_wino3x3": 4.0 / 9.0}
         for name, kid in mfma_fams.items():
             ms, cnt = ops.prof_read(kid)
             if cnt:
@@ -390,6 +393,9 @@ def main():
                 flops = ops.prof_read_work(kid) / cnt
                 kernels[name] = {"launches_timed": cnt, "avg_us": round(us, 3), "avg_bracket_us": round(raw, 3), "flops": flops,
                                  "TFLOPs": round(flops / us / 1e6, 2), "share_of_timed_us": None}
+                if name in executed_share:
+                    kernels[name]["executed_flops"] = flops * executed_share[name]
+                    kernels[name]["executed_TFLOPs"] = round(flops * executed_share[name] / us / 1e6, 2)
         # the dominant hand-written kernel of the path = the family with the largest launches x duration among the timed probes
         # (a probe iteration launches every family as often as a graph replay does, so the probe counts are proportional to
         # the real ones)
@@ -427,9 +433,13 @@ def main():
                 return dict({"kernel": name, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(k["GBps"] / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": k["bytes"],
                              "frac_from_rocprofv3": round(k["bytes"] / rp / 1e3 / HBM_PEAK_GBS, 4) if rp else None}, **common)
+            extra = {}
+            if "executed_flops" in k:  # Winograd: the matrix cores run fewer flops than the convolution has
+                extra = {"executed_flops_per_launch": k["executed_flops"], "executed_TFLOPs": k["executed_TFLOPs"],
+                         "frac_executed": round(k["executed_TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 4)}
             return dict({"kernel": name, "bound": "mfma", "achieved": k["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(k["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": k["flops"],
-                         "frac_from_rocprofv3": round(k["flops"] / rp / 1e6 / F32_MFMA_PEAK_TFLOPS, 4) if rp else None}, **common)
+                         "frac_from_rocprofv3": round(k["flops"] / rp / 1e6 / F32_MFMA_PEAK_TFLOPS, 4) if rp else None}, **extra, **common)
 
         roofline = roofline_of(dom)
         # the largest HBM-bound family as well (the fused front end), when a matrix-core family dominates

@@ -721,13 +721,17 @@ def conv3x3s1_bwd_data(dy, weight):
     return dx
 
 
+def wino3x3_supported(x, cin, cout):
+    return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (8, 16) and cin % 32 == 0 and cout % 32 == 0
+
+
 def wino3x3_map8(x, u):
-    """3x3 / stride 1 / padding 1 convolution of 8x8 maps, filters in the Winograd domain: x [B,KC,8,8], u [16,KC,RC] -> [B,RC,8,8]."""
-    B, KC = x.shape[0], x.shape[1]
+    """3x3 / stride 1 / padding 1 convolution of 8x8 or 16x16 maps, filters in the Winograd domain: x [B,KC,H,H], u [16,KC,RC] -> [B,RC,H,H]."""
+    B, KC, H = x.shape[0], x.shape[1], x.shape[2]
     RC = u.shape[2]
-    y = torch.empty((B, RC, 8, 8), dtype=torch.float32, device=x.device)
-    N.check(N.lib.ee_wino3x3_map8_f32(_chk(x, torch.float32, "x", (B, KC, 8, 8)), _chk(u, torch.float32, "u", (16, KC, RC)), y.data_ptr(), B, KC, RC,
-                                      _stream()), "ee_wino3x3_map8_f32")
+    y = torch.empty((B, RC, H, H), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_wino3x3_f32(_chk(x, torch.float32, "x", (B, KC, H, H)), _chk(u, torch.float32, "u", (16, KC, RC)), y.data_ptr(), B, KC, RC, H,
+                                 _stream()), "ee_wino3x3_f32")
     return y
 
 

@@ -353,6 +353,8 @@ int ee_conv3x3s2_bwd_data_f32(const float *dy, const float *weight, float *dx, i
  * g = weight[r][k] (forward: KC = Cin, RC = Cout) or g = weight[k][r] rotated by 180 degrees (backward-data: KC = Cout, RC = Cin;
  * x = dy) -> y [B,RC,8,8].  KC % 16 == 0, RC % 32 == 0 (else EE_ERR_UNSUPPORTED). */
 int ee_wino3x3_map8_f32(const float *x, const float *u, float *y, int B, int KC, int RC, void *stream);
+/* the same for H x H maps, H = 8 or 16 (layer1: 64 tiles per image, four accumulator blocks per wavefront) */
+int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int RC, int H, void *stream);
 
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.
@@ -453,7 +455,8 @@ int ee_chain_bwd_f32(const float *g_in, const uint8_t *gate, const float *gx, co
 #define EE_K_CONV3_BWD 15   /* ee_conv3x3s1_bwd_data_f32, 4-wavefront kernel */
 #define EE_K_CONV3P_FWD 16  /* ee_conv3x3s1_fwd_f32, pipelined kernel (256-channel 4x4 maps) */
 #define EE_K_CONV3P_BWD 17  /* ee_conv3x3s1_bwd_data_f32, pipelined kernel */
-#define EE_K_COUNT 18
+#define EE_K_WINO 18        /* ee_wino3x3_f32 (forward and backward-data are the same kernel); work = the convolution's algorithmic flops */
+#define EE_K_COUNT 19
 int ee_prof_enable(int on);
 /* records one empty start/stop bracket on `stream` (family EE_K_EMPTY): callers subtract its mean from the other
  * families' means, because a HIP event pair costs ~4-5 us on gfx950 - comparable to the kernels being timed */

@@ -20,6 +20,11 @@ def timeit(fn, iters=30, reps=3):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get("PROBE_EAGER"):  # plain launches, for counter collection
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        return 0.0
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(iters):
@@ -34,9 +39,13 @@ def timeit(fn, iters=30, reps=3):
     return 1e3 * a.elapsed_time(b) / (iters * reps)
 
 
-for c in (128, 64, 256):
-    x = torch.randn(B, c, 8, 8, device=dev)
+SHAPES = ((128, 8), (64, 16)) if os.environ.get("PROBE_EAGER") else ((128, 8), (64, 16), (64, 8), (256, 8))  # counters: the bench's two shapes
+for c, hw in SHAPES:
+    x = torch.randn(B, c, hw, hw, device=dev)
     w = torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5)
     u = EF._rearranged(w, "wino_f").contiguous()
-    print("%3d ch 8x8:  MIOpen %6.1f us   direct MFMA %6.1f us   Winograd MFMA %6.1f us" % (
-        c, timeit(lambda: F.conv2d(x, w, None, 1, 1)), timeit(lambda: ops.conv3x3s1_fwd(x, w)), timeit(lambda: ops.wino3x3_map8(x, u))), flush=True)
+    if os.environ.get("PROBE_EAGER"):
+        timeit(lambda: ops.wino3x3_map8(x, u))
+        continue
+    print("%3d ch %2dx%-2d:  MIOpen %6.1f us   direct MFMA %6.1f us   Winograd MFMA %6.1f us" % (
+        c, hw, hw, timeit(lambda: F.conv2d(x, w, None, 1, 1)), timeit(lambda: ops.conv3x3s1_fwd(x, w)), timeit(lambda: ops.wino3x3_map8(x, u))), flush=True)

@@ -982,17 +982,17 @@ def test_net2_model_uses_the_fused_half_and_draws_the_stock_dropout_mask(ops):
                                rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,Cin,Cout", [(100, 128, 128), (3, 32, 32), (2, 64, 96), (1, 128, 64)])
-def test_conv3x3_winograd_on_8x8_maps_matches_aten(ops, B, Cin, Cout):
+@pytest.mark.parametrize("B,Cin,Cout,H", [(100, 128, 128, 8), (3, 32, 32, 8), (2, 64, 96, 8), (1, 128, 64, 8), (100, 64, 64, 16), (3, 32, 96, 16)])
+def test_conv3x3_winograd_on_8x8_maps_matches_aten(ops, B, Cin, Cout, H):
     """Conv2d(3x3, stride 1, padding 1) on 8x8 maps as Winograd F(2x2, 3x3) on the f32 matrix cores (ee_wino.hip): forward and input
     gradient against float64 direct convolution (error of the order of MIOpen's own Winograd solver) and against ATen; the transformed
     filters follow in-place weight updates."""
     import torch.nn.functional as F
     from eeadv import functional as EF
     g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout)
-    x = torch.randn(B, Cin, 8, 8, generator=g).to(DEV).requires_grad_(True)
+    x = torch.randn(B, Cin, H, H, generator=g).to(DEV).requires_grad_(True)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
-    dy = torch.randn(B, Cout, 8, 8, generator=g).to(DEV)
+    dy = torch.randn(B, Cout, H, H, generator=g).to(DEV)
     for round_ in range(2):
         ref = F.conv2d(x, w, None, 1, 1)
         got = EF.Conv3x3WinoFn.apply(x, w)
@@ -1005,6 +1005,6 @@ def test_conv3x3_winograd_on_8x8_maps_matches_aten(ops, B, Cin, Cout):
         (e64,) = torch.autograd.grad(ref64, [x64], dy.double())
         assert float((gx.double() - e64).abs().max()) < 2e-6 * float(e64.abs().max())
         torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (64 * B) ** 0.5)
+        torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (H * H * B) ** 0.5)
         with torch.no_grad():
             w.mul_(1.25)
