@@ -29,19 +29,23 @@ struct WinoDims {
     int B, KC, RC;  // reduction channels (input channels forward), result channels
 };
 
-// MAP x MAP maps, MAP = 8 (16 tiles = one N block) or 16 (64 tiles = four N blocks per image; the accumulators of all four stay in
-// registers, the output transform runs one N block at a time through LDS).
+// MAP x MAP maps: MAP = 8 (16 tiles = one N block = one image per workgroup), 16 (64 tiles = four N blocks per image; the accumulators
+// of all four stay in registers, the output transform runs one N block at a time through LDS), or 4 (4 tiles per image: the N block
+// spans IMG = 4 images, a workgroup owns four images).
 template <int MAP>
 struct WinoGeo {
-    static constexpr int TX = MAP / 2, T = TX * TX, NB = T / 16;     // tiles per row / per image, N blocks
-    static constexpr int XW = MAP + 4, XP = (MAP + 2) * XW;           // input frame (zero ring), row stride
+    static constexpr int TX = MAP / 2, TI = TX * TX;                  // tiles per row / per image
+    static constexpr int IMG = TI < 16 ? 16 / TI : 1;                 // images per workgroup
+    static constexpr int T = TI * IMG, NB = T / 16;                   // tiles per workgroup, N blocks
+    static constexpr int XW = MAP + 4, XI = (MAP + 2) * XW;           // one image's input frame (zero ring), row stride
+    static constexpr int XP = IMG * XI;                               // frames of one channel
     static constexpr int VT = NB == 1 ? 16 : T + 16;                  // V row stride: the four k of a wavefront on disjoint banks
     static constexpr int VS = WN_CK * VT;                              // one xi's [16 ci][VT]
-    static constexpr int XF4 = MAP * MAP / 64;                         // float4 of x per thread and round (16 ci x MAP^2 / 4 / 256)
+    static constexpr int XF4 = IMG * MAP * MAP / 64;                   // float4 of x per thread and round (16 ci x IMG x MAP^2 / 4 / 256)
     static constexpr size_t lds_bytes = (16 * WN_US + 16 * VS + WN_CK * XP) * sizeof(float);
 };
 
-// x [B][KC][MAP][MAP], u [16][KC][RC] (transformed filters), y [B][RC][MAP][MAP].  grid (B, RC / 32).
+// x [B][KC][MAP][MAP], u [16][KC][RC] (transformed filters), y [B][RC][MAP][MAP].  grid (ceil(B / IMG), RC / 32).
 template <int MAP>
 __global__ __launch_bounds__(WN_NT) void wino3x3_kernel(const float *__restrict__ x, const float *__restrict__ u, float *__restrict__ y, WinoDims d) {
     using G = WinoGeo<MAP>;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(WN_NT) void wino3x3_kernel(const float *__restrict_
     float *vs = us + 16 * WN_US;         // [16 xi][16 ci][VT]
     float *xs = vs + 16 * G::VS;         // [16 ci][MAP + 2][XW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x, co0 = blockIdx.y * WN_CO;
+    const int b = blockIdx.x * G::IMG, co0 = blockIdx.y * WN_CO;  // first image of the workgroup
     const int l15 = lane & 15, lq = lane >> 4;
     for (int i = threadIdx.x; i < WN_CK * G::XP; i += WN_NT) xs[i] = 0.0f;  // zero ring, once (the interior is rewritten every round)
     // staging roles: U slice = 16 xi x 16 ci rows of 32 floats -> 8 lanes (16 B each) per row, 8 rows per thread (rows urow0 + 32 j: the same
@@ -60,7 +64,10 @@ __global__ __launch_bounds__(WN_NT) void wino3x3_kernel(const float *__restrict_
     const int ci_s = urow0 & 15, xi_s = urow0 >> 4;
     const float *ubase = u + (static_cast<size_t>(xi_s) * d.KC + ci_s) * d.RC + co0 + 4 * uq;
     const size_t uxi2 = 2 * static_cast<size_t>(d.KC) * d.RC;
-    const float *xsrc = x + static_cast<size_t>(b) * d.KC * (MAP * MAP) + 4 * threadIdx.x;  // the round's 16 planes are contiguous: float4 tid + 256 k
+    // IMG == 1: the round's 16 planes are contiguous, float4 number tid + 256 k.  IMG == 4 (4x4 maps): float4 tid = (image, ci, row): 64 per image
+    const int ximg = G::IMG > 1 ? (threadIdx.x >> 6) : 0, xb = b + ximg < d.B ? b + ximg : d.B - 1;  // past the batch: a valid image, never stored
+    const float *xsrc = G::IMG > 1 ? x + static_cast<size_t>(xb) * d.KC * (MAP * MAP) + 4 * (threadIdx.x & 63)
+                                   : x + static_cast<size_t>(b) * d.KC * (MAP * MAP) + 4 * threadIdx.x;
     const size_t ustep = static_cast<size_t>(WN_CK) * d.RC, xstep = static_cast<size_t>(WN_CK) * (MAP * MAP);
     float4 u0, u1, u2, u3, u4, u5, u6, u7, x0, x1, x2, x3;
     x1 = x2 = x3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -83,10 +90,11 @@ __global__ __launch_bounds__(WN_NT) void wino3x3_kernel(const float *__restrict_
             x3 = *reinterpret_cast<const float4 *>(xp_ + 12 * WN_NT);                        \
         }                                                                                    \
     } while (0)
-    static_assert(G::XF4 == 1 || G::XF4 == 4, "8x8 or 16x16 maps");
-    auto put_x = [&](float4 v, int k) {  // float4 number tid + 256 k of the round's 16 contiguous planes -> frame interior
-        const int f = threadIdx.x + WN_NT * k, ci = f / (MAP * MAP / 4), q = f - ci * (MAP * MAP / 4), r = q / (MAP / 4), c4 = 4 * (q - r * (MAP / 4));
-        float *dst = xs + ci * G::XP + (1 + r) * G::XW + 1 + c4;
+    static_assert(G::XF4 == 1 || G::XF4 == 4, "4x4, 8x8 or 16x16 maps");
+    auto put_x = [&](float4 v, int k) {  // float4 number tid + 256 k of the round's planes -> frame interior
+        const int f0 = threadIdx.x + WN_NT * k, img = G::IMG > 1 ? f0 >> 6 : 0, f = G::IMG > 1 ? f0 & 63 : f0;
+        const int ci = f / (MAP * MAP / 4), q = f - ci * (MAP * MAP / 4), r = q / (MAP / 4), c4 = 4 * (q - r * (MAP / 4));
+        float *dst = xs + ci * G::XP + img * G::XI + (1 + r) * G::XW + 1 + c4;
         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     };
     f32x4 acc[4][G::NB][2];
@@ -125,8 +133,9 @@ __global__ __launch_bounds__(WN_NT) void wino3x3_kernel(const float *__restrict_
         // ---- V = B^T d B: (ci, tile) pairs tid + 256 k -----------------------------------------------------------------------------------
 #pragma unroll
         for (int k = 0; k < G::NB; ++k) {
-            const int pr = threadIdx.x + WN_NT * k, ci = pr / G::T, t = pr - ci * G::T, ty = t / G::TX, tx = t - ty * G::TX;
-            const float *p = xs + ci * G::XP + (2 * ty) * G::XW + 2 * tx;  // patch rows 2ty-1 .. 2ty+2 of the image = frame rows 2ty .. 2ty+3
+            const int pr = threadIdx.x + WN_NT * k, ci = pr / G::T, t = pr - ci * G::T, img = t / G::TI, ti = t - img * G::TI;
+            const int ty = ti / G::TX, tx = ti - ty * G::TX;
+            const float *p = xs + ci * G::XP + img * G::XI + (2 * ty) * G::XW + 2 * tx;  // patch rows 2ty-1 .. 2ty+2 = frame rows 2ty .. 2ty+3
             float dd[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(WN_NT) void wino3x3_kernel(const float *__restrict_
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int idx = threadIdx.x + k * WN_NT;  // (co, tile of this block)
-            const int co = idx >> 4, tl = idx & 15, t = 16 * nb + tl, ty = t / G::TX, tx = t - ty * G::TX;
+            const int co = idx >> 4, tl = idx & 15, t = 16 * nb + tl, img = t / G::TI, ti = t - img * G::TI, ty = ti / G::TX, tx = ti - ty * G::TX;
             float mm[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -195,9 +204,11 @@ __global__ __launch_bounds__(WN_NT) void wino3x3_kernel(const float *__restrict_
                 t0[j] = (mm[0][j] + mm[1][j]) + mm[2][j];
                 t1[j] = (mm[1][j] - mm[2][j]) - mm[3][j];
             }
-            float *o = y + ((static_cast<size_t>(b) * d.RC + co0 + co) * MAP + 2 * ty) * MAP + 2 * tx;
-            *reinterpret_cast<float2 *>(o) = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]);
-            *reinterpret_cast<float2 *>(o + MAP) = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
+            if (b + img < d.B) {
+                float *o = y + ((static_cast<size_t>(b + img) * d.RC + co0 + co) * MAP + 2 * ty) * MAP + 2 * tx;
+                *reinterpret_cast<float2 *>(o) = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]);
+                *reinterpret_cast<float2 *>(o + MAP) = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
+            }
         }
     }
 }
@@ -210,17 +221,18 @@ int wino_launch(const float *x, const float *u, float *y, const WinoDims &d, hip
     static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(G::lds_bytes)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH(wino3x3_kernel<MAP>, dim3(static_cast<unsigned>(d.B), static_cast<unsigned>(d.RC / WN_CO)), dim3(WN_NT), G::lds_bytes, st, x, u, y, d);
+    EE_LAUNCH(wino3x3_kernel<MAP>, dim3(static_cast<unsigned>((d.B + G::IMG - 1) / G::IMG), static_cast<unsigned>(d.RC / WN_CO)), dim3(WN_NT), G::lds_bytes,
+              st, x, u, y, d);
     return launch_status();
 }
 
 }  // namespace
 
-// y = conv3x3(x) for H x H maps (H = 8 or 16) with the filters given in the transform domain: u [16][KC][RC], u[4i+j][k][r] =
+// y = conv3x3(x) for H x H maps (H = 4, 8 or 16) with the filters given in the transform domain: u [16][KC][RC], u[4i+j][k][r] =
 // (G g G^T)[i][j] of the (r, k) filter pair the product needs (forward: g = w[r][k]; backward-data: g = w[k][r] rotated by 180 degrees).
 EE_API int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int RC, int H, void *stream) {
     if (B < 0 || KC < 1 || RC < 1) return EE_ERR_SHAPE;
-    if (KC % WN_CK != 0 || RC % WN_CO != 0 || (H != 8 && H != 16)) return EE_ERR_UNSUPPORTED;
+    if (KC % WN_CK != 0 || RC % WN_CO != 0 || (H != 4 && H != 8 && H != 16)) return EE_ERR_UNSUPPORTED;
     if (B == 0) return EE_OK;
     if (!x || !u || !y) return EE_ERR_NULL;
     if (!aligned16(x) || !aligned16(u) || !aligned16(y)) return EE_ERR_ALIGN;
@@ -228,6 +240,7 @@ EE_API int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int K
     const WinoDims d{B, KC, RC};
     // the convolution's ALGORITHMIC flops (2 * 9 * KC * RC per output pixel); the kernel executes 4/9 of them (16 multiplies per 2x2 tile)
     ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
+    if (H == 4) return wino_launch<4>(x, u, y, d, as_stream(stream));
     return H == 8 ? wino_launch<8>(x, u, y, d, as_stream(stream)) : wino_launch<16>(x, u, y, d, as_stream(stream));
 }
 

@@ -170,11 +170,11 @@ def conv3(conv, x):
             and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels * conv.out_channels <= 1 << 18):
         return Conv3x3S2Map4Fn.apply(x, conv.weight)  # layer4.0.conv1 at 64x64 inputs: backward-data as one dense product (opt-in)
     if ("conv3" not in _STOCK and "wino" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and x.shape[2] == x.shape[3]
-            and (x.shape[2] == 8 or (x.shape[2] == 16 and "wino16" not in _STOCK))
+            and (x.shape[2] == 8 or (x.shape[2] == 16 and "wino16" not in _STOCK) or (x.shape[2] == 4 and "wino4" not in _STOCK))
             and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
             and conv.weight.is_contiguous()):
-        return Conv3x3WinoFn.apply(x, conv.weight)  # 8x8 / 16x16 maps (layer2, layer1): Winograd F(2x2,3x3) on the matrix cores - 21 us against MIOpen's 29.4, 22 against the direct kernel's 27.7; eager passes included
+        return Conv3x3WinoFn.apply(x, conv.weight)  # 8x8 / 16x16 / 4x4 maps (layer2, layer1, layer3): Winograd F(2x2,3x3) on the matrix cores - 21 us against MIOpen's 29.4, 22 against the direct kernel's 27.7, 28 against 35; eager passes included
     if not (_CONV3_EAGER or PROBE_MFMA_CONV or torch.cuda.is_current_stream_capturing()):
         return conv(x)
     if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)

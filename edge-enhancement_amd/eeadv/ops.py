@@ -722,11 +722,11 @@ def conv3x3s1_bwd_data(dy, weight):
 
 
 def wino3x3_supported(x, cin, cout):
-    return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (8, 16) and cin % 32 == 0 and cout % 32 == 0
+    return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8, 16) and cin % 32 == 0 and cout % 32 == 0
 
 
 def wino3x3_map8(x, u):
-    """3x3 / stride 1 / padding 1 convolution of 8x8 or 16x16 maps, filters in the Winograd domain: x [B,KC,H,H], u [16,KC,RC] -> [B,RC,H,H]."""
+    """3x3 / stride 1 / padding 1 convolution of 4x4, 8x8 or 16x16 maps, filters in the Winograd domain: x [B,KC,H,H], u [16,KC,RC] -> [B,RC,H,H]."""
     B, KC, H = x.shape[0], x.shape[1], x.shape[2]
     RC = u.shape[2]
     y = torch.empty((B, RC, H, H), dtype=torch.float32, device=x.device)

@@ -982,7 +982,7 @@ def test_net2_model_uses_the_fused_half_and_draws_the_stock_dropout_mask(ops):
                                rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H", [(100, 128, 128, 8), (3, 32, 32, 8), (2, 64, 96, 8), (1, 128, 64, 8), (100, 64, 64, 16), (3, 32, 96, 16)])
+@pytest.mark.parametrize("B,Cin,Cout,H", [(100, 128, 128, 8), (3, 32, 32, 8), (2, 64, 96, 8), (1, 128, 64, 8), (100, 64, 64, 16), (3, 32, 96, 16), (100, 256, 256, 4), (7, 32, 64, 4), (1, 64, 32, 4)])
 def test_conv3x3_winograd_on_8x8_maps_matches_aten(ops, B, Cin, Cout, H):
     """Conv2d(3x3, stride 1, padding 1) on 8x8 maps as Winograd F(2x2, 3x3) on the f32 matrix cores (ee_wino.hip): forward and input
     gradient against float64 direct convolution (error of the order of MIOpen's own Winograd solver) and against ATen; the transformed
