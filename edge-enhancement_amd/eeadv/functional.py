@@ -389,6 +389,12 @@ def _rearranged(weight, kind="s1"):
         if kind == "wino_f":
             return torch.einsum("ia,jb,rkab->ijkr", G, G, w).reshape(16, ci, co)
         return torch.einsum("ia,jb,krab->ijkr", G, G, w.flip(2, 3)).reshape(16, co, ci)
+    if kind in ("s2m_f", "s2m_b"):
+        # ee_s2.hip's A operands in reading order: [result block of 32][round of 16 reduction channels][tap][quad][half][m][k]
+        w = weight.detach().reshape(co, ci, 9)
+        if kind == "s2m_f":  # result = co = 32 cb + 16 h + m, reduction = ci = 16 rd + 4 q + k
+            return w.view(co // 32, 2, 16, ci // 16, 4, 4, 9).permute(0, 3, 6, 4, 1, 2, 5)
+        return w.view(co // 16, 4, 4, ci // 32, 2, 16, 9).permute(3, 0, 6, 1, 4, 5, 2)  # result = ci, reduction = co
     idx = _DENSE_IDX.get((weight.device, kind))
     if idx is None:
         n_in, stride = (2, 1) if kind == "s1" else (4, 2)
@@ -470,6 +476,29 @@ class Conv3x3WinoFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
             dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw
+
+
+class Conv3x3S2SmallFn(torch.autograd.Function):
+    """Conv2d(3x3, stride 2, padding 1, bias=False) from an 8x8 or a 4x4 map (ResNet-18 layer3.0 / layer4.0 conv1 at 64x64 inputs,
+    resnet.py:26-31): forward and backward-data on ee_s2.hip (reduction split over the wavefronts, backward by parity classes); the
+    rearranged filters follow the weight's version counter like the Winograd ones; weight gradient on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        w9 = _dense_weight(weight, "s2m_f")
+        _dense_weight(weight, "s2m_b")  # created outside any capture; the backward only reads it
+        ctx.save_for_backward(x, weight)
+        return ops.conv3x3s2_small_fwd(x, w9, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.conv3x3s2_small_bwd_data(dy, _dense_weight(weight, "s2m_b"), weight.shape[1]) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw
 
 

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime
-from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -175,6 +175,11 @@ def conv3(conv, x):
             and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
             and conv.weight.is_contiguous()):
         return Conv3x3WinoFn.apply(x, conv.weight)  # 8x8 / 16x16 / 4x4 maps (layer2, layer1, layer3): Winograd F(2x2,3x3) on the matrix cores - 21 us against MIOpen's 29.4, 22 against the direct kernel's 27.7, 28 against 35; eager passes included
+    if ("conv3" not in _STOCK and "s2small" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and x.shape[2] == x.shape[3]
+            and x.shape[2] in (4, 8) and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
+            and conv.weight.is_contiguous()):
+        return Conv3x3S2SmallFn.apply(x, conv.weight)  # layer3.0 / layer4.0 conv1: split-reduction MFMA kernel, backward by parity classes (ee_s2.hip)
     if not (_CONV3_EAGER or PROBE_MFMA_CONV or torch.cuda.is_current_stream_capturing()):
         return conv(x)
     if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)

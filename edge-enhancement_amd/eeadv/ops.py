@@ -735,6 +735,30 @@ def wino3x3_map8(x, u):
     return y
 
 
+def conv3x3s2_small_supported(x, cin, cout):
+    """ee_s2.hip: 3x3 / stride 2 / padding 1 from an 8x8 or 4x4 map"""
+    return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8) and cin % 32 == 0 and cout % 32 == 0
+
+
+def conv3x3s2_small_fwd(x, w9, cout):
+    """x [B,Cin,H,H] (H = 8 or 4), w9 = the filters rearranged (functional._rearranged kind "s2m_f") -> [B,Cout,H/2,H/2]"""
+    B, Cin, H = x.shape[0], x.shape[1], x.shape[2]
+    y = torch.empty((B, cout, H // 2, H // 2), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_conv3x3s2_small_fwd_f32(_chk(x, torch.float32, "x", (B, Cin, H, H)), _chk(w9, torch.float32, "w9", (cout // 32, Cin // 16, 9, 4, 2, 16, 4)),
+                                             y.data_ptr(), B, Cin, cout, H, _stream()), "ee_conv3x3s2_small_fwd_f32")
+    return y
+
+
+def conv3x3s2_small_bwd_data(dy, w9, cin):
+    """dy [B,Cout,H/2,H/2], w9 = the filters rearranged (kind "s2m_b") -> dx [B,Cin,H,H] (H = 8 or 4)"""
+    B, Cout, OH = dy.shape[0], dy.shape[1], dy.shape[2]
+    dx = torch.empty((B, cin, 2 * OH, 2 * OH), dtype=torch.float32, device=dy.device)
+    N.check(N.lib.ee_conv3x3s2_small_bwd_data_f32(_chk(dy, torch.float32, "dy", (B, Cout, OH, OH)),
+                                                  _chk(w9, torch.float32, "w9", (cin // 32, Cout // 16, 9, 4, 2, 16, 4)), dx.data_ptr(), B, cin, Cout, 2 * OH,
+                                                  _stream()), "ee_conv3x3s2_small_bwd_data_f32")
+    return dx
+
+
 def conv3x3s2_fwd(x, weight):
     """Conv2d(Cin, Cout, 3, stride 2, padding 1, bias=False) forward on ee_conv.hip's implicit GEMM."""
     B, Cin, H, W = x.shape

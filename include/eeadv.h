@@ -356,6 +356,16 @@ int ee_wino3x3_map8_f32(const float *x, const float *u, float *y, int B, int KC,
 /* the same for H x H maps, H = 8 or 16 (layer1: 64 tiles per image, four accumulator blocks per wavefront) */
 int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int RC, int H, void *stream);
 
+/* Conv2d(3x3, stride 2, padding 1, bias=False) between SMALL maps - the first convolution of ResNet-18's layer3 / layer4 at 64x64 inputs
+ * (resnet.py:26-31, :132-137): H = 8 (8x8 -> 4x4) or H = 4 (4x4 -> 2x2) - on the f32 matrix cores with the reduction split over a
+ * workgroup's wavefronts.  The filters arrive rearranged, w9 [R/32][K/16][9][4][2][16][4] with R = result and K = reduction channels:
+ *   forward        x [B,Cin,H,H] -> y [B,Cout,H/2,H/2];  w9[cb][rd][t][q][h][m][k] = weight[32 cb + 16 h + m][16 rd + 4 q + k][t]
+ *   backward-data  dy [B,Cout,H/2,H/2] -> dx [B,Cin,H,H] (all of it written, no multiplication by inserted zeros: four parity classes);
+ *                  w9[cb][rd][t][q][h][m][k] = weight[16 rd + 4 q + k][32 cb + 16 h + m][t]
+ * Cin, Cout multiples of 32 (else EE_ERR_UNSUPPORTED); the weight gradient is not provided. */
+int ee_conv3x3s2_small_fwd_f32(const float *x, const float *w9, float *y, int B, int Cin, int Cout, int H, void *stream);
+int ee_conv3x3s2_small_bwd_data_f32(const float *dy, const float *w9, float *dx, int B, int Cin, int Cout, int H, void *stream);
+
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.
  *   dy [B,K,H/2,W/2], weight [K,3,7,7] -> dx [B,3,H,W];  H, W even. */
@@ -456,7 +466,9 @@ int ee_chain_bwd_f32(const float *g_in, const uint8_t *gate, const float *gx, co
 #define EE_K_CONV3P_FWD 16  /* ee_conv3x3s1_fwd_f32, pipelined kernel (256-channel 4x4 maps) */
 #define EE_K_CONV3P_BWD 17  /* ee_conv3x3s1_bwd_data_f32, pipelined kernel */
 #define EE_K_WINO 18        /* ee_wino3x3_f32 (forward and backward-data are the same kernel); work = the convolution's algorithmic flops */
-#define EE_K_COUNT 19
+#define EE_K_CONV3S2_FWD 19 /* ee_conv3x3s2_small_fwd_f32; work = flops */
+#define EE_K_CONV3S2_BWD 20 /* ee_conv3x3s2_small_bwd_data_f32 */
+#define EE_K_COUNT 21
 int ee_prof_enable(int on);
 /* records one empty start/stop bracket on `stream` (family EE_K_EMPTY): callers subtract its mean from the other
  * families' means, because a HIP event pair costs ~4-5 us on gfx950 - comparable to the kernels being timed */

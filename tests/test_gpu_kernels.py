@@ -982,6 +982,35 @@ def test_net2_model_uses_the_fused_half_and_draws_the_stock_dropout_mask(ops):
                                rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("mt", ["2222", "1111"])
+@pytest.mark.parametrize("B,Cin,Cout,H", [(100, 128, 256, 8), (100, 256, 512, 4), (3, 32, 32, 8), (1, 64, 96, 8), (7, 32, 64, 4), (9, 96, 32, 4), (8, 64, 64, 4), (2, 32, 32, 4)])
+def test_conv3x3_stride2_small_maps_match_aten(ops, monkeypatch, B, Cin, Cout, H, mt):
+    """Conv2d(3x3, stride 2, padding 1) from 8x8 / 4x4 maps on ee_s2.hip (split-reduction MFMA kernel, backward-data by parity classes):
+    forward and input gradient against a float64 convolution and against ATen, odd batch sizes (partly filled workgroups) included,
+    with 32 and with 16 result channels per workgroup (EEADV_S2_MT); the rearranged filters follow in-place weight updates."""
+    import torch.nn.functional as F
+    from eeadv import functional as EF
+    monkeypatch.setenv("EEADV_S2_MT", mt)
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
+    dy = torch.randn(B, Cout, H // 2, H // 2, generator=g).to(DEV)
+    for round_ in range(2):
+        ref = F.conv2d(x, w, None, 2, 1)
+        got = EF.Conv3x3S2SmallFn.apply(x, w)
+        x64, w64 = x.detach().double().requires_grad_(True), w.detach().double()
+        ref64 = F.conv2d(x64, w64, None, 2, 1)
+        assert float((got.double() - ref64).abs().max()) < 1e-6 * float(ref64.abs().max())
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+        (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
+        (e64,) = torch.autograd.grad(ref64, [x64], dy.double())
+        assert float((gx.double() - e64).abs().max()) < 1e-6 * float(e64.abs().max())
+        torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (H * H * B) ** 0.5)
+        with torch.no_grad():
+            w.mul_(1.25)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H", [(100, 128, 128, 8), (3, 32, 32, 8), (2, 64, 96, 8), (1, 128, 64, 8), (100, 64, 64, 16), (3, 32, 96, 16), (100, 256, 256, 4), (7, 32, 64, 4), (1, 64, 32, 4)])
 def test_conv3x3_winograd_on_8x8_maps_matches_aten(ops, B, Cin, Cout, H):
     """Conv2d(3x3, stride 1, padding 1) on 8x8 maps as Winograd F(2x2, 3x3) on the f32 matrix cores (ee_wino.hip): forward and input
