@@ -1,12 +1,13 @@
-// ee_s2.hip - Conv2d(3x3, stride 2, padding 1, bias=False) on small maps (the first convolution of ResNet-18's layer3 / layer4 at 64x64
-// inputs: 8x8 -> 4x4 and 4x4 -> 2x2, resnet.py:26-31, :132-137), forward and backward-data, on the f32 matrix cores.
+// ee_s2.hip - Conv2d(3x3, stride 2, padding 1, bias=False) on small maps (the first convolution of ResNet-18's layer2 / layer3 / layer4 at
+// 64x64 inputs: 16x16 -> 8x8, 8x8 -> 4x4 and 4x4 -> 2x2, resnet.py:26-31, :132-137), forward and backward-data, on the f32 matrix cores.
 //
-// Why a kernel of its own: these are GEMMs with few pixels (1600 / 400 columns) and long reductions (1152 / 2304), which MIOpen serves
-// with an NHWC implicit GEMM between two layout transposes and a zero fill (5 launches, 28-39 us un-profiled), and which the direct
-// kernels of ee_conv.hip tile badly.  Here a workgroup owns 32 result channels x 32 pixels (two v_mfma_f32_16x16x4
-// column blocks: two images of a 4x4 result, eight of a 2x2 one) and its four wavefronts SPLIT THE REDUCTION: per round of 16
-// reduction channels, wavefront w multiplies channel quad w through all nine taps (2 x 2 accumulator tiles, 36 MFMAs, operands read
-// once per two products), and the four partial sums meet in LDS at the end.
+// Why a kernel of its own: these are GEMMs with few pixels (6400 / 1600 / 400 columns) and long reductions (576 / 1152 / 2304), which MIOpen
+// serves with an NHWC implicit GEMM between two layout transposes and a zero fill (5 launches, 28-39 us un-profiled), and which the direct
+// kernels of ee_conv.hip tile badly.  Here a workgroup owns 32 (or 16) result channels x 32 pixels (two
+// v_mfma_f32_16x16x4 column blocks: half an image of an 8x8 result, two images of a 4x4 one, eight of a 2x2 one) and its four wavefronts
+// SPLIT THE REDUCTION: per round of 16 reduction channels, wavefront w multiplies channel quad w through all nine taps (2 x 2
+// accumulator tiles, 36 MFMAs, operands read once per two products), and the four partial sums meet in LDS at the end.  The rounds are
+// double-buffered: a round's products run while the next round is written to the other buffer and the one after that travels.
 //   forward       the round's inputs are scattered into LDS tap by tap (an im2col of 9 x 16 pixels per channel, zero where a tap leaves
 //                 the map), so a B operand is one conflict-free ds_read_b32 at a compile-time offset;
 //   backward-data the four parities of dx are four small stride-1 correlations of dy (1, 2, 2 and 4 taps: no multiplication by the
@@ -29,44 +30,57 @@ using namespace ee;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int S2_NT = 256, S2_CK = 16, S2_RB = 32;
-constexpr int S2_WF = 9 * 4 * 2 * 64;  // one round's filter slab: [tap][quad][half][16 m][4 k] = 4608 floats
 constexpr int S2_RS = 36;              // row stride of the partial-sum exchange: the four k of a wavefront on disjoint banks
 
 struct S2Dims {
     int B, KC, RC;  // reduction channels (Cin forward, Cout backward), result channels
 };
 
-// H = the LARGE map's side (x forward, dx backward); the small map is OH x OH
+// H = the LARGE map's side (x forward, dx backward); the small map is OH x OH.  A workgroup's 32 small-map pixels: H = 4: eight images
+// (four per column block); H = 8: two images; H = 16: four rows of one image (grid.x = 2 B: blockIdx.x & 1 = which half).
 template <int H>
 struct S2Geo {
-    static constexpr int OH = H / 2, PX = OH * OH;  // small-map pixels per image: 16 or 4
-    static constexpr int IPT = 16 / PX;             // images per column block
-    static constexpr int IMG = 2 * IPT;             // images per workgroup
+    static constexpr int OH = H / 2, PX = OH * OH;
+    static constexpr int IMG = H == 16 ? 1 : 32 / PX;  // images per workgroup
 };
 
-// filter staging: a round's slab is 1152 float4 (both 16-channel halves) or 576 (MT = 1: half `h_` of it); float4 number p = tid + 256 j of
-// the workgroup's part sits at source index p (MT = 2) or (p >> 4) * 32 + 16 h + (p & 15).  Registers are NAMED: as an array they went to scratch.
+// float offset (inside a [column block][16 n][4 k] pair of blocks) of small-map pixel (row r, column 0) - r = the row inside the image
+// (H = 4, 8) or inside the workgroup's four rows (H = 16); columns advance by 4 floats
+template <int H>
+__device__ __forceinline__ int s2_slot(int img, int r) {
+    if (H == 16) return (r >> 1) * 64 + 32 * (r & 1);
+    if (H == 8) return img * 64 + 16 * r;
+    return (img >> 2) * 64 + 4 * ((img & 3) * 4 + 2 * r);
+}
+
+// filter staging: a round's slab holds TAPS x 128 float4 (both 16-channel halves; TAPS = 9, or 10 with the shortcut's 1x1 filters as the last
+// tap); a workgroup stages all of it (MT = 2) or half `wh_` of it (MT = 1): WF4 float4, number p = tid + 256 j sits at source index p or
+// (p >> 4) * 32 + 16 wh_ + (p & 15).  The last, partial batch is loaded by everybody (a valid duplicate address) and written by the first
+// LV threads.  Registers are NAMED: as an array they went to scratch.
 #define S2_W_SETUP()                                                                                             \
+    constexpr int TAPS_F4 = TAPS * 128, WF4 = TAPS * 64 * MT, NJ = (WF4 + 255) / 256, LV = WF4 - 256 * (NJ - 1); \
+    static_assert(NJ == (MT == 2 ? 5 : 3), "five / three float4 per thread");                                    \
     const int wh_ = MT == 2 ? 0 : (blockIdx.y & 1);                                                              \
     const float4 *wsrc = reinterpret_cast<const float4 *>(w9) +                                                  \
-                         static_cast<size_t>(MT == 2 ? blockIdx.y : blockIdx.y >> 1) * rounds * (S2_WF / 4);     \
-    const int wp2_ = MT == 2 ? threadIdx.x + 512 : (threadIdx.x < 64 ? threadIdx.x + 512 : threadIdx.x + 256);   \
-    const int wp4_ = threadIdx.x < 128 ? threadIdx.x + 1024 : threadIdx.x + 768;                                 \
+                         static_cast<size_t>(MT == 2 ? blockIdx.y : blockIdx.y >> 1) * rounds * TAPS_F4;         \
+    const int wpl_ = threadIdx.x < LV ? threadIdx.x + 256 * (NJ - 1) : threadIdx.x + 256 * (NJ - 2);             \
     const int ws0_ = MT == 2 ? threadIdx.x : (threadIdx.x >> 4) * 32 + 16 * wh_ + (threadIdx.x & 15);            \
     const int ws1_ = MT == 2 ? threadIdx.x + 256 : ws0_ + 512;                                                   \
-    const int ws2_ = MT == 2 ? wp2_ : (wp2_ >> 4) * 32 + 16 * wh_ + (wp2_ & 15);                                 \
+    const int wsl_ = MT == 2 ? wpl_ : (wpl_ >> 4) * 32 + 16 * wh_ + (wpl_ & 15);                                 \
     float4 w0, w1, w2, w3, w4;                                                                                   \
     w3 = w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f)
 
 #define S2_LOAD_W(round_)                                                                     \
     do {                                                                                      \
-        const float4 *wp_ = wsrc + static_cast<size_t>(round_) * (S2_WF / 4);                 \
+        const float4 *wp_ = wsrc + static_cast<size_t>(round_) * TAPS_F4;                     \
         w0 = wp_[ws0_];                                                                       \
         w1 = wp_[ws1_];                                                                       \
-        w2 = wp_[ws2_];                                                                       \
         if (MT == 2) {                                                                        \
+            w2 = wp_[threadIdx.x + 512];                                                      \
             w3 = wp_[threadIdx.x + 768];                                                      \
-            w4 = wp_[wp4_];                                                                   \
+            w4 = wp_[wsl_];                                                                   \
+        } else {                                                                              \
+            w2 = wp_[wsl_];                                                                   \
         }                                                                                     \
     } while (0)
 
@@ -78,80 +92,111 @@ struct S2Geo {
         if (MT == 2) {                                                                        \
             wd_[threadIdx.x + 512] = w2;                                                      \
             wd_[threadIdx.x + 768] = w3;                                                      \
-            if (threadIdx.x < 128) wd_[threadIdx.x + 1024] = w4;                              \
-        } else if (threadIdx.x < 64) {                                                        \
+            if (threadIdx.x < LV) wd_[threadIdx.x + 1024] = w4;                               \
+        } else if (threadIdx.x < LV) {                                                        \
             wd_[threadIdx.x + 512] = w2;                                                      \
         }                                                                                     \
     } while (0)
 
 constexpr int S2_XS = 9 * 4 * 2 * 64;  // forward: a round's inputs [tap][quad][column block][16 n][4 k] = 4608 floats
 
-// ---- forward: x [B][KC][H][H] -> y [B][RC][H/2][H/2].  grid (ceil(B / IMG), RC / (16 MT)) -------------------------------------------
-template <int H, int MT>
-__global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w9, float *__restrict__ y, S2Dims d) {
+// ---- forward: x [B][KC][H][H] -> y [B][RC][H/2][H/2].  grid (ceil(B / IMG) or 2 B, RC / (16 MT)) ------------------------------------
+// DS: the block's shortcut Conv2d(1x1, stride 2) of the SAME input (resnet.py:137-142) rides along as a tenth tap - its B operand is the centre
+// tap's plane - into accumulators of its own -> y1
+template <int H, int MT, bool DS>
+__global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w9, float *__restrict__ y,
+                                                                 float *__restrict__ y1, S2Dims d) {
     using G = S2Geo<H>;
-    constexpr int OH = G::OH, PX = G::PX, IPT = G::IPT, IMG = G::IMG;
-    constexpr int WFM = 9 * 4 * MT * 64, BUF = WFM + S2_XS, RB = 16 * MT;
-    // two buffers of {filters of a round, inputs}: a round's products run while the next round is written; after the rounds the first
-    // one holds the four wavefronts' partial sums [4][RB][36]
+    constexpr int OH = G::OH, PX = G::PX, IMG = G::IMG, TAPS = DS ? 10 : 9;
+    constexpr int WFM = TAPS * 4 * MT * 64, BUF = WFM + S2_XS, RB = 16 * MT;
+    // two buffers of {filters of a round, inputs}; after the rounds the first one holds the four wavefronts' partial sums [4][RB][36]
     extern __shared__ __align__(16) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
-    const int b0 = blockIdx.x * IMG, co0 = blockIdx.y * RB;
+    const int b0 = H == 16 ? blockIdx.x >> 1 : blockIdx.x * IMG, hh = H == 16 ? blockIdx.x & 1 : 0, co0 = blockIdx.y * RB;
     for (int i = threadIdx.x; i < S2_XS; i += S2_NT) lds[WFM + i] = lds[BUF + WFM + i] = 0.0f;  // the taps that leave the map stay zero: every round rewrites the same other slots
     const int rounds = d.KC / S2_CK;
     S2_W_SETUP();
-    // x of a round: IMG images x 16 channels x H^2 floats = 512 float4, two per thread.  H = 8: float4 tid of image j = (ci, row, half);
-    // H = 4: float4 tid + 256 j = (image, ci, row)
-    int img0, img1, ci_s, row_s, x0_s;
-    if (H == 8) {
-        img0 = 0, img1 = 1, ci_s = threadIdx.x >> 4, row_s = (threadIdx.x & 15) >> 1, x0_s = 4 * (threadIdx.x & 1);
-    } else {
-        img0 = threadIdx.x >> 6, img1 = img0 + 4, ci_s = (threadIdx.x & 63) >> 2, row_s = threadIdx.x & 3, x0_s = 0;
-    }
-    const int bi0 = b0 + img0 < d.B ? b0 + img0 : d.B - 1, bi1 = b0 + img1 < d.B ? b0 + img1 : d.B - 1;  // past the batch: a valid image, never stored
-    const float *xsrc0 = x + (static_cast<size_t>(bi0) * d.KC + ci_s) * (H * H) + row_s * H + x0_s;
-    const float *xsrc1 = x + (static_cast<size_t>(bi1) * d.KC + ci_s) * (H * H) + row_s * H + x0_s;
-    float4 xa, xb;
-    // scatter one float4 (row y, columns x0 .. x0+3 of channel ci_s, image slot img) to the tap planes it feeds
-    auto put = [&](float *xs, float4 v, int img) {
-        const int nt = img / IPT, il = img - nt * IPT;
-        float *base = xs + ((ci_s >> 2) * 2 + nt) * 64 + (ci_s & 3) + 4 * (il * PX);
-        const int o = x0_s >> 1, yh = row_s >> 1;
-        // row taps: even row -> ky 1 at oy = y/2; odd row -> ky 2 at oy = (y-1)/2 and ky 0 at oy = (y+1)/2 (if inside)
-        const bool odd = row_s & 1;
-        const int kyA = odd ? 2 : 1;
-        const bool okB = odd && yh + 1 < OH;
+    // x of a round, float4 number j of a thread (two; three for H = 16, the third by one wavefront):
+    //   H = 4: 8 images x 16 channels x 4 rows:     (image (tid >> 6) + 4 j, ci (tid & 63) >> 2, row tid & 3)
+    //   H = 8: 2 images x 16 channels x 8 rows x 2: (image j, ci tid >> 4, row (tid & 15) >> 1, half tid & 1)
+    //   H = 16: 9 rows (8 hh - 1 ...) x 16 channels x 4: (row (tid >> 6) + 4 j, ci (tid & 63) >> 2, quarter tid & 3)
+    const int ci_s = H == 8 ? threadIdx.x >> 4 : (threadIdx.x & 63) >> 2;
+    const int x0_s = H == 8 ? 4 * (threadIdx.x & 1) : (H == 16 ? 4 * (threadIdx.x & 3) : 0), o_s = x0_s >> 1;
+    // per float4: the two row taps it feeds.  Even input row -> ky 1 at oy = y/2; odd row -> ky 2 at oy = (y-1)/2 and ky 0 at oy = (y+1)/2
+    int offA[3], offB[3];  // LDS float offsets of (tap row, small-map row); < 0: none.  Compile-time indexed after unrolling.
+    const float *src[3];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            if (rt == 1 && !okB) break;
-            const int ky = rt == 0 ? kyA : 0, oy = rt == 0 ? yh : yh + 1;
-            float *p = base + (ky * 3) * 512 + 4 * (oy * OH);
-            p[1 * 512 + 4 * o] = v.x;        // column x0 (even): kx 1
-            p[2 * 512 + 4 * o] = v.y;        // x0+1 (odd): kx 2 at ox = o, kx 0 at ox = o+1
-            p[0 * 512 + 4 * (o + 1)] = v.y;
-            p[1 * 512 + 4 * (o + 1)] = v.z;  // x0+2 (even): kx 1
-            p[2 * 512 + 4 * (o + 1)] = v.w;  // x0+3 (odd): kx 2 at o+1, kx 0 at o+2 (if inside)
-            if (o + 2 < OH) p[0 * 512 + 4 * (o + 2)] = v.w;
+    for (int j = 0; j < 3; ++j) {
+        int img = 0, yy, oyA, kyA, oyB;
+        bool okA = true, okB, live = true;
+        if (H == 16) {
+            const int r = (threadIdx.x >> 6) + 4 * j;  // input row 8 hh - 1 + r, r = 0..8
+            live = j < 2 || threadIdx.x < 64;
+            yy = 8 * hh - 1 + r;
+            const bool odd_r = r & 1;  // odd r = even input row
+            kyA = odd_r ? 1 : 2, oyA = odd_r ? (r - 1) >> 1 : (r >> 1) - 1, okA = live && (odd_r || r >= 2);
+            oyB = r >> 1, okB = live && !odd_r && r <= 6 && yy >= 0;
+            if (yy < 0) yy = 0;  // the padding row: a valid address, never scattered
+            if (!live) yy = 8 * hh;
+        } else {
+            img = H == 8 ? j : (threadIdx.x >> 6) + 4 * j;
+            live = j < 2;
+            yy = H == 8 ? (threadIdx.x & 15) >> 1 : threadIdx.x & 3;
+            const bool odd = yy & 1;
+            kyA = odd ? 2 : 1, oyA = yy >> 1, okA = live;
+            oyB = (yy >> 1) + 1, okB = live && odd && oyB < OH;
         }
+        offA[j] = okA ? kyA * 3 * 512 + s2_slot<H>(img, oyA) : -1;
+        offB[j] = okB ? s2_slot<H>(img, oyB) : -1;
+        const int bi = b0 + img < d.B ? b0 + img : d.B - 1;  // past the batch: a valid image, never stored
+        src[j] = x + (static_cast<size_t>(bi) * d.KC + ci_s) * (H * H) + yy * H + x0_s;
+    }
+    const float *src0 = src[0], *src1 = src[1], *src2 = src[H == 16 ? 2 : 1];
+    const int oA0 = offA[0], oA1 = offA[1], oA2 = offA[2], oB0 = offB[0], oB1 = offB[1], oB2 = offB[2];
+    float4 xa, xb, xc;
+    xc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // scatter one float4 (columns x0 .. x0+3 of channel ci_s) to the tap planes of one (tap row, small-map row)
+    auto put_cols = [&](float *p, float4 v) {
+        p[1 * 512 + 4 * o_s] = v.x;        // column x0 (even): kx 1
+        p[2 * 512 + 4 * o_s] = v.y;        // x0+1 (odd): kx 2 at ox = o, kx 0 at ox = o+1
+        p[0 * 512 + 4 * (o_s + 1)] = v.y;
+        p[1 * 512 + 4 * (o_s + 1)] = v.z;  // x0+2 (even): kx 1
+        p[2 * 512 + 4 * (o_s + 1)] = v.w;  // x0+3 (odd): kx 2 at o+1, kx 0 at o+2 (if inside)
+        if (o_s + 2 < OH) p[0 * 512 + 4 * (o_s + 2)] = v.w;
     };
-    f32x4 acc[MT][2];
+    auto put = [&](float *xs, float4 v, int oA, int oB) {
+        float *base = xs + (ci_s >> 2) * 128 + (ci_s & 3);
+        if (oA >= 0) put_cols(base + oA, v);
+        if (oB >= 0) put_cols(base + oB, v);
+    };
+#define S2_LOAD_X(round_)                                                        \
+    do {                                                                         \
+        const size_t xo_ = static_cast<size_t>(round_) * xstep;                  \
+        xa = *reinterpret_cast<const float4 *>(src0 + xo_);                      \
+        xb = *reinterpret_cast<const float4 *>(src1 + xo_);                      \
+        if (H == 16) xc = *reinterpret_cast<const float4 *>(src2 + xo_);         \
+    } while (0)
+#define S2_PUT_X(dst_)                                                           \
+    do {                                                                         \
+        put(dst_, xa, oA0, oB0);                                                 \
+        put(dst_, xb, oA1, oB1);                                                 \
+        if (H == 16) put(dst_, xc, oA2, oB2);                                    \
+    } while (0)
+    f32x4 acc[MT][2], acc1[MT][2];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int n = 0; n < 2; ++n) acc[m][n] = acc1[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const size_t xstep = static_cast<size_t>(S2_CK) * (H * H);
     S2_LOAD_W(0);
-    xa = *reinterpret_cast<const float4 *>(xsrc0);
-    xb = *reinterpret_cast<const float4 *>(xsrc1);
+    S2_LOAD_X(0);
     __syncthreads();  // the zero fill
     S2_STORE_W(lds);
-    put(lds + WFM, xa, img0);
-    put(lds + WFM, xb, img1);
+    S2_PUT_X(lds + WFM);
     {
         const int nr = rounds > 1 ? 1 : 0;
         S2_LOAD_W(nr);
-        xa = *reinterpret_cast<const float4 *>(xsrc0 + nr * xstep);
-        xb = *reinterpret_cast<const float4 *>(xsrc1 + nr * xstep);
+        S2_LOAD_X(nr);
     }
     __syncthreads();
     const int aofs = wave * (MT * 64) + 4 * l15 + lq, bofs = WFM + wave * 128 + 4 * l15 + lq;
@@ -159,14 +204,12 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
         float *cur = lds + (round & 1) * BUF, *nxt = lds + ((round + 1) & 1) * BUF;
         if (round + 1 < rounds) {  // the other buffer was last read before the barrier that ended the previous round
             S2_STORE_W(nxt);
-            put(nxt + WFM, xa, img0);
-            put(nxt + WFM, xb, img1);
+            S2_PUT_X(nxt + WFM);
         }
         {
             const int nr = round + 2 < rounds ? round + 2 : rounds - 1;  // always issued: a load under a condition costs its own round trip
             S2_LOAD_W(nr);
-            xa = *reinterpret_cast<const float4 *>(xsrc0 + nr * xstep);
-            xb = *reinterpret_cast<const float4 *>(xsrc1 + nr * xstep);
+            S2_LOAD_X(nr);
         }
         const float *ap = cur + aofs, *bp = cur + bofs;
 #pragma unroll
@@ -177,75 +220,109 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
                 const float a = ap[t * (256 * MT) + m * 64];
                 acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v0, acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v1, acc[m][1], 0, 0, 0);
+                if (DS && t == 4) {  // x[2 oy][2 ox]: the centre tap's plane under the 1x1 filters
+                    const float a1 = ap[9 * (256 * MT) + m * 64];
+                    acc1[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, v0, acc1[m][0], 0, 0, 0);
+                    acc1[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, v1, acc1[m][1], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
     }
-    // ---- the four partial sums meet: red[wave][co RB][36], D row = 4 (lane >> 4) + reg, column = lane & 15 ---------------------------------
+#undef S2_LOAD_X
+#undef S2_PUT_X
+    // ---- the four partial sums meet: red[set][wave][co RB][36], D row = 4 (lane >> 4) + reg, column = lane & 15 -----------------------------
+    constexpr int RED = 4 * RB * S2_RS;
+    static_assert((DS ? 2 : 1) * RED <= 2 * BUF, "the exchange fits the staging buffers");
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds[wave * (RB * S2_RS) + (m * 16 + 4 * lq + r) * S2_RS + n * 16 + l15] = acc[m][n][r];
+            for (int r = 0; r < 4; ++r) {
+                const int o = wave * (RB * S2_RS) + (m * 16 + 4 * lq + r) * S2_RS + n * 16 + l15;
+                lds[o] = acc[m][n][r];
+                if (DS) lds[RED + o] = acc1[m][n][r];
+            }
     __syncthreads();
     if (threadIdx.x < 8 * RB) {
         const int co = threadIdx.x >> 3, nq = threadIdx.x & 7;  // four consecutive columns of one result channel
-        const float *rp = lds + co * S2_RS + 4 * nq;
-        float4 s = *reinterpret_cast<const float4 *>(rp);
+        // H = 16: columns 4 nq .. = half a row of the workgroup's four; H = 8: pixels 4 (nq & 3) .. of image nq >> 2; H = 4: the 2x2 plane of image nq
+        const int img = H == 16 ? 0 : (H == 8 ? nq >> 2 : nq), off = H == 16 ? (4 * hh + (nq >> 1)) * 8 + 4 * (nq & 1) : (H == 8 ? 4 * (nq & 3) : 0);
+        const size_t dst = (static_cast<size_t>(b0 + img) * d.RC + co0 + co) * PX + off;
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float4 v = *reinterpret_cast<const float4 *>(rp + w * (RB * S2_RS));
-            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        for (int set = 0; set < (DS ? 2 : 1); ++set) {
+            const float *rp = lds + set * RED + co * S2_RS + 4 * nq;
+            float4 s = *reinterpret_cast<const float4 *>(rp);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 v = *reinterpret_cast<const float4 *>(rp + w * (RB * S2_RS));
+                s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+            }
+            if (b0 + img < d.B) *reinterpret_cast<float4 *>((set == 0 ? y : y1) + dst) = s;
         }
-        // H = 8: columns = pixels 4 (nq & 3) .. of image nq >> 2;  H = 4: the 2x2 plane of image nq
-        const int img = H == 8 ? nq >> 2 : nq, off = H == 8 ? 4 * (nq & 3) : 0;
-        if (b0 + img < d.B) *reinterpret_cast<float4 *>(y + (static_cast<size_t>(b0 + img) * d.RC + co0 + co) * PX + off) = s;
     }
 }
 
-// ---- backward-data: dy [B][KC][H/2][H/2] -> dx [B][RC][H][H].  grid (ceil(B / IMG), RC / (16 MT)) -----------------------------------
+// ---- backward-data: dy [B][KC][H/2][H/2] -> dx [B][RC][H][H].  grid (ceil(B / IMG) or 2 B, RC / (16 MT)) ----------------------------
 // dx[2i+py][2j+px] = sum over the taps of parity class (py, px): row taps py = 0: ky 1 (dy row i); py = 1: ky 0 (row i+1) and ky 2 (row i).
 constexpr int S2_DS = 4 * 4 * 2 * 64;  // dy shifts of a round: [shift sy*2+sx][quad][column block][16 n][4 k] = 2048 floats
 constexpr int S2_OS = 20;              // row stride of the interleave exchange [class][column block][RB ci][20]
 
-template <int H, int MT>
-__global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__restrict__ dy, const float *__restrict__ w9, float *__restrict__ dx, S2Dims d) {
+// DS: plus the backward-data of the block's shortcut Conv2d(1x1, stride 2): dy1 (same shape as dy) under the transposed 1x1 filters (the
+// tenth tap) lands on the even-even parity class only
+template <int H, int MT, bool DS>
+__global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__restrict__ dy, const float *__restrict__ dy1, const float *__restrict__ w9,
+                                                                 float *__restrict__ dx, S2Dims d) {
     using G = S2Geo<H>;
-    constexpr int OH = G::OH, PX = G::PX, IPT = G::IPT, IMG = G::IMG;
-    constexpr int WFM = 9 * 4 * MT * 64, BUF = WFM + S2_DS, RB = 16 * MT, OW = 4 * 2 * RB * S2_OS;  // OW: one accumulator set in the exchange
+    constexpr int OH = G::OH, PX = G::PX, IMG = G::IMG, TAPS = DS ? 10 : 9;
+    constexpr int WFM = TAPS * 4 * MT * 64, D1 = WFM + S2_DS, BUF = D1 + (DS ? 512 : 0), RB = 16 * MT, OW = 4 * 2 * RB * S2_OS;  // OW: one accumulator set in the exchange
     __shared__ __align__(16) float lds[2 * BUF];  // rounds: two buffers of {filters, dy shifts}; afterwards: two accumulator sets
     static_assert(BUF >= OW, "the exchange fits the staging buffers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
-    const int b0 = blockIdx.x * IMG, ci0 = blockIdx.y * RB;
+    const int b0 = H == 16 ? blockIdx.x >> 1 : blockIdx.x * IMG, hh = H == 16 ? blockIdx.x & 1 : 0, ci0 = blockIdx.y * RB;
     for (int i = threadIdx.x; i < S2_DS; i += S2_NT) lds[WFM + i] = lds[BUF + WFM + i] = 0.0f;  // shifted-out slots stay zero
     const int rounds = d.KC / S2_CK;
     S2_W_SETUP();
-    // dy of a round: IMG images x 16 channels x PX floats = 128 float4: threads 0..127 (the others repeat a valid address and skip the write).
-    // H = 8 (4x4 dy): float4 = (image tid >> 6, co (tid & 63) >> 2, row tid & 3);  H = 4 (2x2 dy): float4 = (image tid >> 4, co tid & 15) plane
-    const int dt = threadIdx.x & 127;
-    const int img_s = H == 8 ? dt >> 6 : dt >> 4, co_s = H == 8 ? (dt & 63) >> 2 : dt & 15, row_s = H == 8 ? dt & 3 : 0;
+    // dy of a round, one float4 per thread (the idle threads repeat a valid address and skip the write):
+    //   H = 4 (2x2 dy): 8 images x 16 channels: 128 planes (image tid >> 4, co tid & 15)
+    //   H = 8 (4x4 dy): 2 images x 16 channels x 4 rows: 128 (image tid >> 6, co (tid & 63) >> 2, row tid & 3)
+    //   H = 16 (8x8 dy): rows 4 hh .. 4 hh + 4 (the last one for the shift; row 8 does not exist) x 16 channels x 2 halves: 160
+    //           (row tid >> 5, co (tid & 31) >> 1, half tid & 1)
+    const int dt = H == 16 ? (threadIdx.x < 160 ? threadIdx.x : threadIdx.x - 128) : threadIdx.x & 127;
+    const int img_s = H == 16 ? 0 : (H == 8 ? dt >> 6 : dt >> 4), co_s = H == 16 ? (dt & 31) >> 1 : (H == 8 ? (dt & 63) >> 2 : dt & 15);
+    const int row_s = H == 16 ? dt >> 5 : (H == 8 ? dt & 3 : 0), half_s = H == 16 ? dt & 1 : 0;
+    const int oy_s = H == 16 ? 4 * hh + row_s : row_s;
+    const bool live = (H == 16 ? threadIdx.x < 160 : threadIdx.x < 128) && oy_s < OH;
     const int bi = b0 + img_s < d.B ? b0 + img_s : d.B - 1;
-    const float *dsrc = dy + (static_cast<size_t>(bi) * d.KC + co_s) * PX + 4 * row_s;
-    float4 da;
-    auto put = [&](float *ds, float4 v) {
-        const int nt = img_s / IPT, il = img_s - nt * IPT;
-        float *base = ds + ((co_s >> 2) * 2 + nt) * 64 + (co_s & 3) + 4 * (il * PX);  // shift stride 512 floats
-        if (H == 8) {  // row oy = row_s, columns 0..3: shift (sy, sx) holds dy[i + sy][j + sx] at (i, j)
-            const int oy = row_s;
-            float *p0 = base + 4 * (oy * OH);
-            p0[0] = v.x, p0[4] = v.y, p0[8] = v.z, p0[12] = v.w;                    // (0, 0)
-            p0[512 + 0] = v.y, p0[512 + 4] = v.z, p0[512 + 8] = v.w;                // (0, 1): j = ox - 1
-            if (oy > 0) {
-                float *p1 = base + 4 * ((oy - 1) * OH);
-                p1[1024 + 0] = v.x, p1[1024 + 4] = v.y, p1[1024 + 8] = v.z, p1[1024 + 12] = v.w;  // (1, 0)
-                p1[1536 + 0] = v.y, p1[1536 + 4] = v.z, p1[1536 + 8] = v.w;                          // (1, 1)
+    const size_t doff = (static_cast<size_t>(bi) * d.KC + co_s) * PX + (H == 4 ? 0 : (oy_s < OH ? oy_s : OH - 1) * OH + 4 * half_s);
+    const float *dsrc = dy + doff, *dsrc1 = DS ? dy1 + doff : dy + doff;
+    const bool live1 = DS && live && row_s < 4;  // the shortcut's gradient needs no shifted row
+    float4 da, db;
+    db = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto put1 = [&](float *d1, float4 v) {  // dy1 unshifted: [quad][column block][16 n][4 k]
+        float *p = d1 + (co_s >> 2) * 128 + (co_s & 3) + s2_slot<H>(img_s, row_s) + 16 * half_s;
+        p[0] = v.x, p[4] = v.y, p[8] = v.z, p[12] = v.w;
+    };
+    auto put = [&](float *ds, float4 v) {  // shift (sy, sx) holds dy[i + sy][j + sx] at (i, j); shift stride 512 floats
+        float *base = ds + (co_s >> 2) * 128 + (co_s & 3);
+        if (H == 4) {  // the 2x2 plane: v = dy[0][0], [0][1], [1][0], [1][1]
+            float *p = base + s2_slot<H>(img_s, 0);
+            p[0] = v.x, p[4] = v.y, p[8] = v.z, p[12] = v.w;  // (0, 0)
+            p[512 + 0] = v.y, p[512 + 8] = v.w;               // (0, 1)
+            p[1024 + 0] = v.z, p[1024 + 4] = v.w;             // (1, 0)
+            p[1536 + 0] = v.w;                                // (1, 1)
+        } else {  // four columns 4 half .. of dy row oy: (sy = 0) at small row i = oy, (sy = 1) at i = oy - 1 - inside the workgroup's rows
+            const int r0 = row_s, c0 = 4 * half_s;
+#pragma unroll
+            for (int sy = 0; sy < 2; ++sy) {
+                const int il = r0 - sy;
+                if (il < 0 || il >= (H == 16 ? 4 : OH)) continue;
+                float *p = base + sy * 1024 + s2_slot<H>(img_s, il) + 4 * c0;
+                p[0] = v.x, p[4] = v.y, p[8] = v.z, p[12] = v.w;           // sx = 0: j = ox
+                if (c0 > 0) p[512 - 4] = v.x;                              // sx = 1: j = ox - 1
+                p[512 + 0] = v.y, p[512 + 4] = v.z, p[512 + 8] = v.w;
             }
-        } else {  // the 2x2 plane: v = dy[0][0], [0][1], [1][0], [1][1]
-            base[0] = v.x, base[4] = v.y, base[8] = v.z, base[12] = v.w;  // (0, 0)
-            base[512 + 0] = v.y, base[512 + 8] = v.w;                     // (0, 1)
-            base[1024 + 0] = v.z, base[1024 + 4] = v.w;                   // (1, 0)
-            base[1536 + 0] = v.w;                                         // (1, 1)
         }
     };
     f32x4 acc[4][2][MT];  // [parity class py*2+px][column block][channel half]
@@ -258,13 +335,16 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     const size_t dstep = static_cast<size_t>(S2_CK) * PX;
     S2_LOAD_W(0);
     da = *reinterpret_cast<const float4 *>(dsrc);
+    if (DS) db = *reinterpret_cast<const float4 *>(dsrc1);
     __syncthreads();  // the zero fill
     S2_STORE_W(lds);
-    if (threadIdx.x < 128) put(lds + WFM, da);
+    if (live) put(lds + WFM, da);
+    if (live1) put1(lds + D1, db);
     {
         const int nr = rounds > 1 ? 1 : 0;
         S2_LOAD_W(nr);
         da = *reinterpret_cast<const float4 *>(dsrc + nr * dstep);
+        if (DS) db = *reinterpret_cast<const float4 *>(dsrc1 + nr * dstep);
     }
     __syncthreads();
     const int aofs = wave * (MT * 64) + 4 * l15 + lq, bofs = WFM + wave * 128 + 4 * l15 + lq;
@@ -272,12 +352,14 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
         float *cur = lds + (round & 1) * BUF, *nxt = lds + ((round + 1) & 1) * BUF;
         if (round + 1 < rounds) {
             S2_STORE_W(nxt);
-            if (threadIdx.x < 128) put(nxt + WFM, da);
+            if (live) put(nxt + WFM, da);
+            if (live1) put1(nxt + D1, db);
         }
         {
             const int nr = round + 2 < rounds ? round + 2 : rounds - 1;
             S2_LOAD_W(nr);
             da = *reinterpret_cast<const float4 *>(dsrc + nr * dstep);
+            if (DS) db = *reinterpret_cast<const float4 *>(dsrc1 + nr * dstep);
         }
         const float *ap = cur + aofs, *bp = cur + bofs;
         float bv[4][2];
@@ -294,6 +376,16 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
                 const float a = ap[t * (256 * MT) + m * 64];
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[cls][n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[sh][n], acc[cls][n][m], 0, 0, 0);
+            }
+        }
+        if (DS) {
+            const float *b1 = cur + D1 + wave * 128 + 4 * l15 + lq;
+            const float u0 = b1[0], u1 = b1[64];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float a = ap[9 * (256 * MT) + m * 64];
+                acc[0][0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, u0, acc[0][0][m], 0, 0, 0);
+                acc[0][1][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, u1, acc[0][1][m], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -326,60 +418,63 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     __syncthreads();
     if (wave < 2) spill(lds + wave * OW);
     __syncthreads();
-    // IMG x RB channels x H^2 floats = 512 MT float4 (4 consecutive x of one row): 2 MT per thread
+    // the workgroup's RB channels x 128 large-map pixels = 512 MT float4 (4 consecutive x of one row): 2 MT per thread
 #pragma unroll
     for (int k = 0; k < 2 * MT; ++k) {
         const int f = threadIdx.x + S2_NT * k;
-        constexpr int F4R = H / 4, F4I = RB * H * F4R;  // float4 per row / per image
-        const int img = f / F4I, g = f - img * F4I, ci = g / (H * F4R), q = g - ci * (H * F4R), yy = q / F4R, xq = q - yy * F4R;
-        const int nt = img / IPT, il = img - nt * IPT, i = yy >> 1, py = yy & 1;
+        // (image, channel, large-map row yy inside the workgroup's part, float4 xq of the row)
+        constexpr int F4R = H / 4, ROWS = H == 16 ? 8 : H, F4I = RB * ROWS * F4R;
+        const int img = f / F4I, g = f - img * F4I, ci = g / (ROWS * F4R), q = g - ci * (ROWS * F4R), yy = q / F4R, xq = q - yy * F4R;
+        const int i = yy >> 1, py = yy & 1, sl = s2_slot<H>(img, i);  // block * 64 + 4 * (pixel of (i, 0))
         float out[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int xx = 4 * xq + e, j = xx >> 1, c = py * 2 + (xx & 1), n = il * PX + i * OH + j;
+            const int xx = 4 * xq + e, j = xx >> 1, c = py * 2 + (xx & 1), nt = sl >> 6, n = ((sl & 63) >> 2) + j;
             const int o = ((c * 2 + nt) * RB + ci) * S2_OS + n;
             out[e] = lds[o] + lds[OW + o];
         }
         if (b0 + img < d.B)
-            *reinterpret_cast<float4 *>(dx + (static_cast<size_t>(b0 + img) * d.RC + ci0 + ci) * (H * H) + yy * H + 4 * xq) =
+            *reinterpret_cast<float4 *>(dx + (static_cast<size_t>(b0 + img) * d.RC + ci0 + ci) * (H * H) + (8 * hh + yy) * H + 4 * xq) =
                 make_float4(out[0], out[1], out[2], out[3]);
     }
 }
 
 // 16 MT result channels per workgroup.  B = 100, un-profiled us, MT = 2 / 1: forward 8x8 18.6 / 23.9, 4x4 21.6 / 22.0; backward-data 8x8
-// 19.6 / 18.0, 4x4 35.2 / 27.4 (104 workgroups at MT = 2).  EEADV_S2_MT = four digits (forward 8x8, forward 4x4, backward 8x8, backward
+// 19.6 / 18.0, 4x4 35.2 / 27.4 (104 workgroups at MT = 2).  EEADV_S2_MT = six digits (forward 16x16, 8x8, 4x4, backward 16x16, 8x8,
 // 4x4) overrides, for A/B runs.
 int s2_mt(bool bwd, int H) {
     const char *env = std::getenv("EEADV_S2_MT");  // read per call (tests flip it)
-    const int slot = (bwd ? 2 : 0) + (H == 4 ? 1 : 0);
-    if (env && std::strlen(env) == 4 && (env[slot] == '1' || env[slot] == '2')) return env[slot] - '0';
+    const int slot = (bwd ? 3 : 0) + (H == 16 ? 0 : (H == 8 ? 1 : 2));
+    if (env && std::strlen(env) == 6 && (env[slot] == '1' || env[slot] == '2')) return env[slot] - '0';
     return bwd ? 1 : 2;
 }
 
-template <int H, int MT>
-int s2_launch(bool bwd, const float *in, const float *w9, float *out, const S2Dims &d, hipStream_t st) {
-    const dim3 grid(static_cast<unsigned>((d.B + S2Geo<H>::IMG - 1) / S2Geo<H>::IMG), static_cast<unsigned>(d.RC / (16 * MT)));
+template <int H, int MT, bool DS>
+int s2_launch(bool bwd, const float *in, const float *in1, const float *w9, float *out, float *out1, const S2Dims &d, hipStream_t st) {
+    const dim3 grid(static_cast<unsigned>(H == 16 ? 2 * d.B : (d.B + S2Geo<H>::IMG - 1) / S2Geo<H>::IMG), static_cast<unsigned>(d.RC / (16 * MT)));
     if (bwd) {
-        EE_LAUNCH((conv3s2_bwd_mfma_kernel<H, MT>), grid, dim3(S2_NT), 0, st, in, w9, out, d);
+        EE_LAUNCH((conv3s2_bwd_mfma_kernel<H, MT, DS>), grid, dim3(S2_NT), 0, st, in, in1, w9, out, d);
     } else {
-        constexpr size_t bytes = 2 * (9 * 4 * MT * 64 + S2_XS) * sizeof(float);  // 72 / 54 KB: above the static limit
-        static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3s2_fwd_mfma_kernel<H, MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        constexpr size_t bytes = 2 * ((DS ? 10 : 9) * 4 * MT * 64 + S2_XS) * sizeof(float);  // 54-76 KB: above the static limit
+        static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3s2_fwd_mfma_kernel<H, MT, DS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             static_cast<int>(bytes)) == hipSuccess;
         if (!ok) return EE_ERR_UNSUPPORTED;
-        EE_LAUNCH((conv3s2_fwd_mfma_kernel<H, MT>), grid, dim3(S2_NT), bytes, st, in, w9, out, d);
+        EE_LAUNCH((conv3s2_fwd_mfma_kernel<H, MT, DS>), grid, dim3(S2_NT), bytes, st, in, w9, out, out1, d);
     }
     return launch_status();
 }
 
-int s2_dispatch(bool bwd, const float *in, const float *w9, float *out, const S2Dims &d, int H, hipStream_t st) {
+template <bool DS>
+int s2_dispatch(bool bwd, const float *in, const float *in1, const float *w9, float *out, float *out1, const S2Dims &d, int H, hipStream_t st) {
     const int mt = s2_mt(bwd, H);
-    if (H == 8) return mt == 2 ? s2_launch<8, 2>(bwd, in, w9, out, d, st) : s2_launch<8, 1>(bwd, in, w9, out, d, st);
-    return mt == 2 ? s2_launch<4, 2>(bwd, in, w9, out, d, st) : s2_launch<4, 1>(bwd, in, w9, out, d, st);
+    if (H == 16) return mt == 2 ? s2_launch<16, 2, DS>(bwd, in, in1, w9, out, out1, d, st) : s2_launch<16, 1, DS>(bwd, in, in1, w9, out, out1, d, st);
+    if (H == 8) return mt == 2 ? s2_launch<8, 2, DS>(bwd, in, in1, w9, out, out1, d, st) : s2_launch<8, 1, DS>(bwd, in, in1, w9, out, out1, d, st);
+    return mt == 2 ? s2_launch<4, 2, DS>(bwd, in, in1, w9, out, out1, d, st) : s2_launch<4, 1, DS>(bwd, in, in1, w9, out, out1, d, st);
 }
 
 int s2_check(const void *a, const void *b, const void *c, int B, int KC, int RC, int H) {
     if (B < 0 || KC < 1 || RC < 1) return EE_ERR_SHAPE;
-    if (KC % S2_CK != 0 || RC % S2_RB != 0 || (H != 4 && H != 8)) return EE_ERR_UNSUPPORTED;
+    if (KC % S2_CK != 0 || RC % S2_RB != 0 || (H != 4 && H != 8 && H != 16)) return EE_ERR_UNSUPPORTED;
     if (B == 0) return EE_OK;
     if (!a || !b || !c) return EE_ERR_NULL;
     if (!aligned16(a) || !aligned16(b) || !aligned16(c)) return EE_ERR_ALIGN;
@@ -396,7 +491,7 @@ EE_API int ee_conv3x3s2_small_fwd_f32(const float *x, const float *w9, float *y,
     if (rc != EE_OK || B == 0) return rc;
     const S2Dims d{B, Cin, Cout};
     ProfScope prof(EE_K_CONV3S2_FWD, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
-    return s2_dispatch(false, x, w9, y, d, H, as_stream(stream));
+    return s2_dispatch<false>(false, x, nullptr, w9, y, nullptr, d, H, as_stream(stream));
 }
 
 // dy [B][Cout][H/2][H/2], w9 = the filters as [Cin/32][Cout/16][9][4][2][16][4] (w9[..][t][q][h][m][k] = weight[16 round + 4 q + k]
@@ -406,5 +501,31 @@ EE_API int ee_conv3x3s2_small_bwd_data_f32(const float *dy, const float *w9, flo
     if (rc != EE_OK || B == 0) return rc;
     const S2Dims d{B, Cout, Cin};
     ProfScope prof(EE_K_CONV3S2_BWD, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
-    return s2_dispatch(true, dy, w9, dx, d, H, as_stream(stream));
+    return s2_dispatch<false>(true, dy, nullptr, w9, dx, nullptr, d, H, as_stream(stream));
+}
+
+// The first convolution of a down-sampling BasicBlock TOGETHER with the block's shortcut convolution (resnet.py:26-31, :137-142): both read
+// the same x, and the 1x1 / stride 2 filter sees exactly the 3x3's centre tap.  w10 = the filters as [Cout/32][Cin/16][10][4][2][16][4], taps 0..8
+// the 3x3's (as w9 above), tap 9 the 1x1's (forward: weight1[32 cb + 16 h + m][16 rd + 4 q + k]).
+//   x [B][Cin][H][H] -> y3 = conv3x3s2(x) and y1 = conv1x1s2(x), both [B][Cout][H/2][H/2]
+EE_API int ee_conv3x3s2_pair_fwd_f32(const float *x, const float *w10, float *y3, float *y1, int B, int Cin, int Cout, int H, void *stream) {
+    const int rc = s2_check(x, w10, y3, B, Cin, Cout, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (!y1) return EE_ERR_NULL;
+    if (!aligned16(y1)) return EE_ERR_ALIGN;
+    const S2Dims d{B, Cin, Cout};
+    ProfScope prof(EE_K_CONV3S2_FWD, as_stream(stream), 2.0 * 10.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
+    return s2_dispatch<true>(false, x, nullptr, w10, y3, y1, d, H, as_stream(stream));
+}
+
+// their backward-data in one pass: dx = conv3x3s2^T(dy3) + conv1x1s2^T(dy1).  w10 [Cin/32][Cout/16][10][4][2][16][4] (backward order: tap 9 =
+// weight1[16 rd + 4 q + k][32 cb + 16 h + m])
+EE_API int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, const float *w10, float *dx, int B, int Cin, int Cout, int H, void *stream) {
+    const int rc = s2_check(dy3, w10, dx, B, Cout, Cin, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (!dy1) return EE_ERR_NULL;
+    if (!aligned16(dy1)) return EE_ERR_ALIGN;
+    const S2Dims d{B, Cout, Cin};
+    ProfScope prof(EE_K_CONV3S2_BWD, as_stream(stream), 2.0 * 10.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
+    return s2_dispatch<true>(true, dy3, dy1, w10, dx, nullptr, d, H, as_stream(stream));
 }

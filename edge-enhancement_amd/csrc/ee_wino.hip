@@ -13,6 +13,8 @@
 // flipped, transposed filter.  Exact f32 products; the transforms add a few 1e-7 of relative error (as MIOpen's solver does).
 //
 // CNN-body glue, not a row of SURVEY.md section 8.
+#include <cstdlib>
+
 #include "ee_common.hpp"
 
 namespace {
@@ -215,6 +217,447 @@ __global__ __launch_bounds__(WN_NT) void wino3x3_kernel(const float *__restrict_
 
 #undef WN_PREFETCH
 
+// ---- 4x4 maps (layer3 at 64x64 inputs), second version: producer and consumer wavefronts ------------------------------------------------
+// 200 workgroups of four images = one per CU and, with 256 lanes, ONE wavefront per SIMD: a wavefront issues in order, so its loads' latency,
+// its staging / transform work and its MFMAs simply add up (phase skipping on the generic kernel and on a double-buffered variant of it:
+// 8.4 us of products + 6.6 staging + 6.4 waiting for loads + 10 of launch / prologue / epilogue, nothing hidden behind anything).  Here the
+// workgroup has 512 lanes: wavefronts 0-3 only multiply (the generic kernel's roles: four xi each), wavefronts 4-7 only produce - they keep
+// TWO rounds of U / input loads in flight in two named register sets, transform the input patches from registers (a lane owns one
+// (channel, image, tile) patch and takes the three rows it needs of that 4x4 plane: no pixel staging in LDS) and write U and V of the
+// NEXT round into the other LDS buffer while the consumers multiply the current one.  One barrier per round; each SIMD hosts one wavefront
+// of either kind, so the hardware overlaps the two streams.  Same arithmetic in the same order as the generic kernel.
+constexpr int W4_VS = WN_CK * 16;                 // one xi's V [16 ci][16 tiles]
+constexpr int W4_BUF = 16 * WN_US + 16 * W4_VS;   // U [16][16][48] + V [16][16][16] = 16384 floats
+constexpr size_t W4_LDS = 2 * W4_BUF * sizeof(float);
+constexpr int W4_NT = 512;
+
+__global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino3x3_map4_kernel(const float *__restrict__ x, const float *__restrict__ u, float *__restrict__ y, WinoDims d) {
+    extern __shared__ __align__(16) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool producer = wave >= 4;
+    const int pt = threadIdx.x & 255;  // lane number inside its group of four wavefronts
+    const int b = blockIdx.x * 4, co0 = blockIdx.y * WN_CO;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int urow0 = pt >> 3, uq = pt & 7;
+    const int ci_s = urow0 & 15, xi_s = urow0 >> 4;
+    const float *ubase = u + (static_cast<size_t>(xi_s) * d.KC + ci_s) * d.RC + co0 + 4 * uq;
+    const size_t uxi2 = 2 * static_cast<size_t>(d.KC) * d.RC;
+    // patch of this producer lane: channel ci_x of the round, tile t_x = (image, ty, tx) of the workgroup's 16
+    const int ci_x = pt >> 4, t_x = pt & 15, ty = (t_x >> 1) & 1, tx = t_x & 1;
+    const int xb = b + (t_x >> 2) < d.B ? b + (t_x >> 2) : d.B - 1;  // past the batch: a valid image, never stored
+    const float *xsrc = x + (static_cast<size_t>(xb) * d.KC + ci_x) * 16 + 4 * ty;  // rows ty .. ty+2 of the plane (patch rows 2ty-1 .. 2ty+2 minus the padding one)
+    const size_t ustep = static_cast<size_t>(WN_CK) * d.RC, xstep = static_cast<size_t>(WN_CK) * 16;
+    const int rounds = d.KC / WN_CK;
+    // one round's prefetch of a producer lane: 8 float4 of U, 3 rows of its input plane - two sets (A, B) of NAMED registers filled by
+    // straight-line code (as a struct handed to a lambda they lived in scratch memory)
+    float4 Au0, Au1, Au2, Au3, Au4, Au5, Au6, Au7, Ax0, Ax1, Ax2, Bu0, Bu1, Bu2, Bu3, Bu4, Bu5, Bu6, Bu7, Bx0, Bx1, Bx2;
+#define W4_FETCH(S, round_)                                                                        \
+    do {                                                                                           \
+        const int r_ = (round_) < rounds ? (round_) : rounds - 1; /* always issued */              \
+        const float *up_ = ubase + r_ * ustep;                                                     \
+        const float *xp_ = xsrc + r_ * xstep;                                                      \
+        S##u0 = *reinterpret_cast<const float4 *>(up_);                                            \
+        S##u1 = *reinterpret_cast<const float4 *>(up_ + uxi2);                                     \
+        S##u2 = *reinterpret_cast<const float4 *>(up_ + 2 * uxi2);                                 \
+        S##u3 = *reinterpret_cast<const float4 *>(up_ + 3 * uxi2);                                 \
+        S##u4 = *reinterpret_cast<const float4 *>(up_ + 4 * uxi2);                                 \
+        S##u5 = *reinterpret_cast<const float4 *>(up_ + 5 * uxi2);                                 \
+        S##u6 = *reinterpret_cast<const float4 *>(up_ + 6 * uxi2);                                 \
+        S##u7 = *reinterpret_cast<const float4 *>(up_ + 7 * uxi2);                                 \
+        S##x0 = *reinterpret_cast<const float4 *>(xp_);                                            \
+        S##x1 = *reinterpret_cast<const float4 *>(xp_ + 4);                                        \
+        S##x2 = *reinterpret_cast<const float4 *>(xp_ + 8);                                        \
+    } while (0)
+    // V = B^T d B of this lane's patch from the three rows p0..p2 (rows ty .. ty+2 of the plane) -> buffer `buf`.  Patch rows: ty = 0:
+    // (pad, row 0, 1, 2); ty = 1: (row 1, 2, 3, pad); columns likewise with tx
+    auto transform = [&](float *buf, float4 p0, float4 p1, float4 p2) {
+        const float q0[4] = {p0.x, p0.y, p0.z, p0.w}, q1[4] = {p1.x, p1.y, p1.z, p1.w}, q2[4] = {p2.x, p2.y, p2.z, p2.w};
+        float rw[4][4], dd[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            rw[0][c] = ty ? q0[c] : 0.0f;
+            rw[1][c] = ty ? q1[c] : q0[c];
+            rw[2][c] = ty ? q2[c] : q1[c];
+            rw[3][c] = ty ? 0.0f : q2[c];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dd[i][0] = tx ? rw[i][1] : 0.0f;
+            dd[i][1] = tx ? rw[i][2] : rw[i][0];
+            dd[i][2] = tx ? rw[i][3] : rw[i][1];
+            dd[i][3] = tx ? 0.0f : rw[i][2];
+        }
+        float tt[4][4];  // B^T d
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tt[0][j] = dd[0][j] - dd[2][j];
+            tt[1][j] = dd[1][j] + dd[2][j];
+            tt[2][j] = dd[2][j] - dd[1][j];
+            tt[3][j] = dd[1][j] - dd[3][j];
+        }
+        float *vp = buf + 16 * WN_US + ci_x * 16 + t_x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vp[(4 * i + 0) * W4_VS] = tt[i][0] - tt[i][2];
+            vp[(4 * i + 1) * W4_VS] = tt[i][1] + tt[i][2];
+            vp[(4 * i + 2) * W4_VS] = tt[i][2] - tt[i][1];
+            vp[(4 * i + 3) * W4_VS] = tt[i][1] - tt[i][3];
+        }
+    };
+    // U slice and V of a fetched round -> buffer `buf_`
+#define W4_STAGE(buf_, S)                                                                          \
+    do {                                                                                           \
+        float *ud_ = (buf_) + xi_s * WN_US + ci_s * WN_CP + 4 * uq; /* row urow0 + 32 j -> xi = xi_s + 2 j */ \
+        *reinterpret_cast<float4 *>(ud_) = S##u0;                                                  \
+        *reinterpret_cast<float4 *>(ud_ + 2 * WN_US) = S##u1;                                      \
+        *reinterpret_cast<float4 *>(ud_ + 4 * WN_US) = S##u2;                                      \
+        *reinterpret_cast<float4 *>(ud_ + 6 * WN_US) = S##u3;                                      \
+        *reinterpret_cast<float4 *>(ud_ + 8 * WN_US) = S##u4;                                      \
+        *reinterpret_cast<float4 *>(ud_ + 10 * WN_US) = S##u5;                                     \
+        *reinterpret_cast<float4 *>(ud_ + 12 * WN_US) = S##u6;                                     \
+        *reinterpret_cast<float4 *>(ud_ + 14 * WN_US) = S##u7;                                     \
+        transform(buf_, S##x0, S##x1, S##x2);                                                      \
+    } while (0)
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[a][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // consumer: M_xi += U_xi V_xi for this wavefront's four xi, all 48 operands of the round first, then the 32 products
+    auto multiply = [&](const float *cur) {
+        float a0[4][4], a1[4][4], bv[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int xi = 4 * wave + a;
+            const float *up = cur + xi * WN_US + lq * WN_CP + l15;
+            const float *vp = cur + 16 * WN_US + xi * W4_VS + lq * 16 + l15;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) a0[a][kq] = up[kq * 4 * WN_CP], a1[a][kq] = up[kq * 4 * WN_CP + 16], bv[a][kq] = vp[kq * 4 * 16];
+        }
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[a][kq], bv[a][kq], acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[a][kq], bv[a][kq], acc[a][1], 0, 0, 0);
+            }
+    };
+    // producers: set B holds round r + 1 when iteration r starts (r even), set A round r + 2; the set just staged is refilled with round r + 3
+    if (producer) {
+        W4_FETCH(A, 0);
+        W4_STAGE(lds, A);
+        W4_FETCH(B, 1);
+        W4_FETCH(A, 2);
+    }
+    __syncthreads();
+    for (int round = 0; round < rounds; round += 2) {
+        // iteration `round` (even): current buffer 0, next buffer 1
+        if (producer) {
+            W4_STAGE(lds + W4_BUF, B);  // round + 1 (past the end: the last slice again, nobody reads it)
+            W4_FETCH(B, round + 3);
+        } else {
+            multiply(lds);
+        }
+        __syncthreads();
+        if (round + 1 < rounds) {  // iteration round + 1: current buffer 1, next buffer 0
+            if (producer) {
+                W4_STAGE(lds, A);  // round + 2
+                W4_FETCH(A, round + 4);
+            } else {
+                multiply(lds + W4_BUF);
+            }
+            __syncthreads();
+        }
+    }
+#undef W4_FETCH
+#undef W4_STAGE
+    // ---- output transform Y = A^T M A.  D[row = 4 lq + reg][col = l15] -> ms[xi][co][tile]; one (co, tile) per lane -----------------------
+    float *ms = lds;
+    if (!producer) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ms[((4 * wave + a) * WN_CO + 16 * m + 4 * lq + r) * 16 + l15] = acc[a][m][r];
+    }
+    __syncthreads();
+    {
+        const int idx = threadIdx.x;  // (co, tile)
+        const int co = idx >> 4, tl = idx & 15, img = tl >> 2, oy = (tl >> 1) & 1, ox = tl & 1;
+        float mm[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm[i][j] = ms[((4 * i + j) * WN_CO + co) * 16 + tl];
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t0[j] = (mm[0][j] + mm[1][j]) + mm[2][j];
+            t1[j] = (mm[1][j] - mm[2][j]) - mm[3][j];
+        }
+        if (b + img < d.B) {
+            float *o = y + ((static_cast<size_t>(b + img) * d.RC + co0 + co) * 4 + 2 * oy) * 4 + 2 * ox;
+            *reinterpret_cast<float2 *>(o) = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]);
+            *reinterpret_cast<float2 *>(o + 4) = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
+        }
+    }
+}
+
+// ---- 8x8 and 16x16 maps, second version: the same producer / consumer split --------------------------------------------------------------
+// The generic kernel above runs these maps with one wavefront per SIMD too (16x16: 151 KB of LDS per workgroup; 8x8: two workgroups per CU
+// on little more than half of the CUs): 24.5 us = 10.7 of products + 3.8 transform + 0.9 staging + 9.6 launch / prologue / epilogue on 16x16,
+// added up, not overlapped.  Here: 512 lanes, rounds of EIGHT reduction channels so that two buffers of {U slice, V, pixel frames} fit
+// (8x8: two images per workgroup, 111 KB; 16x16: one image, 151 KB), wavefronts 0-3 multiply the current buffer while wavefronts 4-7, per
+// round r: write U of round r+1 (loaded two rounds earlier into one of two named register sets), transform the pixel frames of round r+1
+// (written during round r-1) into V, write the pixels of round r+2.  One barrier per round.  Same arithmetic in the same order as the
+// generic kernel.
+template <int MAP>
+struct PcGeo {
+    static constexpr int TX = MAP / 2, TI = TX * TX, IMG = MAP == 8 ? 2 : 1, T = TI * IMG, NB = T / 16;
+    static constexpr int CK = 8;
+    static constexpr int US = CK * WN_CP;                             // one xi's U [8 ci][48]
+    static constexpr int VT = T + 16, VS = CK * VT;                   // V row stride (the four k of a wavefront on disjoint banks), one xi's V
+    static constexpr int XW = MAP + 4, XI = (MAP + 2) * XW, XP = IMG * XI, XS = CK * XP;  // pixel frames (zero ring)
+    static constexpr int BUF = 16 * US + 16 * VS + XS;
+    static constexpr int XF4 = CK * IMG * MAP * MAP / 4 / 256;        // float4 of pixels per producer lane and round: 1 or 2
+    static constexpr int PPT = CK * T / 256;                          // patches per producer lane and round: 1 or 2
+    static constexpr size_t lds_bytes = 2 * BUF * sizeof(float);
+};
+
+template <int MAP>
+__global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino3x3_pc_kernel(const float *__restrict__ x, const float *__restrict__ u,
+                                                                                                     float *__restrict__ y, WinoDims d) {
+    using G = PcGeo<MAP>;
+    static_assert(G::XF4 == G::PPT && (G::XF4 == 1 || G::XF4 == 2), "8x8 or 16x16 maps");
+    extern __shared__ __align__(16) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool producer = wave >= 4;
+    const int pt = threadIdx.x & 255;  // lane number inside its group of four wavefronts
+    const int b = blockIdx.x * G::IMG, co0 = blockIdx.y * WN_CO;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int rounds = d.KC / G::CK;
+    // U slice of a round: 16 xi x 8 ci rows of 32 floats = 1024 float4, four per producer lane: rows (xi0 + 4 j, ci_u)
+    const int uq = pt & 7, ci_u = (pt >> 3) & 7, xi0 = pt >> 6;
+    const float *ubase = u + (static_cast<size_t>(xi0) * d.KC + ci_u) * d.RC + co0 + 4 * uq;
+    const size_t uxi4 = 4 * static_cast<size_t>(d.KC) * d.RC, ustep = static_cast<size_t>(G::CK) * d.RC;
+    // pixels of a round: 16x16: the 8 planes are contiguous, float4 number pt + 256 k; 8x8: image pt >> 7, float4 pt & 127 of its 8 planes
+    const int ximg = MAP == 8 ? pt >> 7 : 0, xbi = b + ximg < d.B ? b + ximg : d.B - 1;  // past the batch: a valid image, never stored
+    const float *xsrc = x + static_cast<size_t>(xbi) * d.KC * (MAP * MAP) + 4 * (MAP == 8 ? pt & 127 : pt);
+    const size_t xstep = static_cast<size_t>(G::CK) * (MAP * MAP);
+    for (int i = threadIdx.x; i < G::XS; i += W4_NT) lds[16 * G::US + 16 * G::VS + i] = lds[G::BUF + 16 * G::US + 16 * G::VS + i] = 0.0f;  // zero rings
+    float4 UA0, UA1, UA2, UA3, UB0, UB1, UB2, UB3, XA0, XA1, XB0, XB1;  // NAMED register sets (see the 4x4 kernel)
+    XA1 = XB1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#define PC_FETCH_U(S, round_)                                                                      \
+    do {                                                                                           \
+        const int r_ = (round_) < rounds ? (round_) : rounds - 1; /* always issued */              \
+        const float *up_ = ubase + r_ * ustep;                                                     \
+        S##0 = *reinterpret_cast<const float4 *>(up_);                                             \
+        S##1 = *reinterpret_cast<const float4 *>(up_ + uxi4);                                      \
+        S##2 = *reinterpret_cast<const float4 *>(up_ + 2 * uxi4);                                  \
+        S##3 = *reinterpret_cast<const float4 *>(up_ + 3 * uxi4);                                  \
+    } while (0)
+#define PC_FETCH_X(S, round_)                                                                      \
+    do {                                                                                           \
+        const int r_ = (round_) < rounds ? (round_) : rounds - 1;                                  \
+        const float *xp_ = xsrc + r_ * xstep;                                                      \
+        S##0 = *reinterpret_cast<const float4 *>(xp_);                                             \
+        if (G::XF4 > 1) S##1 = *reinterpret_cast<const float4 *>(xp_ + 4 * 256);                   \
+    } while (0)
+#define PC_STORE_U(buf_, S)                                                                        \
+    do {                                                                                           \
+        float *ud_ = (buf_) + xi0 * G::US + ci_u * WN_CP + 4 * uq;                                 \
+        *reinterpret_cast<float4 *>(ud_) = S##0;                                                   \
+        *reinterpret_cast<float4 *>(ud_ + 4 * G::US) = S##1;                                       \
+        *reinterpret_cast<float4 *>(ud_ + 8 * G::US) = S##2;                                       \
+        *reinterpret_cast<float4 *>(ud_ + 12 * G::US) = S##3;                                      \
+    } while (0)
+    auto put_x = [&](float *xs, float4 v, int k) {  // float4 number k of this lane -> frame interior
+        int ci, img, row, c4;
+        if (MAP == 8) {
+            const int w = pt & 127;
+            img = pt >> 7, ci = w >> 4, row = (w & 15) >> 1, c4 = 4 * (w & 1);
+        } else {
+            const int f = pt + 256 * k, q = f & 63;
+            img = 0, ci = f >> 6, row = q >> 2, c4 = 4 * (q & 3);
+        }
+        float *dst = xs + ci * G::XP + img * G::XI + (1 + row) * G::XW + 1 + c4;
+        dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+    };
+#define PC_PUT_X(buf_, S)                                                                          \
+    do {                                                                                           \
+        put_x((buf_) + 16 * G::US + 16 * G::VS, S##0, 0);                                          \
+        if (G::XF4 > 1) put_x((buf_) + 16 * G::US + 16 * G::VS, S##1, 1);                          \
+    } while (0)
+    // V = B^T d B of this lane's patches, from the frames of `buf` into its V
+    auto transform = [&](float *buf) {
+        const float *xs = buf + 16 * G::US + 16 * G::VS;
+        float *vs = buf + 16 * G::US;
+#pragma unroll
+        for (int k = 0; k < G::PPT; ++k) {
+            const int pr = pt + 256 * k, ci = pr / G::T, t = pr - ci * G::T, img = t / G::TI, ti = t - img * G::TI;
+            const int ty = ti / G::TX, tx = ti - ty * G::TX;
+            const float *p = xs + ci * G::XP + img * G::XI + (2 * ty) * G::XW + 2 * tx;  // patch rows 2ty-1 .. 2ty+2 = frame rows 2ty .. 2ty+3
+            float dd[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dd[i][j] = p[i * G::XW + j];
+            float tt[4][4];  // B^T d
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tt[0][j] = dd[0][j] - dd[2][j];
+                tt[1][j] = dd[1][j] + dd[2][j];
+                tt[2][j] = dd[2][j] - dd[1][j];
+                tt[3][j] = dd[1][j] - dd[3][j];
+            }
+            float *vp = vs + ci * G::VT + t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vp[(4 * i + 0) * G::VS] = tt[i][0] - tt[i][2];
+                vp[(4 * i + 1) * G::VS] = tt[i][1] + tt[i][2];
+                vp[(4 * i + 2) * G::VS] = tt[i][2] - tt[i][1];
+                vp[(4 * i + 3) * G::VS] = tt[i][1] - tt[i][3];
+            }
+        }
+    };
+    f32x4 acc[4][G::NB][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int nb = 0; nb < G::NB; ++nb)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[a][nb][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // consumer: M_xi += U_xi V_xi for this wavefront's four xi; a round's operands first, then its products
+    auto multiply = [&](const float *cur) {
+        float a0[4][2], a1[4][2], bv[4][2][G::NB];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int xi = 4 * wave + a;
+            const float *up = cur + xi * G::US + lq * WN_CP + l15;
+            const float *vp = cur + 16 * G::US + xi * G::VS + lq * G::VT + l15;
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) {
+                a0[a][kq] = up[kq * 4 * WN_CP], a1[a][kq] = up[kq * 4 * WN_CP + 16];
+#pragma unroll
+                for (int nb = 0; nb < G::NB; ++nb) bv[a][kq][nb] = vp[kq * 4 * G::VT + 16 * nb];
+            }
+        }
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int nb = 0; nb < G::NB; ++nb) {
+                    acc[a][nb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[a][kq], bv[a][kq][nb], acc[a][nb][0], 0, 0, 0);
+                    acc[a][nb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[a][kq], bv[a][kq][nb], acc[a][nb][1], 0, 0, 0);
+                }
+    };
+    float *buf0 = lds, *buf1 = lds + G::BUF;
+    // prologue: pixels of rounds 0 and 1 into their frames, U of round 0, V of round 0; sets: UA / XA hold even rounds, UB / XB odd ones
+    if (producer) {
+        PC_FETCH_U(UA, 0);
+        PC_FETCH_X(XA, 0);
+        PC_FETCH_X(XB, 1);
+    }
+    __syncthreads();  // the zero rings
+    if (producer) {
+        PC_PUT_X(buf0, XA);
+        PC_PUT_X(buf1, XB);
+        PC_STORE_U(buf0, UA);
+        PC_FETCH_U(UB, 1);
+        PC_FETCH_U(UA, 2);
+        PC_FETCH_X(XA, 2);
+        PC_FETCH_X(XB, 3);
+    }
+    __syncthreads();
+    if (producer) transform(buf0);
+    __syncthreads();
+    for (int round = 0; round < rounds; round += 2) {
+        // iteration `round` (even): multiply buffer 0; U and V of round + 1 -> buffer 1, pixels of round + 2 -> frames of buffer 0
+        if (producer) {
+            PC_STORE_U(buf1, UB);
+            transform(buf1);
+            PC_PUT_X(buf0, XA);
+            PC_FETCH_U(UB, round + 3);
+            PC_FETCH_X(XA, round + 4);
+        } else {
+            multiply(buf0);
+        }
+        __syncthreads();
+        if (round + 1 < rounds) {  // iteration round + 1: multiply buffer 1; U and V of round + 2 -> buffer 0, pixels of round + 3 -> frames of buffer 1
+            if (producer) {
+                PC_STORE_U(buf0, UA);
+                transform(buf0);
+                PC_PUT_X(buf1, XB);
+                PC_FETCH_U(UA, round + 4);
+                PC_FETCH_X(XB, round + 5);
+            } else {
+                multiply(buf1);
+            }
+            __syncthreads();
+        }
+    }
+#undef PC_FETCH_U
+#undef PC_FETCH_X
+#undef PC_STORE_U
+#undef PC_PUT_X
+    // ---- output transform Y = A^T M A, one N block (16 tiles) at a time.  D[row = 4 lq + reg][col = l15] -> ms[xi][co][tile] ---------------
+    float *ms = lds;
+#pragma unroll
+    for (int nb = 0; nb < G::NB; ++nb) {
+        if (nb > 0) __syncthreads();
+        if (!producer) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ms[((4 * wave + a) * WN_CO + 16 * m + 4 * lq + r) * 16 + l15] = acc[a][nb][m][r];
+        }
+        __syncthreads();
+        {
+            const int idx = threadIdx.x;  // (co, tile of this block)
+            const int co = idx >> 4, tl = idx & 15, t = 16 * nb + tl, img = t / G::TI, ti = t - img * G::TI, ty = ti / G::TX, tx = ti - ty * G::TX;
+            float mm[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mm[i][j] = ms[((4 * i + j) * WN_CO + co) * 16 + tl];
+            float t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t0[j] = (mm[0][j] + mm[1][j]) + mm[2][j];
+                t1[j] = (mm[1][j] - mm[2][j]) - mm[3][j];
+            }
+            if (b + img < d.B) {
+                float *o = y + ((static_cast<size_t>(b + img) * d.RC + co0 + co) * MAP + 2 * ty) * MAP + 2 * tx;
+                *reinterpret_cast<float2 *>(o) = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]);
+                *reinterpret_cast<float2 *>(o + MAP) = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
+            }
+        }
+    }
+}
+
+template <int MAP>
+int wino_pc_launch(const float *x, const float *u, float *y, const WinoDims &d, hipStream_t st) {
+    using G = PcGeo<MAP>;
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_pc_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(G::lds_bytes)) == hipSuccess;
+    if (!ok) return EE_ERR_UNSUPPORTED;
+    EE_LAUNCH(wino3x3_pc_kernel<MAP>, dim3(static_cast<unsigned>((d.B + G::IMG - 1) / G::IMG), static_cast<unsigned>(d.RC / WN_CO)), dim3(W4_NT), G::lds_bytes,
+              st, x, u, y, d);
+    return launch_status();
+}
+
+int wino_map4_launch(const float *x, const float *u, float *y, const WinoDims &d, hipStream_t st) {
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_map4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(W4_LDS)) == hipSuccess;
+    if (!ok) return EE_ERR_UNSUPPORTED;
+    EE_LAUNCH(wino3x3_map4_kernel, dim3(static_cast<unsigned>((d.B + 3) / 4), static_cast<unsigned>(d.RC / WN_CO)), dim3(W4_NT), W4_LDS, st, x, u, y, d);
+    return launch_status();
+}
+
 template <int MAP>
 int wino_launch(const float *x, const float *u, float *y, const WinoDims &d, hipStream_t st) {
     using G = WinoGeo<MAP>;
@@ -240,8 +683,10 @@ EE_API int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int K
     const WinoDims d{B, KC, RC};
     // the convolution's ALGORITHMIC flops (2 * 9 * KC * RC per output pixel); the kernel executes 4/9 of them (16 multiplies per 2x2 tile)
     ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
-    if (H == 4) return wino_launch<4>(x, u, y, d, as_stream(stream));
-    return H == 8 ? wino_launch<8>(x, u, y, d, as_stream(stream)) : wino_launch<16>(x, u, y, d, as_stream(stream));
+    static const bool v1 = std::getenv("EEADV_WINO_V1") != nullptr;  // A/B: the one-wavefront-per-SIMD kernel
+    if (H == 4) return v1 ? wino_launch<4>(x, u, y, d, as_stream(stream)) : wino_map4_launch(x, u, y, d, as_stream(stream));
+    if (H == 8) return v1 ? wino_launch<8>(x, u, y, d, as_stream(stream)) : wino_pc_launch<8>(x, u, y, d, as_stream(stream));
+    return v1 ? wino_launch<16>(x, u, y, d, as_stream(stream)) : wino_pc_launch<16>(x, u, y, d, as_stream(stream));
 }
 
 EE_API int ee_wino3x3_map8_f32(const float *x, const float *u, float *y, int B, int KC, int RC, void *stream) {

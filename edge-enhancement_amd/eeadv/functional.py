@@ -339,6 +339,7 @@ class StemConvFn(torch.autograd.Function):
         """want_stats: returns (y, stats) - stats = the per-workgroup moments of y for bn1 (ops.stem7x7s2_fwd), an EMPTY tensor when the
         convolution ran on MIOpen (the BatchNorm then takes its statistics itself)."""
         ctx.save_for_backward(x, weight)
+        ctx.set_materialize_grads(False)  # or autograd zero-fills a gradient for `stats` on every backward pass (one launch)
         if _STEM_FWD and ops.stem7x7s2_fwd_supported(x, weight):
             if want_stats and _STEM_STATS:
                 y, stats = ops.stem7x7s2_fwd(x, weight, True)
@@ -356,6 +357,8 @@ class StemConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_):
         x, weight = ctx.saved_tensors
+        if dy is None:
+            return None, None, None
         dy = dy.contiguous()
         dx = ops.stem7x7s2_bwd_data(dy, weight, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
         dw = None
@@ -374,7 +377,7 @@ _DENSE_W = {}  # id(weight) -> [weakref(weight), version, W2 buffer]
 _DENSE_IDX = {}
 
 
-def _rearranged(weight, kind="s1"):
+def _rearranged(weight, kind="s1", extra=None):
     """kind "s1": 3x3 / stride 1 / padding 1 on a 2x2 map -> [4 Cin, 4 Cout]; kind "s2": 3x3 / stride 2 / padding 1 from a 4x4 map to
     a 2x2 map -> [16 Cin, 4 Cout] (tap ky = iy - 2 oy + 1, zero where it leaves the 3x3 window)."""
     co, ci = weight.shape[0], weight.shape[1]
@@ -389,12 +392,15 @@ def _rearranged(weight, kind="s1"):
         if kind == "wino_f":
             return torch.einsum("ia,jb,rkab->ijkr", G, G, w).reshape(16, ci, co)
         return torch.einsum("ia,jb,krab->ijkr", G, G, w.flip(2, 3)).reshape(16, co, ci)
-    if kind in ("s2m_f", "s2m_b"):
-        # ee_s2.hip's A operands in reading order: [result block of 32][round of 16 reduction channels][tap][quad][half][m][k]
-        w = weight.detach().reshape(co, ci, 9)
-        if kind == "s2m_f":  # result = co = 32 cb + 16 h + m, reduction = ci = 16 rd + 4 q + k
-            return w.view(co // 32, 2, 16, ci // 16, 4, 4, 9).permute(0, 3, 6, 4, 1, 2, 5)
-        return w.view(co // 16, 4, 4, ci // 32, 2, 16, 9).permute(3, 0, 6, 1, 4, 5, 2)  # result = ci, reduction = co
+    if kind in ("s2m_f", "s2m_b", "s2p_f", "s2p_b"):
+        # ee_s2.hip's A operands in reading order: [result block of 32][round of 16 reduction channels][tap][quad][half][m][k]; "s2p_*": the
+        # block's shortcut 1x1 filters (`extra`, [co, ci, 1, 1]) as a tenth tap
+        w, taps = weight.detach().reshape(co, ci, 9), 9
+        if kind in ("s2p_f", "s2p_b"):
+            w, taps = torch.cat([w, extra.detach().reshape(co, ci, 1)], 2), 10
+        if kind in ("s2m_f", "s2p_f"):  # result = co = 32 cb + 16 h + m, reduction = ci = 16 rd + 4 q + k
+            return w.view(co // 32, 2, 16, ci // 16, 4, 4, taps).permute(0, 3, 6, 4, 1, 2, 5)
+        return w.view(co // 16, 4, 4, ci // 32, 2, 16, taps).permute(3, 0, 6, 1, 4, 5, 2)  # result = ci, reduction = co
     idx = _DENSE_IDX.get((weight.device, kind))
     if idx is None:
         n_in, stride = (2, 1) if kind == "s1" else (4, 2)
@@ -411,22 +417,38 @@ def _rearranged(weight, kind="s1"):
     return g.permute(1, 2, 3, 0, 4, 5).reshape(idx[3] * ci, 4 * co)
 
 
-def _dense_weight(weight, kind="s1"):
+def _versions(weight, extra):
+    return weight._version if extra is None else (weight._version, extra._version)
+
+
+def _dense_weight(weight, kind="s1", extra=None):
+    """The rearranged copy of `weight` (and, for the "s2p_*" kinds, of a second parameter `extra` riding along) for `kind`: built on first
+    use, rebuilt IN PLACE when a version counter moved; inside a graph capture only handed out."""
     ent = _DENSE_W.get((id(weight), kind))
-    if ent is not None and ent[0]() is not weight:
+    if ent is not None and (ent[0]() is not weight or (ent[4]() if ent[4] is not None else None) is not extra):
         ent = None
     if torch.cuda.is_current_stream_capturing():
         if ent is None:
-            raise RuntimeError("dense 2x2-map convolution: first use inside a graph capture (run one eager forward first)")
+            raise RuntimeError("rearranged convolution weights: first use inside a graph capture (run one eager forward first)")
         return ent[2]
-    if ent is None or ent[1] != weight._version:
+    if ent is None or ent[1] != _versions(weight, extra):
         with torch.no_grad():
             if ent is None:
-                ent = _DENSE_W[(id(weight), kind)] = [weakref.ref(weight), weight._version, _rearranged(weight, kind).contiguous(), kind]
+                ent = _DENSE_W[(id(weight), kind)] = [weakref.ref(weight), _versions(weight, extra), _rearranged(weight, kind, extra).contiguous(), kind,
+                                                      None if extra is None else weakref.ref(extra)]
             else:
-                ent[2].copy_(_rearranged(weight, kind))
-                ent[1] = weight._version
+                ent[2].copy_(_rearranged(weight, kind, extra))
+                ent[1] = _versions(weight, extra)
     return ent[2]
+
+
+def _dense_entry_params(ent):
+    """(weight, extra) of a cache entry, (None, None) once either is gone"""
+    w = ent[0]()
+    e = ent[4]() if ent[4] is not None else None
+    if w is None or (ent[4] is not None and e is None):
+        return None, None
+    return w, e
 
 
 def rebuild_dense_weights(model=None):
@@ -437,23 +459,25 @@ def rebuild_dense_weights(model=None):
     own = None if model is None else {id(p) for p in model.parameters()}
     with torch.no_grad():
         for key in list(_DENSE_W):
-            w = _DENSE_W[key][0]()
+            ent = _DENSE_W[key]
+            w, e = _dense_entry_params(ent)
             if w is None:
                 del _DENSE_W[key]
             elif own is None or key[0] in own:
-                _DENSE_W[key][2].copy_(_rearranged(w, _DENSE_W[key][3]))
-                _DENSE_W[key][1] = w._version
+                ent[2].copy_(_rearranged(w, ent[3], e))
+                ent[1] = _versions(w, e)
 
 
 def refresh_dense_weights():
     """Bring every rearranged weight matrix up to date (eagerly, outside any capture): call before replaying a HIP graph
     that contains Conv3x3Map2Fn."""
     for key in list(_DENSE_W):
-        w = _DENSE_W[key][0]()
+        ent = _DENSE_W[key]
+        w, e = _dense_entry_params(ent)
         if w is None:
             del _DENSE_W[key]
-        elif _DENSE_W[key][1] != w._version:
-            _dense_weight(w, _DENSE_W[key][3])
+        elif ent[1] != _versions(w, e):
+            _dense_weight(w, ent[3], e)
 
 
 class Conv3x3WinoFn(torch.autograd.Function):
@@ -500,6 +524,33 @@ class Conv3x3S2SmallFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
             dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw
+
+
+class Conv3x3S2PairFn(torch.autograd.Function):
+    """(conv1(x), downsample[0](x)) of a down-sampling BasicBlock (resnet.py:50-59, :137-142) - Conv2d(3x3, stride 2, padding 1) and
+    Conv2d(1x1, stride 2) of the same input - as ONE launch each way on ee_s2.hip: the 1x1 filter rides along as a tenth tap over the 3x3's
+    centre plane, and the backward pass returns the block's input gradient already summed.  Weight gradients on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, w3, w1):
+        w10 = _dense_weight(w3, "s2p_f", w1)
+        _dense_weight(w3, "s2p_b", w1)  # created outside any capture; the backward only reads it
+        ctx.save_for_backward(x, w3, w1)
+        return ops.conv3x3s2_pair_fwd(x, w10, w3.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy3, dy1):
+        x, w3, w1 = ctx.saved_tensors
+        dy3 = torch.zeros_like(dy1) if dy3 is None else dy3.contiguous()
+        dy1 = torch.zeros_like(dy3) if dy1 is None else dy1.contiguous()
+        dx = ops.conv3x3s2_pair_bwd_data(dy3, dy1, _dense_weight(w3, "s2p_b", w1), w3.shape[1]) if ctx.needs_input_grad[0] else None
+        dw3 = dw1 = None
+        if not _INPUT_GRAD_ONLY:
+            if ctx.needs_input_grad[1]:
+                dw3 = torch.ops.aten.convolution_backward(dy3, x, w3, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            if ctx.needs_input_grad[2]:
+                dw1 = torch.ops.aten.convolution_backward(dy1, x, w1, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw3, dw1
 
 
 class Conv3x3S2Map4Fn(torch.autograd.Function):

@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime
-from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -120,10 +120,35 @@ def head(avgpool, fc, x):
     return fc(x.view(x.size(0), -1))
 
 
-def block_tail(block, bn, out, x, fork):
+def s2_pair(block, x):
+    """(conv1(x), downsample[0](x)) of a down-sampling BasicBlock as one launch each way (functional.Conv3x3S2PairFn, ee_s2.hip), or None:
+    both convolutions read the block's input, and the shortcut's 1x1 / stride 2 filter sees exactly the 3x3's centre tap."""
+    ds, c3 = block.downsample, block.conv1
+    if ("conv3" in _STOCK or "conv" in _STOCK or "s2small" in _STOCK or "s2pair" in _STOCK or ds is None or not isinstance(ds, nn.Sequential) or len(ds) != 2
+            or type(ds[0]) is not nn.Conv2d or type(c3) is not nn.Conv2d or not _dense_f32(x) or x.shape[2] != x.shape[3] or x.shape[2] not in (4, 8, 16)):
+        return None
+    c1 = ds[0]
+    if (c3.kernel_size != (3, 3) or c3.stride != (2, 2) or c3.padding != (1, 1) or c3.dilation != (1, 1) or c3.groups != 1 or c3.bias is not None
+            or c3.padding_mode != "zeros" or c1.kernel_size != (1, 1) or c1.stride != (2, 2) or c1.padding != (0, 0) or c1.groups != 1 or c1.bias is not None
+            or c1.in_channels != c3.in_channels or c1.out_channels != c3.out_channels or c3.in_channels % 32 or c3.out_channels % 32
+            or not c3.weight.is_contiguous() or not c1.weight.is_contiguous()):
+        return None
+    return Conv3x3S2PairFn.apply(x, c3.weight, c1.weight)
+
+
+def block_tail(block, bn, out, x, fork, sc=None):
     """relu(bn(out) + shortcut(x)) - the last line of a residual block (resnet.py:54-59 / :105-110).  With a down-sampling shortcut whose
-    1x1 convolution runs on ee_conv.hip, its BatchNorm and the block's last one are ONE launch each way (functional.BnDualFn)."""
+    1x1 convolution runs on ee_conv.hip, its BatchNorm and the block's last one are ONE launch each way (functional.BnDualFn).
+    sc: the shortcut's convolution if it is already done (s2_pair)."""
     ds = block.downsample
+    if sc is not None:
+        b2 = ds[1]
+        if ("bn" not in _STOCK and "bndual" not in _STOCK and type(b2) is BatchNorm2d and type(bn) is BatchNorm2d and _dense_f32(out) and bn.affine and b2.affine
+                and bn.track_running_stats and b2.track_running_stats and bn.training == b2.training and ops.bn_dual_supported(out) and sc.shape == out.shape):
+            return BnDualFn.apply(out, sc, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.0 if bn.momentum is None else bn.momentum, bn.eps,
+                                  b2.weight, b2.bias, b2.running_mean, b2.running_var, 0.0 if b2.momentum is None else b2.momentum, b2.eps,
+                                  bn.training, fork and _FORK)
+        return bn_act(bn, out, bn_act(b2, sc, relu=False), fork=fork)
     if ("bn" not in _STOCK and "bndual" not in _STOCK and ds is not None and isinstance(ds, nn.Sequential) and len(ds) == 2 and type(ds[0]) is nn.Conv2d
             and type(ds[1]) is BatchNorm2d and type(bn) is BatchNorm2d and _dense_f32(x) and _dense_f32(out) and bn.affine and ds[1].affine
             and bn.track_running_stats and ds[1].track_running_stats and bn.training == ds[1].training and ops.bn_dual_supported(out)):
@@ -176,10 +201,10 @@ def conv3(conv, x):
             and conv.weight.is_contiguous()):
         return Conv3x3WinoFn.apply(x, conv.weight)  # 8x8 / 16x16 / 4x4 maps (layer2, layer1, layer3): Winograd F(2x2,3x3) on the matrix cores - 21 us against MIOpen's 29.4, 22 against the direct kernel's 27.7, 28 against 35; eager passes included
     if ("conv3" not in _STOCK and "s2small" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and x.shape[2] == x.shape[3]
-            and x.shape[2] in (4, 8) and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and (x.shape[2] in (4, 8) or (x.shape[2] == 16 and "s2small16" not in _STOCK)) and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
             and conv.weight.is_contiguous()):
-        return Conv3x3S2SmallFn.apply(x, conv.weight)  # layer3.0 / layer4.0 conv1: split-reduction MFMA kernel, backward by parity classes (ee_s2.hip)
+        return Conv3x3S2SmallFn.apply(x, conv.weight)  # layer2.0 / layer3.0 / layer4.0 conv1: split-reduction MFMA kernel, backward by parity classes (ee_s2.hip)
     if not (_CONV3_EAGER or PROBE_MFMA_CONV or torch.cuda.is_current_stream_capturing()):
         return conv(x)
     if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
@@ -417,6 +442,9 @@ class BasicBlock(nn.Module):
     def forward(self, x, fork=False):
         """x: a tensor, or the two tensors of the previous block's forked output; fork: hand this block's output on the same way"""
         xm, xs = _pair(x)
+        both = s2_pair(self, xm) if self.downsample is not None else None
+        if both is not None:  # conv1 and the shortcut's convolution in one launch; the identity piece xs gets no gradient of its own
+            return block_tail(self, self.bn2, conv3(self.conv2, bn_act(self.bn1, both[0])), xs, fork, sc=both[1])
         out = bn_act(self.bn1, conv3(self.conv1, xm))
         return block_tail(self, self.bn2, conv3(self.conv2, out), xs, fork)
 

@@ -736,12 +736,12 @@ def wino3x3_map8(x, u):
 
 
 def conv3x3s2_small_supported(x, cin, cout):
-    """ee_s2.hip: 3x3 / stride 2 / padding 1 from an 8x8 or 4x4 map"""
-    return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8) and cin % 32 == 0 and cout % 32 == 0
+    """ee_s2.hip: 3x3 / stride 2 / padding 1 from a 16x16, 8x8 or 4x4 map"""
+    return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8, 16) and cin % 32 == 0 and cout % 32 == 0
 
 
 def conv3x3s2_small_fwd(x, w9, cout):
-    """x [B,Cin,H,H] (H = 8 or 4), w9 = the filters rearranged (functional._rearranged kind "s2m_f") -> [B,Cout,H/2,H/2]"""
+    """x [B,Cin,H,H] (H = 16, 8 or 4), w9 = the filters rearranged (functional._rearranged kind "s2m_f") -> [B,Cout,H/2,H/2]"""
     B, Cin, H = x.shape[0], x.shape[1], x.shape[2]
     y = torch.empty((B, cout, H // 2, H // 2), dtype=torch.float32, device=x.device)
     N.check(N.lib.ee_conv3x3s2_small_fwd_f32(_chk(x, torch.float32, "x", (B, Cin, H, H)), _chk(w9, torch.float32, "w9", (cout // 32, Cin // 16, 9, 4, 2, 16, 4)),
@@ -750,12 +750,33 @@ def conv3x3s2_small_fwd(x, w9, cout):
 
 
 def conv3x3s2_small_bwd_data(dy, w9, cin):
-    """dy [B,Cout,H/2,H/2], w9 = the filters rearranged (kind "s2m_b") -> dx [B,Cin,H,H] (H = 8 or 4)"""
+    """dy [B,Cout,H/2,H/2], w9 = the filters rearranged (kind "s2m_b") -> dx [B,Cin,H,H] (H = 16, 8 or 4)"""
     B, Cout, OH = dy.shape[0], dy.shape[1], dy.shape[2]
     dx = torch.empty((B, cin, 2 * OH, 2 * OH), dtype=torch.float32, device=dy.device)
     N.check(N.lib.ee_conv3x3s2_small_bwd_data_f32(_chk(dy, torch.float32, "dy", (B, Cout, OH, OH)),
                                                   _chk(w9, torch.float32, "w9", (cin // 32, Cout // 16, 9, 4, 2, 16, 4)), dx.data_ptr(), B, cin, Cout, 2 * OH,
                                                   _stream()), "ee_conv3x3s2_small_bwd_data_f32")
+    return dx
+
+
+def conv3x3s2_pair_fwd(x, w10, cout):
+    """conv3x3 / stride 2 / padding 1 AND conv1x1 / stride 2 of the same x in one launch (a down-sampling BasicBlock's conv1 and shortcut):
+    x [B,Cin,H,H], w10 = both filter sets rearranged (functional._rearranged kind "s2p_f") -> (y3, y1), each [B,Cout,H/2,H/2]"""
+    B, Cin, H = x.shape[0], x.shape[1], x.shape[2]
+    y3 = torch.empty((B, cout, H // 2, H // 2), dtype=torch.float32, device=x.device)
+    y1 = torch.empty_like(y3)
+    N.check(N.lib.ee_conv3x3s2_pair_fwd_f32(_chk(x, torch.float32, "x", (B, Cin, H, H)), _chk(w10, torch.float32, "w10", (cout // 32, Cin // 16, 10, 4, 2, 16, 4)),
+                                            y3.data_ptr(), y1.data_ptr(), B, Cin, cout, H, _stream()), "ee_conv3x3s2_pair_fwd_f32")
+    return y3, y1
+
+
+def conv3x3s2_pair_bwd_data(dy3, dy1, w10, cin):
+    """dx = conv3x3s2^T(dy3) + conv1x1s2^T(dy1): dy3, dy1 [B,Cout,H/2,H/2], w10 (kind "s2p_b") -> dx [B,Cin,H,H]"""
+    B, Cout, OH = dy3.shape[0], dy3.shape[1], dy3.shape[2]
+    dx = torch.empty((B, cin, 2 * OH, 2 * OH), dtype=torch.float32, device=dy3.device)
+    N.check(N.lib.ee_conv3x3s2_pair_bwd_data_f32(_chk(dy3, torch.float32, "dy3", (B, Cout, OH, OH)), _chk(dy1, torch.float32, "dy1", (B, Cout, OH, OH)),
+                                                 _chk(w10, torch.float32, "w10", (cin // 32, Cout // 16, 10, 4, 2, 16, 4)), dx.data_ptr(), B, cin, Cout, 2 * OH,
+                                                 _stream()), "ee_conv3x3s2_pair_bwd_data_f32")
     return dx
 
 

@@ -356,8 +356,8 @@ int ee_wino3x3_map8_f32(const float *x, const float *u, float *y, int B, int KC,
 /* the same for H x H maps, H = 8 or 16 (layer1: 64 tiles per image, four accumulator blocks per wavefront) */
 int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int RC, int H, void *stream);
 
-/* Conv2d(3x3, stride 2, padding 1, bias=False) between SMALL maps - the first convolution of ResNet-18's layer3 / layer4 at 64x64 inputs
- * (resnet.py:26-31, :132-137): H = 8 (8x8 -> 4x4) or H = 4 (4x4 -> 2x2) - on the f32 matrix cores with the reduction split over a
+/* Conv2d(3x3, stride 2, padding 1, bias=False) between SMALL maps - the first convolution of ResNet-18's layer2 / layer3 / layer4 at 64x64 inputs
+ * (resnet.py:26-31, :132-137): H = 16 (16x16 -> 8x8), 8 (8x8 -> 4x4) or 4 (4x4 -> 2x2) - on the f32 matrix cores with the reduction split over a
  * workgroup's wavefronts.  The filters arrive rearranged, w9 [R/32][K/16][9][4][2][16][4] with R = result and K = reduction channels:
  *   forward        x [B,Cin,H,H] -> y [B,Cout,H/2,H/2];  w9[cb][rd][t][q][h][m][k] = weight[32 cb + 16 h + m][16 rd + 4 q + k][t]
  *   backward-data  dy [B,Cout,H/2,H/2] -> dx [B,Cin,H,H] (all of it written, no multiplication by inserted zeros: four parity classes);
@@ -365,6 +365,12 @@ int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int 
  * Cin, Cout multiples of 32 (else EE_ERR_UNSUPPORTED); the weight gradient is not provided. */
 int ee_conv3x3s2_small_fwd_f32(const float *x, const float *w9, float *y, int B, int Cin, int Cout, int H, void *stream);
 int ee_conv3x3s2_small_bwd_data_f32(const float *dy, const float *w9, float *dx, int B, int Cin, int Cout, int H, void *stream);
+/* The same convolution TOGETHER with the shortcut Conv2d(1x1, stride 2, bias=False) of its BasicBlock (resnet.py:50-59, :137-142: both
+ * read the block's input, and the 1x1 filter sees exactly the 3x3's centre tap): w10 [R/32][K/16][10][4][2][16][4] = w9 with the 1x1
+ * filters as a tenth tap (same index order).  Forward: y3 = conv3x3s2(x), y1 = conv1x1s2(x); backward-data: dx = conv3x3s2^T(dy3) +
+ * conv1x1s2^T(dy1) in one pass (the block's input gradient arrives summed). */
+int ee_conv3x3s2_pair_fwd_f32(const float *x, const float *w10, float *y3, float *y1, int B, int Cin, int Cout, int H, void *stream);
+int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, const float *w10, float *dx, int B, int Cin, int Cout, int H, void *stream);
 
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.

@@ -51,7 +51,7 @@ if FLUSH is not None:  # cold caches: every call preceded by a sweep over PROBE_
             fn()
         return _timeit(both, iters, reps) - t_flush
 
-for cin, cout, hw in ((128, 256, 8), (256, 512, 4)):
+for cin, cout, hw in ((64, 128, 16), (128, 256, 8), (256, 512, 4)):
     x = torch.randn(B, cin, hw, hw, device=dev)
     w = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
     dy = torch.randn(B, cout, hw // 2, hw // 2, device=dev)
@@ -60,11 +60,14 @@ for cin, cout, hw in ((128, 256, 8), (256, 512, 4)):
         timeit(lambda: ops.conv3x3s2_small_fwd(x, wf, cout))
         timeit(lambda: ops.conv3x3s2_small_bwd_data(dy, wb, cin))
         continue
-    for mt in ("2222", "1111"):
+    for mt in ("222222", "111111"):
         os.environ["EEADV_S2_MT"] = mt
         print("   EEADV_S2_MT=%s: forward %6.1f us  backward-data %6.1f us" % (mt, timeit(lambda: ops.conv3x3s2_small_fwd(x, wf, cout)),
                                                                                timeit(lambda: ops.conv3x3s2_small_bwd_data(dy, wb, cin))), flush=True)
     os.environ.pop("EEADV_S2_MT")
+    if hw == 16:
+        print("   ee_conv.hip direct kernels: forward %6.1f us  backward-data %6.1f us" % (
+            timeit(lambda: ops.conv3x3s2_fwd(x, w)), timeit(lambda: ops.conv3x3s2_bwd_data(dy, w, hw, hw))), flush=True)
     mi_f = timeit(lambda: F.conv2d(x, w, None, 2, 1))
     mi_b = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
     print("%3d -> %3d ch %dx%d:  forward MIOpen %6.1f us  ee_s2 %6.1f us   backward-data MIOpen %6.1f us  ee_s2 %6.1f us" % (

@@ -185,7 +185,10 @@ def test_engine_uses_the_chain_and_matches_the_manual_path(monkeypatch):
             res[chain] = xa
         assert state[1].item() > saved[1].item() and state[2].item() == 0  # the draws advanced, by the same amount on both paths
         a, b = res[True].cpu().numpy(), res[False].cpu().numpy()
-        assert float(np.abs(a - cur.cpu().numpy()).max()) > 0 and (a == b).mean() > 0.999, (it, (a == b).mean())
+        # the two back ends of the front end round differently, so sign(g) flips where |g| is inside that noise (0.05-0.15 % of the pixels,
+        # depending on which kernels the CNN in between runs on): such a pixel moves by one step in the other direction, nothing else may differ
+        assert float(np.abs(a - cur.cpu().numpy()).max()) > 0 and (a == b).mean() > 0.998, (it, (a == b).mean())
+        assert float(np.abs(a - b).max()) <= 2 * (2 / 255) + 1e-6
         cur = res[True]
     a = cur.cpu().numpy()
     assert np.array_equal(a[1, :, 24:36, 12:26], x.cpu().numpy()[1, :, 24:36, 12:26])  # NaN gradient inside the flat patch: no update

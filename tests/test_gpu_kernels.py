@@ -982,10 +982,11 @@ def test_net2_model_uses_the_fused_half_and_draws_the_stock_dropout_mask(ops):
                                rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("mt", ["2222", "1111"])
-@pytest.mark.parametrize("B,Cin,Cout,H", [(100, 128, 256, 8), (100, 256, 512, 4), (3, 32, 32, 8), (1, 64, 96, 8), (7, 32, 64, 4), (9, 96, 32, 4), (8, 64, 64, 4), (2, 32, 32, 4)])
+@pytest.mark.parametrize("mt", ["222222", "111111"])
+@pytest.mark.parametrize("B,Cin,Cout,H", [(100, 128, 256, 8), (100, 256, 512, 4), (100, 64, 128, 16), (3, 32, 32, 8), (1, 64, 96, 8), (7, 32, 64, 4), (9, 96, 32, 4), (8, 64, 64, 4),
+                                          (2, 32, 32, 4), (3, 32, 64, 16), (1, 96, 32, 16)])
 def test_conv3x3_stride2_small_maps_match_aten(ops, monkeypatch, B, Cin, Cout, H, mt):
-    """Conv2d(3x3, stride 2, padding 1) from 8x8 / 4x4 maps on ee_s2.hip (split-reduction MFMA kernel, backward-data by parity classes):
+    """Conv2d(3x3, stride 2, padding 1) from 16x16 / 8x8 / 4x4 maps on ee_s2.hip (split-reduction MFMA kernel, backward-data by parity classes):
     forward and input gradient against a float64 convolution and against ATen, odd batch sizes (partly filled workgroups) included,
     with 32 and with 16 result channels per workgroup (EEADV_S2_MT); the rearranged filters follow in-place weight updates."""
     import torch.nn.functional as F
@@ -1009,6 +1010,41 @@ def test_conv3x3_stride2_small_maps_match_aten(ops, monkeypatch, B, Cin, Cout, H
         torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (H * H * B) ** 0.5)
         with torch.no_grad():
             w.mul_(1.25)
+
+
+@pytest.mark.parametrize("mt", ["222222", "111111"])
+@pytest.mark.parametrize("B,Cin,Cout,H", [(100, 64, 128, 16), (100, 128, 256, 8), (100, 256, 512, 4), (3, 32, 64, 16), (5, 64, 32, 8), (9, 32, 32, 4), (1, 96, 64, 4)])
+def test_conv3x3_stride2_with_shortcut_conv_matches_aten(ops, monkeypatch, B, Cin, Cout, H, mt):
+    """A down-sampling BasicBlock's conv1 (3x3, stride 2) and shortcut convolution (1x1, stride 2) of the same input in one launch each way
+    (functional.Conv3x3S2PairFn): both outputs, the summed input gradient and both weight gradients against float64 / ATen; the
+    rearranged filter pair follows in-place updates of either weight."""
+    import torch.nn.functional as F
+    from eeadv import functional as EF
+    monkeypatch.setenv("EEADV_S2_MT", mt)
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=g).to(DEV).requires_grad_(True)
+    w3 = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
+    w1 = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).to(DEV).requires_grad_(True)
+    dy3 = torch.randn(B, Cout, H // 2, H // 2, generator=g).to(DEV)
+    dy1 = torch.randn(B, Cout, H // 2, H // 2, generator=g).to(DEV)
+    for round_ in range(3):
+        r3, r1 = F.conv2d(x, w3, None, 2, 1), F.conv2d(x, w1, None, 2, 0)
+        g3, g1 = EF.Conv3x3S2PairFn.apply(x, w3, w1)
+        x64 = x.detach().double().requires_grad_(True)
+        q3, q1 = F.conv2d(x64, w3.detach().double(), None, 2, 1), F.conv2d(x64, w1.detach().double(), None, 2, 0)
+        assert float((g3.detach().double() - q3).abs().max()) < 1e-6 * float(q3.abs().max())
+        assert float((g1.detach().double() - q1).abs().max()) < 1e-6 * float(q1.abs().max())
+        torch.testing.assert_close(g3, r3, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(g1, r1, rtol=1e-4, atol=1e-4)
+        got = torch.autograd.grad([g3, g1], [x, w3, w1], [dy3, dy1])
+        exp = torch.autograd.grad([r3, r1], [x, w3, w1], [dy3, dy1])
+        (e64,) = torch.autograd.grad([q3, q1], [x64], [dy3.double(), dy1.double()])
+        assert float((got[0].double() - e64).abs().max()) < 1e-6 * float(e64.abs().max())
+        torch.testing.assert_close(got[0], exp[0], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(got[1], exp[1], rtol=1e-4, atol=1e-4 * (H * H * B) ** 0.5)
+        torch.testing.assert_close(got[2], exp[2], rtol=1e-4, atol=1e-4 * (H * H * B) ** 0.5)
+        with torch.no_grad():
+            (w3 if round_ == 0 else w1).mul_(1.25)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H", [(100, 128, 128, 8), (3, 32, 32, 8), (2, 64, 96, 8), (1, 128, 64, 8), (100, 64, 64, 16), (3, 32, 96, 16), (100, 256, 256, 4), (7, 32, 64, 4), (1, 64, 32, 4)])
