@@ -6,8 +6,11 @@
 // kernels of ee_conv.hip tile badly.  Here a workgroup owns 32 (or 16) result channels x 32 pixels (two
 // v_mfma_f32_16x16x4 column blocks: half an image of an 8x8 result, two images of a 4x4 one, eight of a 2x2 one) and its four wavefronts
 // SPLIT THE REDUCTION: per round of 16 reduction channels, wavefront w multiplies channel quad w through all nine taps (2 x 2
-// accumulator tiles, 36 MFMAs, operands read once per two products), and the four partial sums meet in LDS at the end.  The rounds are
-// double-buffered: a round's products run while the next round is written to the other buffer and the one after that travels.
+// accumulator tiles, 36 MFMAs, operands read once per two products), and the four partial sums meet in LDS at the end.  The workgroup has
+// 512 lanes: wavefronts 0-3 only multiply, wavefronts 4-7 only PRODUCE (keep two rounds of loads in flight in two named register sets and
+// write the next round into the other LDS buffer while the current one is multiplied) - a wavefront issues in order, so with four
+// do-everything wavefronts (one per SIMD where the grid gives one workgroup per CU) load latency, staging and products just added up
+// (same finding and same cure as ee_wino.hip).  One barrier per round.
 //   forward       the round's inputs are scattered into LDS tap by tap (an im2col of 9 x 16 pixels per channel, zero where a tap leaves
 //                 the map), so a B operand is one conflict-free ds_read_b32 at a compile-time offset;
 //   backward-data the four parities of dx are four small stride-1 correlations of dy (1, 2, 2 and 4 taps: no multiplication by the
@@ -29,7 +32,7 @@ using namespace ee;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int S2_NT = 256, S2_CK = 16, S2_RB = 32;
+constexpr int S2_NT = 512, S2_CK = 16, S2_RB = 32;  // 256 consumer + 256 producer lanes
 constexpr int S2_RS = 36;              // row stride of the partial-sum exchange: the four k of a wavefront on disjoint banks
 
 struct S2Dims {
@@ -63,38 +66,39 @@ __device__ __forceinline__ int s2_slot(int img, int r) {
     const int wh_ = MT == 2 ? 0 : (blockIdx.y & 1);                                                              \
     const float4 *wsrc = reinterpret_cast<const float4 *>(w9) +                                                  \
                          static_cast<size_t>(MT == 2 ? blockIdx.y : blockIdx.y >> 1) * rounds * TAPS_F4;         \
-    const int wpl_ = threadIdx.x < LV ? threadIdx.x + 256 * (NJ - 1) : threadIdx.x + 256 * (NJ - 2);             \
-    const int ws0_ = MT == 2 ? threadIdx.x : (threadIdx.x >> 4) * 32 + 16 * wh_ + (threadIdx.x & 15);            \
-    const int ws1_ = MT == 2 ? threadIdx.x + 256 : ws0_ + 512;                                                   \
+    const int wpl_ = pt < LV ? pt + 256 * (NJ - 1) : pt + 256 * (NJ - 2);                                        \
+    const int ws0_ = MT == 2 ? pt : (pt >> 4) * 32 + 16 * wh_ + (pt & 15);                                       \
+    const int ws1_ = MT == 2 ? pt + 256 : ws0_ + 512;                                                            \
     const int wsl_ = MT == 2 ? wpl_ : (wpl_ >> 4) * 32 + 16 * wh_ + (wpl_ & 15);                                 \
-    float4 w0, w1, w2, w3, w4;                                                                                   \
-    w3 = w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f)
+    float4 Aw0, Aw1, Aw2, Aw3, Aw4, Bw0, Bw1, Bw2, Bw3, Bw4;                                                     \
+    Aw3 = Aw4 = Bw3 = Bw4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f)
 
-#define S2_LOAD_W(round_)                                                                     \
+#define S2_LOAD_W(S, round_)                                                                  \
     do {                                                                                      \
-        const float4 *wp_ = wsrc + static_cast<size_t>(round_) * TAPS_F4;                     \
-        w0 = wp_[ws0_];                                                                       \
-        w1 = wp_[ws1_];                                                                       \
+        const int r_ = (round_) < rounds ? (round_) : rounds - 1; /* always issued: a load under a condition costs its own round trip */ \
+        const float4 *wp_ = wsrc + static_cast<size_t>(r_) * TAPS_F4;                         \
+        S##w0 = wp_[ws0_];                                                                    \
+        S##w1 = wp_[ws1_];                                                                    \
         if (MT == 2) {                                                                        \
-            w2 = wp_[threadIdx.x + 512];                                                      \
-            w3 = wp_[threadIdx.x + 768];                                                      \
-            w4 = wp_[wsl_];                                                                   \
+            S##w2 = wp_[pt + 512];                                                            \
+            S##w3 = wp_[pt + 768];                                                            \
+            S##w4 = wp_[wsl_];                                                                \
         } else {                                                                              \
-            w2 = wp_[wsl_];                                                                   \
+            S##w2 = wp_[wsl_];                                                                \
         }                                                                                     \
     } while (0)
 
-#define S2_STORE_W(dst_)                                                                      \
+#define S2_STORE_W(dst_, S)                                                                   \
     do {                                                                                      \
         float4 *wd_ = reinterpret_cast<float4 *>(dst_);                                       \
-        wd_[threadIdx.x] = w0;                                                                \
-        wd_[threadIdx.x + 256] = w1;                                                          \
+        wd_[pt] = S##w0;                                                                      \
+        wd_[pt + 256] = S##w1;                                                                \
         if (MT == 2) {                                                                        \
-            wd_[threadIdx.x + 512] = w2;                                                      \
-            wd_[threadIdx.x + 768] = w3;                                                      \
-            if (threadIdx.x < LV) wd_[threadIdx.x + 1024] = w4;                               \
-        } else if (threadIdx.x < LV) {                                                        \
-            wd_[threadIdx.x + 512] = w2;                                                      \
+            wd_[pt + 512] = S##w2;                                                            \
+            wd_[pt + 768] = S##w3;                                                            \
+            if (pt < LV) wd_[pt + 1024] = S##w4;                                              \
+        } else if (pt < LV) {                                                                 \
+            wd_[pt + 512] = S##w2;                                                            \
         }                                                                                     \
     } while (0)
 
@@ -112,6 +116,8 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
     // two buffers of {filters of a round, inputs}; after the rounds the first one holds the four wavefronts' partial sums [4][RB][36]
     extern __shared__ __align__(16) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const bool producer = wave >= 4;
+    const int pt = threadIdx.x & 255;  // lane number inside its group of four wavefronts
     const int b0 = H == 16 ? blockIdx.x >> 1 : blockIdx.x * IMG, hh = H == 16 ? blockIdx.x & 1 : 0, co0 = blockIdx.y * RB;
     for (int i = threadIdx.x; i < S2_XS; i += S2_NT) lds[WFM + i] = lds[BUF + WFM + i] = 0.0f;  // the taps that leave the map stay zero: every round rewrites the same other slots
     const int rounds = d.KC / S2_CK;
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
     //   H = 4: 8 images x 16 channels x 4 rows:     (image (tid >> 6) + 4 j, ci (tid & 63) >> 2, row tid & 3)
     //   H = 8: 2 images x 16 channels x 8 rows x 2: (image j, ci tid >> 4, row (tid & 15) >> 1, half tid & 1)
     //   H = 16: 9 rows (8 hh - 1 ...) x 16 channels x 4: (row (tid >> 6) + 4 j, ci (tid & 63) >> 2, quarter tid & 3)
-    const int ci_s = H == 8 ? threadIdx.x >> 4 : (threadIdx.x & 63) >> 2;
-    const int x0_s = H == 8 ? 4 * (threadIdx.x & 1) : (H == 16 ? 4 * (threadIdx.x & 3) : 0), o_s = x0_s >> 1;
+    const int ci_s = H == 8 ? pt >> 4 : (pt & 63) >> 2;
+    const int x0_s = H == 8 ? 4 * (pt & 1) : (H == 16 ? 4 * (pt & 3) : 0), o_s = x0_s >> 1;
     // per float4: the two row taps it feeds.  Even input row -> ky 1 at oy = y/2; odd row -> ky 2 at oy = (y-1)/2 and ky 0 at oy = (y+1)/2
     int offA[3], offB[3];  // LDS float offsets of (tap row, small-map row); < 0: none.  Compile-time indexed after unrolling.
     const float *src[3];
@@ -130,8 +136,8 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
         int img = 0, yy, oyA, kyA, oyB;
         bool okA = true, okB, live = true;
         if (H == 16) {
-            const int r = (threadIdx.x >> 6) + 4 * j;  // input row 8 hh - 1 + r, r = 0..8
-            live = j < 2 || threadIdx.x < 64;
+            const int r = (pt >> 6) + 4 * j;  // input row 8 hh - 1 + r, r = 0..8
+            live = j < 2 || pt < 64;
             yy = 8 * hh - 1 + r;
             const bool odd_r = r & 1;  // odd r = even input row
             kyA = odd_r ? 1 : 2, oyA = odd_r ? (r - 1) >> 1 : (r >> 1) - 1, okA = live && (odd_r || r >= 2);
@@ -139,9 +145,9 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
             if (yy < 0) yy = 0;  // the padding row: a valid address, never scattered
             if (!live) yy = 8 * hh;
         } else {
-            img = H == 8 ? j : (threadIdx.x >> 6) + 4 * j;
+            img = H == 8 ? j : (pt >> 6) + 4 * j;
             live = j < 2;
-            yy = H == 8 ? (threadIdx.x & 15) >> 1 : threadIdx.x & 3;
+            yy = H == 8 ? (pt & 15) >> 1 : pt & 3;
             const bool odd = yy & 1;
             kyA = odd ? 2 : 1, oyA = yy >> 1, okA = live;
             oyB = (yy >> 1) + 1, okB = live && odd && oyB < OH;
@@ -153,8 +159,8 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
     }
     const float *src0 = src[0], *src1 = src[1], *src2 = src[H == 16 ? 2 : 1];
     const int oA0 = offA[0], oA1 = offA[1], oA2 = offA[2], oB0 = offB[0], oB1 = offB[1], oB2 = offB[2];
-    float4 xa, xb, xc;
-    xc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 Axa, Axb, Axc, Bxa, Bxb, Bxc;  // two NAMED register sets (A holds even rounds, B odd ones)
+    Axc = Bxc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     // scatter one float4 (columns x0 .. x0+3 of channel ci_s) to the tap planes of one (tap row, small-map row)
     auto put_cols = [&](float *p, float4 v) {
         p[1 * 512 + 4 * o_s] = v.x;        // column x0 (even): kx 1
@@ -169,18 +175,18 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
         if (oA >= 0) put_cols(base + oA, v);
         if (oB >= 0) put_cols(base + oB, v);
     };
-#define S2_LOAD_X(round_)                                                        \
-    do {                                                                         \
-        const size_t xo_ = static_cast<size_t>(round_) * xstep;                  \
-        xa = *reinterpret_cast<const float4 *>(src0 + xo_);                      \
-        xb = *reinterpret_cast<const float4 *>(src1 + xo_);                      \
-        if (H == 16) xc = *reinterpret_cast<const float4 *>(src2 + xo_);         \
+#define S2_LOAD_X(S, round_)                                                                   \
+    do {                                                                                       \
+        const size_t xo_ = static_cast<size_t>((round_) < rounds ? (round_) : rounds - 1) * xstep; \
+        S##xa = *reinterpret_cast<const float4 *>(src0 + xo_);                                 \
+        S##xb = *reinterpret_cast<const float4 *>(src1 + xo_);                                 \
+        if (H == 16) S##xc = *reinterpret_cast<const float4 *>(src2 + xo_);                    \
     } while (0)
-#define S2_PUT_X(dst_)                                                           \
-    do {                                                                         \
-        put(dst_, xa, oA0, oB0);                                                 \
-        put(dst_, xb, oA1, oB1);                                                 \
-        if (H == 16) put(dst_, xc, oA2, oB2);                                    \
+#define S2_PUT_X(dst_, S)                                                                      \
+    do {                                                                                       \
+        put(dst_, S##xa, oA0, oB0);                                                            \
+        put(dst_, S##xb, oA1, oB1);                                                            \
+        if (H == 16) put(dst_, S##xc, oA2, oB2);                                               \
     } while (0)
     f32x4 acc[MT][2], acc1[MT][2];
 #pragma unroll
@@ -188,30 +194,8 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = acc1[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const size_t xstep = static_cast<size_t>(S2_CK) * (H * H);
-    S2_LOAD_W(0);
-    S2_LOAD_X(0);
-    __syncthreads();  // the zero fill
-    S2_STORE_W(lds);
-    S2_PUT_X(lds + WFM);
-    {
-        const int nr = rounds > 1 ? 1 : 0;
-        S2_LOAD_W(nr);
-        S2_LOAD_X(nr);
-    }
-    __syncthreads();
-    const int aofs = wave * (MT * 64) + 4 * l15 + lq, bofs = WFM + wave * 128 + 4 * l15 + lq;
-    for (int round = 0; round < rounds; ++round) {
-        float *cur = lds + (round & 1) * BUF, *nxt = lds + ((round + 1) & 1) * BUF;
-        if (round + 1 < rounds) {  // the other buffer was last read before the barrier that ended the previous round
-            S2_STORE_W(nxt);
-            S2_PUT_X(nxt + WFM);
-        }
-        {
-            const int nr = round + 2 < rounds ? round + 2 : rounds - 1;  // always issued: a load under a condition costs its own round trip
-            S2_LOAD_W(nr);
-            S2_LOAD_X(nr);
-        }
-        const float *ap = cur + aofs, *bp = cur + bofs;
+    auto multiply = [&](const float *cur) {
+        const float *ap = cur + wave * (MT * 64) + 4 * l15 + lq, *bp = cur + WFM + wave * 128 + 4 * l15 + lq;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float v0 = bp[t * 512], v1 = bp[t * 512 + 64];
@@ -227,23 +211,62 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
                 }
             }
         }
+    };
+    float *buf0 = lds, *buf1 = lds + BUF;
+    if (producer) {
+        S2_LOAD_W(A, 0);
+        S2_LOAD_X(A, 0);
+    }
+    __syncthreads();  // the zero fill
+    if (producer) {
+        S2_STORE_W(buf0, A);
+        S2_PUT_X(buf0 + WFM, A);
+        S2_LOAD_W(B, 1);
+        S2_LOAD_X(B, 1);
+        S2_LOAD_W(A, 2);
+        S2_LOAD_X(A, 2);
+    }
+    __syncthreads();
+    for (int round = 0; round < rounds; round += 2) {
+        // iteration `round` (even): multiply buffer 0 while round + 1 (set B) goes to buffer 1 (past the end: the last round again, never read)
+        if (producer) {
+            S2_STORE_W(buf1, B);
+            S2_PUT_X(buf1 + WFM, B);
+            S2_LOAD_W(B, round + 3);
+            S2_LOAD_X(B, round + 3);
+        } else {
+            multiply(buf0);
+        }
         __syncthreads();
+        if (round + 1 < rounds) {  // iteration round + 1: multiply buffer 1 while round + 2 (set A) goes to buffer 0
+            if (producer) {
+                S2_STORE_W(buf0, A);
+                S2_PUT_X(buf0 + WFM, A);
+                S2_LOAD_W(A, round + 4);
+                S2_LOAD_X(A, round + 4);
+            } else {
+                multiply(buf1);
+            }
+            __syncthreads();
+        }
     }
 #undef S2_LOAD_X
 #undef S2_PUT_X
     // ---- the four partial sums meet: red[set][wave][co RB][36], D row = 4 (lane >> 4) + reg, column = lane & 15 -----------------------------
     constexpr int RED = 4 * RB * S2_RS;
     static_assert((DS ? 2 : 1) * RED <= 2 * BUF, "the exchange fits the staging buffers");
+    if (!producer) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = wave * (RB * S2_RS) + (m * 16 + 4 * lq + r) * S2_RS + n * 16 + l15;
-                lds[o] = acc[m][n][r];
-                if (DS) lds[RED + o] = acc1[m][n][r];
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int o = wave * (RB * S2_RS) + (m * 16 + 4 * lq + r) * S2_RS + n * 16 + l15;
+                    lds[o] = acc[m][n][r];
+                    if (DS) lds[RED + o] = acc1[m][n][r];
+                }
+    }
     __syncthreads();
     if (threadIdx.x < 8 * RB) {
         const int co = threadIdx.x >> 3, nq = threadIdx.x & 7;  // four consecutive columns of one result channel
@@ -280,6 +303,8 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     __shared__ __align__(16) float lds[2 * BUF];  // rounds: two buffers of {filters, dy shifts}; afterwards: two accumulator sets
     static_assert(BUF >= OW, "the exchange fits the staging buffers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const bool producer = wave >= 4;
+    const int pt = threadIdx.x & 255;  // lane number inside its group of four wavefronts
     const int b0 = H == 16 ? blockIdx.x >> 1 : blockIdx.x * IMG, hh = H == 16 ? blockIdx.x & 1 : 0, ci0 = blockIdx.y * RB;
     for (int i = threadIdx.x; i < S2_DS; i += S2_NT) lds[WFM + i] = lds[BUF + WFM + i] = 0.0f;  // shifted-out slots stay zero
     const int rounds = d.KC / S2_CK;
@@ -289,17 +314,17 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     //   H = 8 (4x4 dy): 2 images x 16 channels x 4 rows: 128 (image tid >> 6, co (tid & 63) >> 2, row tid & 3)
     //   H = 16 (8x8 dy): rows 4 hh .. 4 hh + 4 (the last one for the shift; row 8 does not exist) x 16 channels x 2 halves: 160
     //           (row tid >> 5, co (tid & 31) >> 1, half tid & 1)
-    const int dt = H == 16 ? (threadIdx.x < 160 ? threadIdx.x : threadIdx.x - 128) : threadIdx.x & 127;
+    const int dt = H == 16 ? (pt < 160 ? pt : pt - 128) : pt & 127;
     const int img_s = H == 16 ? 0 : (H == 8 ? dt >> 6 : dt >> 4), co_s = H == 16 ? (dt & 31) >> 1 : (H == 8 ? (dt & 63) >> 2 : dt & 15);
     const int row_s = H == 16 ? dt >> 5 : (H == 8 ? dt & 3 : 0), half_s = H == 16 ? dt & 1 : 0;
     const int oy_s = H == 16 ? 4 * hh + row_s : row_s;
-    const bool live = (H == 16 ? threadIdx.x < 160 : threadIdx.x < 128) && oy_s < OH;
+    const bool live = (H == 16 ? pt < 160 : pt < 128) && oy_s < OH;
     const int bi = b0 + img_s < d.B ? b0 + img_s : d.B - 1;
     const size_t doff = (static_cast<size_t>(bi) * d.KC + co_s) * PX + (H == 4 ? 0 : (oy_s < OH ? oy_s : OH - 1) * OH + 4 * half_s);
     const float *dsrc = dy + doff, *dsrc1 = DS ? dy1 + doff : dy + doff;
     const bool live1 = DS && live && row_s < 4;  // the shortcut's gradient needs no shifted row
-    float4 da, db;
-    db = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 Ada, Adb, Bda, Bdb;  // two NAMED register sets (A holds even rounds, B odd ones)
+    Adb = Bdb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     auto put1 = [&](float *d1, float4 v) {  // dy1 unshifted: [quad][column block][16 n][4 k]
         float *p = d1 + (co_s >> 2) * 128 + (co_s & 3) + s2_slot<H>(img_s, row_s) + 16 * half_s;
         p[0] = v.x, p[4] = v.y, p[8] = v.z, p[12] = v.w;
@@ -333,35 +358,19 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[c][n][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const size_t dstep = static_cast<size_t>(S2_CK) * PX;
-    S2_LOAD_W(0);
-    da = *reinterpret_cast<const float4 *>(dsrc);
-    if (DS) db = *reinterpret_cast<const float4 *>(dsrc1);
-    __syncthreads();  // the zero fill
-    S2_STORE_W(lds);
-    if (live) put(lds + WFM, da);
-    if (live1) put1(lds + D1, db);
-    {
-        const int nr = rounds > 1 ? 1 : 0;
-        S2_LOAD_W(nr);
-        da = *reinterpret_cast<const float4 *>(dsrc + nr * dstep);
-        if (DS) db = *reinterpret_cast<const float4 *>(dsrc1 + nr * dstep);
-    }
-    __syncthreads();
-    const int aofs = wave * (MT * 64) + 4 * l15 + lq, bofs = WFM + wave * 128 + 4 * l15 + lq;
-    for (int round = 0; round < rounds; ++round) {
-        float *cur = lds + (round & 1) * BUF, *nxt = lds + ((round + 1) & 1) * BUF;
-        if (round + 1 < rounds) {
-            S2_STORE_W(nxt);
-            if (live) put(nxt + WFM, da);
-            if (live1) put1(nxt + D1, db);
-        }
-        {
-            const int nr = round + 2 < rounds ? round + 2 : rounds - 1;
-            S2_LOAD_W(nr);
-            da = *reinterpret_cast<const float4 *>(dsrc + nr * dstep);
-            if (DS) db = *reinterpret_cast<const float4 *>(dsrc1 + nr * dstep);
-        }
-        const float *ap = cur + aofs, *bp = cur + bofs;
+#define S2_LOAD_D(S, round_)                                                                   \
+    do {                                                                                       \
+        const size_t do_ = static_cast<size_t>((round_) < rounds ? (round_) : rounds - 1) * dstep; \
+        S##da = *reinterpret_cast<const float4 *>(dsrc + do_);                                 \
+        if (DS) S##db = *reinterpret_cast<const float4 *>(dsrc1 + do_);                        \
+    } while (0)
+#define S2_PUT_D(buf_, S)                                                                      \
+    do {                                                                                       \
+        if (live) put((buf_) + WFM, S##da);                                                    \
+        if (live1) put1((buf_) + D1, S##db);                                                   \
+    } while (0)
+    auto multiply = [&](const float *cur) {
+        const float *ap = cur + wave * (MT * 64) + 4 * l15 + lq, *bp = cur + WFM + wave * 128 + 4 * l15 + lq;
         float bv[4][2];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -388,8 +397,46 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
                 acc[0][1][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, u1, acc[0][1][m], 0, 0, 0);
             }
         }
-        __syncthreads();
+    };
+    float *buf0 = lds, *buf1 = lds + BUF;
+    if (producer) {
+        S2_LOAD_W(A, 0);
+        S2_LOAD_D(A, 0);
     }
+    __syncthreads();  // the zero fill
+    if (producer) {
+        S2_STORE_W(buf0, A);
+        S2_PUT_D(buf0, A);
+        S2_LOAD_W(B, 1);
+        S2_LOAD_D(B, 1);
+        S2_LOAD_W(A, 2);
+        S2_LOAD_D(A, 2);
+    }
+    __syncthreads();
+    for (int round = 0; round < rounds; round += 2) {
+        if (producer) {  // round + 1 (set B) -> buffer 1 while buffer 0 is multiplied
+            S2_STORE_W(buf1, B);
+            S2_PUT_D(buf1, B);
+            S2_LOAD_W(B, round + 3);
+            S2_LOAD_D(B, round + 3);
+        } else {
+            multiply(buf0);
+        }
+        __syncthreads();
+        if (round + 1 < rounds) {
+            if (producer) {  // round + 2 (set A) -> buffer 0 while buffer 1 is multiplied
+                S2_STORE_W(buf0, A);
+                S2_PUT_D(buf0, A);
+                S2_LOAD_W(A, round + 4);
+                S2_LOAD_D(A, round + 4);
+            } else {
+                multiply(buf1);
+            }
+            __syncthreads();
+        }
+    }
+#undef S2_LOAD_D
+#undef S2_PUT_D
     // ---- pairwise sum of the four wavefronts' accumulators through LDS, then the parity interleave ------------------------------------
     // exchange layout [class][column block][ci RB][20]: lane (lq, l15) of tile (m, r) -> ci = 16 m + 4 lq + r, column l15
     auto spill = [&](float *dst) {
@@ -402,7 +449,7 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dst[((c * 2 + n) * RB + m * 16 + 4 * lq + r) * S2_OS + l15] = acc[c][n][m][r];
     };
-    if (wave >= 2) spill(lds + (wave - 2) * OW);
+    if (wave == 2 || wave == 3) spill(lds + (wave - 2) * OW);
     __syncthreads();
     if (wave < 2) {
         const float *src = lds + wave * OW;
@@ -418,9 +465,9 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     __syncthreads();
     if (wave < 2) spill(lds + wave * OW);
     __syncthreads();
-    // the workgroup's RB channels x 128 large-map pixels = 512 MT float4 (4 consecutive x of one row): 2 MT per thread
+    // the workgroup's RB channels x 128 large-map pixels = 512 MT float4 (4 consecutive x of one row): MT per thread
 #pragma unroll
-    for (int k = 0; k < 2 * MT; ++k) {
+    for (int k = 0; k < MT; ++k) {
         const int f = threadIdx.x + S2_NT * k;
         // (image, channel, large-map row yy inside the workgroup's part, float4 xq of the row)
         constexpr int F4R = H / 4, ROWS = H == 16 ? 8 : H, F4I = RB * ROWS * F4R;
