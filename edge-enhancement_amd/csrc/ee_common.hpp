@@ -15,6 +15,29 @@ constexpr int kMaxGrid = 256 * 8; // 256 CUs x 8 workgroups: cap, then grid-stri
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- XCD-aware workgroup numbering for kernels whose workgroups are (image group, result-channel block) pairs ------------------------
+// The 8 XCDs of a gfx950 take the workgroups of a 1-D grid round-robin, and each has an L2 of its own: what two workgroups share is fetched
+// once only if they sit on the same XCD.  weights_local: the channel block runs fastest (an XCD sees the filter slabs of the blocks
+// congruent to it, every image's input goes to min(ncb, 8) XCDs); otherwise an image group's ncb workgroups are numbered 8 apart (one XCD
+// fetches that input once, every XCD fetches all filters).  The host picks the cheaper one from the two footprints (xcd_weights_local) and
+// sizes the grid with xcd_grid; a workgroup whose decode returns false (the padding of the second scheme) exits at once.
+static inline bool xcd_weights_local(double in_bytes, double w_bytes, int ncb) {
+    const int dup = ncb < 8 ? ncb : 8;
+    return in_bytes * dup + w_bytes * (8 / dup) < in_bytes + 8.0 * w_bytes;
+}
+static inline unsigned xcd_grid(int nimg, int ncb, bool weights_local) {
+    return static_cast<unsigned>(weights_local ? nimg : (nimg + 7) / 8 * 8) * static_cast<unsigned>(ncb);
+}
+__device__ __forceinline__ bool xcd_decode(int id, int ncb, int nimg, bool weights_local, int &bx, int &by) {
+    if (weights_local) {
+        bx = id / ncb, by = id - bx * ncb;
+        return true;
+    }
+    const int g = id / (8 * ncb), r = id - g * (8 * ncb);
+    by = r >> 3, bx = g * 8 + (r & 7);
+    return bx < nimg;
+}
+
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 

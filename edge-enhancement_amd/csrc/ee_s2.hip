@@ -37,6 +37,7 @@ constexpr int S2_RS = 36;              // row stride of the partial-sum exchange
 
 struct S2Dims {
     int B, KC, RC;  // reduction channels (Cin forward, Cout backward), result channels
+    int wl;         // XCD numbering with the channel block fastest (ee_common.hpp: xcd_decode)
 };
 
 // H = the LARGE map's side (x forward, dx backward); the small map is OH x OH.  A workgroup's 32 small-map pixels: H = 4: eight images
@@ -63,9 +64,9 @@ __device__ __forceinline__ int s2_slot(int img, int r) {
 #define S2_W_SETUP()                                                                                             \
     constexpr int TAPS_F4 = TAPS * 128, WF4 = TAPS * 64 * MT, NJ = (WF4 + 255) / 256, LV = WF4 - 256 * (NJ - 1); \
     static_assert(NJ == (MT == 2 ? 5 : 3), "five / three float4 per thread");                                    \
-    const int wh_ = MT == 2 ? 0 : (blockIdx.y & 1);                                                              \
+    const int wh_ = MT == 2 ? 0 : (by & 1);                                                                      \
     const float4 *wsrc = reinterpret_cast<const float4 *>(w9) +                                                  \
-                         static_cast<size_t>(MT == 2 ? blockIdx.y : blockIdx.y >> 1) * rounds * TAPS_F4;         \
+                         static_cast<size_t>(MT == 2 ? by : by >> 1) * rounds * TAPS_F4;                         \
     const int wpl_ = pt < LV ? pt + 256 * (NJ - 1) : pt + 256 * (NJ - 2);                                        \
     const int ws0_ = MT == 2 ? pt : (pt >> 4) * 32 + 16 * wh_ + (pt & 15);                                       \
     const int ws1_ = MT == 2 ? pt + 256 : ws0_ + 512;                                                            \
@@ -104,7 +105,7 @@ __device__ __forceinline__ int s2_slot(int img, int r) {
 
 constexpr int S2_XS = 9 * 4 * 2 * 64;  // forward: a round's inputs [tap][quad][column block][16 n][4 k] = 4608 floats
 
-// ---- forward: x [B][KC][H][H] -> y [B][RC][H/2][H/2].  grid (ceil(B / IMG) or 2 B, RC / (16 MT)) ------------------------------------
+// ---- forward: x [B][KC][H][H] -> y [B][RC][H/2][H/2].  1-D grid of (ceil(B / IMG) or 2 B) x RC / (16 MT) workgroups ------------------------------------
 // DS: the block's shortcut Conv2d(1x1, stride 2) of the SAME input (resnet.py:137-142) rides along as a tenth tap - its B operand is the centre
 // tap's plane - into accumulators of its own -> y1
 template <int H, int MT, bool DS>
@@ -118,7 +119,11 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
     const bool producer = wave >= 4;
     const int pt = threadIdx.x & 255;  // lane number inside its group of four wavefronts
-    const int b0 = H == 16 ? blockIdx.x >> 1 : blockIdx.x * IMG, hh = H == 16 ? blockIdx.x & 1 : 0, co0 = blockIdx.y * RB;
+    // 1-D grid numbered for the XCDs' L2s (ee_common.hpp: xcd_decode): channel block fastest where the filters are the bigger footprint (an
+    // XCD then fetches only the slabs of the blocks congruent to it: 4.7 MB on the 4x4 layer, otherwise eight times), image group otherwise
+    int bx, by;
+    if (!xcd_decode(blockIdx.x, d.RC / RB, H == 16 ? 2 * d.B : (d.B + IMG - 1) / IMG, d.wl, bx, by)) return;
+    const int b0 = H == 16 ? bx >> 1 : bx * IMG, hh = H == 16 ? bx & 1 : 0, co0 = by * RB;
     for (int i = threadIdx.x; i < S2_XS; i += S2_NT) lds[WFM + i] = lds[BUF + WFM + i] = 0.0f;  // the taps that leave the map stay zero: every round rewrites the same other slots
     const int rounds = d.KC / S2_CK;
     S2_W_SETUP();
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__
     }
 }
 
-// ---- backward-data: dy [B][KC][H/2][H/2] -> dx [B][RC][H][H].  grid (ceil(B / IMG) or 2 B, RC / (16 MT)) ----------------------------
+// ---- backward-data: dy [B][KC][H/2][H/2] -> dx [B][RC][H][H].  1-D grid of (ceil(B / IMG) or 2 B) x RC / (16 MT) workgroups ----------------------------
 // dx[2i+py][2j+px] = sum over the taps of parity class (py, px): row taps py = 0: ky 1 (dy row i); py = 1: ky 0 (row i+1) and ky 2 (row i).
 constexpr int S2_DS = 4 * 4 * 2 * 64;  // dy shifts of a round: [shift sy*2+sx][quad][column block][16 n][4 k] = 2048 floats
 constexpr int S2_OS = 20;              // row stride of the interleave exchange [class][column block][RB ci][20]
@@ -305,7 +310,9 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
     const bool producer = wave >= 4;
     const int pt = threadIdx.x & 255;  // lane number inside its group of four wavefronts
-    const int b0 = H == 16 ? blockIdx.x >> 1 : blockIdx.x * IMG, hh = H == 16 ? blockIdx.x & 1 : 0, ci0 = blockIdx.y * RB;
+    int bx, by;  // XCD-aware numbering (see the forward kernel)
+    if (!xcd_decode(blockIdx.x, d.RC / RB, H == 16 ? 2 * d.B : (d.B + IMG - 1) / IMG, d.wl, bx, by)) return;
+    const int b0 = H == 16 ? bx >> 1 : bx * IMG, hh = H == 16 ? bx & 1 : 0, ci0 = by * RB;
     for (int i = threadIdx.x; i < S2_DS; i += S2_NT) lds[WFM + i] = lds[BUF + WFM + i] = 0.0f;  // shifted-out slots stay zero
     const int rounds = d.KC / S2_CK;
     S2_W_SETUP();
@@ -498,7 +505,7 @@ int s2_mt(bool bwd, int H) {
 
 template <int H, int MT, bool DS>
 int s2_launch(bool bwd, const float *in, const float *in1, const float *w9, float *out, float *out1, const S2Dims &d, hipStream_t st) {
-    const dim3 grid(static_cast<unsigned>(H == 16 ? 2 * d.B : (d.B + S2Geo<H>::IMG - 1) / S2Geo<H>::IMG), static_cast<unsigned>(d.RC / (16 * MT)));
+    const dim3 grid(xcd_grid(H == 16 ? 2 * d.B : (d.B + S2Geo<H>::IMG - 1) / S2Geo<H>::IMG, d.RC / (16 * MT), d.wl));
     if (bwd) {
         EE_LAUNCH((conv3s2_bwd_mfma_kernel<H, MT, DS>), grid, dim3(S2_NT), 0, st, in, in1, w9, out, d);
     } else {
@@ -536,7 +543,7 @@ int s2_check(const void *a, const void *b, const void *c, int B, int KC, int RC,
 EE_API int ee_conv3x3s2_small_fwd_f32(const float *x, const float *w9, float *y, int B, int Cin, int Cout, int H, void *stream) {
     const int rc = s2_check(x, w9, y, B, Cin, Cout, H);
     if (rc != EE_OK || B == 0) return rc;
-    const S2Dims d{B, Cin, Cout};
+    const S2Dims d{B, Cin, Cout, xcd_weights_local(4.0 * B * Cin * H * H, 36.0 * Cin * Cout, Cout / 32) ? 1 : 0};
     ProfScope prof(EE_K_CONV3S2_FWD, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
     return s2_dispatch<false>(false, x, nullptr, w9, y, nullptr, d, H, as_stream(stream));
 }
@@ -546,7 +553,7 @@ EE_API int ee_conv3x3s2_small_fwd_f32(const float *x, const float *w9, float *y,
 EE_API int ee_conv3x3s2_small_bwd_data_f32(const float *dy, const float *w9, float *dx, int B, int Cin, int Cout, int H, void *stream) {
     const int rc = s2_check(dy, w9, dx, B, Cout, Cin, H);
     if (rc != EE_OK || B == 0) return rc;
-    const S2Dims d{B, Cout, Cin};
+    const S2Dims d{B, Cout, Cin, xcd_weights_local(1.0 * B * Cout * H * H, 36.0 * Cin * Cout, Cin / 32) ? 1 : 0};
     ProfScope prof(EE_K_CONV3S2_BWD, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
     return s2_dispatch<false>(true, dy, nullptr, w9, dx, nullptr, d, H, as_stream(stream));
 }
@@ -560,7 +567,7 @@ EE_API int ee_conv3x3s2_pair_fwd_f32(const float *x, const float *w10, float *y3
     if (rc != EE_OK || B == 0) return rc;
     if (!y1) return EE_ERR_NULL;
     if (!aligned16(y1)) return EE_ERR_ALIGN;
-    const S2Dims d{B, Cin, Cout};
+    const S2Dims d{B, Cin, Cout, xcd_weights_local(4.0 * B * Cin * H * H, 40.0 * Cin * Cout, Cout / 32) ? 1 : 0};
     ProfScope prof(EE_K_CONV3S2_FWD, as_stream(stream), 2.0 * 10.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
     return s2_dispatch<true>(false, x, nullptr, w10, y3, y1, d, H, as_stream(stream));
 }
@@ -572,7 +579,7 @@ EE_API int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, co
     if (rc != EE_OK || B == 0) return rc;
     if (!dy1) return EE_ERR_NULL;
     if (!aligned16(dy1)) return EE_ERR_ALIGN;
-    const S2Dims d{B, Cout, Cin};
+    const S2Dims d{B, Cout, Cin, xcd_weights_local(2.0 * B * Cout * H * H, 40.0 * Cin * Cout, Cin / 32) ? 1 : 0};
     ProfScope prof(EE_K_CONV3S2_BWD, as_stream(stream), 2.0 * 10.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
     return s2_dispatch<true>(true, dy3, dy1, w10, dx, nullptr, d, H, as_stream(stream));
 }

@@ -29,6 +29,7 @@ constexpr int WN_US = WN_CK * WN_CP;           // one xi's [16 ci][48]
 
 struct WinoDims {
     int B, KC, RC;  // reduction channels (input channels forward), result channels
+    int wl;         // producer / consumer kernels: XCD numbering with the channel block fastest (ee_common.hpp: xcd_decode)
 };
 
 // MAP x MAP maps: MAP = 8 (16 tiles = one N block = one image per workgroup), 16 (64 tiles = four N blocks per image; the accumulators
@@ -236,7 +237,11 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave >= 4;
     const int pt = threadIdx.x & 255;  // lane number inside its group of four wavefronts
-    const int b = blockIdx.x * 4, co0 = blockIdx.y * WN_CO;
+    // 1-D grid numbered for the XCDs' L2s (ee_common.hpp: xcd_decode): with the channel block fastest an XCD fetches only the U slices of the
+    // blocks congruent to it (4.2 MB of transformed filters were fetched by all eight: 28 MB of the 32 MB a launch pulled in)
+    int bx, by;
+    if (!xcd_decode(blockIdx.x, d.RC / WN_CO, (d.B + 3) / 4, d.wl, bx, by)) return;
+    const int b = bx * 4, co0 = by * WN_CO;
     const int l15 = lane & 15, lq = lane >> 4;
     const int urow0 = pt >> 3, uq = pt & 7;
     const int ci_s = urow0 & 15, xi_s = urow0 >> 4;
@@ -434,7 +439,9 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave >= 4;
     const int pt = threadIdx.x & 255;  // lane number inside its group of four wavefronts
-    const int b = blockIdx.x * G::IMG, co0 = blockIdx.y * WN_CO;
+    int bx, by;  // XCD-aware numbering (see the 4x4 kernel)
+    if (!xcd_decode(blockIdx.x, d.RC / WN_CO, (d.B + G::IMG - 1) / G::IMG, d.wl, bx, by)) return;
+    const int b = bx * G::IMG, co0 = by * WN_CO;
     const int l15 = lane & 15, lq = lane >> 4;
     const int rounds = d.KC / G::CK;
     // U slice of a round: 16 xi x 8 ci rows of 32 floats = 1024 float4, four per producer lane: rows (xi0 + 4 j, ci_u)
@@ -645,7 +652,7 @@ int wino_pc_launch(const float *x, const float *u, float *y, const WinoDims &d, 
     static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_pc_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(G::lds_bytes)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH(wino3x3_pc_kernel<MAP>, dim3(static_cast<unsigned>((d.B + G::IMG - 1) / G::IMG), static_cast<unsigned>(d.RC / WN_CO)), dim3(W4_NT), G::lds_bytes,
+    EE_LAUNCH(wino3x3_pc_kernel<MAP>, dim3(xcd_grid((d.B + G::IMG - 1) / G::IMG, d.RC / WN_CO, d.wl)), dim3(W4_NT), G::lds_bytes,
               st, x, u, y, d);
     return launch_status();
 }
@@ -654,7 +661,7 @@ int wino_map4_launch(const float *x, const float *u, float *y, const WinoDims &d
     static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_map4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(W4_LDS)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH(wino3x3_map4_kernel, dim3(static_cast<unsigned>((d.B + 3) / 4), static_cast<unsigned>(d.RC / WN_CO)), dim3(W4_NT), W4_LDS, st, x, u, y, d);
+    EE_LAUNCH(wino3x3_map4_kernel, dim3(xcd_grid((d.B + 3) / 4, d.RC / WN_CO, d.wl)), dim3(W4_NT), W4_LDS, st, x, u, y, d);
     return launch_status();
 }
 
@@ -680,7 +687,7 @@ EE_API int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int K
     if (!x || !u || !y) return EE_ERR_NULL;
     if (!aligned16(x) || !aligned16(u) || !aligned16(y)) return EE_ERR_ALIGN;
     if (static_cast<int64_t>(B) * (KC > RC ? KC : RC) * H * H > 0x7fffffffLL) return EE_ERR_SHAPE;
-    const WinoDims d{B, KC, RC};
+    const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
     // the convolution's ALGORITHMIC flops (2 * 9 * KC * RC per output pixel); the kernel executes 4/9 of them (16 multiplies per 2x2 tile)
     ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
     static const bool v1 = std::getenv("EEADV_WINO_V1") != nullptr;  // A/B: the one-wavefront-per-SIMD kernel

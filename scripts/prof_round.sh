@@ -25,12 +25,16 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   CHAIN_BENCH_EAGER=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$ctr -- python3 scripts/chain_bench.py 100x3x64x64 > gpurun_out/${tag}_pmc_$ctr.log 2>&1
   PROBE_EAGER=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${tag}_conv_$ctr -- python3 scripts/conv3_probe.py 100 > gpurun_out/${tag}_pmc_conv_$ctr.log 2>&1
   PROBE_EAGER=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${tag}_wino_$ctr -- python3 scripts/wino_probe.py 100 > gpurun_out/${tag}_pmc_wino_$ctr.log 2>&1
+  PROBE_EAGER=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${tag}_s2_$ctr -- python3 scripts/s2_probe.py 100 > gpurun_out/${tag}_pmc_s2_$ctr.log 2>&1
 done
 rm -f gpurun_out/${tag}_pmc_traffic.json
 python3 scripts/pmc_to_json.py /tmp/pmc_${tag}_FETCH_SIZE /tmp/pmc_${tag}_WRITE_SIZE 100x3x64x64 gpurun_out/${tag}_pmc_traffic.json \
   "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over scripts/chain_bench.py 100x3x64x64 (plain launches); KiB counters, FETCH doubled per guides/MI355X_MICROARCH.md" > gpurun_out/${tag}_pmc_traffic.txt
 python3 scripts/pmc_to_json.py /tmp/pmc_${tag}_conv_FETCH_SIZE /tmp/pmc_${tag}_conv_WRITE_SIZE 100x3x64x64 gpurun_out/${tag}_pmc_traffic.json >> gpurun_out/${tag}_pmc_traffic.txt
 python3 scripts/pmc_to_json.py /tmp/pmc_${tag}_wino_FETCH_SIZE /tmp/pmc_${tag}_wino_WRITE_SIZE 100x3x64x64 gpurun_out/${tag}_pmc_traffic.json >> gpurun_out/${tag}_pmc_traffic.txt
+python3 scripts/pmc_to_json.py /tmp/pmc_${tag}_s2_FETCH_SIZE /tmp/pmc_${tag}_s2_WRITE_SIZE 100x3x64x64 gpurun_out/${tag}_pmc_traffic.json >> gpurun_out/${tag}_pmc_traffic.txt
+t=$(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1)
+python3 scripts/trace_sequence.py "$t" > gpurun_out/${tag}_trace_sequence.txt
 echo "pmc done"
 cut -c1-600 gpurun_out/${tag}_bench.json
 cat gpurun_out/${tag}_pmc_traffic.txt

@@ -39,7 +39,7 @@ def timeit(fn, iters=30, reps=3):
     return 1e3 * a.elapsed_time(b) / (iters * reps)
 
 
-SHAPES = ((128, 8), (64, 16)) if os.environ.get("PROBE_EAGER") else ((128, 8), (64, 16), (256, 4), (64, 8), (256, 8))  # counters: the bench's two shapes
+SHAPES = ((128, 8), (64, 16), (256, 4)) if os.environ.get("PROBE_EAGER") else ((128, 8), (64, 16), (256, 4), (64, 8), (256, 8))  # counters: the three shapes of the bench
 for c, hw in SHAPES:
     x = torch.randn(B, c, hw, hw, device=dev)
     w = torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5)
