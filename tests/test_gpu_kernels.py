@@ -1012,6 +1012,32 @@ def test_conv3x3_stride2_small_maps_match_aten(ops, monkeypatch, B, Cin, Cout, H
             w.mul_(1.25)
 
 
+@pytest.mark.parametrize("H", [4, 8, 16])
+@pytest.mark.parametrize("KC", [16, 48])
+def test_mfma_convs_with_an_odd_number_of_rounds(ops, H, KC):
+    """The producer / consumer kernels run their rounds in pairs (two register sets, two LDS buffers): channel counts that give an ODD
+    number of 16-channel rounds - below what the models use, but what the C ABI admits - through ops directly: Winograd forward with 16 / 48
+    reduction channels, the stride-2 kernel forward (Cin = KC) and backward-data (Cout = KC), against float64."""
+    import torch.nn.functional as F
+    from eeadv import functional as EF
+    g = torch.Generator(device="cpu").manual_seed(H + KC)
+    B = 5
+    x = torch.randn(B, KC, H, H, generator=g).to(DEV)
+    w = (torch.randn(32, KC, 3, 3, generator=g) / (3 * KC ** 0.5)).to(DEV)
+    got = ops.wino3x3_map8(x, EF._rearranged(w, "wino_f").contiguous())
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    assert float((got.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    got = ops.conv3x3s2_small_fwd(x, EF._rearranged(w, "s2m_f").contiguous(), 32)
+    ref = F.conv2d(x.double(), w.double(), None, 2, 1)
+    assert float((got.double() - ref).abs().max()) < 1e-6 * float(ref.abs().max())
+    wb = (torch.randn(KC, 32, 3, 3, generator=g) / (3 * 32 ** 0.5)).to(DEV)  # Cout = KC reduction channels, Cin = 32
+    dy = torch.randn(B, KC, H // 2, H // 2, generator=g).to(DEV)
+    got = ops.conv3x3s2_small_bwd_data(dy, EF._rearranged(wb, "s2m_b").contiguous(), 32)
+    xr = torch.zeros(B, 32, H, H, dtype=torch.float64, device=DEV, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xr, wb.double(), None, 2, 1), [xr], dy.double())
+    assert float((got.double() - ref).abs().max()) < 1e-6 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("mt", ["222222", "111111"])
 @pytest.mark.parametrize("B,Cin,Cout,H", [(100, 64, 128, 16), (100, 128, 256, 8), (100, 256, 512, 4), (3, 32, 64, 16), (5, 64, 32, 8), (9, 32, 32, 4), (1, 96, 64, 4)])
 def test_conv3x3_stride2_with_shortcut_conv_matches_aten(ops, monkeypatch, B, Cin, Cout, H, mt):
