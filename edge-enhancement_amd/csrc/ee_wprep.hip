@@ -1,0 +1,118 @@
+// ee_wprep.hip - the convolution kernels' filters in the order their kernels read them, rebuilt from the nn.Conv2d weights once per
+// optimiser step (inside the captured update graph): Winograd F(2x2, 3x3) filter transforms U = G g G^T (ee_wino.hip), the tap-major slabs
+// of the stride-2 kernels with or without the shortcut's 1x1 filters (ee_s2.hip), the dense [4 Cin, 4 Cout] matrix of a 3x3 convolution
+// on a 2x2 map (layer 4: functional.Conv3x3Map2Fn).  As torch expressions (einsum / cat / permute / advanced indexing, the restatement
+// in functional._rearranged) these were 120 launches and 0.55 ms of a 12.6 ms training step; here one launch per (weight, kind).
+//
+// Every kind is a gather with a closed-form index (plus 16 sums for the Winograd ones): one lane per OUTPUT element, or per filter pair.
+// CNN-body glue, not a row of SURVEY.md section 8.
+#include "ee_common.hpp"
+
+namespace {
+
+using namespace ee;
+
+// U[xi = 4 i + j][k][r] = (G g G^T)[i][j], G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]].
+// forward: g = w[r][k] (k = input channel, r = output channel); backward-data: g = w[k][r] rotated by 180 degrees (k = output channel).
+// One lane per (k, r), r fastest: the 16 stores of a wavefront are contiguous rows.
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float *__restrict__ w, float *__restrict__ u, int Cout, int Cin, int backward) {
+    const int K = backward ? Cout : Cin, R = backward ? Cin : Cout;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= K * R) return;
+    const int k = idx / R, r = idx - k * R;
+    const float *g = w + (static_cast<size_t>(backward ? k : r) * Cin + (backward ? r : k)) * 9;
+    float gg[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) gg[a][b] = backward ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
+    float t[4][3];  // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float s = gg[0][b] + gg[2][b];
+        t[0][b] = gg[0][b];
+        t[1][b] = 0.5f * (s + gg[1][b]);
+        t[2][b] = 0.5f * (s - gg[1][b]);
+        t[3][b] = gg[2][b];
+    }
+    float *o = u + static_cast<size_t>(k) * R + r;
+    const size_t xs = static_cast<size_t>(K) * R;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float s = t[i][0] + t[i][2];
+        o[(4 * i + 0) * xs] = t[i][0];
+        o[(4 * i + 1) * xs] = 0.5f * (s + t[i][1]);
+        o[(4 * i + 2) * xs] = 0.5f * (s - t[i][1]);
+        o[(4 * i + 3) * xs] = t[i][2];
+    }
+}
+
+// out [R/32][K/16][TAPS][4][2][16][4]: out[rb][rd][t][q][h][m][k] = W(r = 32 rb + 16 h + m, kk = 16 rd + 4 q + k, t), where
+// forward (R = Cout, K = Cin): W = w3[r][kk][t] (t < 9) or w1[r][kk]; backward (R = Cin, K = Cout): W = w3[kk][r][t] or w1[kk][r]
+__global__ __launch_bounds__(256) void s2_slab_kernel(const float *__restrict__ w3, const float *__restrict__ w1, float *__restrict__ out, int Cout, int Cin,
+                                                     int backward, int taps) {
+    const int K = backward ? Cout : Cin, R = backward ? Cin : Cout;
+    const size_t total = static_cast<size_t>(R) * K * taps;
+    const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    size_t v = idx;
+    const int k = v & 3;
+    v >>= 2;
+    const int m = v & 15;
+    v >>= 4;
+    const int h = v & 1;
+    v >>= 1;
+    const int q = v & 3;
+    v >>= 2;
+    const int t = static_cast<int>(v % taps);
+    v /= taps;
+    const int rd = static_cast<int>(v % (K / 16)), rb = static_cast<int>(v / (K / 16));
+    const int r = 32 * rb + 16 * h + m, kk = 16 * rd + 4 * q + k;
+    const int co = backward ? kk : r, ci = backward ? r : kk;
+    out[idx] = t < 9 ? w3[(static_cast<size_t>(co) * Cin + ci) * 9 + t] : w1[static_cast<size_t>(co) * Cin + ci];
+}
+
+// 3x3 / stride 1 / padding 1 on a 2x2 map as a dense product: out[(ci, iy, ix)][(co, oy, ox)] = w[co][ci][iy - oy + 1][ix - ox + 1]
+__global__ __launch_bounds__(256) void dense_map2_kernel(const float *__restrict__ w, float *__restrict__ out, int Cout, int Cin) {
+    const size_t total = 16 * static_cast<size_t>(Cout) * Cin;
+    const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int col = static_cast<int>(idx % (4 * static_cast<size_t>(Cout))), row = static_cast<int>(idx / (4 * static_cast<size_t>(Cout)));
+    const int co = col >> 2, oy = (col >> 1) & 1, ox = col & 1, ci = row >> 2, iy = (row >> 1) & 1, ix = row & 1;
+    out[idx] = w[(static_cast<size_t>(co) * Cin + ci) * 9 + (iy - oy + 1) * 3 + (ix - ox + 1)];
+}
+
+}  // namespace
+
+// kind: EE_WPREP_* (eeadv.h).  w [Cout][Cin][3][3]; w1 [Cout][Cin] (the shortcut's 1x1 filters, EE_WPREP_S2P_* only, else NULL);
+// out: see the kind.  Channel counts: multiples of 32 for the stride-2 slabs (16 on the reduction side), any for the others.
+EE_API int ee_conv_weight_prep_f32(int kind, const float *w, const float *w1, float *out, int Cout, int Cin, void *stream) {
+    if (Cout < 1 || Cin < 1) return EE_ERR_SHAPE;
+    if (!w || !out) return EE_ERR_NULL;
+    if (static_cast<int64_t>(Cout) * Cin > (1LL << 26)) return EE_ERR_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const size_t pairs = static_cast<size_t>(Cout) * Cin;
+    switch (kind) {
+        case EE_WPREP_WINO_F:
+        case EE_WPREP_WINO_B:
+            EE_LAUNCH(wino_filter_kernel, dim3(static_cast<unsigned>((pairs + 255) / 256)), dim3(256), 0, st, w, out, Cout, Cin, kind == EE_WPREP_WINO_B ? 1 : 0);
+            break;
+        case EE_WPREP_S2M_F:
+        case EE_WPREP_S2M_B:
+        case EE_WPREP_S2P_F:
+        case EE_WPREP_S2P_B: {
+            const int backward = (kind == EE_WPREP_S2M_B || kind == EE_WPREP_S2P_B) ? 1 : 0, taps = (kind == EE_WPREP_S2P_F || kind == EE_WPREP_S2P_B) ? 10 : 9;
+            const int K = backward ? Cout : Cin, R = backward ? Cin : Cout;
+            if (K % 16 != 0 || R % 32 != 0) return EE_ERR_UNSUPPORTED;
+            if (taps == 10 && !w1) return EE_ERR_NULL;
+            EE_LAUNCH(s2_slab_kernel, dim3(static_cast<unsigned>((pairs * taps + 255) / 256)), dim3(256), 0, st, w, w1, out, Cout, Cin, backward, taps);
+            break;
+        }
+        case EE_WPREP_DENSE_MAP2:
+            EE_LAUNCH(dense_map2_kernel, dim3(static_cast<unsigned>((16 * pairs + 255) / 256)), dim3(256), 0, st, w, out, Cout, Cin);
+            break;
+        default:
+            return EE_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}

@@ -421,6 +421,39 @@ def _versions(weight, extra):
     return weight._version if extra is None else (weight._version, extra._version)
 
 
+# kinds ee_wprep.hip builds in one launch (EE_WPREP_* of eeadv.h); EEADV_WPREP=0: the torch expressions of _rearranged instead (A/B)
+_NATIVE_KIND = {"wino_f": 0, "wino_b": 1, "s2m_f": 2, "s2m_b": 3, "s2p_f": 4, "s2p_b": 5, "s1": 6}
+_WPREP = os.environ.get("EEADV_WPREP", "1") == "1"
+
+
+def _rearranged_shape(weight, kind):
+    co, ci = weight.shape[0], weight.shape[1]
+    if kind in ("wino_f", "wino_b"):
+        return (16, ci, co) if kind == "wino_f" else (16, co, ci)
+    if kind in ("s2m_f", "s2p_f"):
+        return (co // 32, ci // 16, 10 if kind == "s2p_f" else 9, 4, 2, 16, 4)
+    if kind in ("s2m_b", "s2p_b"):
+        return (ci // 32, co // 16, 10 if kind == "s2p_b" else 9, 4, 2, 16, 4)
+    return (4 * ci, 4 * co)  # "s1"
+
+
+def _fill_rearranged(buf, weight, kind, extra):
+    """buf <- the rearranged copy, in place (capturable): one hand-written launch where ee_wprep.hip knows the kind"""
+    if (_WPREP and kind in _NATIVE_KIND and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
+            and (extra is None or (extra.is_contiguous() and extra.dtype == torch.float32))):
+        ops.conv_weight_prep(_NATIVE_KIND[kind], weight.detach(), None if extra is None else extra.detach(), buf)
+    else:
+        buf.copy_(_rearranged(weight, kind, extra))
+
+
+def _new_rearranged(weight, kind, extra):
+    if _WPREP and kind in _NATIVE_KIND and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous():
+        buf = torch.empty(_rearranged_shape(weight, kind), dtype=torch.float32, device=weight.device)
+        _fill_rearranged(buf, weight, kind, extra)
+        return buf
+    return _rearranged(weight, kind, extra).contiguous()
+
+
 def _dense_weight(weight, kind="s1", extra=None):
     """The rearranged copy of `weight` (and, for the "s2p_*" kinds, of a second parameter `extra` riding along) for `kind`: built on first
     use, rebuilt IN PLACE when a version counter moved; inside a graph capture only handed out."""
@@ -434,10 +467,10 @@ def _dense_weight(weight, kind="s1", extra=None):
     if ent is None or ent[1] != _versions(weight, extra):
         with torch.no_grad():
             if ent is None:
-                ent = _DENSE_W[(id(weight), kind)] = [weakref.ref(weight), _versions(weight, extra), _rearranged(weight, kind, extra).contiguous(), kind,
+                ent = _DENSE_W[(id(weight), kind)] = [weakref.ref(weight), _versions(weight, extra), _new_rearranged(weight, kind, extra), kind,
                                                       None if extra is None else weakref.ref(extra)]
             else:
-                ent[2].copy_(_rearranged(weight, kind, extra))
+                _fill_rearranged(ent[2], weight, kind, extra)
                 ent[1] = _versions(weight, extra)
     return ent[2]
 
@@ -464,7 +497,7 @@ def rebuild_dense_weights(model=None):
             if w is None:
                 del _DENSE_W[key]
             elif own is None or key[0] in own:
-                ent[2].copy_(_rearranged(w, ent[3], e))
+                _fill_rearranged(ent[2], w, ent[3], e)
                 ent[1] = _versions(w, e)
 
 

@@ -759,6 +759,16 @@ def conv3x3s2_small_bwd_data(dy, w9, cin):
     return dx
 
 
+def conv_weight_prep(kind, weight, extra, out):
+    """ee_wprep.hip: the filters of one convolution in the order its kernel reads them (kind = EE_WPREP_* of eeadv.h), written into `out`
+    in one launch; `extra` = the shortcut's 1x1 weight for the paired stride-2 kinds."""
+    co, ci = weight.shape[0], weight.shape[1]
+    N.check(N.lib.ee_conv_weight_prep_f32(kind, _chk(weight, torch.float32, "weight", (co, ci, 3, 3)),
+                                          None if extra is None else _chk(extra, torch.float32, "extra", (co, ci, 1, 1)),
+                                          _chk(out, torch.float32, "out"), co, ci, _stream()), "ee_conv_weight_prep_f32")
+    return out
+
+
 def conv3x3s2_pair_fwd(x, w10, cout):
     """conv3x3 / stride 2 / padding 1 AND conv1x1 / stride 2 of the same x in one launch (a down-sampling BasicBlock's conv1 and shortcut):
     x [B,Cin,H,H], w10 = both filter sets rearranged (functional._rearranged kind "s2p_f") -> (y3, y1), each [B,Cout,H/2,H/2]"""

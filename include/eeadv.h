@@ -372,6 +372,21 @@ int ee_conv3x3s2_small_bwd_data_f32(const float *dy, const float *w9, float *dx,
 int ee_conv3x3s2_pair_fwd_f32(const float *x, const float *w10, float *y3, float *y1, int B, int Cin, int Cout, int H, void *stream);
 int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, const float *w10, float *dx, int B, int Cin, int Cout, int H, void *stream);
 
+/* The filters of the convolution kernels above in the order those kernels read them, from the Conv2d weight [Cout,Cin,3,3] (one launch;
+ * the host rebuilds them once per optimiser step, inside the captured update graph):
+ *   EE_WPREP_WINO_F / _B   u [16][K][R] for ee_wino3x3_f32, forward (K = Cin, R = Cout) / backward-data (K = Cout, R = Cin, rotated filters)
+ *   EE_WPREP_S2M_F / _B    w9 [R/32][K/16][9][4][2][16][4] for ee_conv3x3s2_small_*; EE_WPREP_S2P_F / _B: w10 (10 taps) for ee_conv3x3s2_pair_*,
+ *                          w1 [Cout,Cin] = the shortcut's 1x1 filters
+ *   EE_WPREP_DENSE_MAP2    [4 Cin][4 Cout]: a 3x3 / stride 1 / padding 1 convolution on a 2x2 map as one dense product (layer 4) */
+#define EE_WPREP_WINO_F 0
+#define EE_WPREP_WINO_B 1
+#define EE_WPREP_S2M_F 2
+#define EE_WPREP_S2M_B 3
+#define EE_WPREP_S2P_F 4
+#define EE_WPREP_S2P_B 5
+#define EE_WPREP_DENSE_MAP2 6
+int ee_conv_weight_prep_f32(int kind, const float *w, const float *w1, float *out, int Cout, int Cin, void *stream);
+
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.
  *   dy [B,K,H/2,W/2], weight [K,3,7,7] -> dx [B,3,H,W];  H, W even. */

@@ -1012,6 +1012,38 @@ def test_conv3x3_stride2_small_maps_match_aten(ops, monkeypatch, B, Cin, Cout, H
             w.mul_(1.25)
 
 
+@pytest.mark.parametrize("co,ci", [(64, 32), (32, 96), (128, 128)])
+def test_weight_preparation_kernels_match_their_torch_restatement(ops, co, ci):
+    """ee_wprep.hip (one launch per weight and kind) against functional._rearranged's torch expressions: the permutation kinds bit for bit,
+    the Winograd filter transforms within rounding (the einsum sums in another order) and against float64; and the cache rebuilds in place."""
+    from eeadv import functional as EF
+    g = torch.Generator(device="cpu").manual_seed(co + ci)
+    w = torch.randn(co, ci, 3, 3, generator=g).to(DEV)
+    w1 = torch.randn(co, ci, 1, 1, generator=g).to(DEV)
+    for kind in ("s2m_f", "s2m_b", "s2p_f", "s2p_b", "s1"):
+        extra = w1 if kind.startswith("s2p") else None
+        want = EF._rearranged(w, kind, extra).contiguous()
+        got = torch.empty(EF._rearranged_shape(w, kind), device=DEV)
+        ops.conv_weight_prep(EF._NATIVE_KIND[kind], w, extra, got)
+        assert got.shape == want.shape and torch.equal(got, want), kind
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=DEV)
+    for kind in ("wino_f", "wino_b"):
+        got = torch.empty(EF._rearranged_shape(w, kind), device=DEV)
+        ops.conv_weight_prep(EF._NATIVE_KIND[kind], w, None, got)
+        torch.testing.assert_close(got, EF._rearranged(w, kind).contiguous(), rtol=1e-6, atol=1e-6)
+        w64 = w.double() if kind == "wino_f" else w.double().flip(2, 3)
+        want = torch.einsum("ia,jb,rkab->ijkr" if kind == "wino_f" else "ia,jb,krab->ijkr", G, G, w64).reshape(got.shape)
+        assert float((got.double() - want).abs().max()) < 1e-6 * float(want.abs().max())
+    p = torch.nn.Parameter(w.clone())
+    buf = EF._dense_weight(p, "wino_f")
+    ptr = buf.data_ptr()
+    with torch.no_grad():
+        p.mul_(2.0)
+    again = EF._dense_weight(p, "wino_f")
+    assert again.data_ptr() == ptr
+    torch.testing.assert_close(again, EF._rearranged(p, "wino_f").contiguous(), rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("H", [4, 8, 16])
 @pytest.mark.parametrize("KC", [16, 48])
 def test_mfma_convs_with_an_odd_number_of_rounds(ops, H, KC):
