@@ -15,9 +15,9 @@ using namespace ee;
 // U[xi = 4 i + j][k][r] = (G g G^T)[i][j], G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]].
 // forward: g = w[r][k] (k = input channel, r = output channel); backward-data: g = w[k][r] rotated by 180 degrees (k = output channel).
 // One lane per (k, r), r fastest: the 16 stores of a wavefront are contiguous rows.
-__global__ __launch_bounds__(256) void wino_filter_kernel(const float *__restrict__ w, float *__restrict__ u, int Cout, int Cin, int backward) {
+__device__ __forceinline__ void wino_filter_body(const float *__restrict__ w, float *__restrict__ u, int Cout, int Cin, int backward, unsigned block) {
     const int K = backward ? Cout : Cin, R = backward ? Cin : Cout;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = block * 256 + threadIdx.x;
     if (idx >= K * R) return;
     const int k = idx / R, r = idx - k * R;
     const float *g = w + (static_cast<size_t>(backward ? k : r) * Cin + (backward ? r : k)) * 9;
@@ -49,11 +49,11 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float *__restric
 
 // out [R/32][K/16][TAPS][4][2][16][4]: out[rb][rd][t][q][h][m][k] = W(r = 32 rb + 16 h + m, kk = 16 rd + 4 q + k, t), where
 // forward (R = Cout, K = Cin): W = w3[r][kk][t] (t < 9) or w1[r][kk]; backward (R = Cin, K = Cout): W = w3[kk][r][t] or w1[kk][r]
-__global__ __launch_bounds__(256) void s2_slab_kernel(const float *__restrict__ w3, const float *__restrict__ w1, float *__restrict__ out, int Cout, int Cin,
-                                                     int backward, int taps) {
+__device__ __forceinline__ void s2_slab_body(const float *__restrict__ w3, const float *__restrict__ w1, float *__restrict__ out, int Cout, int Cin,
+                                             int backward, int taps, unsigned block) {
     const int K = backward ? Cout : Cin, R = backward ? Cin : Cout;
     const size_t total = static_cast<size_t>(R) * K * taps;
-    const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    const size_t idx = static_cast<size_t>(block) * 256 + threadIdx.x;
     if (idx >= total) return;
     size_t v = idx;
     const int k = v & 3;
@@ -73,13 +73,42 @@ __global__ __launch_bounds__(256) void s2_slab_kernel(const float *__restrict__ 
 }
 
 // 3x3 / stride 1 / padding 1 on a 2x2 map as a dense product: out[(ci, iy, ix)][(co, oy, ox)] = w[co][ci][iy - oy + 1][ix - ox + 1]
-__global__ __launch_bounds__(256) void dense_map2_kernel(const float *__restrict__ w, float *__restrict__ out, int Cout, int Cin) {
+__device__ __forceinline__ void dense_map2_body(const float *__restrict__ w, float *__restrict__ out, int Cout, int Cin, unsigned block) {
     const size_t total = 16 * static_cast<size_t>(Cout) * Cin;
-    const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    const size_t idx = static_cast<size_t>(block) * 256 + threadIdx.x;
     if (idx >= total) return;
     const int col = static_cast<int>(idx % (4 * static_cast<size_t>(Cout))), row = static_cast<int>(idx / (4 * static_cast<size_t>(Cout)));
     const int co = col >> 2, oy = (col >> 1) & 1, ox = col & 1, ci = row >> 2, iy = (row >> 1) & 1, ix = row & 1;
     out[idx] = w[(static_cast<size_t>(co) * Cin + ci) * 9 + (iy - oy + 1) * 3 + (ix - ox + 1)];
+}
+
+__device__ __forceinline__ void wprep_dispatch(int kind, const float *w, const float *w1, float *out, int Cout, int Cin, unsigned block) {
+    if (kind == EE_WPREP_WINO_F || kind == EE_WPREP_WINO_B)
+        wino_filter_body(w, out, Cout, Cin, kind == EE_WPREP_WINO_B ? 1 : 0, block);
+    else if (kind == EE_WPREP_DENSE_MAP2)
+        dense_map2_body(w, out, Cout, Cin, block);
+    else
+        s2_slab_body(w, w1, out, Cout, Cin, (kind == EE_WPREP_S2M_B || kind == EE_WPREP_S2P_B) ? 1 : 0, (kind == EE_WPREP_S2P_F || kind == EE_WPREP_S2P_B) ? 10 : 9, block);
+}
+
+__global__ __launch_bounds__(256) void wprep_kernel(int kind, const float *__restrict__ w, const float *__restrict__ w1, float *__restrict__ out, int Cout, int Cin) {
+    wprep_dispatch(kind, w, w1, out, Cout, Cin, blockIdx.x);
+}
+
+// every (weight, kind) of a model in ONE launch: table[i] = {w, w1, out, kind, Cout, Cin, first block, blocks} (8 x int64), blocks numbered
+// consecutively over the items
+__global__ __launch_bounds__(256) void wprep_batched_kernel(const long long *__restrict__ table, int n) {
+    int i = 0;
+    while (i + 1 < n && static_cast<long long>(blockIdx.x) >= table[8 * (i + 1) + 6]) ++i;  // block-uniform: scalar loads
+    const long long *it = table + 8 * i;
+    wprep_dispatch(static_cast<int>(it[3]), reinterpret_cast<const float *>(it[0]), reinterpret_cast<const float *>(it[1]), reinterpret_cast<float *>(it[2]),
+                   static_cast<int>(it[4]), static_cast<int>(it[5]), blockIdx.x - static_cast<unsigned>(it[6]));
+}
+
+unsigned wprep_blocks(int kind, size_t pairs) {
+    if (kind == EE_WPREP_WINO_F || kind == EE_WPREP_WINO_B) return static_cast<unsigned>((pairs + 255) / 256);
+    if (kind == EE_WPREP_DENSE_MAP2) return static_cast<unsigned>((16 * pairs + 255) / 256);
+    return static_cast<unsigned>((pairs * ((kind == EE_WPREP_S2P_F || kind == EE_WPREP_S2P_B) ? 10 : 9) + 255) / 256);
 }
 
 }  // namespace
@@ -92,27 +121,29 @@ EE_API int ee_conv_weight_prep_f32(int kind, const float *w, const float *w1, fl
     if (static_cast<int64_t>(Cout) * Cin > (1LL << 26)) return EE_ERR_SHAPE;
     hipStream_t st = as_stream(stream);
     const size_t pairs = static_cast<size_t>(Cout) * Cin;
-    switch (kind) {
-        case EE_WPREP_WINO_F:
-        case EE_WPREP_WINO_B:
-            EE_LAUNCH(wino_filter_kernel, dim3(static_cast<unsigned>((pairs + 255) / 256)), dim3(256), 0, st, w, out, Cout, Cin, kind == EE_WPREP_WINO_B ? 1 : 0);
-            break;
-        case EE_WPREP_S2M_F:
-        case EE_WPREP_S2M_B:
-        case EE_WPREP_S2P_F:
-        case EE_WPREP_S2P_B: {
-            const int backward = (kind == EE_WPREP_S2M_B || kind == EE_WPREP_S2P_B) ? 1 : 0, taps = (kind == EE_WPREP_S2P_F || kind == EE_WPREP_S2P_B) ? 10 : 9;
-            const int K = backward ? Cout : Cin, R = backward ? Cin : Cout;
-            if (K % 16 != 0 || R % 32 != 0) return EE_ERR_UNSUPPORTED;
-            if (taps == 10 && !w1) return EE_ERR_NULL;
-            EE_LAUNCH(s2_slab_kernel, dim3(static_cast<unsigned>((pairs * taps + 255) / 256)), dim3(256), 0, st, w, w1, out, Cout, Cin, backward, taps);
-            break;
-        }
-        case EE_WPREP_DENSE_MAP2:
-            EE_LAUNCH(dense_map2_kernel, dim3(static_cast<unsigned>((16 * pairs + 255) / 256)), dim3(256), 0, st, w, out, Cout, Cin);
-            break;
-        default:
-            return EE_ERR_UNSUPPORTED;
+    if (kind < EE_WPREP_WINO_F || kind > EE_WPREP_DENSE_MAP2) return EE_ERR_UNSUPPORTED;
+    if (kind >= EE_WPREP_S2M_F && kind <= EE_WPREP_S2P_B) {
+        const bool backward = kind == EE_WPREP_S2M_B || kind == EE_WPREP_S2P_B;
+        if ((backward ? Cout : Cin) % 16 != 0 || (backward ? Cin : Cout) % 32 != 0) return EE_ERR_UNSUPPORTED;
+        if ((kind == EE_WPREP_S2P_F || kind == EE_WPREP_S2P_B) && !w1) return EE_ERR_NULL;
     }
+    EE_LAUNCH(wprep_kernel, dim3(wprep_blocks(kind, pairs)), dim3(256), 0, st, kind, w, w1, out, Cout, Cin);
+    return launch_status();
+}
+
+// How many 256-lane blocks one (kind, Cout, Cin) item takes in the batched launch below (the host builds the table with it)
+EE_API int ee_conv_weight_prep_blocks(int kind, int Cout, int Cin) {
+    if (kind < EE_WPREP_WINO_F || kind > EE_WPREP_DENSE_MAP2 || Cout < 1 || Cin < 1) return 0;
+    return static_cast<int>(wprep_blocks(kind, static_cast<size_t>(Cout) * Cin));
+}
+
+// All items of a DEVICE-resident table in one launch: table [n][8] int64 = {w, w1 (or 0), out, kind, Cout, Cin, first block, blocks}, first
+// block = the running sum of `blocks` (ee_conv_weight_prep_blocks); total_blocks = that sum.  The caller vouches for the table's contents
+// (same rules as ee_conv_weight_prep_f32 per item).
+EE_API int ee_conv_weight_prep_batched_f32(const void *table_dev, int n_items, int total_blocks, void *stream) {
+    if (n_items < 0 || total_blocks < 0) return EE_ERR_SHAPE;
+    if (n_items == 0 || total_blocks == 0) return EE_OK;
+    if (!table_dev) return EE_ERR_NULL;
+    EE_LAUNCH(wprep_batched_kernel, dim3(static_cast<unsigned>(total_blocks)), dim3(256), 0, as_stream(stream), static_cast<const long long *>(table_dev), n_items);
     return launch_status();
 }

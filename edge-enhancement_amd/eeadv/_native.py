@@ -82,6 +82,8 @@ SIGNATURES = {
     "ee_conv3x3s2_small_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_small_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv_weight_prep_f32": [c_i, c_p, c_p, c_p, c_i, c_i, c_p],
+    "ee_conv_weight_prep_blocks": [c_i, c_i, c_i],
+    "ee_conv_weight_prep_batched_f32": [c_p, c_i, c_i, c_p],
     "ee_conv3x3s2_pair_fwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_pair_bwd_data_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_net2_conv_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],

@@ -769,6 +769,16 @@ def conv_weight_prep(kind, weight, extra, out):
     return out
 
 
+def conv_weight_prep_blocks(kind, cout, cin):
+    return int(N.lib.ee_conv_weight_prep_blocks(kind, cout, cin))
+
+
+def conv_weight_prep_batched(table, n_items, total_blocks):
+    """every item of a device-resident table (int64 [n, 8], see eeadv.h) in one launch"""
+    N.check(N.lib.ee_conv_weight_prep_batched_f32(_chk(table, torch.int64, "table", (n_items, 8)), n_items, total_blocks, _stream()),
+            "ee_conv_weight_prep_batched_f32")
+
+
 def conv3x3s2_pair_fwd(x, w10, cout):
     """conv3x3 / stride 2 / padding 1 AND conv1x1 / stride 2 of the same x in one launch (a down-sampling BasicBlock's conv1 and shortcut):
     x [B,Cin,H,H], w10 = both filter sets rearranged (functional._rearranged kind "s2p_f") -> (y3, y1), each [B,Cout,H/2,H/2]"""

@@ -150,9 +150,10 @@ class _GraphedUpdate:
         if self.eager_left > 0:
             self.eager_left -= 1
             return self._body()
-        from eeadv.functional import refresh_dense_weights
+        from eeadv.functional import prepare_dense_rebuild, refresh_dense_weights
         refresh_dense_weights()  # eager updates since the last forward (version counters moved): before capture AND replay
         if self.graph is None:
+            prepare_dense_rebuild(self.model())  # the item table of the one-launch rebuild: its upload must not fall into the capture
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             if self.sync is None:
@@ -226,11 +227,12 @@ class _GraphedPredsUpdate:
             preds = model(self.x)
             self.adv.copy_(self._attack(preds))
             return self._after_attack(preds)
-        from eeadv.functional import refresh_dense_weights
+        from eeadv.functional import prepare_dense_rebuild, refresh_dense_weights
         refresh_dense_weights()
         if self.g1 is None:
             if not model.training:
                 raise RuntimeError("TRADES / ALP step: the model must be in train mode when the step starts (the .loss() methods leave it there)")
+            prepare_dense_rebuild(model)
             torch.cuda.synchronize()
             self.g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g1, capture_error_mode=runtime.capture_mode()):

@@ -386,6 +386,10 @@ int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, const flo
 #define EE_WPREP_S2P_B 5
 #define EE_WPREP_DENSE_MAP2 6
 int ee_conv_weight_prep_f32(int kind, const float *w, const float *w1, float *out, int Cout, int Cin, void *stream);
+/* every (weight, kind) of a model in ONE launch: table_dev = device array [n_items][8] of int64 {w, w1 or 0, out, kind, Cout, Cin, first
+ * block, blocks}; blocks = ee_conv_weight_prep_blocks(kind, Cout, Cin), first block = their running sum, total_blocks = the sum */
+int ee_conv_weight_prep_blocks(int kind, int Cout, int Cin);
+int ee_conv_weight_prep_batched_f32(const void *table_dev, int n_items, int total_blocks, void *stream);
 
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.

@@ -1013,7 +1013,7 @@ def test_conv3x3_stride2_small_maps_match_aten(ops, monkeypatch, B, Cin, Cout, H
 
 
 @pytest.mark.parametrize("co,ci", [(64, 32), (32, 96), (128, 128)])
-def test_weight_preparation_kernels_match_their_torch_restatement(ops, co, ci):
+def test_weight_preparation_kernels_match_their_torch_restatement(ops, monkeypatch, co, ci):
     """ee_wprep.hip (one launch per weight and kind) against functional._rearranged's torch expressions: the permutation kinds bit for bit,
     the Winograd filter transforms within rounding (the einsum sums in another order) and against float64; and the cache rebuilds in place."""
     from eeadv import functional as EF
@@ -1042,6 +1042,20 @@ def test_weight_preparation_kernels_match_their_torch_restatement(ops, co, ci):
     again = EF._dense_weight(p, "wino_f")
     assert again.data_ptr() == ptr
     torch.testing.assert_close(again, EF._rearranged(p, "wino_f").contiguous(), rtol=1e-6, atol=1e-6)
+    # the batched rebuild (one launch for every cached item of a model) gives the same bits as the per-item launches
+    m = torch.nn.Module()
+    m.a, m.b = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w1.clone())
+    bufs = {k: EF._dense_weight(m.a, k, m.b if k.startswith("s2p") else None) for k in ("wino_f", "wino_b", "s2p_f", "s2p_b", "s2m_f", "s1")}
+    for batched in (True, False):
+        monkeypatch.setattr(EF, "_WPREP_BATCH", batched)
+        with torch.no_grad():
+            m.a.mul_(0.5)
+            m.b.add_(1.0)
+        EF.rebuild_dense_weights(m)
+        for k, bufk in bufs.items():
+            want = torch.empty_like(bufk)
+            ops.conv_weight_prep(EF._NATIVE_KIND[k], m.a.detach(), m.b.detach() if k.startswith("s2p") else None, want)
+            assert torch.equal(bufk, want), (k, batched)
 
 
 @pytest.mark.parametrize("H", [4, 8, 16])
