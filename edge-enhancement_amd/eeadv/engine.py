@@ -44,6 +44,36 @@ class LossSpec:
         raise ValueError(self.kind)
 
 
+# EEADV_FC_HEAD=0: the last two layers + loss of the MNIST classifier as the stock five launches again (A/B)
+_FC_HEAD = os.environ.get("EEADV_FC_HEAD", "1") == "1"
+
+
+def _body_input_grad(model, x_in, spec, through_body):
+    """d loss / d x_in through model.body (through_body) or the whole model: logits -> loss gradient -> autograd.  Models that expose
+    `body_pre` (the classifier up to the last hidden layer's pre-activation: models.Net_2) get `fc2(relu(.))`, the cross-entropy and both
+    backward steps as ONE launch (ops.fc_ce_grad) instead of five."""
+    pre = getattr(model, "body_pre", None) if _FC_HEAD and (through_body or not hasattr(model, "front_chain")) else None
+    if (pre is not None and spec.kind in (CE_SUM, CE_MEAN) and x_in.is_cuda and type(getattr(model, "fc2", None)) is torch.nn.Linear
+            and model.fc2.weight.dtype == torch.float32):
+        with torch.enable_grad():
+            z1 = pre(x_in)
+        if z1.dtype == torch.float32 and ops.fc_ce_grad_supported(z1, model.fc2.weight):
+            dz = ops.fc_ce_grad(z1.detach().contiguous(), model.fc2.weight.detach().contiguous(), model.fc2.bias.detach() if model.fc2.bias is not None else None,
+                                spec.payload, "mean" if spec.kind == CE_MEAN else "sum")
+            with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
+                (g,) = torch.autograd.grad(z1, [x_in], grad_outputs=dz)
+            return g
+        with torch.enable_grad():
+            logits = model.fc2(torch.nn.functional.relu(z1))
+    else:
+        with torch.enable_grad():
+            logits = model.body(x_in) if through_body else model(x_in)
+    d = spec.dlogits(logits.contiguous())
+    with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
+        (g,) = torch.autograd.grad(logits, [x_in], grad_outputs=d)
+    return g
+
+
 def _unwrap(model):
     """DDP / DataParallel wrappers add nothing to an input-gradient step (no parameter gradients are
     produced, so there is nothing to all-reduce): run the wrapped module directly."""
@@ -55,12 +85,7 @@ def _unwrap(model):
 def input_gradient(model, x, spec):
     """g = d loss / d x for the current x (x: leaf ROCm tensor), through autograd end to end."""
     x.requires_grad_(True)
-    with torch.enable_grad():
-        logits = model(x)
-    d = spec.dlogits(logits.contiguous())
-    with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
-        (g,) = torch.autograd.grad(logits, [x], grad_outputs=d)
-    return g
+    return _body_input_grad(model, x, spec, False)
 
 
 def attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi):
@@ -73,11 +98,7 @@ def attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi):
         with torch.no_grad():
             x_in, ctx = model.front_chain(x.detach())
         x_in.requires_grad_(True)
-        with torch.enable_grad():
-            logits = model.body(x_in)
-        d = spec.dlogits(logits.contiguous())
-        with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
-            (g_in,) = torch.autograd.grad(logits, [x_in], grad_outputs=d)
+        g_in = _body_input_grad(model, x_in, spec, True)
         with torch.no_grad():
             model.front_chain_update_(x.detach(), g_in.contiguous(), ctx, x0, step_size, eps, lo, hi, direction)
         return
@@ -85,11 +106,7 @@ def attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi):
         with torch.no_grad():
             x_in, ctx = model.front_manual(x.detach())
         x_in.requires_grad_(True)
-        with torch.enable_grad():
-            logits = model.body(x_in)
-        d = spec.dlogits(logits.contiguous())
-        with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
-            (g_in,) = torch.autograd.grad(logits, [x_in], grad_outputs=d)
+        g_in = _body_input_grad(model, x_in, spec, True)
         with torch.no_grad():
             g_lp, g_edge = model.front_manual_backward(g_in.contiguous(), ctx)
             ops.pgd_step_bcast_(x.detach(), g_lp, g_edge, x0, step_size, eps, lo, hi, direction)

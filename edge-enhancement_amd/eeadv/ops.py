@@ -345,6 +345,23 @@ def ce(logits, labels, reduction="mean", smoothing=0.0, want_loss=True, want_gra
     return loss, d
 
 
+def fc_ce_grad_supported(z1, w2):
+    return z1.dim() == 2 and w2.dim() == 2 and w2.shape[1] == z1.shape[1] and w2.shape[0] <= 64 and z1.shape[1] <= 8192
+
+
+def fc_ce_grad(z1, w2, b2, labels, reduction="sum", want_logits=False):
+    """d CrossEntropyLoss(fc2(relu(z1)), labels) / d z1 in one launch (ee_loss.hip: fc_ce_grad_kernel): z1 [B,Hd], w2 [K,Hd], b2 [K] or None.
+    Returns dz1, or (dz1, logits)."""
+    B, Hd = z1.shape
+    K = w2.shape[0]
+    dz = torch.empty_like(z1)
+    lg = torch.empty((B, K), dtype=torch.float32, device=z1.device) if want_logits else None
+    N.check(N.lib.ee_fc_ce_grad_f32(_chk(z1, torch.float32, "z1"), _chk(w2, torch.float32, "w2", (K, Hd)), _opt(b2, torch.float32, "b2"),
+                                    _chk(labels, torch.int64, "labels", (B,)), dz.data_ptr(), _opt(lg, torch.float32, "logits"), B, Hd, K,
+                                    _inv(B) if reduction == "mean" else 1.0, _stream()), "ee_fc_ce_grad_f32")
+    return (dz, lg) if want_logits else dz
+
+
 def kl_batchmean(zq, zp, want_loss=True, want_dq=True, want_dp=False):
     B, K = zq.shape
     pq = _chk(zq, torch.float32, "zq")

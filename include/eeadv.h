@@ -178,6 +178,11 @@ int ee_pgd_step_bcast_f32(float *x, const float *g_lp, const float *g_edge, cons
  *     dz = gscale * (softmax(z) - w)           gscale = 1 ('sum') or 1/B ('mean')            */
 int ee_ce_f32(const float *logits, const int64_t *labels, int B, int K, float smoothing, float gscale,
               double *row_loss, float *dlogits, void *stream);
+/* The last two layers of the MNIST classifier and the loss behind them, gradient only (MNIST/models_mnist/Net2.py:27-28 + attacks.py:23):
+ * d CrossEntropyLoss(fc2(relu(z1)), labels) / d z1 in one launch.  z1 [B,Hd] = fc1's output, w2 [K,Hd], b2 [K] or NULL, labels [B] ->
+ * dz1 [B,Hd] (and the logits [B,K] if logits_out != NULL); gscale = 1 ("sum") or 1/B ("mean").  K <= 64, Hd <= 8192. */
+int ee_fc_ce_grad_f32(const float *z1, const float *w2, const float *b2, const int64_t *labels, float *dz1, float *logits_out, int B, int Hd,
+                      int K, float gscale, void *stream);
 
 /* nn.KLDivLoss('batchmean')(log_softmax(zq), softmax(zp))  (attacks.py:375, :412, :426):
  *     row_loss_b = sum_k p(log p - log q);  dzq = gscale*(q - p);  dzp = gscale*p*((log p - log q) - row_loss_b)

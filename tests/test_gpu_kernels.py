@@ -1012,6 +1012,35 @@ def test_conv3x3_stride2_small_maps_match_aten(ops, monkeypatch, B, Cin, Cout, H
             w.mul_(1.25)
 
 
+@pytest.mark.parametrize("B,Hd,K,reduction", [(50, 1024, 10, "sum"), (7, 1024, 10, "mean"), (3, 100, 64, "sum"), (1, 33, 2, "mean")])
+def test_fc_ce_grad_matches_autograd(ops, B, Hd, K, reduction):
+    """fc2(relu(z1)) + CrossEntropyLoss + both backward steps in one launch (the tail of MNIST's Net_2 inside the attack loop) against
+    float64 autograd; logits too; the ReLU gate at exact zeros and NaN as torch's threshold_backward has it."""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(B * Hd + K)
+    z1 = torch.randn(B, Hd, generator=g)
+    z1[0, :5] = 0.0  # relu'(0) = 0
+    w2 = torch.randn(K, Hd, generator=g) / Hd ** 0.5
+    b2 = torch.randn(K, generator=g)
+    y = torch.randint(0, K, (B,), generator=g)
+    z64 = z1.double().requires_grad_(True)
+    loss = F.cross_entropy(F.linear(F.relu(z64), w2.double(), b2.double()), y, reduction=reduction)
+    (want,) = torch.autograd.grad(loss, [z64])
+    dz, lg = ops.fc_ce_grad(z1.to(DEV), w2.to(DEV), b2.to(DEV), y.to(DEV), reduction, want_logits=True)
+    assert float((dz.cpu().double() - want).abs().max()) < 2e-6 * max(float(want.abs().max()), 1e-3)
+    torch.testing.assert_close(lg.cpu().double(), F.linear(F.relu(z1.double()), w2.double(), b2.double()), rtol=1e-5, atol=1e-5)
+    assert float(dz[0, :5].abs().max()) == 0.0
+    dz2 = ops.fc_ce_grad(z1.to(DEV), w2.to(DEV), None, y.to(DEV), reduction)  # no bias
+    loss = F.cross_entropy(F.linear(F.relu(z64), w2.double()), y, reduction=reduction)
+    (want,) = torch.autograd.grad(loss, [z64])
+    assert float((dz2.cpu().double() - want).abs().max()) < 2e-6 * max(float(want.abs().max()), 1e-3)
+    zn = z1.clone()
+    zn[0, 7] = float("nan")  # relu keeps the NaN (the row's logits and gradient are NaN), its own gate is closed
+    dzn = ops.fc_ce_grad(zn.to(DEV), w2.to(DEV), b2.to(DEV), y.to(DEV), reduction).cpu()
+    open_gate = int((zn[0, 8:] > 0).nonzero()[0]) + 8
+    assert float(dzn[0, 7]) == 0.0 and bool(torch.isnan(dzn[0, open_gate])) and (B == 1 or bool(torch.isfinite(dzn[1:]).all()))
+
+
 @pytest.mark.parametrize("co,ci", [(64, 32), (32, 96), (128, 128)])
 def test_weight_preparation_kernels_match_their_torch_restatement(ops, monkeypatch, co, ci):
     """ee_wprep.hip (one launch per weight and kind) against functional._rearranged's torch expressions: the permutation kinds bit for bit,
