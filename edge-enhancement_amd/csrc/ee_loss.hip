@@ -259,6 +259,63 @@ __global__ __launch_bounds__(kBlock) void fc_ce_grad_kernel(const float *__restr
     }
 }
 
+// The same for K <= 16 classes and Hd <= 1024 (the MNIST shape: 10 x 1024): a lane owns four hidden units and keeps their fc2 weights in
+// registers for both directions (one round of independent loads instead of per-class dependent rounds and a second pass over W2): 10.9 -> 6 us
+__global__ __launch_bounds__(kBlock) void fc_ce_grad_small_kernel(const float *__restrict__ z1, const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                  const int64_t *__restrict__ labels, int Hd, int K, float gscale, float *__restrict__ dz1,
+                                                                  float *__restrict__ logits_out) {
+    constexpr int KM = 16, JP = 4;
+    __shared__ float part[kRowsPerBlock][KM], lg[KM], dl[KM];
+    const int row = blockIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const float *z = z1 + static_cast<size_t>(row) * Hd;
+    float zv[JP], w[KM][JP];
+    bool in[JP];
+#pragma unroll
+    for (int i = 0; i < JP; ++i) {
+        const int j = threadIdx.x + kBlock * i;
+        in[i] = j < Hd;
+        zv[i] = z[in[i] ? j : 0];  // clamped address, masked below
+    }
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int i = 0; i < JP; ++i) {
+            const int j = threadIdx.x + kBlock * i;
+            w[k][i] = w2[static_cast<size_t>(k < K ? k : K - 1) * Hd + (in[i] ? j : 0)];
+        }
+    float hv[JP];
+#pragma unroll
+    for (int i = 0; i < JP; ++i) hv[i] = !in[i] ? 0.0f : (zv[i] > 0.0f ? zv[i] : (zv[i] != zv[i] ? zv[i] : 0.0f));
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < JP; ++i) acc = fmaf(in[i] ? w[k][i] : 0.0f, hv[i], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) part[wave][k] = acc;
+    }
+    __syncthreads();
+    const int tk = static_cast<int>(threadIdx.x);
+    if (tk < KM) lg[tk] = tk < K ? (((part[0][tk] + part[1][tk]) + part[2][tk]) + part[3][tk]) + (b2 ? b2[tk] : 0.0f) : 0.0f;
+    __syncthreads();
+    if (wave == 0) {
+        float mx, lse;
+        row_stats(lg, K, lane, mx, lse);
+        const int y = static_cast<int>(labels[row]);
+        if (lane < KM) dl[lane] = lane < K ? (expf((lg[lane] - mx) - lse) - (lane == y ? 1.0f : 0.0f)) * gscale : 0.0f;
+        if (logits_out && lane < K) logits_out[static_cast<size_t>(row) * K + lane] = lg[lane];
+    }
+    __syncthreads();
+    float *d = dz1 + static_cast<size_t>(row) * Hd;
+#pragma unroll
+    for (int i = 0; i < JP; ++i) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) acc = fmaf(dl[k], k < K ? w[k][i] : 0.0f, acc);
+        if (in[i]) d[threadIdx.x + kBlock * i] = zv[i] > 0.0f ? acc : 0.0f;
+    }
+}
+
 }  // namespace
 
 EE_API int ee_ce_f32(const float *logits, const int64_t *labels, int B, int K, float smoothing, float gscale, double *row_loss,
@@ -331,7 +388,10 @@ EE_API int ee_fc_ce_grad_f32(const float *z1, const float *w2, const float *b2, 
     if (K > kFcMaxK || Hd > kFcMaxH) return EE_ERR_UNSUPPORTED;
     if (B == 0) return EE_OK;
     if (!z1 || !w2 || !labels || !dz1) return EE_ERR_NULL;
-    EE_LAUNCH(fc_ce_grad_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), (static_cast<size_t>(Hd) + 2 * kFcMaxK) * sizeof(float), as_stream(stream), z1, w2,
-              b2, labels, Hd, K, gscale, dz1, logits_out);
+    if (K <= 16 && Hd <= 4 * kBlock)
+        EE_LAUNCH(fc_ce_grad_small_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, as_stream(stream), z1, w2, b2, labels, Hd, K, gscale, dz1, logits_out);
+    else
+        EE_LAUNCH(fc_ce_grad_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), (static_cast<size_t>(Hd) + 2 * kFcMaxK) * sizeof(float), as_stream(stream), z1, w2,
+                  b2, labels, Hd, K, gscale, dz1, logits_out);
     return launch_status();
 }

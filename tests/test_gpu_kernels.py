@@ -1012,7 +1012,7 @@ def test_conv3x3_stride2_small_maps_match_aten(ops, monkeypatch, B, Cin, Cout, H
             w.mul_(1.25)
 
 
-@pytest.mark.parametrize("B,Hd,K,reduction", [(50, 1024, 10, "sum"), (7, 1024, 10, "mean"), (3, 100, 64, "sum"), (1, 33, 2, "mean")])
+@pytest.mark.parametrize("B,Hd,K,reduction", [(50, 1024, 10, "sum"), (7, 1024, 10, "mean"), (3, 100, 64, "sum"), (1, 33, 2, "mean"), (4, 1500, 10, "sum"), (5, 1000, 16, "mean")])
 def test_fc_ce_grad_matches_autograd(ops, B, Hd, K, reduction):
     """fc2(relu(z1)) + CrossEntropyLoss + both backward steps in one launch (the tail of MNIST's Net_2 inside the attack loop) against
     float64 autograd; logits too; the ReLU gate at exact zeros and NaN as torch's threshold_backward has it."""
