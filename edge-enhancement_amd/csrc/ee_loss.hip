@@ -395,3 +395,4 @@ EE_API int ee_fc_ce_grad_f32(const float *z1, const float *w2, const float *b2, 
                   b2, labels, Hd, K, gscale, dz1, logits_out);
     return launch_status();
 }
+

@@ -44,27 +44,25 @@ class LossSpec:
         raise ValueError(self.kind)
 
 
-# EEADV_FC_HEAD=0: the last two layers + loss of the MNIST classifier as the stock five launches again (A/B)
+# EEADV_FC_HEAD=0: the classifier's head + loss as separate launches again (A/B)
 _FC_HEAD = os.environ.get("EEADV_FC_HEAD", "1") == "1"
 
 
 def _body_input_grad(model, x_in, spec, through_body):
     """d loss / d x_in through model.body (through_body) or the whole model: logits -> loss gradient -> autograd.  Models that expose
-    `body_pre` (the classifier up to the last hidden layer's pre-activation: models.Net_2) get `fc2(relu(.))`, the cross-entropy and both
-    backward steps as ONE launch (ops.fc_ce_grad) instead of five."""
+    `body_pre` / `head_grad` / `head_from_pre` and whose head_grad answers (models.Net_2: from fc1's output on) get the rest of the classifier,
+    the cross-entropy and the way back as ONE launch (ops.fc_ce_grad) instead of five; the ResNets' head_grad declines (measured slower)."""
     pre = getattr(model, "body_pre", None) if _FC_HEAD and (through_body or not hasattr(model, "front_chain")) else None
-    if (pre is not None and spec.kind in (CE_SUM, CE_MEAN) and x_in.is_cuda and type(getattr(model, "fc2", None)) is torch.nn.Linear
-            and model.fc2.weight.dtype == torch.float32):
+    if pre is not None and spec.kind in (CE_SUM, CE_MEAN) and x_in.is_cuda and hasattr(model, "head_grad"):
         with torch.enable_grad():
-            z1 = pre(x_in)
-        if z1.dtype == torch.float32 and ops.fc_ce_grad_supported(z1, model.fc2.weight):
-            dz = ops.fc_ce_grad(z1.detach().contiguous(), model.fc2.weight.detach().contiguous(), model.fc2.bias.detach() if model.fc2.bias is not None else None,
-                                spec.payload, "mean" if spec.kind == CE_MEAN else "sum")
+            z = pre(x_in)
+        dz = model.head_grad(z.detach(), spec.payload, "mean" if spec.kind == CE_MEAN else "sum")
+        if dz is not None:
             with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
-                (g,) = torch.autograd.grad(z1, [x_in], grad_outputs=dz)
+                (g,) = torch.autograd.grad(z, [x_in], grad_outputs=dz)
             return g
         with torch.enable_grad():
-            logits = model.fc2(torch.nn.functional.relu(z1))
+            logits = model.head_from_pre(z)
     else:
         with torch.enable_grad():
             logits = model.body(x_in) if through_body else model(x_in)

@@ -371,7 +371,16 @@ class Net_2(nn.Module):
         self.fc2 = nn.Linear(1024, 10)
 
     def body(self, x):
-        return self.fc2(F.relu(self.body_pre(x)))
+        return self.head_from_pre(self.body_pre(x))
+
+    def head_from_pre(self, z1):
+        return self.fc2(F.relu(z1))
+
+    def head_grad(self, z1, labels, reduction):
+        """d CrossEntropyLoss(head_from_pre(z1), labels) / d z1 in one launch, or None where the fused kernel does not apply"""
+        if type(self.fc2) is nn.Linear and z1.is_cuda and z1.dtype == torch.float32 and self.fc2.weight.dtype == torch.float32 and ops.fc_ce_grad_supported(z1, self.fc2.weight):
+            return ops.fc_ce_grad(z1.contiguous(), self.fc2.weight.detach().contiguous(), None if self.fc2.bias is None else self.fc2.bias.detach(), labels, reduction)
+        return None
 
     def body_pre(self, x):
         """fc1's output, i.e. the body without `fc2(relu(.))`: engine fuses those two layers with the cross-entropy gradient
@@ -518,7 +527,8 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
-    def body(self, x):
+    def body_pre(self, x):
+        """the classifier up to the last block's output (engine fuses the head with the cross-entropy gradient inside the attack loop)"""
         # every block output but the last feeds two consumers (the next block's convolution and its identity branch): forked outputs
         x, moments = stem_conv(self.conv1, x, want_stats=True)  # the convolution's epilogue collects bn1's batch statistics
         x = stem_bn_pool(self.bn1, self.maxpool, x, fork=True, conv_stats=moments)
@@ -526,7 +536,19 @@ class ResNet(nn.Module):
         for i, blk in enumerate(blocks):
             x = blk(x, fork=i + 1 < len(blocks))
         _bump_bn_counters(self)
-        return head(self.avgpool, self.fc, x)
+        return x
+
+    def body(self, x):
+        return self.head_from_pre(self.body_pre(x))
+
+    def head_from_pre(self, feat):
+        return head(self.avgpool, self.fc, feat)
+
+    def head_grad(self, feat, labels, reduction):
+        """no fused head for the ResNets: pool + fc + cross-entropy + both backward steps as ONE launch (one workgroup per image, 100 workgroups)
+        was built and measured 1.5 % SLOWER end to end than ee_head.hip's forward, the loss kernel and ee_head.hip's backward (400 / 25 / 200
+        workgroups, 21 us together) - engine falls back to head_from_pre"""
+        return None
 
     def forward(self, x):
         return self.body(x)
