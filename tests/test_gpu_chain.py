@@ -194,6 +194,37 @@ def test_engine_uses_the_chain_and_matches_the_manual_path(monkeypatch):
     assert np.array_equal(a[1, :, 24:36, 12:26], x.cpu().numpy()[1, :, 24:36, 12:26])  # NaN gradient inside the flat patch: no update
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_whole_attack_is_reproducible_bit_for_bit(train):
+    """PGD-10 on resnet18_EE_square (the bench's model, graph replays + one eager probe iteration) twice from the same iterate and the same
+    Philox state: no kernel of an iteration is MIOpen's any more (whose backward-data used atomics: two runs of the stock network differ,
+    profiles/round2_c_stock_miopen_nondeterminism.txt), every reduction here runs in a fixed order, so the adversarial batch comes out
+    IDENTICAL - eval mode and train mode (batch-statistics BatchNorm, as the reference's attack runs it)."""
+    from eeadv import engine, models, runtime
+    torch.manual_seed(5)
+    m = models.make_resnet_ee(18, "tiny", True, cize=64, r=8, w=1.0, with_gf=False, low=38.0, high=76.0, alpha=0.0, sigma=1.0,
+                              type_canny="CannyFilter_step125_1", epsilon=16 / 255, n_queries=1).to(DEV)
+    m.train(train)
+    x = torch.rand(20, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 200, (20,), device=DEV)
+    spec = engine.LossSpec(engine.CE_SUM, y)
+    runs = []
+    runtime.reseed()
+    torch.manual_seed(9)
+    state = runtime.draw_state(x.device)
+    saved = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    engine.pgd_loop(m, x, x.clone(), spec, 10, 2 / 255, 16 / 255, use_graph=True)  # builds the graph (its warm-up passes draw too)
+    state0 = state.clone()
+    for _ in range(2):
+        state.copy_(state0)  # the same Add_Square draws
+        live = m.state_dict()
+        for k, v in saved.items():  # the same BatchNorm buffers
+            live[k].data.copy_(v)
+        runs.append(engine.pgd_loop(m, x, x.clone(), spec, 10, 2 / 255, 16 / 255, use_graph=True).clone())
+    assert float((runs[0] - x).abs().max()) > 1e-3
+    assert torch.equal(runs[0], runs[1])
+
+
 @pytest.mark.parametrize("H,W,r,C,B", [(224, 224, 16, 3, 4), (64, 64, 8, 3, 5), (28, 28, 4, 1, 3), (7, 9, 2, 2, 3), (96, 128, 12, 1, 2), (256, 256, 16, 1, 2),
                                        (50, 70, 6, 2, 2)])
 def test_band_lowpass_kernel_vs_float64_operator_UNPINNED(ops, H, W, r, C, B):
