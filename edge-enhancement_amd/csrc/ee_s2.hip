@@ -493,9 +493,9 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     }
 }
 
-// 16 MT result channels per workgroup.  B = 100, un-profiled us, MT = 2 / 1: forward 8x8 18.6 / 23.9, 4x4 21.6 / 22.0; backward-data 8x8
-// 19.6 / 18.0, 4x4 35.2 / 27.4 (104 workgroups at MT = 2).  EEADV_S2_MT = six digits (forward 16x16, 8x8, 4x4, backward 16x16, 8x8,
-// 4x4) overrides, for A/B runs.
+// 16 MT result channels per workgroup.  B = 100, un-profiled us (scripts/s2_probe.py), MT = 2 / 1: forward 16x16 20.2 / 22.7, 8x8 17.2 / 22.3,
+// 4x4 18.1 / 19.7; backward-data 16x16 20.2 / 18.6, 8x8 16.2 / 15.5, 4x4 27.7 / 18.1 (104 workgroups at MT = 2) -> 2 forward, 1 backward.
+// EEADV_S2_MT = six digits (forward 16x16, 8x8, 4x4, backward 16x16, 8x8, 4x4) overrides, for A/B runs.
 int s2_mt(bool bwd, int H) {
     const char *env = std::getenv("EEADV_S2_MT");  // read per call (tests flip it)
     const int slot = (bwd ? 3 : 0) + (H == 16 ? 0 : (H == 8 ? 1 : 2));
