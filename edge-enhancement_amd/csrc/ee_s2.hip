@@ -109,7 +109,7 @@ constexpr int S2_XS = 9 * 4 * 2 * 64;  // forward: a round's inputs [tap][quad][
 // DS: the block's shortcut Conv2d(1x1, stride 2) of the SAME input (resnet.py:137-142) rides along as a tenth tap - its B operand is the centre
 // tap's plane - into accumulators of its own -> y1
 template <int H, int MT, bool DS>
-__global__ __launch_bounds__(S2_NT) void conv3s2_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w9, float *__restrict__ y,
+__global__ __launch_bounds__(S2_NT, 4) void conv3s2_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w9, float *__restrict__ y,
                                                                  float *__restrict__ y1, S2Dims d) {
     using G = S2Geo<H>;
     constexpr int OH = G::OH, PX = G::PX, IMG = G::IMG, TAPS = DS ? 10 : 9;
