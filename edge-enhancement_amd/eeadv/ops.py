@@ -5,7 +5,6 @@ must never reach a kernel), and enqueues ONE library call on torch's current HIP
 computes on the CPU and nothing falls back to torch ops: a CPU tensor raises.
 """
 import ctypes
-import math
 
 import numpy as np
 import torch
