@@ -469,7 +469,9 @@ class targeted_ALP(ALP):  # attacks.py:276-333 (PGD_Linf and loss are textual co
 def free_at_repeat(model, criterion, optimizer, x, y, noise, fgsm_step, clip_eps, want_grad=False):
     """One repeat of the free-AT inner loop, ImageNet/free_imagenet/AT_free_imagenet_ddp.py:287-309, on the persistent
     buffer `noise` (updated in place on its first len(x) rows; the clamp covers the WHOLE buffer, :307).
-    Returns (loss, output).  PARITY UNPINNED: the script cannot be imported (argv + process group at import)."""
+    Returns (loss, output).  PINNED since round 3: tests/golden/freeat.npz holds a run of the reference's own train()
+    (the FunctionDef compiled from the parsed script, tests/golden/make_golden.py section 11); tests/test_oracle_golden.py
+    requires this function to reproduce its buffer, logits, gradients and weights bit for bit after every repeat."""
     n = x.size(0)
     noise_batch = noise[0:n].clone().requires_grad_(True)  # Variable(global_noise_data[0:n], requires_grad=True)
     in1 = x + noise_batch

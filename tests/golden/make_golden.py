@@ -680,6 +680,94 @@ def gen_add_square():
     save("add_square", **out)
 
 
+# --------------------------------------------------------------------------
+# 11. free-AT (ImageNet/free_imagenet/AT_free_imagenet_ddp.py:263-309): the reference's own train()
+# --------------------------------------------------------------------------
+class TinyBNNet(nn.Module):
+    """TinyNet with a train-mode BatchNorm between the convolution and the ReLU (free-AT keeps model.train(), :277)."""
+
+    def __init__(self, cin, hw, ncls, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w1 = nn.Parameter(torch.randn(8, cin, 3, 3, generator=g) * 0.5)
+        self.bn = nn.BatchNorm2d(8)
+        self.w2 = nn.Parameter(torch.randn(ncls, 8 * (hw // 2) * (hw // 2), generator=g) * 0.2)
+
+    def forward(self, x):
+        h = F.relu(self.bn(F.conv2d(x, self.w1, padding=1)))
+        h = F.avg_pool2d(h, 2)
+        return F.linear(h.flatten(1), self.w2)
+
+
+def _reference_free_at_train(ns):
+    """The script cannot be imported: it parses argv, asks `managpu` for GPUs and imports a name that does not exist
+    (`from utils.core import PGD`, :16) at module level.  Its train() (:263-309) is self-contained, so ONLY that FunctionDef
+    is taken from the parsed source and compiled, unmodified, in a namespace holding what it reads: `args`, the module-level
+    `global_noise_data` (:261), `Variable`, `time`, and AverageMeter / accuracy of the reference's own utils/helper.py."""
+    import ast
+    path = os.path.join(REF, "ImageNet", "free_imagenet", "AT_free_imagenet_ddp.py")
+    tree = ast.parse(open(path).read(), path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "train"]
+    assert len(fn) == 1 and (fn[0].lineno, fn[0].end_lineno) == (263, 324), (fn[0].lineno, fn[0].end_lineno)
+    mod = ast.Module(body=fn, type_ignores=[])
+    exec(compile(mod, path, "exec"), ns)
+    return ns["train"]
+
+
+def gen_free_at():
+    import time
+    from torch.autograd import Variable
+    sys.modules.setdefault("easydict", types.ModuleType("easydict")).EasyDict = dict  # utils/helper.py:9, never called here
+    import utils.helper as rhelper
+    out = {}
+    B, C, HW, K = 3, 2, 8, 10
+    a = e = 4.0 / 255  # AT_free_imagenet_ddp.py:130-131 with the defaults of :91-99
+    for tag, net_cls, seed in (("plain", TinyNet, 3), ("bn", TinyBNNet, 4)):
+        torch.manual_seed(700 + seed)
+        batches = []
+        for b in range(2):
+            x = torch.rand(B, C, HW, HW)
+            x[0, 0, 0, :2] = torch.tensor([0.0, 1.0])  # x + delta leaves [0, 1] here: the in-place clamp masks the gradient
+            batches.append((x, torch.randint(0, K, (B,))))
+        batches.append((torch.rand(2, C, HW, HW), torch.randint(0, K, (2,))))  # a short last batch: rows 2.. are only clamped
+        net = net_cls(C, HW, K, seed)
+        rec = Recorder(net)
+        noise0 = torch.zeros(B + 1, C, HW, HW)
+        noise0[B:] = 0.5  # a row beyond every batch: only the buffer-wide clamp_ (:307) touches it
+        ns = {"args": Args(n_repeats=4, fgsm_step=a, clip_eps=e, local_rank=0), "global_noise_data": noise0.clone(),
+              "Variable": Variable, "time": time, "torch": torch, "AverageMeter": rhelper.AverageMeter, "accuracy": rhelper.accuracy}
+        train = _reference_free_at_train(ns)
+        deltas, weights, bn_means = [], [], []
+
+        class RecSGD(torch.optim.SGD):
+            def step(self, closure=None):  # :309, the last statement of a repeat: delta already moved (:306-307)
+                r = super().step(closure)
+                deltas.append(ns["global_noise_data"].clone().numpy())
+                weights.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy())
+                if hasattr(net, "bn"):
+                    bn_means.append(net.bn.running_mean.clone().numpy())
+                return r
+        opt = RecSGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        logits = []
+        fwd = rec.forward
+        rec.forward = lambda x: (lambda z: (logits.append(z.detach().numpy().copy()), z)[1])(fwd(x))
+        train(batches, rec, nn.CrossEntropyLoss(), opt, 0, 1, "cpu", None)
+        assert rec.training and len(deltas) == 12 and len(rec.gs) == 12
+        out[tag + "__noise0"] = noise0.numpy()
+        for b, (x, y) in enumerate(batches):
+            out[tag + "__x%d" % b], out[tag + "__y%d" % b] = x.numpy(), y.numpy()
+        out[tag + "__step_eps"] = np.array([a, e], np.float64)
+        out[tag + "__sgd"] = np.array([0.05, 0.9, 1e-4], np.float64)
+        out[tag + "__deltas"] = np.stack(deltas)          # [12, B+1, C, H, W]: the buffer after every repeat
+        out[tag + "__weights"] = np.stack(weights)        # [12, P]: all parameters after every optimizer.step()
+        for i in range(12):  # in1 of each repeat, the gradient that reached it (dL/din1, BEFORE the clamp mask), the logits
+            out[tag + "__in1_%d" % i], out[tag + "__gin1_%d" % i], out[tag + "__logits_%d" % i] = rec.xs[i], rec.gs[i], logits[i]
+        if bn_means:
+            out[tag + "__bn_running_mean"] = np.stack(bn_means)
+        print("  free_at", tag, "delta range", float(out[tag + "__deltas"][-1][:B].min()), float(out[tag + "__deltas"][-1][:B].max()))
+    save("freeat", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_kernels()
@@ -692,3 +780,4 @@ if __name__ == "__main__":
     gen_targeted()
     gen_linf()
     gen_add_square()
+    gen_free_at()

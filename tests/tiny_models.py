@@ -22,3 +22,19 @@ class TinyNet(nn.Module):
         h = F.relu(F.conv2d(x, self.w1, padding=1))
         h = F.avg_pool2d(h, 2)
         return F.linear(h.flatten(1), self.w2)
+
+
+class TinyBNNet(nn.Module):
+    """TinyNet with a BatchNorm between the convolution and the ReLU (the free-AT fixtures: the loop stays in train mode)."""
+
+    def __init__(self, cin, hw, ncls, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w1 = nn.Parameter(torch.randn(8, cin, 3, 3, generator=g) * 0.5)
+        self.bn = nn.BatchNorm2d(8)
+        self.w2 = nn.Parameter(torch.randn(ncls, 8 * (hw // 2) * (hw // 2), generator=g) * 0.2)
+
+    def forward(self, x):
+        h = F.relu(self.bn(F.conv2d(x, self.w1, padding=1)))
+        h = F.avg_pool2d(h, 2)
+        return F.linear(h.flatten(1), self.w2)
