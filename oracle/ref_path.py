@@ -15,11 +15,12 @@ Parity status
              from the reference itself; Trades.PGD_Linf / PGD_L2, ALP.PGD_Linf, targeted_ALP.{PGD_Linf,tarPGD_Linf}
              (linf_loops.npz: the reference's methods run with their one `torch.randn(.., device='cuda')` drawing on the
              host) and Add_Square (add_square.npz: the reference's forward run with `Tensor.cuda` as the identity, its
-             own draws recorded) - see tests/golden/make_golden.py for the two stand-ins.
+             own draws recorded) - see tests/golden/make_golden.py for the two stand-ins; the free-AT step (freeat.npz, round
+             3: the script cannot be imported - argv, managpu, a missing name at module level - so the `train` FunctionDef alone
+             is compiled from its parsed source and run on the host, make_golden.py section 11).
   unpinned : HighFreqSuppress (torch.rfft is gone; behaviour on the non-Hermitian +-r row restated from
              SURVEY.md a13), get_thin_kernels (needs cv2) and therefore CannyFilter / CannyFilter_BPDA
-             (fixtures in canny_full_unpinned.npz use the derived table below); the free-AT step (the script
-             parses argv and joins a process group at import - restated from its lines 286-309).
+             (fixtures in canny_full_unpinned.npz use the derived table below).
 """
 import math
 
