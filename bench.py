@@ -52,7 +52,14 @@ WORKLOADS = {
                         eps=0.062745098039216, alpha=0.003921568627451, steps=10, lr=0.1, momentum=0.9, wd=2e-4, beta=6.0),
     "mnist_ee_at": dict(arch="Net2_EE_square", method="EE_BPDA3_AT_square", batch=50, shape=(1, 28, 28), classes=10,
                         eps=0.3, alpha=0.01, steps=40, lr=0.1, momentum=0.3, wd=1e-4),
+    # BASELINE config 5: ImageNet/free_imagenet/AT_free_imagenet_ddp.py at its defaults (:41-99) with `-a resnet50`: global batch 256
+    # over 8 ranks = 32 per rank, clip_eps 4/255, fgsm_step 4/255, n_repeats 4, lr 0.1, momentum 0.9, wd 1e-4; SyncBatchNorm at N > 1
+    # (:149).  One step = one batch through its 4 repeats (:286-309): each repeat is forward + CE + backward (weight AND input
+    # gradient) + noise update + SGD step.
+    "imagenet_free_at": dict(arch="resnet50", method="free_AT", batch=32, shape=(3, 224, 224), classes=1000,
+                             eps=4.0 / 255, alpha=4.0 / 255, steps=4, lr=0.1, momentum=0.9, wd=1e-4),
 }
+OTHER_WORKLOADS = ("tiny_trades", "mnist_ee_at", "imagenet_free_at")  # the other BASELINE configs, timed briefly behind the headline one
 
 
 class Args:
@@ -65,6 +72,8 @@ def build_model(cfg, oracle=False):
         from oracle import ref_path as R
         if cfg["arch"] == "resnet18":
             return R.resnet18()
+        if cfg["arch"] == "resnet50":
+            return R.resnet50(num_classes=cfg["classes"], imagenet_pool=True)
         if cfg["arch"] == "resnet18_EE_square":
             front = R.EEFront(64, 3, 8, 1.0, 38.0, 76.0, 0.0, 1.0, "CannyFilter_step125_1", False, True, cfg["eps"], 1)
             return R.EEModel(front, R.resnet18())
@@ -75,6 +84,8 @@ def build_model(cfg, oracle=False):
     from eeadv import models as M
     if cfg["arch"] == "resnet18":
         return M.make_resnet(18, "tiny")
+    if cfg["arch"] == "resnet50":
+        return M.make_resnet(50, "imagenet")
     if cfg["arch"] == "resnet18_EE_square":
         return M.make_resnet_ee(18, "tiny", True, cize=64, r=8, w=1.0, with_gf=False, low=38.0, high=76.0, alpha=0, sigma=1.0,
                                 type_canny="CannyFilter_step125_1", epsilon=cfg["eps"], n_queries=1)
@@ -103,11 +114,12 @@ def host_cores():
     return n
 
 
-def cpu_baseline(cfg, seconds_target=25.0):
-    """The oracle's step on the host cores (cpu_baseline.kind = 'port')."""
+def cpu_baseline(cfg, seconds_target=25.0, threads=None):
+    """The oracle's step on the host cores (cpu_baseline.kind = 'port'): oracle/ref_path.py, pinned to the reference, the same
+    step with torch CPU ops.  threads: default = the cores this process may use (cgroup quota)."""
     import torch.nn.functional as F
     from oracle import ref_path as R
-    threads = host_cores()
+    threads = threads or host_cores()
     torch.set_num_threads(threads)
     torch.manual_seed(1)
     model = build_model(cfg, oracle=True).train()
@@ -116,8 +128,13 @@ def cpu_baseline(cfg, seconds_target=25.0):
     x = torch.rand(B, *cfg["shape"])
     y = torch.randint(0, cfg["classes"], (B,))
     args = Args(random=True, epsilon=cfg["eps"])
+    noise = torch.zeros(B, *cfg["shape"]) if cfg["method"] == "free_AT" else None
 
     def step():
+        if cfg["method"] == "free_AT":
+            for _ in range(cfg["steps"]):
+                R.free_at_repeat(model, F.cross_entropy, opt, x, y, noise, cfg["alpha"], cfg["eps"])
+            return
         if cfg["method"] == "TRADES":
             tr = R.Trades(cfg["alpha"], cfg["eps"], cfg["steps"], cfg["beta"])
             preds = model(x)
@@ -132,15 +149,116 @@ def cpu_baseline(cfg, seconds_target=25.0):
         opt.step()
 
     t0 = time.perf_counter()
-    step()  # warm-up (also sizes the sample)
-    warm = time.perf_counter() - t0
+    if cfg["method"] == "free_AT":  # a whole step is ~20 s on 16 cores: one repeat warms up
+        R.free_at_repeat(model, F.cross_entropy, opt, x, y, noise, cfg["alpha"], cfg["eps"])
+        warm = (time.perf_counter() - t0) * cfg["steps"]
+    else:
+        step()  # warm-up (also sizes the sample)
+        warm = time.perf_counter() - t0
     n = max(1, min(40, int(seconds_target / max(warm, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(n):
         step()
     dt = time.perf_counter() - t0
     return {"value": round(B * n / dt, 2), "unit": "adversarial images/s", "cores": threads, "kind": "port",
-            "sample": "%d training steps of batch %d (after 1 warm-up step), %.1f s, torch CPU ops, %d threads" % (n, B, dt, threads)}
+            "sample": "%d training steps of batch %d (after a warm-up), %.1f s, torch CPU ops, %d threads" % (n, B, dt, threads)}
+
+
+class Job:
+    """One workload on this rank: model, optimiser, gradient exchange, resident synthetic batches, and `step(i)` = one step of the
+    reference's train() loop for that config (trainer.train_batch; free-AT: trainer.free_at_repeat x n_repeats)."""
+
+    def __init__(self, name, cfg, dev, world, rank, channels_last=False):
+        from utils.helper import set_seed
+        from eeadv import ddp, trainer
+        self.name, self.cfg, self.dev, self.world = name, cfg, dev, world
+        set_seed(1 + rank)  # experiments_imagenet.py:61: seed + rank
+        model = build_model(cfg).to(dev).train()
+        if channels_last:
+            model = model.to(memory_format=torch.channels_last)
+        self.free_at = cfg["method"] == "free_AT"
+        if self.free_at and world > 1:  # AT_free_imagenet_ddp.py:149
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        self.model = model
+        self.optimizer = trainer.make_sgd(model.parameters(), lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"])
+        # N > 1: one flat gradient buffer all-reduced over RCCL between the captured halves of the update (eeadv.ddp.FlatGradSync);
+        # the attack needs no collective at all.  EEADV_GRAD_SYNC=ddp: DistributedDataParallel + the eager update instead.
+        self.sync, self.run_model = None, model
+        if world > 1:
+            if ddp.grad_sync_mode() == "ddp":
+                self.run_model = ddp.wrap(model, dev)
+            else:
+                self.sync = ddp.FlatGradSync(model)
+        self.dargs = driver_args(cfg)
+        self.criterion = trainer.Criterion() if self.free_at else trainer.make_criterion(self.dargs)
+        B = cfg["batch"]
+        self.batches = [(torch.rand(B, *cfg["shape"], device=dev), torch.randint(0, cfg["classes"], (B,), device=dev)) for _ in range(4)]
+        # :261: the persistent perturbation has GLOBAL-batch rows on every rank; a rank reads and updates its first B rows
+        self.noise = torch.zeros(B * world, *cfg["shape"], device=dev) if self.free_at else None
+        self.free_step = trainer.FreeAtStep(self.run_model, self.criterion, self.optimizer, self.noise, cfg["alpha"], cfg["eps"],
+                                            cfg["steps"], sync=self.sync) if self.free_at else None
+
+    def step(self, i):
+        from eeadv import trainer
+        x, y = self.batches[i % len(self.batches)]
+        if self.free_at:
+            return self.free_step(x, y)
+        return trainer.train_batch(self.run_model, self.criterion, self.optimizer, self.dargs, x, y, self.dev, sync=self.sync)
+
+    def describe(self):
+        cfg = self.cfg
+        if self.free_at:
+            return "%s: %s free-AT, per-rank batch %d x %s, %d repeats per batch, clip_eps %.4f fgsm_step %.4f, each repeat = fwd + bwd (weights and input) + noise update + SGD%s" % (
+                self.name, cfg["arch"], cfg["batch"], "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"],
+                ", SyncBatchNorm + gradient all-reduce (RCCL)" if self.world > 1 else "")
+        return "%s: %s %s, per-rank batch %d x %s, PGD-%d eps %.4f alpha %.4f, train step incl. SGD%s" % (
+            self.name, cfg["arch"], cfg["method"], cfg["batch"], "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"],
+            ", DDP all-reduce (RCCL)" if self.world > 1 else "")
+
+    def grad_sync(self):
+        if self.world == 1:
+            return None
+        if self.sync is None:
+            return "DistributedDataParallel, eager update (EEADV_GRAD_SYNC=ddp)"
+        return "flat %.1f MB in %d pieces, %s" % (self.sync.flat.numel() * 4 / 1e6, len(self.sync.pieces), self.sync.describe())
+
+
+def fence(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def time_other_workload(name, dev, world, rank, steps, warmup):
+    """A short timed run of another BASELINE config behind the headline one (same contract: barrier + synchronize on both sides, max
+    over ranks); returns {"value", "ms_per_step", "steps", "config"}."""
+    from eeadv import engine, trainer
+    cfg = dict(WORKLOADS[name])
+    engine.clear_graphs()
+    trainer.clear_update_graphs()
+    engine.PROBE_ITERS = 0
+    job = Job(name, cfg, dev, world, rank)
+    for i in range(SETUP_STEPS + warmup):
+        job.step(i)
+    fence(world)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = job.step(i)
+    fence(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res = {"value": round(world * cfg["batch"] * steps / dt, 2), "unit": "adversarial images/s", "ms_per_step": round(1e3 * dt / steps, 3),
+           "steps": steps, "warmup": warmup, "final_loss": round(float(last[0].item()), 5),
+           "config": {"workload": job.describe(), "global_batch": world * cfg["batch"], "grad_sync": job.grad_sync()}}
+    del job, last
+    engine.clear_graphs()
+    trainer.clear_update_graphs()
+    torch.cuda.empty_cache()
+    return res
 
 
 SETUP_STEPS = 3
@@ -265,6 +383,9 @@ def main():
                     help="also time the section-8 kernels alone at 16x the batch (off by default: those launches would enter the "
                          "rocprofv3 per-kernel averages of this command, which must agree with `roofline.avg_launch_us`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="time only the headline workload")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each of the other BASELINE configs")
+    ap.add_argument("--extras-timeout", type=int, default=420, help="seconds after which the headline line is printed without the extra legs")
     ap.add_argument("--dry-launch", action="store_true", help="only prove that --gpus N starts N ranks (gloo, no GPU needed)")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-miopen-benchmark", action="store_true",
@@ -292,57 +413,37 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from utils.helper import set_seed
-    from eeadv import engine, ops, trainer, _native as N
+    from eeadv import engine, ops, runtime, trainer, _native as N
 
     os.environ["EEADV_GRAPH"] = "0" if a.no_graph else "1"
     engine.PROBE_ITERS = 0 if a.no_graph else a.probe_iters
-    set_seed(1 + rank)  # experiments_imagenet.py:61: seed + rank
-    model = build_model(cfg).to(dev).train()
-    if a.channels_last:
-        model = model.to(memory_format=torch.channels_last)
-    optimizer = trainer.make_sgd(model.parameters(), lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"])
-    from eeadv import ddp
-    # N > 1: one flat gradient buffer all-reduced over RCCL between the two captured halves of the update (eeadv.ddp.FlatGradSync);
-    # the attack needs no collective at all.  The model is not wrapped: DistributedDataParallel's reducer needs an eager backward
-    run_model = model
-    sync = ddp.FlatGradSync(model) if world > 1 else None
-    dargs = driver_args(cfg)
-    criterion = trainer.make_criterion(dargs)
+    job = Job(a.workload, cfg, dev, world, rank, channels_last=a.channels_last)
+    sync = job.sync
     B = cfg["batch"]
-    batches = [(torch.rand(B, *cfg["shape"], device=dev), torch.randint(0, cfg["classes"], (B,), device=dev)) for _ in range(4)]
-
     probe_iters = engine.PROBE_ITERS
 
     def run(n):
         last = None
         for i in range(n):
-            x, y = batches[i % len(batches)]
             engine.PROBE_ITERS = probe_iters if i % max(1, a.probe_every) == 0 else 0
             if trainer.PHASE_EVENTS is not None:
                 trainer.PHASE_EVENTS.start()
-            last = trainer.train_batch(run_model, criterion, optimizer, dargs, x, y, dev, sync=sync)
+            last = job.step(i)
             ops.prof_mark_empty()  # one empty event bracket per step: the bracket's own cost, measured live
         return last
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     bracket_cost_us = calibrate_bracket(ops, N, cfg, dev)
     run(SETUP_STEPS)  # one-off setup, not warm-up: MIOpen algorithm search and the two HIP-graph captures (the update graph is
-    fence()           # captured on the third step of a configuration) must not land in the timed region when W < 3
+    fence(world)      # captured on the third step of a configuration) must not land in the timed region when W < 3
     run(a.warmup)
-    fence()
+    fence(world)
     ops.prof_reset()
     ops.prof_enable(True)
     if world > 1:
         trainer.PHASE_EVENTS = trainer.PhaseEvents()  # per-rank device time of attack / backward / all-reduce / SGD
     t0 = time.perf_counter()
     last = run(a.steps)
-    fence()
+    fence(world)
     dt = time.perf_counter() - t0
     ops.prof_enable(False)
     phases = trainer.PHASE_EVENTS.summary() if trainer.PHASE_EVENTS is not None else None
@@ -352,6 +453,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(last[0].item())
+    workload_text, grad_sync_text = job.describe(), job.grad_sync()
+    non_default_switches = runtime.non_default_switches()
 
     if rank == 0:
         C, H, W = cfg["shape"]
@@ -446,16 +549,14 @@ def main():
         # the largest HBM-bound family as well (the fused front end), when a matrix-core family dominates
         roofline_hbm = roofline_of(dom_hbm) if dom_hbm != dom else None
         out = {
-            "metric": "adversarial images/sec (PGD-%d, %s)" % (cfg["steps"], cfg["arch"]),
+            "metric": "adversarial images/sec (%s, %s)" % ("free-AT x%d" % cfg["steps"] if cfg["method"] == "free_AT" else "PGD-%d" % cfg["steps"], cfg["arch"]),
             "value": round(world * B * a.steps / dt, 2), "unit": "adversarial images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s %s, per-rank batch %d x %s, PGD-%d eps %.4f alpha %.4f, train step incl. SGD%s" % (
-                a.workload, cfg["arch"], cfg["method"], B, "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"],
-                ", DDP all-reduce (RCCL)" if world > 1 else ""),
+            "config": {"workload": workload_text,
                 "global_batch": world * B, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-                "backend": dist.get_backend() if world > 1 else None, "grad_sync": None if sync is None else
-                "flat %.1f MB in %d pieces, between the captured backward and the captured SGD step" % (sync.flat.numel() * 4 / 1e6, len(sync.pieces)),
+                "backend": dist.get_backend() if world > 1 else None, "grad_sync": grad_sync_text,
+                "switches": non_default_switches,
                 "rank0_phase_ms": phases, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": probe_iters, "probe_every": a.probe_every,
                 "device": (N.lib.ee_device_name() or b"?").decode()},
             "roofline": roofline, "roofline_front_end": roofline_hbm, "kernels": kernels, "final_loss": round(loss_val, 5),
@@ -465,9 +566,54 @@ def main():
         }
         if world == 1 and a.large_batch:
             out["kernels_large_batch"] = large_batch_kernels(cfg, dev)
+    else:
+        out = None
+
+    # ---- everything below is outside the timed region of the headline workload; the ONE JSON line is printed at the very end, or by
+    # the watchdog if an extra leg does not come back (a collective of a config that has never run on this node must not cost the line)
+    printed = []
+
+    def emit():
+        if rank == 0 and not printed:
+            printed.append(1)
+            print(json.dumps(out), flush=True)
+
+    def watchdog():
+        sys.stderr.write("[bench] the extra workloads did not finish within %d s: printing the headline line without them\n" % a.extras_timeout)
+        if rank == 0:
+            out["other_workloads_error"] = "timed out after %d s" % a.extras_timeout
+        emit()
+        os._exit(0)
+
+    import threading
+    timer = threading.Timer(a.extras_timeout, watchdog)
+    timer.daemon = True
+    timer.start()
+    del job, last
+    others = {}
+    if not a.no_other_workloads and a.workload == "tiny_ee_at":
+        # the other BASELINE configs, ~10 steps each (the free-AT one at every N: it is the DDP config 5; the single-GPU ones at N = 1)
+        for name in OTHER_WORKLOADS:
+            if world > 1 and name != "imagenet_free_at":
+                continue
+            try:
+                others[name] = time_other_workload(name, dev, world, rank, a.other_steps, 2)
+            except Exception as exc:  # noqa: BLE001 - reported on the line, the headline number stands
+                others[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                if world > 1:
+                    break  # ranks may have diverged: no further collectives
+    if rank == 0:
+        if others:
+            out["other_workloads"] = others
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out), flush=True)
+            # all the cores this process may use AND n = 8 (the survey container's count), same step
+            out["cpu_baseline"] = cpu_baseline(cfg, 14.0)
+            if out["cpu_baseline"]["cores"] != 8:
+                out["cpu_baseline_8_threads"] = cpu_baseline(cfg, 10.0, threads=8)
+            if "imagenet_free_at" in others and "error" not in others["imagenet_free_at"]:
+                others["imagenet_free_at"]["cpu_baseline"] = cpu_baseline(dict(WORKLOADS["imagenet_free_at"]), 12.0)
+    timer.cancel()
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

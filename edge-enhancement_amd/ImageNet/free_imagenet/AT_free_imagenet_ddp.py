@@ -105,20 +105,25 @@ def _say(line, log_dir):
             print(line, file=f)
 
 
+_STEPS = {}  # id(model) -> trainer.FreeAtStep (its captured repeat lives across epochs; a new learning rate re-captures)
+
+
 def train(train_loader, net, criterion, optimizer, epoch, args, device, log_dir, noise, sync=None):
     """:263-327."""
     batch_time, data_time, losses, top1, top5 = (AverageMeter() for _ in range(5))
     net.train()
+    step = _STEPS.get(id(net))
+    if step is None or step.noise is not noise or step.optimizer is not optimizer:
+        step = _STEPS[id(net)] = trainer.FreeAtStep(net, criterion, optimizer, noise, args.fgsm_step, args.clip_eps, args.n_repeats, sync=sync)
     end = time.time()
     for i, (input, target) in enumerate(train_loader):
         if args.max_batches is not None and i >= args.max_batches:
             break
         target, input = target.to(device), input.to(device)
         data_time.update(time.time() - end)
-        for _ in range(args.n_repeats):
-            loss, output = trainer.free_at_repeat(net, criterion, optimizer, input, target, noise, args.fgsm_step, args.clip_eps, sync=sync)
-            batch_time.update(time.time() - end)
-            end = time.time()
+        loss, output = step(input, target)  # the n_repeats repeats of :286-309
+        batch_time.update((time.time() - end) / args.n_repeats, args.n_repeats)
+        end = time.time()
         if i % args.print_freq == 0:  # the reference syncs with .item() on every repeat (:296); here only when it prints
             prec1, prec5 = accuracy(output, target, topk=(1, min(5, args.num_classes)))
             losses.update(loss.item(), input.size(0))
@@ -165,13 +170,13 @@ def main(argv=None, parser=None, build=build_model, dirs_of=output_dirs, eval_at
     model = build(args).to(device)
     # SyncBatchNorm issues collectives in every forward: a captured attack graph would have to contain them, which has never run
     # on a multi-GPU node - the PGD evaluation of a multi-rank SyncBatchNorm job therefore runs eagerly unless the user insists
-    if ddp.world() > 1:
-        os.environ.setdefault("EEADV_GRAPH", "0")
+    # one rank: the repeat (trainer.FreeAtStep) and the evaluation attack replay captured HIP graphs, as in the other drivers
+    os.environ.setdefault("EEADV_GRAPH", "0" if ddp.world() > 1 else "1")
     # :149-152: SyncBatchNorm, and instead of DistributedDataParallel one flat gradient buffer all-reduced per repeat (ddp.FlatGradSync)
     if ddp.world() > 1:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-    sync = ddp.FlatGradSync(model) if ddp.world() > 1 else None
-    net = model
+    # (EEADV_GRAD_SYNC=ddp: DistributedDataParallel as in the reference, :151-152)
+    net, sync = ddp.make_grad_sync(model, device, find_unused_parameters=True)
     criterion = trainer.Criterion()
     optimizer = trainer.make_sgd(net.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
     if ddp.rank() == 0:

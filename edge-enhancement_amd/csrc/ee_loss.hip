@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void fc_ce_grad_kernel(const float *__restr
     for (int j = threadIdx.x; j < Hd; j += kBlock) {
         float acc = 0.0f;
         for (int k = 0; k < K; ++k) acc = fmaf(dl[k], w2[static_cast<size_t>(k) * Hd + j], acc);
-        d[j] = z[j] > 0.0f ? acc : 0.0f;  // threshold_backward: the gradient where the input was positive
+        d[j] = (z[j] <= 0.0f) ? 0.0f : acc;  // threshold_backward: zero where the input was <= 0, so a NaN input passes the gradient
     }
 }
 
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void fc_ce_grad_small_kernel(const float *_
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < KM; ++k) acc = fmaf(dl[k], k < K ? w[k][i] : 0.0f, acc);
-        if (in[i]) d[threadIdx.x + kBlock * i] = zv[i] > 0.0f ? acc : 0.0f;
+        if (in[i]) d[threadIdx.x + kBlock * i] = (zv[i] <= 0.0f) ? 0.0f : acc;  // as above: !(z <= 0), NaN included
     }
 }
 

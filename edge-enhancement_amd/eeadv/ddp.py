@@ -65,6 +65,16 @@ def shard_indices(n, r=None, w=None):
     return idx[r:per * w:w]
 
 
+def grad_sync_mode():
+    """EEADV_GRAD_SYNC = flat (default): FlatGradSync below - graph-capturable update, segment-wise all-reduce overlapped with the
+    backward.  ddp: torch's DistributedDataParallel (`wrap`) + the eager update - the stock multi-rank path, kept selectable in every
+    multi-rank entry point (drivers, free-AT scripts, bench.py) as the known-good reference for FlatGradSync."""
+    mode = os.environ.get("EEADV_GRAD_SYNC", "flat").lower()
+    if mode not in ("flat", "ddp"):
+        raise ValueError("EEADV_GRAD_SYNC must be 'flat' or 'ddp', not %r" % mode)
+    return mode
+
+
 def wrap(model, device=None, sync_bn=False, bucket_cap_mb=16, find_unused_parameters=False):
     """DistributedDataParallel around `model` (identity when world == 1).  SyncBatchNorm only where the
     reference converts (its ImageNet scripts, experiments_imagenet.py:125); the Tiny / MNIST configs keep
@@ -85,55 +95,131 @@ class FlatGradSync:
 
       * every parameter's .grad is a view into ONE flat fp32 buffer (45.1 MB for ResNet-18/200, 102 MB for ResNet-50/1000);
         backward accumulates into the views, `zero_()` is one memset;
-      * `all_reduce_()` sums the buffer over the ranks in `chunks` contiguous pieces (async, on RCCL's stream; the caller's
-        stream waits on the device, the host does not block) - pieces >= 8 MB keep every xGMI peer link busy (SURVEY 5.8);
-        the 1 / world scaling is ONE pass over the buffer, done where the caller wants it (`scale_()`, captured with the SGD step);
-      * parameters are broadcast from rank 0 once, buffers (BatchNorm statistics) on request - DistributedDataParallel
-        broadcasts rank 0's buffers before every forward, which amounts to "rank 0's running statistics are the model's";
-        `broadcast_buffers()` before a validation pass gives the same statistics.
+      * the buffer is laid out in BACKWARD order: a model that names its segments (`grad_segments()`: parameter lists, the segment
+        whose gradients are complete first comes first - models.ResNet: [layer4 + fc], [layer3], [stem + layer1 + layer2]) gets one
+        contiguous piece per segment, and `start(i)` issues the all-reduce of piece i as soon as the backward of segment i has been
+        enqueued - asynchronous, on RCCL's stream, which waits for the compute stream's work up to that point on the device; the
+        backward of the remaining segments is enqueued behind it on the compute stream and runs meanwhile (trainer._GraphedUpdate
+        replays one captured graph per segment).  layer4 + fc are 76 % of ResNet-18's parameters and their gradients exist after
+        ~15 % of the backward's time, so the bulk of the exchange hides behind the rest of the backward.  `finish()` makes the compute
+        stream wait for all outstanding pieces (the host never blocks).  Models without segments: `chunks` even pieces >= 8 MB
+        (every xGMI peer link busy, SURVEY 5.8), deepest parameters first;
+      * the 1 / world scaling is ONE pass over the buffer, done where the caller wants it (`scale_()`, captured with the SGD step);
+      * parameters and buffers are broadcast from rank 0 once at construction; buffers (BatchNorm statistics) again on request -
+        DistributedDataParallel broadcasts rank 0's buffers before every forward, which amounts to "rank 0's running statistics are
+        the model's"; `broadcast_buffers()` before a validation pass gives the same statistics where they are read in eval mode.
+        Difference that remains: the eval-mode attack INSIDE training of ALP / TRADES on a non-SyncBN model reads rank-local running
+        statistics here, rank 0's under DDP (EEADV_GRAD_SYNC=ddp selects DDP);
+      * a parameter that never receives a gradient keeps .grad = None like under the reference's DDP (SGD then skips it: no weight
+        decay, no momentum): the first backward is watched through post-accumulate hooks, and parameters it did not reach lose their
+        view (`_settle`); their slots in the flat buffer stay zero and travel along.
     ImageNet/experiments_imagenet.py:128-129, free_imagenet/AT_free_imagenet_ddp.py:151-152 (DDP(model)), README.md:21."""
 
     def __init__(self, model, chunks=3, broadcast=True):
         self.model = model
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views, off = [], 0
+        trainable = [p for p in model.parameters() if p.requires_grad]
+        segs = getattr(model, "grad_segments", None)
+        segs = [[p for p in seg if p.requires_grad] for seg in segs()] if segs is not None else None
+        if segs is not None:
+            segs = [seg for seg in segs if seg]
+            seen = {id(p) for seg in segs for p in seg}
+            rest = [p for p in trainable if id(p) not in seen]
+            if rest or len(seen) != sum(len(seg) for seg in segs) or len(seen) > len(trainable):
+                raise ValueError("grad_segments() must partition the trainable parameters (%d left over)" % len(rest))
+            self.params = [p for seg in segs for p in seg]
+        else:
+            self.params = trainable[::-1]  # backward order, roughly: the deepest layer's gradients first in memory
         for p in self.params:
             if p.dtype != torch.float32:
                 raise TypeError("FlatGradSync: fp32 parameters only")
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        dev = self.params[0].device
+        pad = lambda k: (k + 63) // 64 * 64  # every piece starts on a 256-byte boundary
+        if segs is not None:
+            sizes = [sum(p.numel() for p in seg) for seg in segs]
+            starts, n = [], 0
+            for sz in sizes:
+                starts.append(n)
+                n += pad(sz)
+            self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.pieces = [self.flat[st:st + pad(sz)] for st, sz in zip(starts, sizes)]
+            self.views = []
+            for st, seg in zip(starts, segs):
+                off = st
+                for p in seg:
+                    self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+            self.segmented = True
+        else:
+            n = sum(p.numel() for p in self.params)
+            self.flat = torch.zeros(pad(n), dtype=torch.float32, device=dev)
+            self.views, off = [], 0
+            for p in self.params:
+                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            k = max(1, min(int(chunks), (n + (1 << 21) - 1) >> 21))  # never below ~8 MB a piece
+            step = pad((n + k - 1) // k)
+            self.pieces = [self.flat[i:min(i + step, pad(n))] for i in range(0, n, step)]
+            self.segmented = False
         self.world = world() if dist.is_initialized() else 1
         # EEADV_FORCE_COLLECTIVES=1: issue the collectives at world size 1 as well (scripts/ddp_same_gpu.py with RCCL on a
-        # one-GPU box: communicator set-up, the async all-reduce between the two captured graphs, the watchdog next to a capture)
+        # one-GPU box: communicator set-up, the async all-reduce between the captured graphs, the watchdog next to a capture)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("EEADV_FORCE_COLLECTIVES", "0") == "1")
-        # contiguous pieces, element counts rounded to 64 (256 B)
-        k = max(1, min(int(chunks), (n + (1 << 21) - 1) >> 21))  # never below ~8 MB a piece
-        step = ((n + k - 1) // k + 63) // 64 * 64
-        self.pieces = [self.flat[i:min(i + step, n)] for i in range(0, n, step)]
+        self._works = []
+        self._live = [True] * len(self.params)
+        self._touched, self._hooks = set(), []
+        for i, p in enumerate(self.params):
+            self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touched.add(i)))
         self.attach()
         if broadcast and self.active:
             self.broadcast_parameters()
+            self.broadcast_buffers()
+
+    def describe(self):
+        return ("one piece per model segment (%s MB), each all-reduced on RCCL's stream while the backward of the next segment runs; "
+                "SGD graph after the last" % " + ".join("%.1f" % (p.numel() * 4 / 1e6) for p in self.pieces)) if self.segmented else \
+            "all-reduced between the captured backward and the captured SGD step"
+
+    def _settle(self):
+        """After the first backward: parameters it did not reach get .grad = None for good (see the class docstring)."""
+        if not self._hooks:
+            return
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for i, p in enumerate(self.params):
+            if i not in self._touched:
+                self._live[i] = False
+                if p.grad is self.views[i]:
+                    p.grad = None
 
     def attach(self):
         """(Re-)install the views as the parameters' .grad: anything that set them to None (optimizer.zero_grad(), the .loss()
         methods of ALP / TRADES, attacks.py:265-266) is undone; gradient VALUES are not touched."""
-        for p, v in zip(self.params, self.views):
-            if p.grad is not v:
+        for p, v, live in zip(self.params, self.views, self._live):
+            if live and p.grad is not v:
                 p.grad = v
 
     def zero_(self):
         self.attach()
         self.flat.zero_()
 
-    def all_reduce_(self):
+    def start(self, piece=None):
+        """Issue the asynchronous all-reduce of one piece (segment index) or of all of them."""
         if not self.active:
             return
-        works = [dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True) for piece in reversed(self.pieces)]  # deepest layers first
+        todo = self.pieces if piece is None else [self.pieces[piece]]
+        self._works += [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in todo]
+
+    def finish(self):
+        """The current stream waits (on the device) for every piece issued since the last finish()."""
+        self._settle()  # the first whole backward has been through autograd by now
+        works, self._works = self._works, []
         for w in works:
             w.wait()
+
+    def all_reduce_(self):
+        self.start()
+        self.finish()
 
     def scale_(self):
         if self.world > 1:
@@ -154,6 +240,15 @@ class FlatGradSync:
         with torch.no_grad():
             for b in self.model.buffers():
                 dist.broadcast(b, 0)
+
+
+def make_grad_sync(model, device=None, find_unused_parameters=False):
+    """(model to call, FlatGradSync or None) of a multi-rank run per EEADV_GRAD_SYNC (grad_sync_mode); (model, None) at world 1."""
+    if world() == 1:
+        return model, None
+    if grad_sync_mode() == "ddp":
+        return wrap(model, device, find_unused_parameters=find_unused_parameters), None
+    return model, FlatGradSync(model)
 
 
 def gather_mean(*scalars):

@@ -240,8 +240,8 @@ def run(spec, build_model, argv=None):
     # (experiments_imagenet.py:125-129): same averaged gradients, and the update stays capturable as HIP graphs
     if ddp.world() > 1 and spec.get("sync_bn", False):
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-    sync = ddp.FlatGradSync(model) if ddp.world() > 1 else None
-    net = model
+    # (EEADV_GRAD_SYNC=ddp: DistributedDataParallel + the eager update instead - ddp.grad_sync_mode)
+    net, sync = ddp.make_grad_sync(model, device if use_cuda else None)
     if use_cuda:
         torch.backends.cudnn.benchmark = False  # experiments_tinyimagenet.py:111-112
         torch.backends.cudnn.deterministic = True

@@ -551,6 +551,7 @@ def rebuild_dense_weights(model=None):
     items, see prepare_dense_rebuild)."""
     with torch.no_grad():
         groups, single = _rebuild_batches(model)
+        rebuilt = {k for _, ident in groups for k in ident[0]} | set(single)
         for dev, ident in groups:
             if ident not in _WPREP_TABLES and torch.cuda.is_current_stream_capturing():
                 single.extend(ident[0])  # no host-to-device copy of a new table inside a capture: item by item this once
@@ -566,6 +567,17 @@ def rebuild_dense_weights(model=None):
             w, e = _dense_entry_params(ent)
             _fill_rearranged(ent[2], w, ent[3], e)
             ent[1] = _versions(w, e)
+    return rebuilt
+
+
+def invalidate_dense_except(param_ids, keys):
+    """After the REPLAY of a captured optimiser step that ends with rebuild_dense_weights: the replay moved the weights without moving
+    their version counters and rebuilt only the cache entries that existed at capture (`keys`).  Entries of the same parameters
+    (`param_ids`) created later - a first forward at another input size takes another kernel kind - are marked stale here, so that
+    the next refresh_dense_weights() / _dense_weight() rebuilds them instead of trusting an unchanged version counter."""
+    for key, ent in _DENSE_W.items():
+        if key[0] in param_ids and key not in keys:
+            ent[1] = None
 
 
 # EEADV_WPREP_BATCH=1: every item of a model in ONE launch from a device-resident table instead of one launch per (weight, kind).  Measured

@@ -541,6 +541,38 @@ class ResNet(nn.Module):
     def body(self, x):
         return self.head_from_pre(self.body_pre(x))
 
+    # ---- the same forward cut into three pieces at layer boundaries, for the data-parallel update (trainer._GraphedUpdate with a
+    # ddp.FlatGradSync): the backward of each piece is a captured graph of its own, and the all-reduce of a piece's gradients is issued
+    # while the next piece's backward runs.  A piece maps the previous piece's output (a tensor, or the pair of a forked block output)
+    # to its own; together they are exactly forward().
+    def segment_fns(self):
+        def first(x):
+            if hasattr(self, "front"):
+                x = self.front(x)
+            x, moments = stem_conv(self.conv1, x, want_stats=True)
+            x = stem_bn_pool(self.bn1, self.maxpool, x, fork=True, conv_stats=moments)
+            for blk in list(self.layer1) + list(self.layer2):
+                x = blk(x, fork=True)
+            return x
+
+        def middle(x):
+            for blk in self.layer3:
+                x = blk(x, fork=True)
+            return x
+
+        def last(x):
+            blocks = list(self.layer4)
+            for i, blk in enumerate(blocks):
+                x = blk(x, fork=i + 1 < len(blocks))
+            _bump_bn_counters(self)
+            return self.head_from_pre(x)
+        return [first, middle, last]
+
+    def grad_segments(self):
+        """Parameter lists in the order their gradients become complete during backward (ddp.FlatGradSync lays its buffer out so)."""
+        own = lambda *mods: [p for m in mods for p in m.parameters()]
+        return [own(self.layer4, self.fc), own(self.layer3), own(self.conv1, self.bn1, self.layer1, self.layer2)]
+
     def head_from_pre(self, feat):
         return head(self.avgpool, self.fc, feat)
 

@@ -1,4 +1,6 @@
 """Process-wide switches of the host layer."""
+import os
+
 import torch
 
 _CPU_PLUMBING = False
@@ -64,3 +66,9 @@ def capture_mode():
     confines the check to the capturing thread (the launches that get captured are the same)."""
     import torch.distributed as dist
     return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+
+
+def non_default_switches():
+    """Every EEADV_* environment switch that is set in this process, for the bench line's `config.switches`: a number measured with
+    an A/B switch thrown says so.  EEADV_GRAPH is left out (bench.py sets it itself and reports `hip_graph`)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("EEADV_") and k != "EEADV_GRAPH"}

@@ -104,9 +104,17 @@ def _sgd_signature(optimizer):
 
 
 class _GraphedUpdate:
-    """sync = None: forward + loss + backward + SGD as ONE graph.  sync = ddp.FlatGradSync (N > 1): TWO graphs with the gradient
-    all-reduce between them - [forward, loss, memset of the flat gradient, backward] | RCCL all-reduce of the flat buffer in a few
-    pieces | [1 / world scaling, SGD step] - the collective itself is not captured."""
+    """sync = None: forward + loss + backward + SGD as ONE graph.  sync = ddp.FlatGradSync (N > 1): the gradient exchange sits between
+    captured graphs - the collective itself is never captured:
+
+      model without segments:  [forward, loss, memset of the flat gradient, backward] | all-reduce | [1 / world, SGD step]
+      model with segment_fns() (the ResNets: stem..layer2 | layer3 | layer4 + head), round 3:
+        [forward, loss, memset, backward of the LAST segment]   -> all-reduce of its piece starts (76 % of ResNet-18's gradient bytes)
+        [backward of the middle segment]                        -> its piece starts; the first piece is on the wire meanwhile
+        [backward of the first segment]                         -> its piece starts
+        wait for the three pieces (on the device) | [1 / world, SGD step, rebuild of the weight-derived buffers]
+      The forward is cut by detaching at the segment boundaries; the backward of a segment is torch.autograd.backward from its
+      outputs with the gradients the later segment left on the detached copies - the same arithmetic as one backward pass."""
 
     def __init__(self, model, criterion, optimizer, data_adv, target, sync=None):
         self.model, self.criterion, self.optimizer = weakref.ref(model), criterion, weakref.ref(optimizer)
@@ -115,6 +123,9 @@ class _GraphedUpdate:
         self.sync = sync
         self.graph = self.graph2 = None
         self.eager_left = EAGER_UPDATES_BEFORE_CAPTURE
+        self.segmented = (sync is not None and getattr(sync, "segmented", False) and hasattr(model, "segment_fns") and _SEGMENTED
+                          and len(sync.pieces) == len(model.segment_fns()))
+        self.seg_graphs = []
 
     def _fwd_bwd(self):
         model, optimizer = self.model(), self.optimizer()
@@ -127,22 +138,86 @@ class _GraphedUpdate:
         loss.backward()
         return loss.detach(), output.detach()
 
+    # ---- segmented form -------------------------------------------------------------------------------------------------
+    def _seg_first(self):
+        """forward of every segment (detached at the boundaries), loss, memset, backward of the last segment"""
+        fns = self.model().segment_fns()
+        h, self._cuts = self.x, []
+        for fn in fns[:-1]:
+            out = fn(h)
+            outs = out if isinstance(out, tuple) else (out,)
+            det = tuple(o.detach().requires_grad_(True) for o in outs)
+            self._cuts.append((outs, det))
+            h = det if isinstance(out, tuple) else det[0]
+        output = fns[-1](h)
+        loss = self.criterion(output, self.y)
+        self.sync.zero_()
+        loss.backward()
+        return loss.detach(), output.detach()
+
+    def _seg_back(self, i):
+        """backward of segment i from the gradients segment i + 1 left on the detached copies of its outputs"""
+        outs, det = self._cuts[i]
+        pairs = [(o, d.grad) for o, d in zip(outs, det) if d.grad is not None]  # a forked output whose second copy nobody read has none
+        torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+
+    def _seg_body(self):
+        n = len(self.sync.pieces)
+        out = self._seg_first()
+        self.sync.start(0)
+        for k in range(1, n):
+            self._seg_back(n - 1 - k)
+            self.sync.start(k)
+        self.sync.finish()
+        self._step()
+        self._cuts = []
+        return out
+
     def _step(self):
         if self.sync is not None:
             self.sync.scale_()
         self.optimizer().step()
-        if torch.cuda.is_current_stream_capturing():
+        if self.x.is_cuda and torch.cuda.is_current_stream_capturing():
             # a replayed update moves the weights but not their version counters: the weight-derived buffers of
             # functional.Conv3x3Map2Fn are rebuilt by the graph itself, right behind the update
             from eeadv.functional import rebuild_dense_weights
-            rebuild_dense_weights(self.model())
+            self._rebuilt = rebuild_dense_weights(self.model())
+            self._param_ids = {id(p) for p in self.model().parameters()}
 
     def _body(self):
+        if self.segmented:
+            return self._seg_body()
         out = self._fwd_bwd()
         if self.sync is not None:
             self.sync.all_reduce_()
         self._step()
         return out
+
+    def _capture(self):
+        from eeadv.functional import prepare_dense_rebuild
+        prepare_dense_rebuild(self.model())  # the item table of the one-launch rebuild: its upload must not fall into the capture
+        torch.cuda.synchronize()
+        mode = runtime.capture_mode()
+        self.graph = torch.cuda.CUDAGraph()
+        if self.sync is None:
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                self.loss, self.output = self._body()
+            return
+        if self.segmented:
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                self.loss, self.output = self._seg_first()
+            for k in range(1, len(self.sync.pieces)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graph.pool(), capture_error_mode=mode):
+                    self._seg_back(len(self.sync.pieces) - 1 - k)
+                self.seg_graphs.append(g)
+        else:
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                self.loss, self.output = self._fwd_bwd()
+        self.sync.all_reduce_()  # the captured backward did not run: this reduces the warm-up's gradients, harmlessly,
+        self.graph2 = torch.cuda.CUDAGraph()  # and keeps every rank's collective count equal
+        with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=mode):
+            self._step()
 
     def __call__(self, data_adv, target):
         self.x.copy_(data_adv)
@@ -150,33 +225,38 @@ class _GraphedUpdate:
         if self.eager_left > 0:
             self.eager_left -= 1
             return self._body()
-        from eeadv.functional import prepare_dense_rebuild, refresh_dense_weights
+        from eeadv.functional import refresh_dense_weights
         refresh_dense_weights()  # eager updates since the last forward (version counters moved): before capture AND replay
         if self.graph is None:
-            prepare_dense_rebuild(self.model())  # the item table of the one-launch rebuild: its upload must not fall into the capture
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            if self.sync is None:
-                with torch.cuda.graph(self.graph, capture_error_mode=runtime.capture_mode()):
-                    self.loss, self.output = self._body()
-            else:
-                with torch.cuda.graph(self.graph, capture_error_mode=runtime.capture_mode()):
-                    self.loss, self.output = self._fwd_bwd()
-                self.sync.all_reduce_()  # the captured backward did not run: this reduces the warm-up's gradients, harmlessly,
-                self.graph2 = torch.cuda.CUDAGraph()  # and keeps every rank's collective count equal
-                with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=runtime.capture_mode()):
-                    self._step()
+            self._capture()
         self.graph.replay()
         if self.sync is not None:
+            if self.segmented:
+                self.sync.start(0)
+                for k, g in enumerate(self.seg_graphs, 1):
+                    g.replay()
+                    self.sync.start(k)
+            else:
+                self.sync.start()
             if PHASE_EVENTS is not None:
                 PHASE_EVENTS.mark("backward")
-            self.sync.all_reduce_()
+            self.sync.finish()
             if PHASE_EVENTS is not None:
-                PHASE_EVENTS.mark("all_reduce")
+                PHASE_EVENTS.mark("all_reduce")  # what of the exchange the backward did NOT hide
             self.graph2.replay()
             if PHASE_EVENTS is not None:
                 PHASE_EVENTS.mark("sgd")
+        _mark_stale(self)
         return self.loss.clone(), self.output.clone()
+
+
+def _mark_stale(update):
+    """filter copies that did not exist when `update`'s graph was captured are not rebuilt by its replay (functional.invalidate_dense_except)"""
+    from eeadv.functional import invalidate_dense_except
+    invalidate_dense_except(update._param_ids, update._rebuilt)
+
+
+_SEGMENTED = os.environ.get("EEADV_SEGMENTED_SYNC", "1") == "1"  # 0: one all-reduce after the whole captured backward (round 2's form)
 
 
 class _GraphedPredsUpdate:
@@ -186,13 +266,14 @@ class _GraphedPredsUpdate:
     own and draws its random start eagerly), so the step is TWO captured graphs around it that share one memory pool: the first forward
     (its saved activations stay where the second graph's backward reads them), and everything after the attack.  Eager, these were ~1200
     launches from Python per step behind a replayed attack - 9 ms of host time against 18 ms on the device, close enough for the
-    device to wait on the host between small kernels."""
+    device to wait on the host between small kernels.  With a ddp.FlatGradSync (N > 1, round 3) the second graph ends behind the
+    backward, the flat gradient is all-reduced, and a THIRD graph holds the 1 / world scaling and the SGD step."""
 
-    def __init__(self, model, criterion, optimizer, args, input, target, device):
+    def __init__(self, model, criterion, optimizer, args, input, target, device, sync=None):
         self.model, self.criterion, self.optimizer = weakref.ref(model), criterion, weakref.ref(optimizer)
-        self.args, self.device = args, device
+        self.args, self.device, self.sync = args, device, sync
         self.x, self.y, self.adv = torch.empty_like(input), torch.empty_like(target), torch.empty_like(input)
-        self.g1 = self.g2 = None
+        self.g1 = self.g2 = self.g3 = None
         self.eager_left = EAGER_UPDATES_BEFORE_CAPTURE
 
     def _attack(self, preds):
@@ -203,20 +284,36 @@ class _GraphedPredsUpdate:
             return self.criterion.PGD_Linf(model, self.x, self.y)
         return self.criterion.tarPGD_Linf(model, self.x, self.y, self.device)
 
-    def _after_attack(self, preds):
+    def _loss_backward(self, preds):
         model, optimizer = self.model(), self.optimizer()
         output = model(self.adv)
         if self.args.method_name == 'TRADES':
             loss = self.criterion.loss(model, preds, self.adv, self.y, optimizer)
         else:
             loss = self.criterion.loss(model, preds, output, self.y, optimizer)
-        optimizer.zero_grad(set_to_none=True)
+        if self.sync is None:
+            optimizer.zero_grad(set_to_none=True)
+        else:
+            self.sync.zero_()  # .loss() called optimizer.zero_grad() (attacks.py:265-266, :422-423): the views go back in
         loss.backward()
-        optimizer.step()
-        if torch.cuda.is_current_stream_capturing():
-            from eeadv.functional import rebuild_dense_weights
-            rebuild_dense_weights(model)
         return loss.detach(), output.detach()
+
+    def _step(self):
+        model, optimizer = self.model(), self.optimizer()
+        if self.sync is not None:
+            self.sync.scale_()
+        optimizer.step()
+        if self.x.is_cuda and torch.cuda.is_current_stream_capturing():
+            from eeadv.functional import rebuild_dense_weights
+            self._rebuilt = rebuild_dense_weights(model)
+            self._param_ids = {id(p) for p in model.parameters()}
+
+    def _after_attack(self, preds):
+        out = self._loss_backward(preds)
+        if self.sync is not None:
+            self.sync.all_reduce_()
+        self._step()
+        return out
 
     def __call__(self, input, target):
         model = self.model()
@@ -234,18 +331,39 @@ class _GraphedPredsUpdate:
                 raise RuntimeError("TRADES / ALP step: the model must be in train mode when the step starts (the .loss() methods leave it there)")
             prepare_dense_rebuild(model)
             torch.cuda.synchronize()
+            mode = runtime.capture_mode()
             self.g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g1, capture_error_mode=runtime.capture_mode()):
+            with torch.cuda.graph(self.g1, capture_error_mode=mode):
                 self.preds = model(self.x)
             self.adv.copy_(self._attack(self.preds))  # leaves the model in eval mode, as in the eager step: the second capture starts there
             self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode=runtime.capture_mode()):
-                self.loss, self.output = self._after_attack(self.preds)
+            if self.sync is None:
+                with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode=mode):
+                    self.loss, self.output = self._after_attack(self.preds)
+            else:
+                with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode=mode):
+                    self.loss, self.output = self._loss_backward(self.preds)
+                self.sync.all_reduce_()  # keeps every rank's collective count equal (the captured backward did not run)
+                self.g3 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g3, pool=self.g1.pool(), capture_error_mode=mode):
+                    self._step()
             # the captures recorded the kernels without running them: run the step they stand for
         self.g1.replay()
         self.adv.copy_(self._attack(self.preds))
+        if PHASE_EVENTS is not None:
+            PHASE_EVENTS.mark("attack")
         self.g2.replay()
+        if self.sync is not None:
+            if PHASE_EVENTS is not None:
+                PHASE_EVENTS.mark("backward")
+            self.sync.all_reduce_()
+            if PHASE_EVENTS is not None:
+                PHASE_EVENTS.mark("all_reduce")
+            self.g3.replay()
+            if PHASE_EVENTS is not None:
+                PHASE_EVENTS.mark("sgd")
         model.train()  # where criterion.loss() leaves it
+        _mark_stale(self)
         return self.loss.clone(), self.output.clone()
 
 
@@ -288,7 +406,7 @@ def _graphable_update(model, criterion, optimizer, args, data_adv):
 
 def _graphable_preds_update(model, criterion, optimizer, args, input, sync):
     from eeadv import engine
-    return (engine.graphs_enabled() and input.is_cuda and sync is None and type(optimizer) is torch.optim.SGD and model.training
+    return (engine.graphs_enabled() and input.is_cuda and type(optimizer) is torch.optim.SGD and model.training
             and not isinstance(model, (nn.parallel.DistributedDataParallel, nn.DataParallel)) and _GRAPH_PREDS
             and args.method_name in ('TRADES', 'ALP', 'tarALP'))
 
@@ -324,7 +442,7 @@ def train_batch(model, criterion, optimizer, args, input, target, device, avmixu
         key = ("preds", args.method_name, tuple(input.shape), tuple(target.shape), target.dtype, input.device.index)
         update = slot[3].get(key)
         if update is None:
-            update = slot[3][key] = _GraphedPredsUpdate(model, criterion, optimizer, args, input, target, device)
+            update = slot[3][key] = _GraphedPredsUpdate(model, criterion, optimizer, args, input, target, device, sync)
         return update(input.detach(), target)
     data_adv, preds, new_target = attack_for_training(model, criterion, args, input, target, device, avmixup)
     if PHASE_EVENTS is not None:
@@ -381,14 +499,72 @@ def free_at_repeat(model, criterion, optimizer, input, target, noise, fgsm_step,
         sync.zero_()
     loss.backward()
     if sync is not None:
-        sync.all_reduce_()  # on RCCL's stream; the noise update below runs meanwhile
+        sync.start()  # asynchronous, on RCCL's stream; the noise update below runs on the compute stream meanwhile
     ops.freeat_update_masked_(noise, in1.grad.contiguous(), x, float(fgsm_step), float(clip_eps))
     if sync is not None:
+        sync.finish()  # the compute stream waits for the reduction here (on the device; the host does not block)
         sync.scale_()
     optimizer.step()
     if return_input_grad:  # dL/din1, BEFORE the clamp mask (tests)
         return loss.detach(), output.detach(), in1.grad.detach()
     return loss.detach(), output.detach()
+
+
+class FreeAtStep:
+    """One batch through the `n_repeats` repeats of free adversarial training (AT_free_imagenet_ddp.py:286-309) - the "step" of
+    BASELINE config 5.  With HIP graphs enabled and no collective inside the repeat (one rank: plain BatchNorm, no gradient exchange)
+    ONE repeat - add_clamp, forward, cross-entropy, zero_grad, backward (weight and input gradients), the noise update, the SGD step
+    and the rebuild of the weight-derived filter buffers - is captured after two eager repeats and replayed `n_repeats` times per
+    batch: ResNet-50 at batch 32 is ~1100 launches per repeat, which the host cannot issue as fast as the device runs them.
+    With a gradient exchange (`sync`, N > 1) or SyncBatchNorm the repeats run eagerly through free_at_repeat."""
+
+    def __init__(self, model, criterion, optimizer, noise, fgsm_step, clip_eps, n_repeats, sync=None):
+        self.model, self.criterion, self.optimizer, self.noise = model, criterion, optimizer, noise
+        self.fgsm_step, self.clip_eps, self.n_repeats, self.sync = float(fgsm_step), float(clip_eps), int(n_repeats), sync
+        self.graph, self.sig, self.eager_left = None, None, EAGER_UPDATES_BEFORE_CAPTURE
+
+    def _graphable(self, x):
+        from eeadv import engine
+        m = self.model
+        return (engine.graphs_enabled() and x.is_cuda and self.sync is None and type(self.optimizer) is torch.optim.SGD and m.training
+                and not isinstance(m, (nn.parallel.DistributedDataParallel, nn.DataParallel))
+                and not any(isinstance(k, nn.SyncBatchNorm) for k in m.modules()))
+
+    def _repeat(self, x, y):
+        return free_at_repeat(self.model, self.criterion, self.optimizer, x, y, self.noise, self.fgsm_step, self.clip_eps, sync=self.sync)
+
+    def __call__(self, x, y):
+        if not self._graphable(x):
+            for _ in range(self.n_repeats):
+                out = self._repeat(x, y)
+            return out
+        sig = (_sgd_signature(self.optimizer), tuple(x.shape), tuple(y.shape))
+        if sig != self.sig:  # a new learning rate (adjust_learning_rate_free, once per epoch) or batch shape: a new graph
+            self.sig, self.graph, self.eager_left = sig, None, max(self.eager_left, 1 if self.graph is not None else 0)
+            self.x, self.y = torch.empty_like(x), torch.empty_like(y)
+        self.x.copy_(x)
+        self.y.copy_(y)
+        done = 0
+        while self.eager_left > 0 and done < self.n_repeats:
+            self.eager_left -= 1
+            done += 1
+            out = self._repeat(self.x, self.y)
+        if done == self.n_repeats:
+            return out
+        from eeadv.functional import prepare_dense_rebuild, rebuild_dense_weights, refresh_dense_weights
+        refresh_dense_weights()
+        if self.graph is None:
+            prepare_dense_rebuild(self.model)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode=runtime.capture_mode()):
+                self.loss, self.output = self._repeat(self.x, self.y)
+                self._rebuilt = rebuild_dense_weights(self.model)
+                self._param_ids = {id(p) for p in self.model.parameters()}
+        for _ in range(self.n_repeats - done):
+            self.graph.replay()
+        _mark_stale(self)
+        return self.loss.clone(), self.output.clone()
 
 
 def attack_for_validation(model, args, input, target, device, num_steps, step_size, n_class):

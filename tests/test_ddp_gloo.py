@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from tiny_models import Args, TinyNet
+from tiny_models import Args, TinyNet, TinySegNet
 
 
 def _free_port():
@@ -120,7 +120,8 @@ def _flat_worker(rank, world, port, out_dir):
     torch.manual_seed(rank)  # DIFFERENT initial weights: FlatGradSync must broadcast rank 0's
     model = TinyNet(2, 8, 10, 7 + rank)
     sync = ddp.FlatGradSync(model, chunks=3)
-    assert all(p.grad is v for p, v in zip(sync.params, sync.views)) and sync.flat.numel() == sum(p.numel() for p in model.parameters())
+    n_par = sum(p.numel() for p in model.parameters())
+    assert all(p.grad is v for p, v in zip(sync.params, sync.views)) and n_par <= sync.flat.numel() < n_par + 64
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     g = torch.Generator().manual_seed(123)
     X, Y = torch.rand(8, 2, 8, 8, generator=g), torch.randint(0, 10, (8,), generator=g)
@@ -184,3 +185,73 @@ def test_flat_gradient_sync_two_ranks(tmp_path):
             np.testing.assert_allclose(p.detach().numpy(), q.numpy(), rtol=1e-5, atol=1e-6)
     finally:
         runtime.allow_cpu_plumbing(False)
+
+
+def _seg_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "edge-enhancement_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    from eeadv import ddp, runtime, trainer
+    runtime.allow_cpu_plumbing(True)
+    ddp.setup(device="cpu")
+    model = TinySegNet(2, 8, 10, 11 + rank)  # different weights per rank: rank 0's are broadcast
+    model.register_buffer("stat", torch.full((3,), float(rank + 1)))  # buffers too, once, at construction
+    sync = ddp.FlatGradSync(model)
+    assert sync.segmented and len(sync.pieces) == 3 and float(model.stat[0]) == 1.0
+    # the buffer is laid out in backward order, one 256-byte-aligned piece per segment
+    assert [p.numel() for p in sync.pieces] == [(n + 63) // 64 * 64 for n in (model.w3.numel() + 5, model.w2.numel(), model.w1.numel())]
+    assert model.w3.grad.data_ptr() == sync.flat.data_ptr() and model.w1.grad.data_ptr() == sync.pieces[2].data_ptr()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    g = torch.Generator().manual_seed(321)
+    X, Y = torch.rand(8, 2, 8, 8, generator=g), torch.randint(0, 10, (8,), generator=g)
+    idx = ddp.shard_indices(8)
+    x, y = X[idx], Y[idx]
+    crit = trainer.Criterion()
+    issued = []
+    start = sync.start
+    sync.start = lambda piece=None: (issued.append(piece), start(piece))[1]
+    upd = trainer._GraphedUpdate(model, crit, opt, x, y, sync)
+    assert upd.segmented
+    unused0 = model.unused.detach().clone()
+    for step in range(3):  # the eager form of the segmented update (the captured form replays exactly these calls)
+        upd.x.copy_(x)
+        upd.y.copy_(y)
+        loss, out = upd._body()
+        assert model.unused.grad is None  # never reached by a backward: no view, SGD skips it (no weight decay on it)
+    assert issued == [0, 1, 2] * 3  # one all-reduce per segment, each issued right after that segment's backward
+    assert torch.equal(model.unused.detach(), unused0)
+    torch.save({"params": [p.detach().clone() for p in model.parameters()], "loss": float(loss)}, os.path.join(out_dir, "s%d.pt" % rank))
+    ddp.teardown()
+
+
+def test_segmented_gradient_sync_two_ranks(tmp_path):
+    """Round 3: the data-parallel update cut at the model's segment boundaries (trainer._GraphedUpdate with a segmented
+    ddp.FlatGradSync): forward detached at the cuts, backward segment by segment, the all-reduce of a segment's piece issued
+    before the next segment's backward.  Identical parameters on both ranks, equal to ONE process running an ordinary
+    forward / backward per shard and averaging the gradients by hand; an unused parameter keeps grad None."""
+    port = _free_port()
+    mp.spawn(_seg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(str(tmp_path / "s0.pt"), weights_only=False)
+    r1 = torch.load(str(tmp_path / "s1.pt"), weights_only=False)
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    import torch.nn.functional as F
+    net = TinySegNet(2, 8, 10, 11)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    g = torch.Generator().manual_seed(321)
+    X, Y = torch.rand(8, 2, 8, 8, generator=g), torch.randint(0, 10, (8,), generator=g)
+    for step in range(3):
+        grads = []
+        for idx in ([0, 2, 4, 6], [1, 3, 5, 7]):
+            net.zero_grad()
+            F.cross_entropy(net(X[idx]), Y[idx]).backward()
+            grads.append([None if p.grad is None else p.grad.clone() for p in net.parameters()])
+        for p, g0, g1 in zip(net.parameters(), *grads):
+            p.grad = None if g0 is None else (g0 + g1) / 2
+        opt.step()
+    for p, q in zip(net.parameters(), r0["params"]):
+        np.testing.assert_allclose(p.detach().numpy(), q.numpy(), rtol=1e-5, atol=1e-6)
