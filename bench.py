@@ -509,8 +509,8 @@ def main():
         weight = lambda k: kernels[k]["launches_timed"] * kernels[k]["avg_us"]
         # forward and backward-data of one convolution weigh the same to within the run-to-run noise: shares compared at 1 %, the
         # forward family named on a tie, so that the line names the same kernel every run
-        rank = lambda k: (round(weight(k) / tot, 2), k.endswith("_fwd"), weight(k))
-        dom = max(kernels, key=rank) if kernels else None
+        order = lambda k: (round(weight(k) / tot, 2), k.endswith("_fwd"), weight(k))
+        dom = max(kernels, key=order) if kernels else None
         hbm_fams = [k for k in kernels if "bytes" in kernels[k]]
         dom_hbm = max(hbm_fams, key=weight) if hbm_fams else None
 
