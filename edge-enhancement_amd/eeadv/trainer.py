@@ -510,6 +510,32 @@ def free_at_repeat(model, criterion, optimizer, input, target, noise, fgsm_step,
     return loss.detach(), output.detach()
 
 
+def awp_train_batch(model, awp_adversary, criterion, optimizer, args, input, target, epoch, device, l1=0.0):
+    """One step of the AWP train loop (AWP/Tiny_imagenet/experiments_tiny_awp.py:256-286; `awp_adversary`: AdvWeightPerturb of
+    AWP/Tiny_imagenet/models_tiny_awp/utils_awp.py): PGD through the hot path, then - from epoch `args.awp_warmup` on - the weight
+    perturbation computed on a proxy copy is added to the model for the robust forward / backward / SGD step and removed again.
+    Returns (loss, output) detached."""
+    if args.method_name not in ('AT_AWP', 'EE_AT_AWP'):
+        raise NotImplementedError('Wrong method name!')
+    data_adv = A.PGD(model, args, input, target, args.num_steps_1, args.step_size_1)
+    awp = None
+    if epoch >= args.awp_warmup:
+        awp = awp_adversary.calc_awp(inputs_adv=data_adv, targets=target)
+        awp_adversary.perturb(awp)
+    robust_output = model(data_adv)
+    robust_loss = criterion(robust_output, target)
+    if l1:
+        for name, param in model.named_parameters():
+            if 'bn' not in name and 'bias' not in name:
+                robust_loss = robust_loss + l1 * param.abs().sum()
+    optimizer.zero_grad()
+    robust_loss.backward()
+    optimizer.step()
+    if awp is not None:
+        awp_adversary.restore(awp)
+    return robust_loss.detach(), robust_output.detach()
+
+
 class FreeAtStep:
     """One batch through the `n_repeats` repeats of free adversarial training (AT_free_imagenet_ddp.py:286-309) - the "step" of
     BASELINE config 5.  With HIP graphs enabled and no collective inside the repeat (one rank: plain BatchNorm, no gradient exchange)

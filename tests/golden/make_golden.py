@@ -768,6 +768,71 @@ def gen_free_at():
     save("freeat", **out)
 
 
+# --------------------------------------------------------------------------
+# 12. AWP (AWP/Tiny_imagenet/models_tiny_awp/utils_awp.py + the step of experiments_tiny_awp.py:256-286)
+# --------------------------------------------------------------------------
+class TinyModuleNet(nn.Module):
+    """conv (with bias) -> BatchNorm -> ReLU -> avgpool2 -> linear, built from nn modules so that the state_dict keys read
+    `conv.weight`, `bn.weight`, `fc.weight` ...: AWP (utils_awp.py:8-18) perturbs the entries named '*weight*' with more than one dimension."""
+
+    def __init__(self, cin, hw, ncls, seed):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.conv = nn.Conv2d(cin, 8, 3, padding=1)
+        self.bn = nn.BatchNorm2d(8)
+        self.fc = nn.Linear(8 * (hw // 2) * (hw // 2), ncls)
+
+    def forward(self, x):
+        h = F.relu(self.bn(self.conv(x)))
+        return self.fc(F.avg_pool2d(h, 2).flatten(1))
+
+
+def gen_awp():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_utils_awp", os.path.join(REF, "AWP", "Tiny_imagenet", "models_tiny_awp", "utils_awp.py"))
+    rawp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rawp)  # torch only
+    out = {}
+    B, C, HW, K = 4, 2, 8, 10
+    torch.manual_seed(90)
+    x = torch.rand(B, C, HW, HW)
+    y = torch.randint(0, K, (B,))
+    eps, alpha, steps, gamma = 0.062745098039216, 0.007843137254902, 3, 0.01
+    args = Args(random=False, epsilon=eps)
+    net, proxy = TinyModuleNet(C, HW, K, 95), TinyModuleNet(C, HW, K, 96)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=2e-4)
+    proxy_opt = torch.optim.SGD(proxy.parameters(), lr=0.01)  # experiments_tiny_awp.py:118
+    adv = rawp.AdvWeightPerturb(model=net, proxy=proxy, proxy_optim=proxy_opt, gamma=gamma)
+    crit = nn.CrossEntropyLoss()
+    flat = lambda m: torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy().copy()
+    rec = {k: [] for k in ("adv", "diff_w1", "diff_w2", "perturbed", "loss", "logits", "after", "bn_mean")}
+    for step in range(3):  # the loop body of :256-286 with the reference's own PGD and AdvWeightPerturb
+        net.train()
+        data_adv = rattacks.PGD(net, args, x, y, steps, alpha)
+        awp = adv.calc_awp(inputs_adv=data_adv, targets=y)
+        adv.perturb(awp)
+        rec["perturbed"].append(flat(net))
+        robust_output = net(data_adv)
+        robust_loss = crit(robust_output, y)
+        opt.zero_grad()
+        robust_loss.backward()
+        opt.step()
+        adv.restore(awp)
+        assert list(awp.keys()) == ["conv.weight", "fc.weight"]  # bn.weight and the biases are 1-d: skipped (:13-14)
+        rec["adv"].append(data_adv.numpy().copy())
+        rec["diff_w1"].append(awp["conv.weight"].numpy().copy())
+        rec["diff_w2"].append(awp["fc.weight"].numpy().copy())
+        rec["loss"].append(float(robust_loss.detach()))
+        rec["logits"].append(robust_output.detach().numpy().copy())
+        rec["after"].append(flat(net))
+        rec["bn_mean"].append(net.bn.running_mean.numpy().copy())
+    out["x"], out["y"] = x.numpy(), y.numpy()
+    out["cfg"] = np.array([eps, alpha, steps, gamma, 0.1, 0.9, 2e-4, 0.01], np.float64)
+    for k, v in rec.items():
+        out[k] = np.stack(v) if k != "loss" else np.array(v, np.float64)
+    save("awp", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_kernels()
@@ -781,3 +846,4 @@ if __name__ == "__main__":
     gen_linf()
     gen_add_square()
     gen_free_at()
+    gen_awp()

@@ -71,3 +71,19 @@ class TinySegNet(nn.Module):
         for fn in self.segment_fns():
             x = fn(x)
         return x
+
+
+class TinyModuleNet(nn.Module):
+    """conv (with bias) -> BatchNorm -> ReLU -> avgpool2 -> linear, built from nn modules so that the state_dict keys read
+    `conv.weight`, `bn.weight`, `fc.weight` ...: AWP (utils_awp.py:8-18) perturbs the entries named '*weight*' with more than one dimension."""
+
+    def __init__(self, cin, hw, ncls, seed):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.conv = nn.Conv2d(cin, 8, 3, padding=1)
+        self.bn = nn.BatchNorm2d(8)
+        self.fc = nn.Linear(8 * (hw // 2) * (hw // 2), ncls)
+
+    def forward(self, x):
+        h = F.relu(self.bn(self.conv(x)))
+        return self.fc(F.avg_pool2d(h, 2).flatten(1))
