@@ -178,7 +178,7 @@ class Job:
             model = model.to(memory_format=torch.channels_last)
         self.free_at = cfg["method"] == "free_AT"
         if self.free_at and world > 1:  # AT_free_imagenet_ddp.py:149
-            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+            model = ddp.convert_sync_batchnorm(model)
         self.model = model
         self.optimizer = trainer.make_sgd(model.parameters(), lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"])
         # N > 1: one flat gradient buffer all-reduced over RCCL between the captured halves of the update (eeadv.ddp.FlatGradSync);

@@ -1056,6 +1056,121 @@ void launch_bwd(bool relu, hipStream_t st, const float *dy, const float *dy2, co
         EE_LAUNCH((bn_bwd_kernel<NT, VEC, false>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
 }
 
+
+// ---- SyncBatchNorm (ImageNet/experiments_imagenet.py:125, free_imagenet/AT_free_imagenet_ddp.py:149): the batch statistics of a
+// data-parallel run are those of the GLOBAL batch.  Per layer and direction the ranks exchange one small tensor (host side,
+// torch.distributed over RCCL: eeadv/syncbn.py); the kernels here are the local halves around that exchange, built on the split
+// kernels above (any channel size, C x S workgroups):
+//   forward   bn_split_stats_kernel -> bn_moments_kernel: this rank's (mean, M2, count) per channel          -> all_gather
+//             bn_sync_apply_kernel: Chan's merge of the W ranks' moments in RANK ORDER (the same bits on every rank), running
+//             statistics with the global count, y = [relu]((x - mean) * invstd * gamma + beta [+ residual])
+//   backward  bn_split_bwd_partial_kernel -> bn_sums_kernel: this rank's (sum dz, sum dz * xhat) per channel -> all_reduce
+//             bn_sync_bwd_apply_kernel: dx = gamma * invstd * (dz - SUM dz / N - xhat * SUM dz xhat / N) with the global sums and N;
+//             dgamma / dbeta stay this rank's sums (the gradient exchange of the training step averages them like every other
+//             parameter gradient - torch's SyncBatchNorm does the same)
+__global__ __launch_bounds__(64) void bn_moments_kernel(const float *__restrict__ ws, float *__restrict__ moments, BnShape s, int S) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= s.C) return;
+    const int total = s.B * (s.HW / 4);
+    const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
+    float sum = 0.0f;
+    for (int i = 0; i < S; ++i) sum += ws[(static_cast<size_t>(c) * S + i) * 2];
+    const float mean = sum / n;
+    float m2 = 0.0f;
+    for (int i = 0; i < S; ++i) {  // the same recombination, in the same order, as combine_slices
+        const Slice sl = my_slice(total, S, i);
+        const float cnt = 4.0f * static_cast<float>(sl.end - sl.begin);
+        if (cnt > 0.0f) {
+            const float d = ws[(static_cast<size_t>(c) * S + i) * 2] / cnt - mean;
+            m2 += ws[(static_cast<size_t>(c) * S + i) * 2 + 1] + cnt * (d * d);
+        }
+    }
+    moments[3 * c + 0] = mean;
+    moments[3 * c + 1] = m2;
+    moments[3 * c + 2] = n;
+}
+
+__global__ __launch_bounds__(64) void bn_sums_kernel(const float *__restrict__ ws, float *__restrict__ sums, int C, int S) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.0f, b = 0.0f;
+    for (int i = 0; i < S; ++i) {
+        a += ws[(static_cast<size_t>(c) * S + i) * 2];
+        b += ws[(static_cast<size_t>(c) * S + i) * 2 + 1];
+    }
+    sums[2 * c] = a;
+    sums[2 * c + 1] = b;
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(SPLIT_NT) void bn_sync_apply_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, const float *__restrict__ all_moments, int W,
+                                                                 float *running_mean, float *running_var, float momentum, float eps,
+                                                                 float *__restrict__ y, float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                                 BnShape s, int S) {
+    const int c = blockIdx.x, sl_i = blockIdx.y;
+    Moments t{0.0f, 0.0f, 0.0f};
+    for (int r = 0; r < W; ++r) {  // every lane of every workgroup on every rank: the same merge in the same order
+        const float *m = all_moments + (static_cast<size_t>(r) * s.C + c) * 3;
+        t = merge(t, Moments{m[2], m[0], m[1]});
+    }
+    const float var = t.n > 0.0f ? t.m2 / t.n : 0.0f;
+    const float mean = t.mean, invstd = 1.0f / sqrtf(var + eps);
+    if (sl_i == 0 && threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            const float unbiased = (t.n > 1.0f) ? var * (t.n / (t.n - 1.0f)) : var;
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+    const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *r4 = reinterpret_cast<const float4 *>(res);
+    float4 *y4 = reinterpret_cast<float4 *>(y);
+    struct XR {
+        float4 x, r;
+    };
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return XR{x4[o], RES ? r4[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f)}; },
+              [&](XR in, size_t o) {
+        const float4 v = in.x;
+        float4 r = make_float4((v.x - mean) * a + b0, (v.y - mean) * a + b0, (v.z - mean) * a + b0, (v.w - mean) * a + b0);
+        if (RES) {
+            const float4 q = in.r;
+            r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+        }
+        if (RELU) {
+            r.x = relu_nan(r.x); r.y = relu_nan(r.y); r.z = relu_nan(r.z); r.w = relu_nan(r.w);
+        }
+        y4[o] = r;
+    });
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(SPLIT_NT) void bn_sync_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
+                                                                     const float *__restrict__ x, const float *__restrict__ beta, const float *__restrict__ gamma,
+                                                                     const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+                                                                     const float *__restrict__ global_sums, float n_global, float *__restrict__ dx,
+                                                                     float *__restrict__ dres, BnShape s, int S) {
+    const int c = blockIdx.x, sl_i = blockIdx.y;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float w = (gamma ? gamma[c] : 1.0f) * invstd;
+    const float m1 = global_sums[2 * c] / n_global, m2 = global_sums[2 * c + 1] / n_global;
+    const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *y4 = reinterpret_cast<const float4 *>(y), *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *dx4 = reinterpret_cast<float4 *>(dx), *dr4 = reinterpret_cast<float4 *>(dres);
+    const bool want_x = dx != nullptr;
+    const MaskArgs mk = mask_args(y, gamma, beta, invstd, c);
+    for_slice(s, c, my_slice(s.B * (s.HW / 4), S, sl_i), [&](size_t o) { return bwd_load(dy4, reinterpret_cast<const float4 *>(dy2), y4, x4, o, RELU, want_x, mean, mk); }, [&](BwdIn in, size_t o) {
+        const float4 g = masked_dz(in, RELU);
+        if (dres) dr4[o] = g;
+        if (dx) {
+            const float4 v = in.x;
+            dx4[o] = make_float4(w * ((g.x - m1) - ((v.x - mean) * invstd) * m2), w * ((g.y - m1) - ((v.y - mean) * invstd) * m2),
+                                 w * ((g.z - m1) - ((v.z - mean) * invstd) * m2), w * ((g.w - m1) - ((v.w - mean) * invstd) * m2));
+        }
+    });
+}
+
 inline bool al16(const void *q) { return !q || aligned16(q); }
 
 }  // namespace
@@ -1259,3 +1374,91 @@ EE_API int ee_bn_dual_bwd_f32(const float *dy, const float *dy2, const float *y,
     return launch_status();
 }
 
+// ---- SyncBatchNorm: the local halves around the two exchanges (see the kernels above; eeadv/syncbn.py does the collectives) ----------
+// workspace: ee_syncbn_workspace_floats(B, C, HW) floats.  moments [C][3] = (mean, M2, count) of this rank's batch.
+EE_API int ee_syncbn_workspace_floats(int B, int C, int HW) {
+    if (B < 1 || C < 1 || HW < 1 || HW % 4) return 0;
+    return C * split_slices(static_cast<int64_t>(B) * (HW / 4)) * 2;
+}
+
+static int syncbn_check(int B, int C, int HW) {
+    if (B < 1 || C < 1 || HW < 1) return EE_ERR_SHAPE;
+    if (HW % 4) return EE_ERR_UNSUPPORTED;
+    if (static_cast<int64_t>(B) * C * HW / 4 > 0x7fffffffLL) return EE_ERR_SHAPE;
+    return EE_OK;
+}
+
+EE_API int ee_syncbn_stats_f32(const float *x, float *workspace, float *moments, int B, int C, int HW, void *stream) {
+    if (const int e = syncbn_check(B, C, HW)) return e;
+    if (!x || !workspace || !moments) return EE_ERR_NULL;
+    if (!aligned16(x)) return EE_ERR_ALIGN;
+    const BnShape s{B, C, HW};
+    const int S = split_slices(static_cast<int64_t>(B) * (HW / 4));
+    hipStream_t st = as_stream(stream);
+    EE_LAUNCH(bn_split_stats_kernel, dim3(static_cast<unsigned>(C), static_cast<unsigned>(S)), dim3(SPLIT_NT), 0, st, x, workspace, s, S);
+    EE_LAUNCH(bn_moments_kernel, dim3(static_cast<unsigned>((C + 63) / 64)), dim3(64), 0, st, workspace, moments, s, S);
+    return launch_status();
+}
+
+// all_moments [W][C][3]: every rank's moments in rank order (all_gather).  Writes y, save_mean / save_invstd (the GLOBAL batch's) and
+// updates running_* (nullable) with the global count.
+EE_API int ee_syncbn_apply_f32(const float *x, const float *residual, const float *gamma, const float *beta, const float *all_moments, int W,
+                               float *running_mean, float *running_var, float momentum, float eps, int relu, float *y, float *save_mean,
+                               float *save_invstd, int B, int C, int HW, void *stream) {
+    if (const int e = syncbn_check(B, C, HW)) return e;
+    if (W < 1) return EE_ERR_SHAPE;
+    if (!x || !y || !all_moments || !save_mean || !save_invstd) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(y) || !al16(residual)) return EE_ERR_ALIGN;
+    const BnShape s{B, C, HW};
+    const int S = split_slices(static_cast<int64_t>(B) * (HW / 4));
+    const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(S)), block(SPLIT_NT);
+    hipStream_t st = as_stream(stream);
+    if (relu && residual)
+        EE_LAUNCH((bn_sync_apply_kernel<true, true>), grid, block, 0, st, x, residual, gamma, beta, all_moments, W, running_mean, running_var, momentum, eps, y, save_mean, save_invstd, s, S);
+    else if (relu)
+        EE_LAUNCH((bn_sync_apply_kernel<true, false>), grid, block, 0, st, x, residual, gamma, beta, all_moments, W, running_mean, running_var, momentum, eps, y, save_mean, save_invstd, s, S);
+    else if (residual)
+        EE_LAUNCH((bn_sync_apply_kernel<false, true>), grid, block, 0, st, x, residual, gamma, beta, all_moments, W, running_mean, running_var, momentum, eps, y, save_mean, save_invstd, s, S);
+    else
+        EE_LAUNCH((bn_sync_apply_kernel<false, false>), grid, block, 0, st, x, residual, gamma, beta, all_moments, W, running_mean, running_var, momentum, eps, y, save_mean, save_invstd, s, S);
+    return launch_status();
+}
+
+// sums [C][2] = this rank's (sum dz, sum dz * xhat), dz = relu ? (dy + dy2) * (y > 0) : dy + dy2 (dy2, y nullable as in ee_bn_act_bwd2_f32)
+EE_API int ee_syncbn_bwd_sums_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *beta,
+                                  const float *save_mean, const float *save_invstd, int relu, float *workspace, float *sums, int B, int C, int HW,
+                                  void *stream) {
+    if (const int e = syncbn_check(B, C, HW)) return e;
+    if (!dy || !x || !save_mean || !save_invstd || !workspace || !sums) return EE_ERR_NULL;
+    if (!aligned16(dy) || !aligned16(x) || !al16(dy2) || !al16(y)) return EE_ERR_ALIGN;
+    const BnShape s{B, C, HW};
+    const int S = split_slices(static_cast<int64_t>(B) * (HW / 4));
+    const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(S)), block(SPLIT_NT);
+    hipStream_t st = as_stream(stream);
+    if (relu)
+        EE_LAUNCH((bn_split_bwd_partial_kernel<true>), grid, block, 0, st, dy, dy2, y, x, gamma, beta, save_mean, save_invstd, nullptr, nullptr, 0.0f, 1, workspace, s, S);
+    else
+        EE_LAUNCH((bn_split_bwd_partial_kernel<false>), grid, block, 0, st, dy, dy2, y, x, gamma, beta, save_mean, save_invstd, nullptr, nullptr, 0.0f, 1, workspace, s, S);
+    EE_LAUNCH(bn_sums_kernel, dim3(static_cast<unsigned>((C + 63) / 64)), dim3(64), 0, st, workspace, sums, C, S);
+    return launch_status();
+}
+
+// global_sums [C][2]: the all-reduced sums; n_global: elements per channel over all ranks.  dx and / or dresidual (= dz), nullable.
+EE_API int ee_syncbn_bwd_apply_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *beta,
+                                   const float *save_mean, const float *save_invstd, const float *global_sums, double n_global, int relu, float *dx,
+                                   float *dresidual, int B, int C, int HW, void *stream) {
+    if (const int e = syncbn_check(B, C, HW)) return e;
+    if (!dy || !x || !save_mean || !save_invstd || !global_sums) return EE_ERR_NULL;
+    if (!(n_global >= 1.0)) return EE_ERR_SHAPE;
+    if (!aligned16(dy) || !aligned16(x) || !al16(dy2) || !al16(y) || !al16(dx) || !al16(dresidual)) return EE_ERR_ALIGN;
+    if (!dx && !dresidual) return EE_OK;
+    const BnShape s{B, C, HW};
+    const int S = split_slices(static_cast<int64_t>(B) * (HW / 4));
+    const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(S)), block(SPLIT_NT);
+    hipStream_t st = as_stream(stream);
+    if (relu)
+        EE_LAUNCH((bn_sync_bwd_apply_kernel<true>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, global_sums, static_cast<float>(n_global), dx, dresidual, s, S);
+    else
+        EE_LAUNCH((bn_sync_bwd_apply_kernel<false>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, save_mean, save_invstd, global_sums, static_cast<float>(n_global), dx, dresidual, s, S);
+    return launch_status();
+}

@@ -66,6 +66,11 @@ SIGNATURES = {
     "ee_chain_fwd_f32": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_f, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "ee_chain_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
     "ee_bn_workspace_floats": [c_i, c_i, c_i],
+    "ee_syncbn_workspace_floats": [c_i, c_i, c_i],
+    "ee_syncbn_stats_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "ee_syncbn_apply_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "ee_syncbn_bwd_sums_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p],
+    "ee_syncbn_bwd_apply_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_bn_act_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_bn_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_bn_act_bwd2_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],

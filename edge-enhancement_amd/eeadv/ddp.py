@@ -75,6 +75,16 @@ def grad_sync_mode():
     return mode
 
 
+def convert_sync_batchnorm(model):
+    """torch.nn.SyncBatchNorm.convert_sync_batchnorm of the reference's ImageNet scripts (experiments_imagenet.py:125,
+    AT_free_imagenet_ddp.py:149) onto eeadv.syncbn.SyncBatchNorm2d: the fused BatchNorm kernels around one collective per layer and
+    direction.  EEADV_STOCK_SYNCBN=1: torch's own SyncBatchNorm (A/B, and the known-good path)."""
+    if os.environ.get("EEADV_STOCK_SYNCBN", "0") == "1":
+        return torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    from . import syncbn
+    return syncbn.convert_sync_batchnorm(model)
+
+
 def wrap(model, device=None, sync_bn=False, bucket_cap_mb=16, find_unused_parameters=False):
     """DistributedDataParallel around `model` (identity when world == 1).  SyncBatchNorm only where the
     reference converts (its ImageNet scripts, experiments_imagenet.py:125); the Tiny / MNIST configs keep
@@ -82,7 +92,7 @@ def wrap(model, device=None, sync_bn=False, bucket_cap_mb=16, find_unused_parame
     if world() == 1:
         return model
     if sync_bn:
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        model = convert_sync_batchnorm(model)
     ids = [torch.device(device).index] if device is not None and torch.device(device).type == "cuda" else None
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
                                                      find_unused_parameters=find_unused_parameters)

@@ -239,7 +239,7 @@ def run(spec, build_model, argv=None):
     # N > 1: the bare model + one flat gradient buffer all-reduced per step (ddp.FlatGradSync) instead of DistributedDataParallel
     # (experiments_imagenet.py:125-129): same averaged gradients, and the update stays capturable as HIP graphs
     if ddp.world() > 1 and spec.get("sync_bn", False):
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        model = ddp.convert_sync_batchnorm(model)
     # (EEADV_GRAD_SYNC=ddp: DistributedDataParallel + the eager update instead - ddp.grad_sync_mode)
     net, sync = ddp.make_grad_sync(model, device if use_cuda else None)
     if use_cuda:

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_step125_1, HighFreqSuppress, ee_front_end,
                         get_gaussian_kernel)
 
-from . import hfs as _hfs, ops, runtime
+from . import hfs as _hfs, ops, runtime, syncbn as _syncbn
 from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
@@ -49,6 +49,8 @@ def bn_act(bn, x, residual=None, relu=True, fork=False):
             and bn.track_running_stats and (residual is None or (residual.is_contiguous() and residual.dtype == torch.float32))):
         return BnActFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                              0.0 if bn.momentum is None else bn.momentum, bn.eps, bn.training, relu, fork and _FORK)
+    if isinstance(bn, _syncbn.SyncBatchNorm2d):  # multi-rank ImageNet scripts: fused kernels around one collective each way (eeadv.syncbn)
+        return _syncbn.sync_bn_act(bn, x, residual, relu)
     out = bn(x)
     if residual is not None:
         out = out + residual

@@ -591,6 +591,69 @@ def bn_act_bwd(dy, y, x, gamma, save_mean, save_invstd, running_mean, running_va
     return dx, dres, dg, db
 
 
+# ---- SyncBatchNorm: the local halves around the two exchanges (ee_bn.hip; the collectives live in eeadv/syncbn.py) --------------------
+def syncbn_supported(x):
+    return x.dim() >= 3 and x.shape[0] > 0 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and N.lib.ee_syncbn_workspace_floats(
+        x.shape[0], x.shape[1], x[0, 0].numel()) > 0
+
+
+def _syncbn_workspace(x, B, C, HW):
+    return torch.empty(N.lib.ee_syncbn_workspace_floats(B, C, HW), dtype=torch.float32, device=x.device)
+
+
+def syncbn_stats(x):
+    """this rank's (mean, M2, count) per channel: [C, 3]"""
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    moments = torch.empty((C, 3), dtype=torch.float32, device=x.device)
+    ws = _syncbn_workspace(x, B, C, HW)
+    N.check(N.lib.ee_syncbn_stats_f32(_chk(x, torch.float32, "x"), ws.data_ptr(), moments.data_ptr(), B, C, HW, _stream()), "ee_syncbn_stats_f32")
+    return moments
+
+
+def syncbn_apply(x, residual, gamma, beta, all_moments, running_mean, running_var, momentum, eps, relu):
+    """all_moments [W, C, 3] (rank order) -> (y, save_mean, save_invstd) of the global batch; running statistics updated in place"""
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    W = all_moments.shape[0]
+    pm = _chk(all_moments, torch.float32, "all_moments", (W, C, 3))
+    ptr = lambda t: None if t is None else t.data_ptr()
+    y = torch.empty_like(x)
+    sm = torch.empty(C, dtype=torch.float32, device=x.device)
+    si = torch.empty(C, dtype=torch.float32, device=x.device)
+    pr = None if residual is None else _chk(residual, torch.float32, "residual", x.shape)
+    N.check(N.lib.ee_syncbn_apply_f32(_chk(x, torch.float32, "x"), pr, ptr(gamma), ptr(beta), pm, W, ptr(running_mean), ptr(running_var), float(momentum),
+                                      float(eps), 1 if relu else 0, y.data_ptr(), sm.data_ptr(), si.data_ptr(), B, C, HW, _stream()), "ee_syncbn_apply_f32")
+    return y, sm, si
+
+
+def syncbn_bwd_sums(dy, dy2, y, x, gamma, beta, save_mean, save_invstd, relu):
+    """this rank's (sum dz, sum dz * xhat) per channel: [C, 2]"""
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    ptr = lambda t: None if t is None else t.data_ptr()
+    sums = torch.empty((C, 2), dtype=torch.float32, device=x.device)
+    ws = _syncbn_workspace(x, B, C, HW)
+    N.check(N.lib.ee_syncbn_bwd_sums_f32(_chk(dy, torch.float32, "dy", x.shape), None if dy2 is None else _chk(dy2, torch.float32, "dy2", x.shape),
+                                         None if y is None else _chk(y, torch.float32, "y", x.shape), _chk(x, torch.float32, "x"), ptr(gamma), ptr(beta),
+                                         save_mean.data_ptr(), save_invstd.data_ptr(), 1 if relu else 0, ws.data_ptr(), sums.data_ptr(), B, C, HW, _stream()),
+            "ee_syncbn_bwd_sums_f32")
+    return sums
+
+
+def syncbn_bwd_apply(dy, dy2, y, x, gamma, beta, save_mean, save_invstd, global_sums, n_global, relu, want_dx=True, want_dres=False):
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    ptr = lambda t: None if t is None else t.data_ptr()
+    dx = torch.empty_like(x) if want_dx else None
+    dres = torch.empty_like(x) if want_dres else None
+    N.check(N.lib.ee_syncbn_bwd_apply_f32(_chk(dy, torch.float32, "dy", x.shape), None if dy2 is None else _chk(dy2, torch.float32, "dy2", x.shape),
+                                          None if y is None else _chk(y, torch.float32, "y", x.shape), _chk(x, torch.float32, "x"), ptr(gamma), ptr(beta),
+                                          save_mean.data_ptr(), save_invstd.data_ptr(), _chk(global_sums, torch.float32, "global_sums", (C, 2)),
+                                          float(n_global), 1 if relu else 0, ptr(dx), ptr(dres), B, C, HW, _stream()), "ee_syncbn_bwd_apply_f32")
+    return dx, dres
+
+
 def bn_dual_supported(x):
     return x.dim() == 4 and x.shape[0] > 0 and N.lib.ee_bn_dual_supported(x.shape[0], x.shape[1], x[0, 0].numel()) == 1
 

@@ -285,6 +285,29 @@ int ee_bn_act_bwd2_f32(const float *dy, const float *dy2, const float *y, const 
                        int relu, float *dx, float *dresidual, float *dgamma, float *dbeta, float *workspace, int B, int C, int HW,
                        void *stream);
 
+/* SyncBatchNorm (ImageNet/experiments_imagenet.py:125, ImageNet/free_imagenet/AT_free_imagenet_ddp.py:149: the reference converts with
+ * torch.nn.SyncBatchNorm.convert_sync_batchnorm): the LOCAL halves of a BatchNorm whose batch statistics are those of all ranks' batches.
+ * The caller exchanges one small tensor per layer and direction between them (eeadv/syncbn.py over torch.distributed / RCCL):
+ *   forward:  ee_syncbn_stats_f32 -> moments [C][3] = this rank's (mean, M2 about it, element count)   | all_gather -> all_moments [W][C][3]
+ *             ee_syncbn_apply_f32: merges the W ranks' moments in rank order (Chan's update: the same bits on every rank), writes
+ *             save_mean / save_invstd of the global batch, updates running_* (nullable) with the global count (unbiased variance) and
+ *             y = [relu]((x - mean) * invstd * gamma + beta [+ residual])
+ *   backward: ee_syncbn_bwd_sums_f32 -> sums [C][2] = this rank's (sum dz, sum dz * xhat), which are also its dbeta / dgamma | all_reduce
+ *             ee_syncbn_bwd_apply_f32: dx = gamma * invstd * (dz - SUM dz / N - xhat * SUM dz xhat / N) with the global sums, N = n_global;
+ *             dresidual = dz.  dy2 / y nullable as in ee_bn_act_bwd2_f32.
+ * H*W % 4 == 0, 16-byte aligned tensors; workspace: ee_syncbn_workspace_floats(B, C, HW) floats (0 = unsupported shape). */
+int ee_syncbn_workspace_floats(int B, int C, int HW);
+int ee_syncbn_stats_f32(const float *x, float *workspace, float *moments, int B, int C, int HW, void *stream);
+int ee_syncbn_apply_f32(const float *x, const float *residual, const float *gamma, const float *beta, const float *all_moments, int W,
+                        float *running_mean, float *running_var, float momentum, float eps, int relu, float *y, float *save_mean,
+                        float *save_invstd, int B, int C, int HW, void *stream);
+int ee_syncbn_bwd_sums_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *beta,
+                           const float *save_mean, const float *save_invstd, int relu, float *workspace, float *sums, int B, int C, int HW,
+                           void *stream);
+int ee_syncbn_bwd_apply_f32(const float *dy, const float *dy2, const float *y, const float *x, const float *gamma, const float *beta,
+                            const float *save_mean, const float *save_invstd, const float *global_sums, double n_global, int relu, float *dx,
+                            float *dresidual, int B, int C, int HW, void *stream);
+
 /* The end of a residual block with a down-sampling shortcut (resnet.py:54-59 with :137-142): y = relu(bn_a(xa) + bn_b(xb)), bn_a = the
  * block's second BatchNorm on its convolution's output, bn_b = the shortcut's BatchNorm on the 1x1 convolution's output - both per
  * channel, so ONE launch each way instead of two; results bit-identical to ee_bn_act_fwd_f32(xb, relu=0) -> ee_bn_act_fwd_f32(xa,

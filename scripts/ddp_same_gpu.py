@@ -25,6 +25,48 @@ class Args(dict):
     __getattr__ = dict.get
 
 
+def run_config(rank, world, dev, method, segmented, steps=6):
+    """`steps` training steps (two eager updates, the capture, replays) of one configuration from a fixed seed; returns the flat parameters"""
+    trainer._SEGMENTED = segmented
+    trainer.clear_update_graphs()
+    engine.clear_graphs()
+    torch.manual_seed(1 + rank)
+    model = make_resnet_ee(18, "tiny", square=True, cize=64, r=16, w=0.5, low=60.0, high=120.0, alpha=0.0, sigma=1,
+                           type_canny="CannyFilter_step125_1", epsilon=0.05, n_queries=1).to(dev).train()
+    sync = ddp.FlatGradSync(model)  # broadcasts rank 0's weights and buffers (the ranks were seeded differently)
+    opt = trainer.make_sgd(model.parameters(), lr=0.05, momentum=0.9, weight_decay=2e-4)  # what bench.py and the drivers build (torch's fused SGD)
+    args = Args(method_name=method, random=True, epsilon=16 / 255, num_steps_1=4, step_size_1=2 / 255, num_classes=200, beta=6.0)
+    crit = trainer.make_criterion(args)
+    trainer.PHASE_EVENTS = trainer.PhaseEvents()
+    g = torch.Generator(device="cpu").manual_seed(100 + rank)
+    for step in range(steps):
+        x = torch.rand(16, 3, 64, 64, generator=g).to(dev)
+        y = torch.randint(0, 200, (16,), generator=g).to(dev)
+        trainer.PHASE_EVENTS.start()
+        loss, out = trainer.train_batch(model, crit, opt, args, x, y, dev, sync=sync)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss), loss
+    # same initial weights (broadcast) + averaged gradients -> identical parameters on every rank
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    ref = flat.clone()
+    dist.broadcast(ref, 0)
+    diff = float((flat - ref).abs().max())
+    stats = torch.cat([b.detach().flatten().float() for n, b in model.named_buffers() if "running" in n])
+    upd = list(list(trainer._UPDATES.values())[0][3].values())[0]
+    shape = ("%d backward graphs, pieces %s MB" % (1 + len(upd.seg_graphs), [round(p.numel() * 4 / 1e6, 1) for p in sync.pieces])
+             if hasattr(upd, "seg_graphs") else "graphs g1 g2 g3: %s" % [g is not None for g in (upd.g1, upd.g2, upd.g3)])
+    print("rank %d %s segmented=%s: loss %.4f  max |param - rank0 param| = %.3e  attack graphs %d  %s  bn stats finite %s\n   phases (ms): %s" % (
+        rank, method, segmented, float(loss), diff, len(engine._GRAPHS), shape, bool(torch.isfinite(stats).all()), trainer.PHASE_EVENTS.summary()), flush=True)
+    assert diff == 0.0
+    assert len(engine._GRAPHS) >= 1  # the attack replayed a captured graph
+    if hasattr(upd, "seg_graphs"):
+        assert upd.graph2 is not None and len(upd.seg_graphs) == (2 if segmented else 0)
+    else:
+        assert upd.g3 is not None  # TRADES: forward | attack | loss + backward | all-reduce | SGD
+    trainer.PHASE_EVENTS = None
+    return flat
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ["EEADV_GRAPH"] = "1"
@@ -35,35 +77,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.manual_seed(1 + rank)
-    model = make_resnet_ee(18, "tiny", square=True, cize=64, r=16, w=0.5, low=60.0, high=120.0, alpha=0.0, sigma=1,
-                           type_canny="CannyFilter_step125_1", epsilon=0.05, n_queries=1).to(dev).train()
-    sync = ddp.FlatGradSync(model)  # broadcasts rank 0's weights (the ranks were seeded differently)
-    net = model
-    opt = trainer.make_sgd(net.parameters(), lr=0.05, momentum=0.9, weight_decay=2e-4)  # what bench.py and the drivers build (torch's fused SGD)
-    args = Args(method_name="EE_BPDA3_AT_square", random=True, epsilon=16 / 255, num_steps_1=4, step_size_1=2 / 255, num_classes=200)
-    crit = trainer.make_criterion(args)
-    trainer.PHASE_EVENTS = trainer.PhaseEvents()
-    for step in range(6):  # two eager updates, the capture, three replays
-        x = torch.rand(16, 3, 64, 64, device=dev)
-        y = torch.randint(0, 200, (16,), device=dev)
-        trainer.PHASE_EVENTS.start()
-        loss, out = trainer.train_batch(net, crit, opt, args, x, y, dev, sync=sync)
-    torch.cuda.synchronize()
-    assert torch.isfinite(loss), loss
-    # same initial weights (DDP broadcast) + averaged gradients -> identical parameters on every rank
-    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
-    ref = flat.clone()
-    dist.broadcast(ref, 0)
-    diff = float((flat - ref).abs().max())
-    stats = torch.cat([b.detach().flatten().float() for n, b in model.named_buffers() if "running" in n])
-    print("rank %d: loss %.4f  max |param - rank0 param| = %.3e  graphs %d  bn stats finite %s" % (
-        rank, float(loss), diff, len(engine._GRAPHS), bool(torch.isfinite(stats).all())), flush=True)
-    assert diff == 0.0
-    assert len(engine._GRAPHS) == 1  # the attack replayed a captured graph
-    upd = list(trainer._UPDATES.values())[0][3]
-    assert len(upd) == 1 and list(upd.values())[0].graph2 is not None  # ... and the update replayed its two graphs around the all-reduce
-    print("rank %d phases (ms): %s" % (rank, trainer.PHASE_EVENTS.summary()), flush=True)
+    one = run_config(rank, world, dev, "EE_BPDA3_AT_square", segmented=False)
+    seg = run_config(rank, world, dev, "EE_BPDA3_AT_square", segmented=True)
+    # the backward cut at the layer boundaries is the same arithmetic: the two forms agree to the run-to-run noise of MIOpen's weight-gradient kernels
+    rel = float((one - seg).abs().max() / one.abs().max())
+    print("rank %d: segmented vs one-piece update, max relative parameter difference after 6 steps: %.3e" % (rank, rel), flush=True)
+    assert rel < 1e-4, rel
+    run_config(rank, world, dev, "TRADES", segmented=True, steps=5)
     dist.barrier()
     dist.destroy_process_group()
 
