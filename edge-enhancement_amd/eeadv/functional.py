@@ -570,6 +570,14 @@ def rebuild_dense_weights(model=None):
     return rebuilt
 
 
+def invalidate_params(param_ids):
+    """Mark the cached rearranged copies of these parameters stale: for updates that move weights without advancing their version
+    counters (torch's fused SGD - trainer._FusedSGD calls this after every step)."""
+    for key, ent in _DENSE_W.items():
+        if key[0] in param_ids:
+            ent[1] = None
+
+
 def invalidate_dense_except(param_ids, keys):
     """After the REPLAY of a captured optimiser step that ends with rebuild_dense_weights: the replay moved the weights without moving
     their version counters and rebuilt only the cache entries that existed at capture (`keys`).  Entries of the same parameters

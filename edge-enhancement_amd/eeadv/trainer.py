@@ -32,6 +32,24 @@ class Criterion:
 _FUSED_SGD = os.environ.get("EEADV_FUSED_SGD", "1") == "1"  # 0: torch's default (foreach) SGD, five multi-tensor launches per step
 
 
+class _FusedSGD(torch.optim.SGD):
+    """torch.optim.SGD(fused=True) that tells the weight-derived caches about its update.  torch's fused kernel (`_fused_sgd_`) moves the
+    parameters WITHOUT advancing their version counters (measured: `_version` 0 -> 0 across a fused step, 0 -> 1 across the foreach one),
+    and functional._dense_weight decides by version counter whether the rearranged / Winograd-transformed copy of a filter is current:
+    after an eager fused step the hand-written convolutions would keep multiplying by the OLD filters (found in round 3 by comparing
+    two models with equal parameters).  step() therefore marks this optimiser's parameters' cache entries stale; inside a captured
+    update the graph rebuilds them itself (functional.rebuild_dense_weights) and replays mark nothing."""
+
+    def step(self, closure=None):
+        out = super().step(closure)
+        from eeadv.functional import invalidate_params
+        ids = getattr(self, "_param_ids", None)
+        if ids is None:
+            ids = self._param_ids = {id(p) for g in self.param_groups for p in g["params"]}
+        invalidate_params(ids)
+        return out
+
+
 def make_sgd(params, lr, momentum=0.0, weight_decay=0.0):
     """optim.SGD(params, lr, momentum, weight_decay) of the drivers (experiments_tinyimagenet.py:128-129).  On the device the update runs as
     torch's FUSED implementation - weight decay, momentum and the parameter update of all tensors in one launch instead of five
@@ -39,7 +57,7 @@ def make_sgd(params, lr, momentum=0.0, weight_decay=0.0):
     params = list(params)
     if _FUSED_SGD and params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
         try:
-            return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, fused=True)
+            return _FusedSGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, fused=True)
         except (TypeError, RuntimeError):
             pass
     return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
@@ -399,14 +417,14 @@ PHASE_EVENTS = None  # bench.py installs a PhaseEvents for the timed steps of an
 
 def _graphable_update(model, criterion, optimizer, args, data_adv):
     from eeadv import engine
-    return (engine.graphs_enabled() and data_adv.is_cuda and isinstance(criterion, Criterion) and type(optimizer) is torch.optim.SGD
+    return (engine.graphs_enabled() and data_adv.is_cuda and isinstance(criterion, Criterion) and isinstance(optimizer, torch.optim.SGD)
             and not isinstance(model, (nn.parallel.DistributedDataParallel, nn.DataParallel)) and model.training
             and args.method_name not in ('ALP', 'tarALP', 'TRADES', 'AVmixup', 'tarAVmixup'))
 
 
 def _graphable_preds_update(model, criterion, optimizer, args, input, sync):
     from eeadv import engine
-    return (engine.graphs_enabled() and input.is_cuda and type(optimizer) is torch.optim.SGD and model.training
+    return (engine.graphs_enabled() and input.is_cuda and isinstance(optimizer, torch.optim.SGD) and model.training
             and not isinstance(model, (nn.parallel.DistributedDataParallel, nn.DataParallel)) and _GRAPH_PREDS
             and args.method_name in ('TRADES', 'ALP', 'tarALP'))
 
@@ -552,7 +570,7 @@ class FreeAtStep:
     def _graphable(self, x):
         from eeadv import engine
         m = self.model
-        return (engine.graphs_enabled() and x.is_cuda and self.sync is None and type(self.optimizer) is torch.optim.SGD and m.training
+        return (engine.graphs_enabled() and x.is_cuda and self.sync is None and isinstance(self.optimizer, torch.optim.SGD) and m.training
                 and not isinstance(m, (nn.parallel.DistributedDataParallel, nn.DataParallel))
                 and not any(isinstance(k, nn.SyncBatchNorm) for k in m.modules()))
 
