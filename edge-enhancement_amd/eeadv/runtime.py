@@ -40,24 +40,34 @@ def philox_ticket(device, n_elements):
 
 
 _DRAW_STATE = {}
+_DRAW_STALE = set()
 
 
 def draw_state(device):
     """Device-resident {seed, offset, ticket, -} of the in-graph random draws (Add_Square): an int64[4] tensor whose offset the
     drawing kernel advances by itself (ee_square_draw_f32, ee_chain_fwd_f32: the last workgroup to finish, counted by the ticket),
     so that a replayed HIP graph never repeats its numbers.  Seeded from torch's CUDA generator of
-    the device at first use (torch.manual_seed before the first forward governs it); reseed() re-reads the generator."""
+    the device at first use (torch.manual_seed before the first forward governs it); reseed() makes the next use re-read the generator."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _DRAW_STATE.get(idx)
-    if st is None:
+    if st is None or idx in _DRAW_STALE:
+        if torch.cuda.is_current_stream_capturing():
+            if st is None:
+                raise RuntimeError("eeadv.runtime.draw_state: first use inside a graph capture (call it once eagerly, e.g. one eager forward)")
+            return st  # re-seeding waits for the next eager use: the generator cannot be read during a capture
         seed, off = philox_ticket(torch.device("cuda", idx), 4)
-        st = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off, 0, 0], dtype=torch.int64, device=torch.device("cuda", idx))
-        _DRAW_STATE[idx] = st
+        vals = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off, 0, 0], dtype=torch.int64)
+        if st is None:
+            st = _DRAW_STATE[idx] = vals.to(torch.device("cuda", idx))
+        else:
+            st.copy_(vals)  # IN PLACE: captured graphs hold this tensor's address
+        _DRAW_STALE.discard(idx)
     return st
 
 
 def reseed():
-    _DRAW_STATE.clear()
+    """The next draw_state() of every device re-reads torch's CUDA generator (into the SAME tensor: captured graphs keep drawing from it)."""
+    _DRAW_STALE.update(_DRAW_STATE.keys())
 
 
 def capture_mode():

@@ -25,25 +25,30 @@ class Args(dict):
     __getattr__ = dict.get
 
 
-def run_config(rank, world, dev, method, segmented, steps=6):
+def run_config(rank, world, dev, method, segmented, steps=6, batch=16, timed_from=0):
     """`steps` training steps (two eager updates, the capture, replays) of one configuration from a fixed seed; returns the flat parameters"""
     trainer._SEGMENTED = segmented
     trainer.clear_update_graphs()
     engine.clear_graphs()
     torch.manual_seed(1 + rank)
     runtime.reseed()  # the device-resident Philox state of the in-graph draws (Add_Square) restarts from the generator too
+    runtime.draw_state(dev)
     model = make_resnet_ee(18, "tiny", square=True, cize=64, r=16, w=0.5, low=60.0, high=120.0, alpha=0.0, sigma=1,
                            type_canny="CannyFilter_step125_1", epsilon=0.05, n_queries=1).to(dev).train()
     sync = ddp.FlatGradSync(model)  # broadcasts rank 0's weights and buffers (the ranks were seeded differently)
     opt = trainer.make_sgd(model.parameters(), lr=0.05, momentum=0.9, weight_decay=2e-4)  # what bench.py and the drivers build (torch's fused SGD)
     args = Args(method_name=method, random=True, epsilon=16 / 255, num_steps_1=4, step_size_1=2 / 255, num_classes=200, beta=6.0)
     crit = trainer.make_criterion(args)
-    trainer.PHASE_EVENTS = trainer.PhaseEvents()
+    trainer.PHASE_EVENTS = None
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
     for step in range(steps):
-        x = torch.rand(16, 3, 64, 64, generator=g).to(dev)
-        y = torch.randint(0, 200, (16,), generator=g).to(dev)
-        trainer.PHASE_EVENTS.start()
+        x = torch.rand(batch, 3, 64, 64, generator=g).to(dev)
+        y = torch.randint(0, 200, (batch,), generator=g).to(dev)
+        if step == timed_from:  # phase times of the replayed steps only
+            torch.cuda.synchronize()
+            trainer.PHASE_EVENTS = trainer.PhaseEvents()
+        if trainer.PHASE_EVENTS is not None:
+            trainer.PHASE_EVENTS.start()
         loss, out = trainer.train_batch(model, crit, opt, args, x, y, dev, sync=sync)
     torch.cuda.synchronize()
     assert torch.isfinite(loss), loss
@@ -85,6 +90,9 @@ def main():
     print("rank %d: segmented vs one-piece update, max relative parameter difference after 6 steps: %.3e" % (rank, rel), flush=True)
     # (a free-running comparison: six SGD steps at lr 0.05 on batch 16 amplify rounding-level differences; tests/test_gpu_ddp.py compares step by step)
     run_config(rank, world, dev, "TRADES", segmented=True, steps=5)
+    if os.environ.get("DDP_TIMING", "0") == "1":  # what cutting the backward into three graphs + three collectives costs per step (batch 100, replays only)
+        for segmented in (False, True, False, True):
+            run_config(rank, world, dev, "EE_BPDA3_AT_square", segmented=segmented, steps=16, batch=100, timed_from=6)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -58,6 +58,7 @@ def test_segmented_update_equals_the_one_piece_update(monkeypatch, graphs):
         for model, sync, upd in ((ma, sa, ua), (mb, sb, ub)):
             runtime.reseed()
             torch.manual_seed(5 + k)  # the Add_Square draws inside the forward
+            runtime.draw_state(torch.device(DEV))  # re-read now: a capture cannot
             loss, out = upd(x, y)
             res.append((float(loss), _flat(model).clone(), sync.flat.clone(), out.clone()))
         (la, pa, ga, outa), (lb, pb, gb, outb) = res
@@ -86,6 +87,7 @@ def test_filter_caches_follow_an_eager_fused_sgd_step():
     def fwd():
         runtime.reseed()
         torch.manual_seed(4)
+        runtime.draw_state(torch.device(DEV))
         with torch.no_grad():
             return model(x)
     before = fwd()
