@@ -481,11 +481,9 @@ def main():
                 us = max(raw - overhead_us, 0.5)  # event pair cost removed
                 kernels[name] = {"launches_timed": cnt, "avg_us": round(us, 3), "avg_bracket_us": round(raw, 3), "bytes": nbytes,
                                  "GBps": round(nbytes / us / 1e3, 1), "share_of_timed_us": None}
-        # matrix-core families (the residual blocks' 3x3 convolutions, ee_conv.hip): the library sums the floating-point
+        # matrix-core families (the residual blocks' 3x3 convolutions, ee_wino.hip / ee_s2.hip): the library sums the floating-point
         # operations its timed launches declared (2 * 9 * Cin * Cout * B * H * W each), so mixed shapes average correctly
-        mfma_fams = {"ee_conv3x3s1_fwd": N.K_CONV3_FWD, "ee_conv3x3s1_bwd_data": N.K_CONV3_BWD,
-                     "ee_conv3x3s1_pipe_fwd": N.K_CONV3P_FWD, "ee_conv3x3s1_pipe_bwd_data": N.K_CONV3P_BWD, "ee_wino3x3": N.K_WINO,
-                     "ee_conv3x3s2_small_fwd": N.K_CONV3S2_FWD, "ee_conv3x3s2_small_bwd_data": N.K_CONV3S2_BWD}
+        mfma_fams = {"ee_wino3x3": N.K_WINO, "ee_conv3x3s2_small_fwd": N.K_CONV3S2_FWD, "ee_conv3x3s2_small_bwd_data": N.K_CONV3S2_BWD}
         # Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile where the convolution has 36: `flops` stays the convolution's
         # algorithmic count, `executed_flops` = 4/9 of it is what the matrix cores actually do
         executed_share = {"ee_wino3x3": 4.0 / 9.0}

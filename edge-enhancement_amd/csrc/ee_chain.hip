@@ -129,7 +129,6 @@ struct FwdParams {
     unsigned long long *state;    // {seed, offset, ticket, -}: Philox state of the device-side draws, advanced by the last workgroup
     int B, sq_size;
     float eps, two_eps, alpha, high, w;
-    int dbg;  // EEADV_CHAIN_DBG (measurement only): bit 0 skips the edge loop, bit 1 the low-pass, bit 2 combine + stage out
 };
 
 template <int C, int H, int W, bool SQUARE>
@@ -286,7 +285,7 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
 
     if (wave < kSW) {
         // ---- edge filter on 4-pixel groups: ee_edge.hip's arithmetic, whole image in the frame ----------------------------------
-        for (int idx = tid; idx < ((p.dbg & 1) ? 0 : H * W4); idx += kST) {
+        for (int idx = tid; idx < H * W4; idx += kST) {
             const int i = idx / W4, lx = idx - i * W4, jb = 4 * lx;
             float b[C][3][6];
             blur_group<C, FH, FW>(xr, wt, i, jb + kColHalo - 2, i, jb, H, W, b);
@@ -304,7 +303,7 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
             *reinterpret_cast<float4 *>(p.gy + pix) = make_float4(gys[0], gys[1], gys[2], gys[3]);
             if (p.edge) *reinterpret_cast<float4 *>(p.edge + pix) = make_float4(e[0], e[1], e[2], e[3]);
         }
-    } else if (!(p.dbg & 2)) {
+    } else {
         // ---- low-pass of add_square(x), plane c = wave - kSW; the result replaces the plane (this wave is its only reader) -----------
         const int c = wave - kSW, lane = tid & 63, li = lane & 15, lg = lane >> 4;
         float *xc = xs + c * D::HP * D::AS;
@@ -319,7 +318,6 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
                 for (int r = 0; r < 4; ++r) xc[(16 * ht + 4 * lg + r) * D::AS + 16 * wt_ + li] = y[ht][wt_][r];
     }
     __syncthreads();
-    if (p.dbg & 4) return;
 
     // ---- combine + stage out (everybody): x_in = clamp(x_lp + w * e), gate = code | 1[0 <= x_lp + w * e <= 1]; 16 B / 4 B per lane --------
     constexpr int NT = (kSW + C) * kWave;
@@ -350,7 +348,6 @@ struct BwdParams {
     const float *tables;
     float alpha, high, w;       // edge filter / front end
     float step, eps, lo, hi;    // update (step carries the direction's sign)
-    int dbg;                    // EEADV_CHAIN_DBG (measurement only): bit 0 skips stages 3 + 4, bit 1 the low-pass
 };
 
 template <int C, int H, int W>
@@ -458,7 +455,7 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_bwd_kernel(BwdParams 
     if (wave < kSW) {
         // ---- stage 3: gb = pad^T(Sx^T ggx + Sy^T ggy) ------------------------------------------------------------------------------------
 #pragma unroll 1
-        for (int idx = tid; idx < ((p.dbg & 1) ? 0 : NPOS); idx += kST) {
+        for (int idx = tid; idx < NPOS; idx += kST) {
             const int i = idx / W4, jb = 4 * (idx - i * W4);
             float cells[3][6];
 #pragma unroll
@@ -490,7 +487,7 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_bwd_kernel(BwdParams 
         }
         // ---- stage 4: g_edge = pad^T(G^T gb), parked in the (now dead) ggx frame at this thread's own groups -----------------------------
 #pragma unroll 1
-        for (int idx = tid; idx < ((p.dbg & 1) ? 0 : NPOS); idx += kST) {
+        for (int idx = tid; idx < NPOS; idx += kST) {
             const int i = idx / W4, jb = 4 * (idx - i * W4);
             float cells[3][6];
 #pragma unroll
@@ -509,9 +506,9 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_bwd_kernel(BwdParams 
         const int c = wave - kSW, lane = tid & 63, li = lane & 15, lg = lane >> 4;
         float *gc = gh + c * D::HP * D::AS;
         f32x4 y[D::HT][D::WT], ef[2];
-        if (!(p.dbg & 2)) lowpass_front<H, W>(tab, [&](int h, int w) -> float { return gc[h * D::AS + w]; }, ef);
+        lowpass_front<H, W>(tab, [&](int h, int w) -> float { return gc[h * D::AS + w]; }, ef);
         __syncthreads();  // B - in the middle of the chain, so that neither side waits long for the other
-        if (!(p.dbg & 2)) lowpass_back<H, W>(tab, ef, y);
+        lowpass_back<H, W>(tab, ef, y);
 #pragma unroll
         for (int ht = 0; ht < D::HT; ++ht)
 #pragma unroll
@@ -623,14 +620,6 @@ Shape shape_of(int C, int H, int W) {
 
 inline bool al16(const void *q) { return !q || aligned16(q); }
 
-int chain_dbg() {
-    static const int v = [] {
-        const char *e = getenv("EEADV_CHAIN_DBG");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
-
 }  // namespace
 
 EE_API int ee_chain_supported(int C, int H, int W) { return shape_of(C, H, W) != S_NONE; }
@@ -663,7 +652,6 @@ EE_API int ee_chain_fwd_f32(const float *x, int B, int C, int H, int W, const fl
     p.B = B; p.sq_size = sq_size;
     p.eps = eps; p.two_eps = static_cast<float>(2.0 * static_cast<double>(eps));
     p.alpha = alpha; p.high = high; p.w = w;
-    p.dbg = chain_dbg();
     const Weights wt = load_weights(weights27);
     hipStream_t st = as_stream(stream);
     ProfScope prof(EE_K_CHAIN_FWD, st);
@@ -688,7 +676,6 @@ EE_API int ee_chain_bwd_f32(const float *g_in, const uint8_t *gate, const float 
     p.g_in = g_in; p.gate = gate; p.gx = gx; p.gy = gy; p.x = x; p.x0 = x0; p.tables = tables;
     p.alpha = alpha; p.high = high; p.w = w;
     p.step = dir > 0 ? step : -step; p.eps = eps; p.lo = lo; p.hi = hi;
-    p.dbg = chain_dbg();
     const Weights wt = load_weights(weights27);
     hipStream_t st = as_stream(stream);
     ProfScope prof(EE_K_CHAIN_BWD, st);

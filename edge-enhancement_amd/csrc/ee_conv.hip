@@ -474,684 +474,3 @@ EE_API int ee_stem7x7s2_fwd_stats_f32(const float *x, const float *weight, float
               stats, K, H, W, tiles_r, tiles_c);
     return launch_status();
 }
-
-// =====================================================================================================================
-// Conv2d(3x3, stride 1, padding 1, bias=False) of the residual blocks (Tiny_ImageNet/models_tinyimagenet/resnet.py:26-31),
-// forward and backward-data, as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32).
-//
-// Why: at the reference batch (100 x 64x64 images) the 64-channel 16x16 layers are 1.9 GFLOP each; MIOpen's best fp32
-// solver (Winograd F(2,3)) needs 36 us for them either way, i.e. ~30 % of the f32 matrix rate, and they are 8 of the
-// ~40 convolution launches of a PGD iteration.
-//
-//   D[rc][p] = sum_{kc, tap} A[rc][(kc, tap)] * Bm[(kc, tap)][p]
-//   forward : rc = output channel, kc = input channel,  A = W[rc][kc][tap],      Bm = x [n, kc, h+kh-1, w+kw-1]
-//   backward: rc = input channel,  kc = output channel, A = W[kc][rc][8 - tap],  Bm = dy[n, kc, h+kh-1, w+kw-1]
-//
-// A workgroup (4 wavefronts) owns 64 result channels x 64 pixels = (64 / W) whole rows of the (image, row) sequence; per
-// round 16 reduction channels: their weights in LDS as [kc][tap][65] (result channel fastest: conflict-free operand reads)
-// and a zero-bordered frame [kc][rows + 2][W + 2].  One MFMA step takes the two channels 2c, 2c+1 (lane halves) at one tap.
-// The next round's operands are requested from global memory before this round's MFMAs (registers), so one L2 round trip
-// overlaps one round of multiplies.  Measured (rocprofv3, B=100): 64ch 16x16 31 us forward / 34 us backward (MIOpen 36);
-// 128ch 8x8 37 / 40 us (MIOpen 30-36: not used there).  An 8-channel round was latency-bound at every barrier (37 / 46 us);
-// a prefetch distance of two rounds needs 299 VGPRs and loses the second workgroup per CU (36-43 us).
-// =====================================================================================================================
-namespace {
-
-constexpr int C3_CK = 16, C3_WS = 66;  // 66: the four weight-staging sub-roles of a wavefront land on disjoint bank groups
-
-struct Conv3Dims {
-    int B, KC, RC, H, W;  // reduction channels, result channels
-    int dbg;              // EEADV_CONV3_DBG (measurement only, grouped kernel): 1 no weight loads, 2 no frame loads, 4 no MFMAs, 8 no LDS staging
-};
-
-template <bool BWD, int TW>
-__global__ __launch_bounds__(256) void conv3x3s1_kernel(const float *__restrict__ in, const float *__restrict__ w, float *__restrict__ out,
-                                                        Conv3Dims d) {
-    constexpr int PR = 64 / TW;                   // rows of the tile
-    constexpr int FRW = TW + 2, FRH = PR + 2;     // frame
-    constexpr int WTOT = C3_CK * 9 * 64, FTOT = C3_CK * FRH * FRW;
-    constexpr int WPT = WTOT / 256, FPT = (FTOT + 255) / 256;  // elements staged per thread and round
-    static_assert(WTOT % 256 == 0, "weight tile must divide over the workgroup");
-    __shared__ float ws[C3_CK * 9 * C3_WS];       // [kc][tap][result channel (+1 pad)]
-    __shared__ float fr[FTOT];                    // [kc][frame row][frame col]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31, kk = lane >> 5;
-    const int rt = wave >> 1, pt = wave & 1;      // result-channel tile and pixel tile of this wavefront
-    const int rc_base = static_cast<int>(blockIdx.y) * 64;
-    const int g0 = static_cast<int>(blockIdx.x) * PR;  // first (image, row) of the tile
-    const int rows_total = d.B * d.H;
-    // this lane's pixel (B-operand column)
-    const int pj = pt * 32 + i;
-    const int rj = pj / TW, wj = pj - rj * TW;
-    const int gj = g0 + rj;
-    const bool pv = gj < rows_total;
-    const int nj = pv ? gj / d.H : 0, hj = pv ? gj - nj * d.H : 0;
-    const bool top = hj == 0, bot = hj == d.H - 1;
-    const float *bbase = fr + kk * (FRH * FRW) + rj * FRW + wj;
-    const float *abase = ws + kk * (9 * C3_WS) + rt * 32 + i;
-    const size_t plane = static_cast<size_t>(d.H) * TW;
-
-    // ---- staging roles, fixed per thread: 32-bit element offsets relative to the round's first reduction channel ---------
-    // weights: global reads run along (kc, tap) (forward) or (rc, tap) (backward), both contiguous.  KC % 16 == 0 and
-    // RC % 64 == 0 are guaranteed by the launcher, so no load needs a predicate (a predicated load is a branch: it would
-    // serialise the round trips) and the per-round address update is one add of a wave-uniform stride.
-    // weights: each thread owns 36 CONTIGUOUS floats of the round (9 x 16-B loads, no index arithmetic per element):
-    //   forward : result channel rl = tid / 4, reduction channels 4*(tid % 4) .. +3, all 9 taps   (W[rc][kc][tap] is contiguous in kc, tap)
-    //   backward: reduction channel kc = tid / 16, result channels 4*(tid % 16) .. +3, all 9 taps (W[kc][rc][tap] is contiguous in rc, tap)
-    static_assert(WPT == 36 && C3_CK == 16, "the weight roles below assume 16-channel rounds");
-    const int wq = BWD ? (threadIdx.x >> 4) : (threadIdx.x >> 2), wp = BWD ? (threadIdx.x & 15) : (threadIdx.x & 3);
-    const unsigned wsrc0 = static_cast<unsigned>(BWD ? (wq * d.RC + rc_base + 4 * wp) * 9 : ((rc_base + wq) * d.KC + 4 * wp) * 9);
-    unsigned fsrc[FPT];
-    bool fok[FPT];
-#pragma unroll
-    for (int j = 0; j < FPT; ++j) {
-        const int idx = threadIdx.x + j * 256;
-        const int fc = idx % FRW, tq = idx / FRW;
-        const int frow = tq % FRH, kc = idx < FTOT ? tq / FRH : 0;
-        const int g = g0 - 1 + frow, c = fc - 1;
-        fok[j] = idx < FTOT && g >= 0 && g < rows_total && c >= 0 && c < TW;
-        const int gc = fok[j] ? g : 0, cc = fok[j] ? c : 0;
-        const int n = gc / d.H, h = gc - n * d.H;
-        fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(plane) + h * TW + cc);
-    }
-    const unsigned wstep = static_cast<unsigned>(BWD ? C3_CK * d.RC * 9 : C3_CK * 9), fstep = static_cast<unsigned>(C3_CK * plane);
-    float4 wv4[WPT / 4];
-    float fv[FPT];
-    auto prefetch = [&](unsigned round) {
-        const unsigned wo = round * wstep, fo = round * fstep;
-#pragma unroll
-        for (int j = 0; j < WPT / 4; ++j) wv4[j] = *reinterpret_cast<const float4 *>(w + wsrc0 + wo + 4 * j);
-#pragma unroll
-        for (int j = 0; j < FPT; ++j) fv[j] = in[fsrc[j] + fo];
-    };
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned rounds = static_cast<unsigned>(d.KC / C3_CK);
-    prefetch(0);
-    for (unsigned round = 0; round < rounds; ++round) {
-        __syncthreads();  // the previous round's MFMAs have read their operands
-#pragma unroll
-        for (int j = 0; j < WPT / 4; ++j) {
-            const float v4[4] = {wv4[j].x, wv4[j].y, wv4[j].z, wv4[j].w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = 4 * j + u;  // element e of the thread's 36: (sub-channel e / 9, tap e % 9), compile-time
-                if (!BWD) ws[((wp * 4 + e / 9) * 9 + e % 9) * C3_WS + wq] = v4[u];
-                else ws[(wq * 9 + 8 - e % 9) * C3_WS + 4 * wp + e / 9] = v4[u];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < FPT; ++j)
-            if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;
-        __syncthreads();
-        if (round + 1 < rounds) prefetch(round + 1);  // next round's operands travel while this round multiplies
-        // operands of half a round into registers first (LDS reads in flight together), then the MFMAs back to back
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float av[C3_CK / 4 * 9], bv[C3_CK / 4 * 9];
-#pragma unroll
-            for (int c2 = 0; c2 < C3_CK / 4; ++c2) {
-                const float *ap = abase + (half * (C3_CK / 4) + c2) * (2 * 9 * C3_WS);
-                const float *bp = bbase + (half * (C3_CK / 4) + c2) * (2 * FRH * FRW);
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        av[c2 * 9 + kh * 3 + kw] = ap[(kh * 3 + kw) * C3_WS];
-                        float b = bp[kh * FRW + kw];
-                        if (kh == 0 && top) b = 0.0f;  // the frame row above belongs to the previous image
-                        if (kh == 2 && bot) b = 0.0f;
-                        bv[c2 * 9 + kh * 3 + kw] = b;
-                    }
-            }
-            // (two accumulator chains change nothing: the stalls counted by SQ_WAIT_INST_ANY are the MFMA issue cadence itself)
-#pragma unroll
-            for (int q = 0; q < C3_CK / 4 * 9; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
-        }
-    }
-    if (!pv) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rc = rc_base + rt * 32 + acc_row(r, lane);
-        out[(static_cast<size_t>(nj) * d.RC + rc) * plane + static_cast<size_t>(hj) * TW + wj] = acc[r];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Software-pipelined version (round 2).  Counters on the kernel above (rocprofv3 --pmc, 128ch 8x8): matrix pipe 28 % busy, LDS
-// 14 %, 5 % of wave cycles waiting on LDS - nothing is saturated; each round is a serial chain [barrier, stage, barrier, 72
-// operand reads, wait, 36 multiplies, 72 reads, wait, 36 multiplies] and phase-skipping (EEADV_CONV3_DBG) shows the multiply
-// time (15 us) ADDED to everything else (16 us) instead of hiding it; a second wavefront per SIMD does not change that (it
-// runs the same phases at the same time).  Here one wavefront overlaps its own phases:
-//   * operands come out of LDS through a ring of 4 register pairs, requested 3 multiplies ahead of their use: the ds_reads sit
-//     between the (dependent, 64-cycle) MFMAs in program order and issue while the previous MFMA executes;
-//   * LDS is double-buffered: the next round's weights / frame (prefetched from global memory one round earlier) are written
-//     into the other buffer one element per multiply, so a round needs ONE barrier, at its end;
-//   * the global prefetch for the round after next is issued as soon as the staging registers are free.
-// Same tiles, same operand order (bit-identical sums) as the kernel above.  RT = 2, KG = 1: 64 result channels x 64 pixels,
-// 4 wavefronts; RT = 1, KG = 2: 32 x 64 with the reduction split over two 2-wavefront groups (twice the workgroups on the
-// 4x4 layers), partial tiles added in group order through LDS.
-// ---------------------------------------------------------------------------------------------------------------------
-// A barrier among the wavefronts of ONE reduction group (gfx950 has no named barriers): an LDS counter that only grows; every
-// wavefront adds 1 and sleeps until the count reaches `target` (generation x wavefronts per group).  All wavefronts of a
-// workgroup are resident together, so the wait cannot deadlock.
-__device__ __forceinline__ void group_barrier(unsigned *ctr, unsigned target) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <bool BWD, int TW, int RT, int KG>
-__global__ __launch_bounds__(256) void conv3x3s1_pipe_kernel(const float *__restrict__ in, const float *__restrict__ w, float *__restrict__ out,
-                                                             Conv3Dims d) {
-    constexpr int PR = 64 / TW, FRW = TW + 2, FRH = PR + 2;
-    constexpr int RCW = 32 * RT, WSS = RCW + 2, GT = 128 * RT;
-    constexpr int WTOT = C3_CK * 9 * RCW, FTOT = C3_CK * FRH * FRW;
-    constexpr int WPT = WTOT / GT, FPT = (FTOT + GT - 1) / GT;
-    constexpr int BUF = (C3_CK * 9 * WSS + FTOT + 3) & ~3;  // floats of one (weights, frame) buffer
-    constexpr int NQ = C3_CK / 2 * 9;                        // multiplies per round and wavefront (72)
-    constexpr int LOOK = 3, RING = 4;  // 3 x (2 reads + 1 write) = 9 LDS operations in flight: lgkmcnt counts to 15
-    static_assert(WPT == 36 && 2 * RT * KG == 4 && WPT + FPT <= NQ - 8, "4 wavefronts; staging fits inside the multiply stream");
-    extern __shared__ __align__(16) float lds[];
-    __shared__ unsigned gctr[KG];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kg = wave / (2 * RT), tw = wave - kg * (2 * RT), rt = tw >> 1, pt = tw & 1;
-    const int gtid = static_cast<int>(threadIdx.x) - kg * GT;
-    float *gbuf = lds + kg * (2 * BUF);
-    if (KG > 1) {
-        if (threadIdx.x < KG) gctr[threadIdx.x] = 0u;
-        __syncthreads();
-    }
-    unsigned gen = 0;
-    auto gsync = [&]() {
-        if (KG == 1) __syncthreads();
-        else group_barrier(&gctr[kg], ++gen * (2 * RT));
-    };
-    const int i = lane & 31, kk = lane >> 5;
-    const int rc_base = static_cast<int>(blockIdx.y) * RCW;
-    const int g0 = static_cast<int>(blockIdx.x) * PR;
-    const int rows_total = d.B * d.H;
-    const int pj = pt * 32 + i;
-    const int rj = pj / TW, wj = pj - rj * TW;
-    const int gj = g0 + rj;
-    const bool pv = gj < rows_total;
-    const int nj = pv ? gj / d.H : 0, hj = pv ? gj - nj * d.H : 0;
-    const bool top = hj == 0, bot = hj == d.H - 1;
-    const int boff = C3_CK * 9 * WSS + kk * (FRH * FRW) + rj * FRW + wj;  // this lane's frame operand, relative to a buffer
-    const int aoff = kk * (9 * WSS) + rt * 32 + i;
-    const size_t plane = static_cast<size_t>(d.H) * TW;
-    const int wq = BWD ? gtid / (8 * RT) : (gtid >> 2), wp = BWD ? gtid % (8 * RT) : (gtid & 3);
-    const unsigned wsrc0 = static_cast<unsigned>(BWD ? (wq * d.RC + rc_base + 4 * wp) * 9 : ((rc_base + wq) * d.KC + 4 * wp) * 9);
-    unsigned fsrc[FPT];
-    bool fok[FPT];
-#pragma unroll
-    for (int j = 0; j < FPT; ++j) {
-        const int idx = gtid + j * GT;
-        const int fc = idx % FRW, tq = idx / FRW;
-        const int frow = tq % FRH, kc = idx < FTOT ? tq / FRH : 0;
-        const int g = g0 - 1 + frow, c = fc - 1;
-        fok[j] = idx < FTOT && g >= 0 && g < rows_total && c >= 0 && c < TW;
-        const int gc = fok[j] ? g : 0, cc = fok[j] ? c : 0;
-        const int n = gc / d.H, h = gc - n * d.H;
-        fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(plane) + h * TW + cc);
-    }
-    const unsigned wstep = static_cast<unsigned>(BWD ? C3_CK * d.RC * 9 : C3_CK * 9), fstep = static_cast<unsigned>(C3_CK * plane);
-    float wv[WPT], fv[FPT];
-    auto prefetch = [&](unsigned round) {
-        const unsigned wo = round * wstep, fo = round * fstep;
-#pragma unroll
-        for (int j = 0; j < WPT / 4; ++j) {
-            const float4 t = *reinterpret_cast<const float4 *>(w + wsrc0 + wo + 4 * j);
-            wv[4 * j] = t.x; wv[4 * j + 1] = t.y; wv[4 * j + 2] = t.z; wv[4 * j + 3] = t.w;
-        }
-#pragma unroll
-        for (int j = 0; j < FPT; ++j) fv[j] = in[fsrc[j] + fo];
-    };
-    // staging element e of this thread (e < WPT: weight, else frame) into buffer `b`
-    auto stage = [&](float *b, int e) {
-        if (e < WPT) {
-            if (!BWD) b[((wp * 4 + e / 9) * 9 + e % 9) * WSS + wq] = wv[e];
-            else b[(wq * 9 + 8 - e % 9) * WSS + 4 * wp + e / 9] = wv[e];
-        } else {
-            const int j = e - WPT;
-            if (gtid + j * GT < FTOT) b[C3_CK * 9 * WSS + gtid + j * GT] = fok[j] ? fv[j] : 0.0f;
-        }
-    };
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned iters = static_cast<unsigned>(d.KC / C3_CK / KG);
-    prefetch(kg);
-#pragma unroll
-    for (int e = 0; e < WPT + FPT; ++e) stage(gbuf, e);
-    if (iters > 1) prefetch(kg + KG);
-    gsync();
-    for (unsigned it = 0; it < iters; ++it) {
-        const float *cur = gbuf + (it & 1) * BUF;
-        float *nxt = gbuf + ((it + 1) & 1) * BUF;
-        const bool more = it + 1 < iters, more2 = it + 2 < iters;
-        float ra[RING], rb[RING];
-        auto fetch = [&](int q) {  // operands of multiply q: channels 2 (q / 9) + kk, tap q % 9
-            const int c2 = q / 9, tap = q % 9, kh = tap / 3, kw = tap % 3;
-            ra[q % RING] = cur[aoff + c2 * (2 * 9 * WSS) + tap * WSS];
-            float b = cur[boff + c2 * (2 * FRH * FRW) + kh * FRW + kw];
-            if (kh == 0 && top) b = 0.0f;  // the frame row above belongs to the previous image
-            if (kh == 2 && bot) b = 0.0f;
-            rb[q % RING] = b;
-        };
-#pragma unroll
-        for (int q = 0; q < LOOK; ++q) fetch(q);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (q + LOOK < NQ) fetch(q + LOOK);
-            if (more && q < WPT + FPT) stage(nxt, q);
-            if (more2 && q == WPT + FPT) prefetch(kg + (it + 2) * KG);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[q % RING], rb[q % RING], acc, 0, 0, 0);
-        }
-        gsync();  // everybody has read `cur` and written `nxt`
-    }
-    if (KG > 1) {  // partial tiles meet in LDS, group 0 adds them in group order
-        __syncthreads();
-        float *red = lds;  // [KG - 1][2 RT][16][64]
-        if (kg > 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[(((kg - 1) * (2 * RT) + tw) * 16 + r) * 64 + lane] = acc[r];
-        }
-        __syncthreads();
-        if (kg != 0) return;
-#pragma unroll
-        for (int g = 1; g < KG; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += red[(((g - 1) * (2 * RT) + tw) * 16 + r) * 64 + lane];
-    }
-    if (!pv) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rc = rc_base + rt * 32 + acc_row(r, lane);
-        out[(static_cast<size_t>(nj) * d.RC + rc) * plane + static_cast<size_t>(hj) * TW + wj] = acc[r];
-    }
-}
-
-template <bool BWD, int TW, int RT, int KG>
-void conv3_pipe_launch(const float *in, const float *w, float *out, const Conv3Dims &dims, int64_t gx, hipStream_t st) {
-    constexpr int PR = 64 / TW, FRW = TW + 2, FRH = PR + 2, WSS = 32 * RT + 2;
-    constexpr int BUF = (C3_CK * 9 * WSS + C3_CK * FRH * FRW + 3) & ~3;
-    constexpr size_t bytes = sizeof(float) * static_cast<size_t>(KG) * 2 * BUF;
-    static bool opted = false;
-    if (!opted && bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3s1_pipe_kernel<BWD, TW, RT, KG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(bytes)) != hipSuccess)
-            (void)hipGetLastError();
-        opted = true;
-    }
-    const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(dims.RC / (32 * RT))), block(256);
-    EE_LAUNCH((conv3x3s1_pipe_kernel<BWD, TW, RT, KG>), grid, block, bytes, st, in, w, out, dims);
-}
-
-// EEADV_CONV3_KG: 0 forces the 4-wavefront kernel, 10 / 11 the pipelined kernel (64 x 64 tiles / 32 x 64 tiles with a 2-way
-// reduction split) wherever its tiling exists - A/B measurements; unset: the measured choice below
-int conv3_variant() {
-    static const int v = [] {
-        const char *e = getenv("EEADV_CONV3_KG");
-        return e ? atoi(e) : -1;
-    }();
-    return v;
-}
-
-template <bool BWD>
-int conv3_launch(const float *in, const float *w, float *out, int B, int KC, int RC, int H, int W, hipStream_t st) {
-    if (B < 0 || KC < 1 || RC < 1 || H < 1 || W < 1) return EE_ERR_SHAPE;
-    if (W > 64 || 64 % W != 0 || KC % C3_CK != 0 || RC % 64 != 0) return EE_ERR_UNSUPPORTED;
-    if (B == 0) return EE_OK;
-    if (!in || !w || !out) return EE_ERR_NULL;
-    const int PR = 64 / W;
-    const int64_t rows = static_cast<int64_t>(B) * H;
-    const int64_t gx = (rows + PR - 1) / PR;
-    if (gx > 0x7fffffffLL) return EE_ERR_SHAPE;
-    if (static_cast<int64_t>(B) * KC * H * W > 0x7fffffffLL || static_cast<int64_t>(KC) * RC * 9 > 0x7fffffffLL) return EE_ERR_SHAPE;  // 32-bit offsets
-    const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(RC / 64)), block(256);
-    static const int dbg = [] {
-        const char *e = getenv("EEADV_CONV3_DBG");
-        return e ? atoi(e) : 0;
-    }();
-    const Conv3Dims dims{B, KC, RC, H, W, dbg};
-    const int rounds = KC / C3_CK, var = conv3_variant();
-    const int64_t wgs64 = gx * (RC / 64);
-    // Measured, un-profiled, B = 100 (fwd us: 4-wavefront kernel / pipelined 64x64 / pipelined 32x64 split / MIOpen Winograd):
-    //   64ch 16x16  28.5 / 35 / -  / 32.3      128ch 8x8  31.9 / 31.6 / - / 29.4      256ch 4x4  57.8 / 59 / 34 / 37.5
-    // so the pipelined kernel is the default only where the 64-channel tiling leaves most of the chip idle (<= 128 workgroups).
-    int pipe = 0;
-    if (var == 10 && W >= 4) pipe = 10;
-    else if (var == 11 && W >= 4 && W <= 16) pipe = 11;
-    else if (var == -1 && W == 4 && wgs64 <= 128) pipe = 11;
-    if (pipe == 11 && rounds % 2 != 0) pipe = 0;
-    const double flops = 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * W;
-    ProfScope prof(pipe ? (BWD ? EE_K_CONV3P_BWD : EE_K_CONV3P_FWD) : (BWD ? EE_K_CONV3_BWD : EE_K_CONV3_FWD), st, flops);
-    if (pipe == 10) {
-        switch (W) {
-            case 64: conv3_pipe_launch<BWD, 64, 2, 1>(in, w, out, dims, gx, st); break;
-            case 32: conv3_pipe_launch<BWD, 32, 2, 1>(in, w, out, dims, gx, st); break;
-            case 16: conv3_pipe_launch<BWD, 16, 2, 1>(in, w, out, dims, gx, st); break;
-            case 8: conv3_pipe_launch<BWD, 8, 2, 1>(in, w, out, dims, gx, st); break;
-            default: conv3_pipe_launch<BWD, 4, 2, 1>(in, w, out, dims, gx, st); break;
-        }
-        return launch_status();
-    }
-    if (pipe == 11) {
-        switch (W) {
-            case 16: conv3_pipe_launch<BWD, 16, 1, 2>(in, w, out, dims, gx, st); break;
-            case 8: conv3_pipe_launch<BWD, 8, 1, 2>(in, w, out, dims, gx, st); break;
-            default: conv3_pipe_launch<BWD, 4, 1, 2>(in, w, out, dims, gx, st); break;
-        }
-        return launch_status();
-    }
-    switch (W) {
-        case 64: EE_LAUNCH((conv3x3s1_kernel<BWD, 64>), grid, block, 0, st, in, w, out, dims); break;
-        case 32: EE_LAUNCH((conv3x3s1_kernel<BWD, 32>), grid, block, 0, st, in, w, out, dims); break;
-        case 16: EE_LAUNCH((conv3x3s1_kernel<BWD, 16>), grid, block, 0, st, in, w, out, dims); break;
-        case 8: EE_LAUNCH((conv3x3s1_kernel<BWD, 8>), grid, block, 0, st, in, w, out, dims); break;
-        case 4: EE_LAUNCH((conv3x3s1_kernel<BWD, 4>), grid, block, 0, st, in, w, out, dims); break;
-        case 2: EE_LAUNCH((conv3x3s1_kernel<BWD, 2>), grid, block, 0, st, in, w, out, dims); break;
-        default: EE_LAUNCH((conv3x3s1_kernel<BWD, 1>), grid, block, 0, st, in, w, out, dims); break;
-    }
-    return launch_status();
-}
-
-}  // namespace
-
-EE_API int ee_conv3x3s1_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream) {
-    return conv3_launch<false>(x, weight, y, B, Cin, Cout, H, W, as_stream(stream));
-}
-
-EE_API int ee_conv3x3s1_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W, void *stream) {
-    return conv3_launch<true>(dy, weight, dx, B, Cout, Cin, H, W, as_stream(stream));
-}
-
-// =====================================================================================================================
-// Conv2d(3x3, stride 2, padding 1, bias=False) - the first convolution of layers 2-4 (resnet.py:26-31 with stride 2),
-// forward, on the same f32-MFMA implicit GEMM.  0.94 GFLOP at the reference batch, for which MIOpen's solvers need ~50 us
-// (Winograd-stride2) or an NHWC implicit GEMM wrapped in three layout transposes and a zero fill.
-//   y[n,co,oh,ow] = sum_{ci,kh,kw} W[co][ci][kh][kw] * x[n, ci, 2oh-1+kh, 2ow-1+kw]
-// H even, so input row (n, 2oh-1+kh) is row 2g-1+kh of the flattened (image, row) sequence for output row g = n*OH + oh: a
-// tile of 64 / OW consecutive output rows reads 2*PR + 1 consecutive input rows, whatever images it spans; only the row above
-// an image's first row has to be masked (the column left of the image is a zero column of the frame).
-// =====================================================================================================================
-namespace {
-
-template <int TOW>
-__global__ __launch_bounds__(256) void conv3x3s2_fwd_kernel(const float *__restrict__ in, const float *__restrict__ w, float *__restrict__ out,
-                                                            Conv3Dims d) {  // d.H, d.W: INPUT size; KC = Cin, RC = Cout
-    constexpr int PR = 64 / TOW;                       // output rows of the tile
-    constexpr int FRH = 2 * PR + 1, FRW = 2 * TOW + 2;  // frame: input rows 2g0-1 .. 2(g0+PR)-1, columns -1 .. W-1 (+1 pad)
-    constexpr int TWI = 2 * TOW;                        // input width
-    constexpr int WTOT = C3_CK * 9 * 64, FTOT = C3_CK * FRH * FRW;
-    constexpr int WPT = WTOT / 256, FPT = (FTOT + 255) / 256;
-    __shared__ float ws[C3_CK * 9 * C3_WS];
-    __shared__ float fr[FTOT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31, kk = lane >> 5;
-    const int rt = wave >> 1, pt = wave & 1;
-    const int rc_base = static_cast<int>(blockIdx.y) * 64;
-    const int OH = d.H / 2;
-    const int g0 = static_cast<int>(blockIdx.x) * PR;   // first output (image, row)
-    const int orows_total = d.B * OH, irows_total = d.B * d.H;
-    const int pj = pt * 32 + i;
-    const int rj = pj / TOW, wj = pj - rj * TOW;
-    const int gj = g0 + rj;
-    const bool pv = gj < orows_total;
-    const int nj = pv ? gj / OH : 0, ohj = pv ? gj - nj * OH : 0;
-    const bool top = ohj == 0;
-    const float *bbase = fr + kk * (FRH * FRW) + (2 * rj) * FRW + 2 * wj;
-    const float *abase = ws + kk * (9 * C3_WS) + rt * 32 + i;
-    const size_t iplane = static_cast<size_t>(d.H) * TWI, oplane = static_cast<size_t>(OH) * TOW;
-
-    // weights: thread = (result channel tid / 4, reduction channels 4*(tid % 4) .. +3, all taps) = 36 contiguous floats, 9 x 16-B loads
-    static_assert(WPT == 36 && C3_CK == 16, "the weight roles below assume 16-channel rounds");
-    const int wq = threadIdx.x >> 2, wp = threadIdx.x & 3;
-    const unsigned wsrc0 = static_cast<unsigned>(((rc_base + wq) * d.KC + 4 * wp) * 9);
-    unsigned fsrc[FPT];
-    bool fok[FPT];
-#pragma unroll
-    for (int j = 0; j < FPT; ++j) {
-        const int idx = threadIdx.x + j * 256;
-        const int fc = idx % FRW, tq = idx / FRW;
-        const int frow = tq % FRH, kc = idx < FTOT ? tq / FRH : 0;
-        const int g = 2 * g0 - 1 + frow, c = fc - 1;
-        fok[j] = idx < FTOT && g >= 0 && g < irows_total && c >= 0 && c < TWI;
-        const int gc = fok[j] ? g : 0, cc = fok[j] ? c : 0;
-        const int n = gc / d.H, h = gc - n * d.H;
-        fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(iplane) + h * TWI + cc);
-    }
-    const unsigned wstep = static_cast<unsigned>(C3_CK * 9), fstep = static_cast<unsigned>(C3_CK * iplane);
-    float4 wv4[WPT / 4];
-    float fv[FPT];
-    auto prefetch = [&](unsigned round) {
-        const unsigned wo = round * wstep, fo = round * fstep;
-#pragma unroll
-        for (int j = 0; j < WPT / 4; ++j) wv4[j] = *reinterpret_cast<const float4 *>(w + wsrc0 + wo + 4 * j);
-#pragma unroll
-        for (int j = 0; j < FPT; ++j) fv[j] = in[fsrc[j] + fo];
-    };
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned rounds = static_cast<unsigned>(d.KC / C3_CK);
-    prefetch(0);
-    for (unsigned round = 0; round < rounds; ++round) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < WPT / 4; ++j) {
-            const float v4[4] = {wv4[j].x, wv4[j].y, wv4[j].z, wv4[j].w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = 4 * j + u;
-                ws[((wp * 4 + e / 9) * 9 + e % 9) * C3_WS + wq] = v4[u];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < FPT; ++j)
-            if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;
-        __syncthreads();
-        if (round + 1 < rounds) prefetch(round + 1);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float av[C3_CK / 4 * 9], bv[C3_CK / 4 * 9];
-#pragma unroll
-            for (int c2 = 0; c2 < C3_CK / 4; ++c2) {
-                const float *ap = abase + (half * (C3_CK / 4) + c2) * (2 * 9 * C3_WS);
-                const float *bp = bbase + (half * (C3_CK / 4) + c2) * (2 * FRH * FRW);
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        av[c2 * 9 + kh * 3 + kw] = ap[(kh * 3 + kw) * C3_WS];
-                        float b = bp[kh * FRW + kw];
-                        if (kh == 0 && top) b = 0.0f;  // the input row above an image's first row belongs to the previous image
-                        bv[c2 * 9 + kh * 3 + kw] = b;
-                    }
-            }
-#pragma unroll
-            for (int q = 0; q < C3_CK / 4 * 9; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
-        }
-    }
-    if (!pv) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rc = rc_base + rt * 32 + acc_row(r, lane);
-        out[(static_cast<size_t>(nj) * d.RC + rc) * oplane + static_cast<size_t>(ohj) * TOW + wj] = acc[r];
-    }
-}
-
-}  // namespace
-
-EE_API int ee_conv3x3s2_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream) {
-    if (B < 0 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return EE_ERR_SHAPE;
-    const int OW = W / 2;
-    if ((H & 1) || (W & 1) || OW > 64 || 64 % OW != 0 || Cin % C3_CK != 0 || Cout % 64 != 0) return EE_ERR_UNSUPPORTED;
-    if (B == 0) return EE_OK;
-    if (!x || !weight || !y) return EE_ERR_NULL;
-    if (static_cast<int64_t>(B) * Cin * H * W > 0x7fffffffLL || static_cast<int64_t>(Cin) * Cout * 9 > 0x7fffffffLL) return EE_ERR_SHAPE;
-    const int PR = 64 / OW;
-    const int64_t orows = static_cast<int64_t>(B) * (H / 2);
-    const dim3 grid(static_cast<unsigned>((orows + PR - 1) / PR), static_cast<unsigned>(Cout / 64)), block(256);
-    const Conv3Dims dims{B, Cin, Cout, H, W, 0};
-    hipStream_t st = as_stream(stream);
-    switch (OW) {
-        case 64: EE_LAUNCH((conv3x3s2_fwd_kernel<64>), grid, block, 0, st, x, weight, y, dims); break;
-        case 32: EE_LAUNCH((conv3x3s2_fwd_kernel<32>), grid, block, 0, st, x, weight, y, dims); break;
-        case 16: EE_LAUNCH((conv3x3s2_fwd_kernel<16>), grid, block, 0, st, x, weight, y, dims); break;
-        case 8: EE_LAUNCH((conv3x3s2_fwd_kernel<8>), grid, block, 0, st, x, weight, y, dims); break;
-        case 4: EE_LAUNCH((conv3x3s2_fwd_kernel<4>), grid, block, 0, st, x, weight, y, dims); break;
-        case 2: EE_LAUNCH((conv3x3s2_fwd_kernel<2>), grid, block, 0, st, x, weight, y, dims); break;
-        default: EE_LAUNCH((conv3x3s2_fwd_kernel<1>), grid, block, 0, st, x, weight, y, dims); break;
-    }
-    return launch_status();
-}
-
-// =====================================================================================================================
-// Backward-data of the stride-2 3x3 convolution, on the dy grid (MIOpen: Winograd-dilation 52 us, or an NHWC implicit GEMM
-// plus three transposes and a zero fill, for 0.94 GFLOP).
-//   dx[n,ci,2a+ph,2b+pw] = sum_{co,u,v} dy[n,co,a+u,b+v] * W[co,ci,kh(ph,u),kw(pw,v)],   (ph,u) -> kh: (0,0)->1, (1,0)->2, (1,1)->0
-// i.e. every dy cell (a,b) produces the 2x2 input cell above it from the 2x2 window of dy cells at (a..a+1, b..b+1): a GEMM
-// D[(ci,ph,pw)][cell] with K = (co,u,v), 9 of every 16 weight entries non-zero (the zero ones are written once).  Rows are
-// ordered ci*4 + ph*2 + pw, so the four accumulator registers r..r+3 of a lane are the 2x2 cell of one input channel and
-// leave as two 8-byte stores.  Workgroup: 16 input channels x 64 cells, 32 output channels per round.
-// =====================================================================================================================
-namespace {
-
-constexpr int S2B_CK = 32;  // output channels (reduction) per round
-
-template <int TOW>
-__global__ __launch_bounds__(256) void conv3x3s2_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ w, float *__restrict__ dx,
-                                                            Conv3Dims d) {  // d.H, d.W: size of dx; KC = Cout, RC = Cin
-    constexpr int PR = 64 / TOW;
-    constexpr int FRH = PR + 1, FRW = TOW + 2;  // cells a .. a+PR, b .. b+TOW (+1 pad)
-    constexpr int FTOT = S2B_CK * FRH * FRW, FPT = (FTOT + 255) / 256;
-    constexpr int WROW = 66;
-    __shared__ float ws[S2B_CK * 4 * WROW];  // [kc][t = u*2+v][row = ci_l*4 + ph*2 + pw]
-    __shared__ float fr[FTOT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31, kk = lane >> 5;
-    const int rt = wave >> 1, pt = wave & 1;
-    const int ci_base = static_cast<int>(blockIdx.y) * 16;
-    const int OH = d.H / 2;
-    const int g0 = static_cast<int>(blockIdx.x) * PR;
-    const int rows_total = d.B * OH;
-    const int pj = pt * 32 + i;
-    const int rj = pj / TOW, wj = pj - rj * TOW;
-    const int gj = g0 + rj;
-    const bool pv = gj < rows_total;
-    const int nj = pv ? gj / OH : 0, aj = pv ? gj - nj * OH : 0;
-    const bool last_row = aj == OH - 1;
-    const float *bbase = fr + kk * (FRH * FRW) + rj * FRW + wj;
-    const float *abase = ws + kk * (4 * WROW) + rt * 32 + i;
-    const size_t oplane = static_cast<size_t>(OH) * TOW;
-
-    for (int idx = threadIdx.x; idx < S2B_CK * 4 * WROW; idx += 256) ws[idx] = 0.0f;  // the structural zeros, once
-
-    // weights: 32 co x 16 ci pairs per round, two pairs per thread, the nine taps of a pair are contiguous
-    unsigned wsrc[2], wdst[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pair = threadIdx.x + j * 256;
-        const int kc = pair >> 4, cl = pair & 15;
-        wsrc[j] = static_cast<unsigned>((kc * d.RC + ci_base + cl) * 9);
-        wdst[j] = static_cast<unsigned>(kc * 4 * WROW + cl * 4);
-    }
-    unsigned fsrc[FPT];
-    bool fok[FPT];
-#pragma unroll
-    for (int j = 0; j < FPT; ++j) {
-        const int idx = threadIdx.x + j * 256;
-        const int fc = idx % FRW, tq = idx / FRW;
-        const int frow = tq % FRH, kc = idx < FTOT ? tq / FRH : 0;
-        const int g = g0 + frow;
-        fok[j] = idx < FTOT && g < rows_total && fc < TOW;
-        const int gc = fok[j] ? g : 0, cc = fok[j] ? fc : 0;
-        const int n = gc / OH, a = gc - n * OH;
-        fsrc[j] = static_cast<unsigned>((n * d.KC + kc) * static_cast<int>(oplane) + a * TOW + cc);
-    }
-    const unsigned wstep = static_cast<unsigned>(S2B_CK * d.RC * 9), fstep = static_cast<unsigned>(S2B_CK * oplane);
-    float wv[2][9], fv[FPT];
-    auto prefetch = [&](unsigned round) {
-        const unsigned wo = round * wstep, fo = round * fstep;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 9; ++t) wv[j][t] = w[wsrc[j] + wo + t];
-#pragma unroll
-        for (int j = 0; j < FPT; ++j) fv[j] = dy[fsrc[j] + fo];
-    };
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned rounds = static_cast<unsigned>(d.KC / S2B_CK);
-    prefetch(0);
-    for (unsigned round = 0; round < rounds; ++round) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ph = kh == 1 ? 0 : 1, u = kh == 0 ? 1 : 0, pw = kw == 1 ? 0 : 1, v = kw == 0 ? 1 : 0;
-                    ws[wdst[j] + (u * 2 + v) * WROW + ph * 2 + pw] = wv[j][kh * 3 + kw];
-                }
-#pragma unroll
-        for (int j = 0; j < FPT; ++j)
-            if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;
-        __syncthreads();
-        if (round + 1 < rounds) prefetch(round + 1);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float av[S2B_CK / 4 * 4], bv[S2B_CK / 4 * 4];
-#pragma unroll
-            for (int c2 = 0; c2 < S2B_CK / 4; ++c2) {
-                const float *ap = abase + (half * (S2B_CK / 4) + c2) * (2 * 4 * WROW);
-                const float *bp = bbase + (half * (S2B_CK / 4) + c2) * (2 * FRH * FRW);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        av[c2 * 4 + u * 2 + v] = ap[(u * 2 + v) * WROW];
-                        float b = bp[u * FRW + v];
-                        if (u == 1 && last_row) b = 0.0f;  // the dy row below an image's last row belongs to the next image
-                        bv[c2 * 4 + u * 2 + v] = b;
-                    }
-            }
-#pragma unroll
-            for (int q = 0; q < S2B_CK / 4 * 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
-        }
-    }
-    if (!pv) return;
-    // registers 4j .. 4j+3 of a lane: rows (2j + (lane >> 5)) * 4 + {0,1,2,3} = input channel 2j + (lane >> 5) of this tile, (ph, pw)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ci = ci_base + rt * 8 + 2 * j + kk;
-        float *o = dx + ((static_cast<size_t>(nj) * d.RC + ci) * d.H + 2 * aj) * (2 * TOW) + 2 * wj;
-        *reinterpret_cast<float2 *>(o) = make_float2(acc[4 * j + 0], acc[4 * j + 1]);
-        *reinterpret_cast<float2 *>(o + 2 * TOW) = make_float2(acc[4 * j + 2], acc[4 * j + 3]);
-    }
-}
-
-}  // namespace
-
-EE_API int ee_conv3x3s2_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W, void *stream) {
-    if (B < 0 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return EE_ERR_SHAPE;
-    const int OW = W / 2;
-    if ((H & 1) || (W & 1) || OW > 64 || 64 % OW != 0 || Cout % S2B_CK != 0 || Cin % 16 != 0) return EE_ERR_UNSUPPORTED;
-    if (B == 0) return EE_OK;
-    if (!dy || !weight || !dx) return EE_ERR_NULL;
-    if (reinterpret_cast<uintptr_t>(dx) & 7u) return EE_ERR_ALIGN;
-    if (static_cast<int64_t>(B) * Cout * (H / 2) * OW > 0x7fffffffLL || static_cast<int64_t>(Cin) * Cout * 9 > 0x7fffffffLL) return EE_ERR_SHAPE;
-    const int PR = 64 / OW;
-    const int64_t rows = static_cast<int64_t>(B) * (H / 2);
-    const dim3 grid(static_cast<unsigned>((rows + PR - 1) / PR), static_cast<unsigned>(Cin / 16)), block(256);
-    const Conv3Dims dims{B, Cout, Cin, H, W, 0};
-    hipStream_t st = as_stream(stream);
-    switch (OW) {
-        case 64: EE_LAUNCH((conv3x3s2_bwd_kernel<64>), grid, block, 0, st, dy, weight, dx, dims); break;
-        case 32: EE_LAUNCH((conv3x3s2_bwd_kernel<32>), grid, block, 0, st, dy, weight, dx, dims); break;
-        case 16: EE_LAUNCH((conv3x3s2_bwd_kernel<16>), grid, block, 0, st, dy, weight, dx, dims); break;
-        case 8: EE_LAUNCH((conv3x3s2_bwd_kernel<8>), grid, block, 0, st, dy, weight, dx, dims); break;
-        case 4: EE_LAUNCH((conv3x3s2_bwd_kernel<4>), grid, block, 0, st, dy, weight, dx, dims); break;
-        case 2: EE_LAUNCH((conv3x3s2_bwd_kernel<2>), grid, block, 0, st, dy, weight, dx, dims); break;
-        default: EE_LAUNCH((conv3x3s2_bwd_kernel<1>), grid, block, 0, st, dy, weight, dx, dims); break;
-    }
-    return launch_status();
-}

@@ -13,8 +13,6 @@
 // flipped, transposed filter.  Exact f32 products; the transforms add a few 1e-7 of relative error (as MIOpen's solver does).
 //
 // CNN-body glue, not a row of SURVEY.md section 8.
-#include <cstdlib>
-
 #include "ee_common.hpp"
 
 namespace {
@@ -23,7 +21,7 @@ using namespace ee;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WN_NT = 256, WN_CK = 16, WN_CO = 32;
+constexpr int WN_CK = 16, WN_CO = 32;
 constexpr int WN_CP = 48;                      // U row stride in LDS: the four k of a wavefront on disjoint banks (32 + 16)
 constexpr int WN_US = WN_CK * WN_CP;           // one xi's [16 ci][48]
 
@@ -31,192 +29,6 @@ struct WinoDims {
     int B, KC, RC;  // reduction channels (input channels forward), result channels
     int wl;         // producer / consumer kernels: XCD numbering with the channel block fastest (ee_common.hpp: xcd_decode)
 };
-
-// MAP x MAP maps: MAP = 8 (16 tiles = one N block = one image per workgroup), 16 (64 tiles = four N blocks per image; the accumulators
-// of all four stay in registers, the output transform runs one N block at a time through LDS), or 4 (4 tiles per image: the N block
-// spans IMG = 4 images, a workgroup owns four images).
-template <int MAP>
-struct WinoGeo {
-    static constexpr int TX = MAP / 2, TI = TX * TX;                  // tiles per row / per image
-    static constexpr int IMG = TI < 16 ? 16 / TI : 1;                 // images per workgroup
-    static constexpr int T = TI * IMG, NB = T / 16;                   // tiles per workgroup, N blocks
-    static constexpr int XW = MAP + 4, XI = (MAP + 2) * XW;           // one image's input frame (zero ring), row stride
-    static constexpr int XP = IMG * XI;                               // frames of one channel
-    static constexpr int VT = NB == 1 ? 16 : T + 16;                  // V row stride: the four k of a wavefront on disjoint banks
-    static constexpr int VS = WN_CK * VT;                              // one xi's [16 ci][VT]
-    static constexpr int XF4 = IMG * MAP * MAP / 64;                   // float4 of x per thread and round (16 ci x IMG x MAP^2 / 4 / 256)
-    static constexpr size_t lds_bytes = (16 * WN_US + 16 * VS + WN_CK * XP) * sizeof(float);
-};
-
-// x [B][KC][MAP][MAP], u [16][KC][RC] (transformed filters), y [B][RC][MAP][MAP].  grid (ceil(B / IMG), RC / 32).
-template <int MAP>
-__global__ __launch_bounds__(WN_NT) void wino3x3_kernel(const float *__restrict__ x, const float *__restrict__ u, float *__restrict__ y, WinoDims d) {
-    using G = WinoGeo<MAP>;
-    extern __shared__ __align__(16) float lds[];
-    float *us = lds;                     // [16 xi][16 ci][48]; after the rounds: M of one N block [16 xi][32 co][16 tiles] (32 KB)
-    float *vs = us + 16 * WN_US;         // [16 xi][16 ci][VT]
-    float *xs = vs + 16 * G::VS;         // [16 ci][MAP + 2][XW]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * G::IMG, co0 = blockIdx.y * WN_CO;  // first image of the workgroup
-    const int l15 = lane & 15, lq = lane >> 4;
-    for (int i = threadIdx.x; i < WN_CK * G::XP; i += WN_NT) xs[i] = 0.0f;  // zero ring, once (the interior is rewritten every round)
-    // staging roles: U slice = 16 xi x 16 ci rows of 32 floats -> 8 lanes (16 B each) per row, 8 rows per thread (rows urow0 + 32 j: the same
-    // ci, xi two further each); x chunk = 16 ci x MAP^2 px -> XF4 float4 per thread.  The prefetch registers are NAMED and the loads
-    // straight-line code: as an array (under a lambda, or in a loop the compiler would not unroll) they lived in scratch memory.
-    const int urow0 = threadIdx.x >> 3, uq = threadIdx.x & 7;
-    const int ci_s = urow0 & 15, xi_s = urow0 >> 4;
-    const float *ubase = u + (static_cast<size_t>(xi_s) * d.KC + ci_s) * d.RC + co0 + 4 * uq;
-    const size_t uxi2 = 2 * static_cast<size_t>(d.KC) * d.RC;
-    // IMG == 1: the round's 16 planes are contiguous, float4 number tid + 256 k.  IMG == 4 (4x4 maps): float4 tid = (image, ci, row): 64 per image
-    const int ximg = G::IMG > 1 ? (threadIdx.x >> 6) : 0, xb = b + ximg < d.B ? b + ximg : d.B - 1;  // past the batch: a valid image, never stored
-    const float *xsrc = G::IMG > 1 ? x + static_cast<size_t>(xb) * d.KC * (MAP * MAP) + 4 * (threadIdx.x & 63)
-                                   : x + static_cast<size_t>(b) * d.KC * (MAP * MAP) + 4 * threadIdx.x;
-    const size_t ustep = static_cast<size_t>(WN_CK) * d.RC, xstep = static_cast<size_t>(WN_CK) * (MAP * MAP);
-    float4 u0, u1, u2, u3, u4, u5, u6, u7, x0, x1, x2, x3;
-    x1 = x2 = x3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#define WN_PREFETCH(round_)                                                                  \
-    do {                                                                                     \
-        const float *up_ = ubase + (round_) * ustep;                                         \
-        const float *xp_ = xsrc + (round_) * xstep;                                          \
-        u0 = *reinterpret_cast<const float4 *>(up_);                                         \
-        u1 = *reinterpret_cast<const float4 *>(up_ + uxi2);                                  \
-        u2 = *reinterpret_cast<const float4 *>(up_ + 2 * uxi2);                              \
-        u3 = *reinterpret_cast<const float4 *>(up_ + 3 * uxi2);                              \
-        u4 = *reinterpret_cast<const float4 *>(up_ + 4 * uxi2);                              \
-        u5 = *reinterpret_cast<const float4 *>(up_ + 5 * uxi2);                              \
-        u6 = *reinterpret_cast<const float4 *>(up_ + 6 * uxi2);                              \
-        u7 = *reinterpret_cast<const float4 *>(up_ + 7 * uxi2);                              \
-        x0 = *reinterpret_cast<const float4 *>(xp_);                                         \
-        if (G::XF4 > 1) {                                                                    \
-            x1 = *reinterpret_cast<const float4 *>(xp_ + 4 * WN_NT);                         \
-            x2 = *reinterpret_cast<const float4 *>(xp_ + 8 * WN_NT);                         \
-            x3 = *reinterpret_cast<const float4 *>(xp_ + 12 * WN_NT);                        \
-        }                                                                                    \
-    } while (0)
-    static_assert(G::XF4 == 1 || G::XF4 == 4, "4x4, 8x8 or 16x16 maps");
-    auto put_x = [&](float4 v, int k) {  // float4 number tid + 256 k of the round's planes -> frame interior
-        const int f0 = threadIdx.x + WN_NT * k, img = G::IMG > 1 ? f0 >> 6 : 0, f = G::IMG > 1 ? f0 & 63 : f0;
-        const int ci = f / (MAP * MAP / 4), q = f - ci * (MAP * MAP / 4), r = q / (MAP / 4), c4 = 4 * (q - r * (MAP / 4));
-        float *dst = xs + ci * G::XP + img * G::XI + (1 + r) * G::XW + 1 + c4;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    };
-    f32x4 acc[4][G::NB][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int nb = 0; nb < G::NB; ++nb)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) acc[a][nb][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int rounds = d.KC / WN_CK;
-    WN_PREFETCH(0);
-    for (int round = 0; round < rounds; ++round) {
-        __syncthreads();  // the previous round's MFMAs have read us / vs; (first round: the zero ring is written)
-        {
-            float *ud = us + xi_s * WN_US + ci_s * WN_CP + 4 * uq;  // row urow0 + 32 j -> xi = xi_s + 2 j
-            *reinterpret_cast<float4 *>(ud) = u0;
-            *reinterpret_cast<float4 *>(ud + 2 * WN_US) = u1;
-            *reinterpret_cast<float4 *>(ud + 4 * WN_US) = u2;
-            *reinterpret_cast<float4 *>(ud + 6 * WN_US) = u3;
-            *reinterpret_cast<float4 *>(ud + 8 * WN_US) = u4;
-            *reinterpret_cast<float4 *>(ud + 10 * WN_US) = u5;
-            *reinterpret_cast<float4 *>(ud + 12 * WN_US) = u6;
-            *reinterpret_cast<float4 *>(ud + 14 * WN_US) = u7;
-        }
-        put_x(x0, 0);
-        if (G::XF4 > 1) {
-            put_x(x1, 1);
-            put_x(x2, 2);
-            put_x(x3, 3);
-        }
-        __syncthreads();
-        {
-            const int nr = round + 1 < rounds ? round + 1 : round;  // always issued (the last round re-reads its own slice): a load under a
-            WN_PREFETCH(nr);                                          // condition kept the registers in scratch memory
-        }
-        // ---- V = B^T d B: (ci, tile) pairs tid + 256 k -----------------------------------------------------------------------------------
-#pragma unroll
-        for (int k = 0; k < G::NB; ++k) {
-            const int pr = threadIdx.x + WN_NT * k, ci = pr / G::T, t = pr - ci * G::T, img = t / G::TI, ti = t - img * G::TI;
-            const int ty = ti / G::TX, tx = ti - ty * G::TX;
-            const float *p = xs + ci * G::XP + img * G::XI + (2 * ty) * G::XW + 2 * tx;  // patch rows 2ty-1 .. 2ty+2 = frame rows 2ty .. 2ty+3
-            float dd[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dd[i][j] = p[i * G::XW + j];
-            float tt[4][4];  // B^T d
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tt[0][j] = dd[0][j] - dd[2][j];
-                tt[1][j] = dd[1][j] + dd[2][j];
-                tt[2][j] = dd[2][j] - dd[1][j];
-                tt[3][j] = dd[1][j] - dd[3][j];
-            }
-            float *vp = vs + ci * G::VT + t;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                vp[(4 * i + 0) * G::VS] = tt[i][0] - tt[i][2];
-                vp[(4 * i + 1) * G::VS] = tt[i][1] + tt[i][2];
-                vp[(4 * i + 2) * G::VS] = tt[i][2] - tt[i][1];
-                vp[(4 * i + 3) * G::VS] = tt[i][1] - tt[i][3];
-            }
-        }
-        __syncthreads();
-        // ---- M_xi += U_xi V_xi for this wavefront's four xi: A[m = l15][k = lq] = U[xi][ci = 4 kq + lq][co], B[k = lq][n = l15] = V[xi][ci][tile] ----
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int xi = 4 * wave + a;
-            const float *up = us + xi * WN_US + lq * WN_CP + l15;
-            const float *vp = vs + xi * G::VS + lq * G::VT + l15;
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                const float a0 = up[kq * 4 * WN_CP], a1 = up[kq * 4 * WN_CP + 16];
-#pragma unroll
-                for (int nb = 0; nb < G::NB; ++nb) {
-                    const float bv = vp[kq * 4 * G::VT + 16 * nb];
-                    acc[a][nb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[a][nb][0], 0, 0, 0);
-                    acc[a][nb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[a][nb][1], 0, 0, 0);
-                }
-            }
-        }
-    }
-    // ---- output transform Y = A^T M A, one N block (16 tiles) at a time.  D[row = 4 lq + reg][col = l15] -> ms[xi][co][tile] ---------------
-    float *ms = us;
-#pragma unroll
-    for (int nb = 0; nb < G::NB; ++nb) {
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ms[((4 * wave + a) * WN_CO + 16 * m + 4 * lq + r) * 16 + l15] = acc[a][nb][m][r];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int idx = threadIdx.x + k * WN_NT;  // (co, tile of this block)
-            const int co = idx >> 4, tl = idx & 15, t = 16 * nb + tl, img = t / G::TI, ti = t - img * G::TI, ty = ti / G::TX, tx = ti - ty * G::TX;
-            float mm[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mm[i][j] = ms[((4 * i + j) * WN_CO + co) * 16 + tl];
-            float t0[4], t1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t0[j] = (mm[0][j] + mm[1][j]) + mm[2][j];
-                t1[j] = (mm[1][j] - mm[2][j]) - mm[3][j];
-            }
-            if (b + img < d.B) {
-                float *o = y + ((static_cast<size_t>(b + img) * d.RC + co0 + co) * MAP + 2 * ty) * MAP + 2 * tx;
-                *reinterpret_cast<float2 *>(o) = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]);
-                *reinterpret_cast<float2 *>(o + MAP) = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
-            }
-        }
-    }
-}
-
-#undef WN_PREFETCH
 
 // ---- 4x4 maps (layer3 at 64x64 inputs), second version: producer and consumer wavefronts ------------------------------------------------
 // 200 workgroups of four images = one per CU and, with 256 lanes, ONE wavefront per SIMD: a wavefront issues in order, so its loads' latency,
@@ -665,17 +477,6 @@ int wino_map4_launch(const float *x, const float *u, float *y, const WinoDims &d
     return launch_status();
 }
 
-template <int MAP>
-int wino_launch(const float *x, const float *u, float *y, const WinoDims &d, hipStream_t st) {
-    using G = WinoGeo<MAP>;
-    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(G::lds_bytes)) == hipSuccess;
-    if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH(wino3x3_kernel<MAP>, dim3(static_cast<unsigned>((d.B + G::IMG - 1) / G::IMG), static_cast<unsigned>(d.RC / WN_CO)), dim3(WN_NT), G::lds_bytes,
-              st, x, u, y, d);
-    return launch_status();
-}
-
 }  // namespace
 
 // y = conv3x3(x) for H x H maps (H = 4, 8 or 16) with the filters given in the transform domain: u [16][KC][RC], u[4i+j][k][r] =
@@ -690,12 +491,7 @@ EE_API int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int K
     const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
     // the convolution's ALGORITHMIC flops (2 * 9 * KC * RC per output pixel); the kernel executes 4/9 of them (16 multiplies per 2x2 tile)
     ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
-    static const bool v1 = std::getenv("EEADV_WINO_V1") != nullptr;  // A/B: the one-wavefront-per-SIMD kernel
-    if (H == 4) return v1 ? wino_launch<4>(x, u, y, d, as_stream(stream)) : wino_map4_launch(x, u, y, d, as_stream(stream));
-    if (H == 8) return v1 ? wino_launch<8>(x, u, y, d, as_stream(stream)) : wino_pc_launch<8>(x, u, y, d, as_stream(stream));
-    return v1 ? wino_launch<16>(x, u, y, d, as_stream(stream)) : wino_pc_launch<16>(x, u, y, d, as_stream(stream));
-}
-
-EE_API int ee_wino3x3_map8_f32(const float *x, const float *u, float *y, int B, int KC, int RC, void *stream) {
-    return ee_wino3x3_f32(x, u, y, B, KC, RC, 8, stream);
+    if (H == 4) return wino_map4_launch(x, u, y, d, as_stream(stream));
+    if (H == 8) return wino_pc_launch<8>(x, u, y, d, as_stream(stream));
+    return wino_pc_launch<16>(x, u, y, d, as_stream(stream));
 }

@@ -95,16 +95,6 @@ __global__ __launch_bounds__(256) void wprep_kernel(int kind, const float *__res
     wprep_dispatch(kind, w, w1, out, Cout, Cin, blockIdx.x);
 }
 
-// every (weight, kind) of a model in ONE launch: table[i] = {w, w1, out, kind, Cout, Cin, first block, blocks} (8 x int64), blocks numbered
-// consecutively over the items
-__global__ __launch_bounds__(256) void wprep_batched_kernel(const long long *__restrict__ table, int n) {
-    int i = 0;
-    while (i + 1 < n && static_cast<long long>(blockIdx.x) >= table[8 * (i + 1) + 6]) ++i;  // block-uniform: scalar loads
-    const long long *it = table + 8 * i;
-    wprep_dispatch(static_cast<int>(it[3]), reinterpret_cast<const float *>(it[0]), reinterpret_cast<const float *>(it[1]), reinterpret_cast<float *>(it[2]),
-                   static_cast<int>(it[4]), static_cast<int>(it[5]), blockIdx.x - static_cast<unsigned>(it[6]));
-}
-
 unsigned wprep_blocks(int kind, size_t pairs) {
     if (kind == EE_WPREP_WINO_F || kind == EE_WPREP_WINO_B) return static_cast<unsigned>((pairs + 255) / 256);
     if (kind == EE_WPREP_DENSE_MAP2) return static_cast<unsigned>((16 * pairs + 255) / 256);
@@ -128,22 +118,5 @@ EE_API int ee_conv_weight_prep_f32(int kind, const float *w, const float *w1, fl
         if ((kind == EE_WPREP_S2P_F || kind == EE_WPREP_S2P_B) && !w1) return EE_ERR_NULL;
     }
     EE_LAUNCH(wprep_kernel, dim3(wprep_blocks(kind, pairs)), dim3(256), 0, st, kind, w, w1, out, Cout, Cin);
-    return launch_status();
-}
-
-// How many 256-lane blocks one (kind, Cout, Cin) item takes in the batched launch below (the host builds the table with it)
-EE_API int ee_conv_weight_prep_blocks(int kind, int Cout, int Cin) {
-    if (kind < EE_WPREP_WINO_F || kind > EE_WPREP_DENSE_MAP2 || Cout < 1 || Cin < 1) return 0;
-    return static_cast<int>(wprep_blocks(kind, static_cast<size_t>(Cout) * Cin));
-}
-
-// All items of a DEVICE-resident table in one launch: table [n][8] int64 = {w, w1 (or 0), out, kind, Cout, Cin, first block, blocks}, first
-// block = the running sum of `blocks` (ee_conv_weight_prep_blocks); total_blocks = that sum.  The caller vouches for the table's contents
-// (same rules as ee_conv_weight_prep_f32 per item).
-EE_API int ee_conv_weight_prep_batched_f32(const void *table_dev, int n_items, int total_blocks, void *stream) {
-    if (n_items < 0 || total_blocks < 0) return EE_ERR_SHAPE;
-    if (n_items == 0 || total_blocks == 0) return EE_OK;
-    if (!table_dev) return EE_ERR_NULL;
-    EE_LAUNCH(wprep_batched_kernel, dim3(static_cast<unsigned>(total_blocks)), dim3(256), 0, as_stream(stream), static_cast<const long long *>(table_dev), n_items);
     return launch_status();
 }

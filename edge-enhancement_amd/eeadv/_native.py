@@ -83,13 +83,10 @@ SIGNATURES = {
     "ee_bn_relu_pool_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     # dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, rm, rv, eps, training, dx, dgamma, dbeta, workspace, B, C, H, W, stream
     "ee_bn_relu_pool_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "ee_wino3x3_map8_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_wino3x3_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_small_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_small_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv_weight_prep_f32": [c_i, c_p, c_p, c_p, c_i, c_i, c_p],
-    "ee_conv_weight_prep_blocks": [c_i, c_i, c_i],
-    "ee_conv_weight_prep_batched_f32": [c_p, c_i, c_i, c_p],
     "ee_conv3x3s2_pair_fwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_pair_bwd_data_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_net2_conv_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],
@@ -98,10 +95,6 @@ SIGNATURES = {
     "ee_maxpool3s2_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_conv1x1s2_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "ee_conv1x1s2_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    "ee_conv3x3s1_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    "ee_conv3x3s1_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    "ee_conv3x3s2_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    "ee_conv3x3s2_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "ee_stem7x7s2_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_stem7x7s2_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_stem7x7s2_fwd_stats_floats": [c_i, c_i, c_i, c_i],
@@ -118,7 +111,8 @@ _RESTYPE = {"ee_strerror": ctypes.c_char_p, "ee_device_name": ctypes.c_char_p, "
 
 # kernel-family ids of include/eeadv.h (ee_prof_*)
 (K_PGD_STEP, K_FRONTEND_FWD, K_FRONTEND_BWD, K_EDGE_FWD, K_EDGE_BWD, K_CE, K_PGD_STEP_BCAST, K_EMPTY, K_HFS, K_CHAIN_FWD, K_CHAIN_BWD,
- K_HFS_SQ_FWD, K_HFS_SQ_BWD, K_SQUARE_DRAW, K_CONV3_FWD, K_CONV3_BWD, K_CONV3P_FWD, K_CONV3P_BWD, K_WINO, K_CONV3S2_FWD, K_CONV3S2_BWD) = range(21)
+ K_HFS_SQ_FWD, K_HFS_SQ_BWD, K_SQUARE_DRAW) = range(14)
+K_WINO, K_CONV3S2_FWD, K_CONV3S2_BWD = 18, 19, 20  # 14 - 17: the direct 3x3 kernels removed in round 3
 
 
 class EEError(RuntimeError):

@@ -21,7 +21,7 @@ from .functional import input_grad_only, refresh_dense_weights
 CE_SUM, CE_MEAN, KL, SOFTCE = "ce_sum", "ce_mean", "kl", "softce"
 # the input-gradient pass runs on the calling thread: handing it to autograd's device thread puts cross-thread stream
 # synchronisation into the captured graph (a 40 us idle gap in front of the first backward kernel of every iteration)
-_MT_BACKWARD = os.environ.get("EEADV_MT_BACKWARD", "0") == "1"
+_MT_BACKWARD = False
 
 
 class LossSpec:
@@ -44,8 +44,7 @@ class LossSpec:
         raise ValueError(self.kind)
 
 
-# EEADV_FC_HEAD=0: the classifier's head + loss as separate launches again (A/B)
-_FC_HEAD = os.environ.get("EEADV_FC_HEAD", "1") == "1"
+_FC_HEAD = True  # models that offer head_grad (Net_2) get head + loss + way back as one launch; False: separate launches
 
 
 def _body_input_grad(model, x_in, spec, through_body):
@@ -210,14 +209,9 @@ def pgd_loop(model, x0, x_init, spec, num_steps, step_size, eps, direction=1, lo
             # the probed iterations come LAST: their first kernel then follows an iteration's last one, caches as warm as inside the
             # graph (as the attack's first iteration, right behind the parameter update, the front-end kernel read its tables cold and
             # measured 23 ... 45 us from run to run against rocprofv3's 24 over the in-graph launches)
-            from . import models as _models
-            _models.PROBE_MFMA_CONV = True  # the probe launches what the graph replays (MFMA convolutions included)
-            try:
-                for _ in range(probe):
-                    attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi)
-                    x = x.detach()
-            finally:
-                _models.PROBE_MFMA_CONV = False
+            for _ in range(probe):  # eager passes launch exactly what the graph replays
+                attack_step_(model, x, x0, spec, step_size, eps, direction, lo, hi)
+                x = x.detach()
         return x
 
     x = x_init.detach().contiguous()

@@ -135,7 +135,6 @@ class AddSquareFn(torch.autograd.Function):
         return ops.add_square_bwd(g.contiguous(), x, ctx.eps, stripe, sq_sign, sq_pos, sq_size), None, None, None, None, None
 
 
-_MASK_FROM_X = os.environ.get("EEADV_BN_MASK_FROM_X", "1") == "1"  # 0: the BatchNorm backward reads y for its ReLU mask (A/B)
 
 
 def _two_pieces(grads):
@@ -154,7 +153,7 @@ class BnActFn(torch.autograd.Function):
     def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu, fork=False):
         y, sm, si = ops.bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, eps, training, relu)
         # the backward's ReLU mask is y > 0; without a residual it is recomputed from x (the forward's expression), and y is not kept for it
-        keep_y = relu and (residual is not None or not _MASK_FROM_X)
+        keep_y = relu and residual is not None
         ctx.save_for_backward(x, y if keep_y else None, gamma, sm, si, None if training else running_mean, None if training else running_var,
                               beta if relu and not keep_y else None)
         ctx.cfg = (eps, training, relu, residual is not None)
@@ -276,58 +275,6 @@ class Conv1x1S2Fn(torch.autograd.Function):
         return dx, dw
 
 
-class Conv3x3Fn(torch.autograd.Function):
-    """Conv2d(3x3, stride 1, padding 1, bias=False) (resnet.py:26-31): forward and backward-data on ee_conv.hip's f32-MFMA
-    implicit GEMM, the weight gradient (once per training step) on MIOpen."""
-
-    @staticmethod
-    def forward(ctx, x, weight):
-        ctx.save_for_backward(x, weight)
-        return ops.conv3x3s1_fwd(x, weight)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = ops.conv3x3s1_bwd_data(dy, weight) if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return dx, dw
-
-
-class Conv3x3S2Fn(torch.autograd.Function):
-    """Conv2d(3x3, stride 2, padding 1, bias=False), the first convolution of ResNet layers 2-4: forward and / or backward-data
-    on ee_conv.hip's f32-MFMA implicit GEMMs (each where it beats MIOpen, the caller decides); weight gradient on MIOpen."""
-
-    @staticmethod
-    def forward(ctx, x, weight, mfma_fwd, mfma_bwd):
-        ctx.save_for_backward(x, weight)
-        ctx.mfma_bwd = mfma_bwd
-        if mfma_fwd:
-            return ops.conv3x3s2_fwd(x, weight)
-        return torch.ops.aten.convolution(x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        want_w = ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY
-        want_x = ctx.needs_input_grad[0]
-        dx = None
-        if want_x and ctx.mfma_bwd:
-            dx = ops.conv3x3s2_bwd_data(dy, weight, x.shape[2], x.shape[3])
-            want_x = False
-        dw = None
-        if want_x or want_w:
-            gx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [want_x, want_w, False])
-            if want_x:
-                dx = gx
-        return dx, dw, None, None
-
-
-_STEM_FWD = os.environ.get("EEADV_STEM_FWD", "1") == "1"  # 0: the stem's forward back on MIOpen (A/B)
-_STEM_STATS = os.environ.get("EEADV_STEM_STATS", "1") == "1"  # 0: bn1 takes its batch statistics in its own pass over the stem's output (A/B)
 
 
 class StemConvFn(torch.autograd.Function):
@@ -340,8 +287,8 @@ class StemConvFn(torch.autograd.Function):
         convolution ran on MIOpen (the BatchNorm then takes its statistics itself)."""
         ctx.save_for_backward(x, weight)
         ctx.set_materialize_grads(False)  # or autograd zero-fills a gradient for `stats` on every backward pass (one launch)
-        if _STEM_FWD and ops.stem7x7s2_fwd_supported(x, weight):
-            if want_stats and _STEM_STATS:
+        if ops.stem7x7s2_fwd_supported(x, weight):
+            if want_stats:
                 y, stats = ops.stem7x7s2_fwd(x, weight, True)
                 ctx.mark_non_differentiable(stats)
                 return y, stats
@@ -421,9 +368,9 @@ def _versions(weight, extra):
     return weight._version if extra is None else (weight._version, extra._version)
 
 
-# kinds ee_wprep.hip builds in one launch (EE_WPREP_* of eeadv.h); EEADV_WPREP=0: the torch expressions of _rearranged instead (A/B)
+# kinds ee_wprep.hip builds in one launch (EE_WPREP_* of eeadv.h); _rearranged's torch expressions are their restatement (tests) and the
+# path of anything the kernel does not take
 _NATIVE_KIND = {"wino_f": 0, "wino_b": 1, "s2m_f": 2, "s2m_b": 3, "s2p_f": 4, "s2p_b": 5, "s1": 6}
-_WPREP = os.environ.get("EEADV_WPREP", "1") == "1"
 
 
 def _rearranged_shape(weight, kind):
@@ -439,7 +386,7 @@ def _rearranged_shape(weight, kind):
 
 def _fill_rearranged(buf, weight, kind, extra):
     """buf <- the rearranged copy, in place (capturable): one hand-written launch where ee_wprep.hip knows the kind"""
-    if (_WPREP and kind in _NATIVE_KIND and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
+    if (kind in _NATIVE_KIND and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
             and (extra is None or (extra.is_contiguous() and extra.dtype == torch.float32))):
         ops.conv_weight_prep(_NATIVE_KIND[kind], weight.detach(), None if extra is None else extra.detach(), buf)
     else:
@@ -447,7 +394,7 @@ def _fill_rearranged(buf, weight, kind, extra):
 
 
 def _new_rearranged(weight, kind, extra):
-    if _WPREP and kind in _NATIVE_KIND and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous():
+    if kind in _NATIVE_KIND and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous():
         buf = torch.empty(_rearranged_shape(weight, kind), dtype=torch.float32, device=weight.device)
         _fill_rearranged(buf, weight, kind, extra)
         return buf
@@ -484,89 +431,25 @@ def _dense_entry_params(ent):
     return w, e
 
 
-_WPREP_TABLES = {}  # tuple of cache keys -> (device table, items, total blocks, keep-alive tensors)
-
-
-def _wprep_table(ident):
-    """The device-resident item table of ee_conv_weight_prep_batched_f32 for these cache entries; ident = (cache keys, their live
-    (weight, buffer) pointers) - built once per identity, rebuilt if a parameter's storage moved"""
-    tab = _WPREP_TABLES.get(ident)
-    keys = ident[0]
-    if tab is None:
-        rows = []
-        for key in keys:
-            ent = _DENSE_W[key]
-            w, e = _dense_entry_params(ent)
-            kind = _NATIVE_KIND[ent[3]]
-            blocks = ops.conv_weight_prep_blocks(kind, w.shape[0], w.shape[1])
-            rows.append([w.data_ptr(), 0 if e is None else e.data_ptr(), ent[2].data_ptr(), kind, w.shape[0], w.shape[1], 0, blocks])
-        rows.sort(key=lambda r: -r[7])  # a block finds its item by a linear scan: the items with the most blocks first
-        first = 0
-        for r in rows:
-            r[6] = first
-            first += r[7]
-        dev = _DENSE_W[keys[0]][2].device
-        if len(_WPREP_TABLES) > 16:
-            _WPREP_TABLES.clear()
-        tab = _WPREP_TABLES[ident] = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), first)
-    return tab
-
-
-def _rebuild_batches(model):
-    """(keys for the one-launch rebuild grouped by device, entries to rebuild one by one) of a model's cached filters (all models: None)"""
-    own = None if model is None else {id(p) for p in model.parameters()}
-    batch, single = [], []
-    for key in list(_DENSE_W):
-        ent = _DENSE_W[key]
-        w, e = _dense_entry_params(ent)
-        if w is None:
-            del _DENSE_W[key]
-        elif own is None or key[0] in own:
-            if (_WPREP and _WPREP_BATCH and ent[3] in _NATIVE_KIND and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
-                    and (e is None or (e.is_contiguous() and e.dtype == torch.float32))):
-                batch.append(key)
-            else:
-                single.append(key)
-    groups = []
-    for dev in {(_DENSE_W[k][2].device) for k in batch}:
-        keys = tuple(k for k in batch if _DENSE_W[k][2].device == dev)
-        # a table holds raw pointers: its identity includes the live (weight, extra, buffer) pointers, so storage that moved gets a new one
-        ptrs = tuple((_DENSE_W[k][0]().data_ptr(), 0 if _DENSE_W[k][4] is None else _DENSE_W[k][4]().data_ptr(), _DENSE_W[k][2].data_ptr()) for k in keys)
-        groups.append((dev, (keys, ptrs)))
-    return groups, single
-
-
-def prepare_dense_rebuild(model=None):
-    """Build (eagerly: a host-to-device copy) the item tables rebuild_dense_weights will launch from - call before capturing a graph that
-    ends with it."""
-    for _, ident in _rebuild_batches(model)[0]:
-        _wprep_table(ident)
-
-
 def rebuild_dense_weights(model=None):
     """Unconditional in-place rebuild of the rearranged matrices - capturable: a captured optimiser step ends with it, because
     replaying a graph updates the weights without moving their Python-side version counters.  `model`: only ITS weights - a
     captured graph must not bake in copies into the buffers of another live model (tests, A/B scripts), which would write
-    freed memory once that model is gone.  Everything ee_wprep.hip knows goes out as ONE launch per device (a device-resident table of
-    items, see prepare_dense_rebuild)."""
+    freed memory once that model is gone.  One ee_wprep.hip launch per (weight, kind): ~30 back-to-back launches of a few us inside the
+    replayed graph (one mixed launch from a device-resident table was built in round 2, measured no faster there, and removed in
+    round 3).  Returns the cache keys it rebuilt."""
+    own = None if model is None else {id(p) for p in model.parameters()}
+    rebuilt = set()
     with torch.no_grad():
-        groups, single = _rebuild_batches(model)
-        rebuilt = {k for _, ident in groups for k in ident[0]} | set(single)
-        for dev, ident in groups:
-            if ident not in _WPREP_TABLES and torch.cuda.is_current_stream_capturing():
-                single.extend(ident[0])  # no host-to-device copy of a new table inside a capture: item by item this once
-                continue
-            table, n, total = _wprep_table(ident)
-            with torch.cuda.device(dev):
-                ops.conv_weight_prep_batched(table, n, total)
-            for k in ident[0]:
-                w, e = _dense_entry_params(_DENSE_W[k])
-                _DENSE_W[k][1] = _versions(w, e)
-        for k in single:
-            ent = _DENSE_W[k]
+        for key in list(_DENSE_W):
+            ent = _DENSE_W[key]
             w, e = _dense_entry_params(ent)
-            _fill_rearranged(ent[2], w, ent[3], e)
-            ent[1] = _versions(w, e)
+            if w is None:
+                del _DENSE_W[key]
+            elif own is None or key[0] in own:
+                _fill_rearranged(ent[2], w, ent[3], e)
+                ent[1] = _versions(w, e)
+                rebuilt.add(key)
     return rebuilt
 
 
@@ -586,12 +469,6 @@ def invalidate_dense_except(param_ids, keys):
     for key, ent in _DENSE_W.items():
         if key[0] in param_ids and key not in keys:
             ent[1] = None
-
-
-# EEADV_WPREP_BATCH=1: every item of a model in ONE launch from a device-resident table instead of one launch per (weight, kind).  Measured
-# on the bench: 8150 / 8152 against 8083 / 8163 img/s - inside a replayed graph 29 small back-to-back launches cost nothing a big mixed
-# one saves - so it stays off.
-_WPREP_BATCH = os.environ.get("EEADV_WPREP_BATCH", "0") == "1"
 
 
 def refresh_dense_weights():
@@ -616,13 +493,13 @@ class Conv3x3WinoFn(torch.autograd.Function):
         u = _dense_weight(weight, "wino_f")
         _dense_weight(weight, "wino_b")  # created outside any capture; the backward only reads it
         ctx.save_for_backward(x, weight)
-        return ops.wino3x3_map8(x, u)
+        return ops.wino3x3(x, u)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = ops.wino3x3_map8(dy, _dense_weight(weight, "wino_b")) if ctx.needs_input_grad[0] else None
+        dx = ops.wino3x3(dy, _dense_weight(weight, "wino_b")) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
             dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
@@ -677,30 +554,6 @@ class Conv3x3S2PairFn(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 dw1 = torch.ops.aten.convolution_backward(dy1, x, w1, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw3, dw1
-
-
-class Conv3x3S2Map4Fn(torch.autograd.Function):
-    """Conv2d(Cin, Cout, 3, stride 2, padding 1, bias=False) from a 4x4 map to a 2x2 map (layer4.0.conv1 at 64x64 inputs, resnet.py:26-31):
-    the BACKWARD-DATA as one dense product [B, 4 Cout] x [4 Cout, 16 Cin] (22 us on the BLAS against 39 us for MIOpen's NHWC implicit
-    GEMM + its three layout transposes + zero fill, un-profiled; 9/16 of the matrix are structural zeros); forward (27 us either way)
-    and weight gradient stay on MIOpen."""
-
-    @staticmethod
-    def forward(ctx, x, weight):
-        _dense_weight(weight, "s2")  # created / refreshed outside any capture; the backward only reads it
-        ctx.save_for_backward(x, weight)
-        return torch.ops.aten.convolution(x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        B = dy.shape[0]
-        dx = torch.mm(dy.reshape(B, -1), _dense_weight(weight, "s2").t()).view_as(x) if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return dx, dw
 
 
 class Conv3x3Map2Fn(torch.autograd.Function):

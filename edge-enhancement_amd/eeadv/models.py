@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime, syncbn as _syncbn
-from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Fn, Conv3x3Map2Fn, Conv3x3S2Fn, Conv3x3S2Map4Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Map2Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -62,8 +62,7 @@ def _pair(x):
     return x if isinstance(x, tuple) else (x, x)
 
 
-# EEADV_FORK=0: block outputs as ONE tensor again (autograd adds the two consumers' gradients in a launch of its own): A/B switch
-_FORK = os.environ.get("EEADV_FORK", "1") == "1"
+_FORK = True  # block outputs as a pair of tensors over one buffer (False: autograd adds the two consumers' gradients in a launch of its own)
 
 
 # EEADV_STOCK_GLUE=bn,pool,head,conv,stem,dense,conv3 (any subset) routes that piece of the CNN body through the stock ATen / MIOpen ops instead of
@@ -71,20 +70,7 @@ _FORK = os.environ.get("EEADV_FORK", "1") == "1"
 _STOCK = frozenset(t for t in os.environ.get("EEADV_STOCK_GLUE", "").split(",") if t)
 
 
-# ee_conv.hip's f32-MFMA 3x3 convolution takes maps 16..64 wide (29 us against 36 us for MIOpen's Winograd on the 64-channel
-# 16x16 layer; equal on 8x8, where the stock solver stays)
 _CHAIN = os.environ.get("EEADV_CHAIN", "1") == "1"  # the front end of a PGD iteration as two launches (ee_chain.hip) instead of six
-_CONV3_MINW = int(os.environ.get("EEADV_CONV3_MINW", "16"))
-_CONV3_W4 = os.environ.get("EEADV_CONV3_W4", "1") == "1"  # ... and the 4x4 maps of layer3 (split-reduction kernel: 34 us against 37.5)
-_CONV3_EAGER = os.environ.get("EEADV_CONV3_EAGER", "0") == "1"  # use the MFMA 3x3 convolutions outside graph capture as well
-# bench.py's probe iterations (engine.PROBE_ITERS) run outside the captured graph so that the library's event hooks can time
-# their kernels: engine sets this around them, and the probe then launches the same convolution kernels the graph replays
-PROBE_MFMA_CONV = False
-# layer4.0.conv1's backward-data as a dense [B, 4 Cout] x [4 Cout, 16 Cin] product: 22 us against 39 in isolation, but inside the step its
-# 33.6 MB matrix comes from HBM every pass and the gain drowns in the noise (6220 vs 6211 img/s): opt-in
-_DENSE_S2 = os.environ.get("EEADV_DENSE_S2", "0") == "1"
-_CONV3S2_BWD_MINOW = int(os.environ.get("EEADV_CONV3S2_BWD_MINOW", "8"))  # its backward-data kernel: 29 us vs 36 on layer2.0 un-profiled, +0.5 % end to end (35 / 69 us vs 34 / 39 at 4 / 2: not there)
-_CONV3S2_MINOW = int(os.environ.get("EEADV_CONV3S2_MINOW", "8"))  # narrowest OUTPUT map the stride-2 MFMA convolution takes (24 us vs 50 at 8; no gain at 4)
 
 
 # ee_conv.hip's stride-2 1x1 shortcut kernel reads its operands straight from L2, one wavefront per 32x32 tile: built for the 16 / 8 / 4-wide
@@ -189,45 +175,21 @@ def shortcut(block, x):
 
 
 def conv3(conv, x):
-    """A block's 3x3 convolution; on a 2x2 map (layer4 at 64x64 inputs) it is one dense product (functional.Conv3x3Map2Fn)."""
-    if ("dense" not in _STOCK and x.shape[2] == 2 and x.shape[3] == 2 and type(conv) is nn.Conv2d and _dense_f32(x)
-            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
-            and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"):
-        return Conv3x3Map2Fn.apply(x, conv.weight)
-    # The MFMA convolutions below are a few us faster on the device and tens of us slower on the host (a Python autograd
-    # Function + ctypes launch + a separate ATen call for the weight gradient against one ATen call): they pay where the
-    # host cost vanishes, i.e. while a HIP graph is being captured, and lose in eager, host-bound passes (TRADES / ALP
-    # updates: 4.2 k -> 4.9 k img/s with this rule).
-    if (_DENSE_S2 and "dense" not in _STOCK and x.shape[2] == 4 and x.shape[3] == 4 and type(conv) is nn.Conv2d and _dense_f32(x)
-            and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1)
-            and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels * conv.out_channels <= 1 << 18):
-        return Conv3x3S2Map4Fn.apply(x, conv.weight)  # layer4.0.conv1 at 64x64 inputs: backward-data as one dense product (opt-in)
-    if ("conv3" not in _STOCK and "wino" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and x.shape[2] == x.shape[3]
-            and (x.shape[2] == 8 or (x.shape[2] == 16 and "wino16" not in _STOCK) or (x.shape[2] == 4 and "wino4" not in _STOCK))
-            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-            and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
-            and conv.weight.is_contiguous()):
-        return Conv3x3WinoFn.apply(x, conv.weight)  # 8x8 / 16x16 / 4x4 maps (layer2, layer1, layer3): Winograd F(2x2,3x3) on the matrix cores - 21 us against MIOpen's 29.4, 22 against the direct kernel's 27.7, 28 against 35; eager passes included
-    if ("conv3" not in _STOCK and "s2small" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and x.shape[2] == x.shape[3]
-            and (x.shape[2] in (4, 8) or (x.shape[2] == 16 and "s2small16" not in _STOCK)) and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1)
-            and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
-            and conv.weight.is_contiguous()):
-        return Conv3x3S2SmallFn.apply(x, conv.weight)  # layer2.0 / layer3.0 / layer4.0 conv1: split-reduction MFMA kernel, backward by parity classes (ee_s2.hip)
-    if not (_CONV3_EAGER or PROBE_MFMA_CONV or torch.cuda.is_current_stream_capturing()):
+    """A block's 3x3 convolution.  stride 1 on 16x16 / 8x8 / 4x4 maps (ResNet-18 layers 1-3 at 64x64 inputs): Winograd F(2x2,3x3) on the matrix
+    cores (ee_wino.hip); stride 1 on a 2x2 map (layer 4): one dense product (functional.Conv3x3Map2Fn); stride 2 from a 16 / 8 / 4-wide map: the
+    split-reduction kernel of ee_s2.hip (backward by parity classes); every other shape - the ImageNet-size maps - is MIOpen's."""
+    plain = (type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+             and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros" and x.shape[2] == x.shape[3] and conv.weight.is_contiguous())
+    if not plain:
         return conv(x)
-    if ("conv3s2" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
-            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
-            and conv.padding_mode == "zeros" and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[3] // 2 <= 64
-            and 64 % (x.shape[3] // 2) == 0 and conv.in_channels % 16 == 0 and conv.out_channels % 64 == 0 and conv.weight.is_contiguous()):
-        ow = x.shape[3] // 2
-        mfma_fwd, mfma_bwd = ow >= _CONV3S2_MINOW, ow >= _CONV3S2_BWD_MINOW
-        if mfma_fwd or mfma_bwd:
-            return Conv3x3S2Fn.apply(x, conv.weight, mfma_fwd, mfma_bwd)
-    if ("conv3" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
-            and conv.padding_mode == "zeros" and (_CONV3_MINW <= x.shape[3] <= 64 or (x.shape[3] == 4 and _CONV3_W4)) and 64 % x.shape[3] == 0
-            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.weight.is_contiguous()):
-        return Conv3x3Fn.apply(x, conv.weight)  # 16x16 / 8x8 maps: implicit GEMM on the f32 matrix cores (ee_conv.hip)
+    hw, by32 = x.shape[2], conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
+    if conv.stride == (1, 1):
+        if hw == 2 and "dense" not in _STOCK:
+            return Conv3x3Map2Fn.apply(x, conv.weight)
+        if hw in (4, 8, 16) and by32 and "conv3" not in _STOCK and "wino" not in _STOCK:
+            return Conv3x3WinoFn.apply(x, conv.weight)
+    elif conv.stride == (2, 2) and hw in (4, 8, 16) and by32 and "conv3" not in _STOCK and "s2small" not in _STOCK:
+        return Conv3x3S2SmallFn.apply(x, conv.weight)
     return conv(x)
 
 

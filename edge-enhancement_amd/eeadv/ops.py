@@ -781,30 +781,11 @@ def conv1x1s2_bwd(dy, weight, H, W):
     return dx
 
 
-def conv3x3s1_fwd(x, weight):
-    """Conv2d(Cin, Cout, 3, 1, 1, bias=False) (resnet.py:26-31) on ee_conv.hip's implicit GEMM."""
-    B, Cin, H, W = x.shape
-    Cout = weight.shape[0]
-    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
-    N.check(N.lib.ee_conv3x3s1_fwd_f32(_chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight", (Cout, Cin, 3, 3)), y.data_ptr(), B,
-                                       Cin, Cout, H, W, _stream()), "ee_conv3x3s1_fwd_f32")
-    return y
-
-
-def conv3x3s1_bwd_data(dy, weight):
-    B, Cout, H, W = dy.shape
-    Cin = weight.shape[1]
-    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
-    N.check(N.lib.ee_conv3x3s1_bwd_data_f32(_chk(dy, torch.float32, "dy"), _chk(weight, torch.float32, "weight", (Cout, Cin, 3, 3)),
-                                            dx.data_ptr(), B, Cin, Cout, H, W, _stream()), "ee_conv3x3s1_bwd_data_f32")
-    return dx
-
-
 def wino3x3_supported(x, cin, cout):
     return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8, 16) and cin % 32 == 0 and cout % 32 == 0
 
 
-def wino3x3_map8(x, u):
+def wino3x3(x, u):
     """3x3 / stride 1 / padding 1 convolution of 4x4, 8x8 or 16x16 maps, filters in the Winograd domain: x [B,KC,H,H], u [16,KC,RC] -> [B,RC,H,H]."""
     B, KC, H = x.shape[0], x.shape[1], x.shape[2]
     RC = u.shape[2]
@@ -848,16 +829,6 @@ def conv_weight_prep(kind, weight, extra, out):
     return out
 
 
-def conv_weight_prep_blocks(kind, cout, cin):
-    return int(N.lib.ee_conv_weight_prep_blocks(kind, cout, cin))
-
-
-def conv_weight_prep_batched(table, n_items, total_blocks):
-    """every item of a device-resident table (int64 [n, 8], see eeadv.h) in one launch"""
-    N.check(N.lib.ee_conv_weight_prep_batched_f32(_chk(table, torch.int64, "table", (n_items, 8)), n_items, total_blocks, _stream()),
-            "ee_conv_weight_prep_batched_f32")
-
-
 def conv3x3s2_pair_fwd(x, w10, cout):
     """conv3x3 / stride 2 / padding 1 AND conv1x1 / stride 2 of the same x in one launch (a down-sampling BasicBlock's conv1 and shortcut):
     x [B,Cin,H,H], w10 = both filter sets rearranged (functional._rearranged kind "s2p_f") -> (y3, y1), each [B,Cout,H/2,H/2]"""
@@ -876,27 +847,6 @@ def conv3x3s2_pair_bwd_data(dy3, dy1, w10, cin):
     N.check(N.lib.ee_conv3x3s2_pair_bwd_data_f32(_chk(dy3, torch.float32, "dy3", (B, Cout, OH, OH)), _chk(dy1, torch.float32, "dy1", (B, Cout, OH, OH)),
                                                  _chk(w10, torch.float32, "w10", (cin // 32, Cout // 16, 10, 4, 2, 16, 4)), dx.data_ptr(), B, cin, Cout, 2 * OH,
                                                  _stream()), "ee_conv3x3s2_pair_bwd_data_f32")
-    return dx
-
-
-def conv3x3s2_fwd(x, weight):
-    """Conv2d(Cin, Cout, 3, stride 2, padding 1, bias=False) forward on ee_conv.hip's implicit GEMM."""
-    B, Cin, H, W = x.shape
-    Cout = weight.shape[0]
-    y = torch.empty((B, Cout, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    N.check(N.lib.ee_conv3x3s2_fwd_f32(_chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight", (Cout, Cin, 3, 3)), y.data_ptr(), B,
-                                       Cin, Cout, H, W, _stream()), "ee_conv3x3s2_fwd_f32")
-    return y
-
-
-def conv3x3s2_bwd_data(dy, weight, H, W):
-    """d loss / d x of Conv2d(Cin, Cout, 3, stride 2, padding 1): dy [B,Cout,H/2,W/2] -> [B,Cin,H,W] (ee_conv.hip)."""
-    B, Cout = dy.shape[0], dy.shape[1]
-    Cin = weight.shape[1]
-    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
-    N.check(N.lib.ee_conv3x3s2_bwd_data_f32(_chk(dy, torch.float32, "dy", (B, Cout, H // 2, W // 2)),
-                                            _chk(weight, torch.float32, "weight", (Cout, Cin, 3, 3)), dx.data_ptr(), B, Cin, Cout, H, W, _stream()),
-            "ee_conv3x3s2_bwd_data_f32")
     return dx
 
 

@@ -29,7 +29,7 @@ class Criterion:
         return self._host(output, target)
 
 
-_FUSED_SGD = os.environ.get("EEADV_FUSED_SGD", "1") == "1"  # 0: torch's default (foreach) SGD, five multi-tensor launches per step
+_FUSED_SGD = True  # False: torch's default (foreach) SGD, five multi-tensor launches per step
 
 
 class _FusedSGD(torch.optim.SGD):
@@ -212,8 +212,6 @@ class _GraphedUpdate:
         return out
 
     def _capture(self):
-        from eeadv.functional import prepare_dense_rebuild
-        prepare_dense_rebuild(self.model())  # the item table of the one-launch rebuild: its upload must not fall into the capture
         torch.cuda.synchronize()
         mode = runtime.capture_mode()
         self.graph = torch.cuda.CUDAGraph()
@@ -342,12 +340,11 @@ class _GraphedPredsUpdate:
             preds = model(self.x)
             self.adv.copy_(self._attack(preds))
             return self._after_attack(preds)
-        from eeadv.functional import prepare_dense_rebuild, refresh_dense_weights
+        from eeadv.functional import refresh_dense_weights
         refresh_dense_weights()
         if self.g1 is None:
             if not model.training:
                 raise RuntimeError("TRADES / ALP step: the model must be in train mode when the step starts (the .loss() methods leave it there)")
-            prepare_dense_rebuild(model)
             torch.cuda.synchronize()
             mode = runtime.capture_mode()
             self.g1 = torch.cuda.CUDAGraph()
@@ -429,7 +426,7 @@ def _graphable_preds_update(model, criterion, optimizer, args, input, sync):
             and args.method_name in ('TRADES', 'ALP', 'tarALP'))
 
 
-_GRAPH_PREDS = os.environ.get("EEADV_GRAPH_TRADES", "1") == "1"  # 0: the TRADES / ALP step around the attack stays eager (A/B)
+_GRAPH_PREDS = True  # False: the TRADES / ALP step around the attack stays eager
 
 
 def backward_and_step(loss, optimizer, sync=None):
@@ -595,10 +592,9 @@ class FreeAtStep:
             out = self._repeat(self.x, self.y)
         if done == self.n_repeats:
             return out
-        from eeadv.functional import prepare_dense_rebuild, rebuild_dense_weights, refresh_dense_weights
+        from eeadv.functional import rebuild_dense_weights, refresh_dense_weights
         refresh_dense_weights()
         if self.graph is None:
-            prepare_dense_rebuild(self.model)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode=runtime.capture_mode()):

@@ -361,27 +361,12 @@ int ee_maxpool3s2_bwd_f32(const float *dy, const uint8_t *code, float *dx, int p
 int ee_conv1x1s2_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream);
 int ee_conv1x1s2_bwd_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W, void *stream);
 
-/* Conv2d(Cin, Cout, kernel_size=3, stride=1, padding=1, bias=False) of the residual blocks (resnet.py:26-31), forward and
- * backward-data, as an implicit GEMM on the exact-f32 matrix cores.  x / dx [B,Cin,H,W], y / dy [B,Cout,H,W], weight
- * [Cout,Cin,3,3].  W must divide 64, the reduction channel count (Cin forward, Cout backward) be a multiple of 16 and the
- * result channel count a multiple of 64 (EE_ERR_UNSUPPORTED otherwise: every ResNet stage qualifies both ways).  The weight gradient is not provided. */
-int ee_conv3x3s1_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream);
-int ee_conv3x3s1_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W,
-                              void *stream);
-
-/* Conv2d(Cin, Cout, kernel_size=3, stride=2, padding=1, bias=False) - the first convolution of ResNet layers 2-4 - forward:
- * x [B,Cin,H,W] -> y [B,Cout,H/2,W/2].  H, W even, W/2 divides 64, Cin % 16 == 0, Cout % 64 == 0 (else EE_ERR_UNSUPPORTED). */
-int ee_conv3x3s2_fwd_f32(const float *x, const float *weight, float *y, int B, int Cin, int Cout, int H, int W, void *stream);
-/* its backward-data: dy [B,Cout,H/2,W/2] -> dx [B,Cin,H,W] (all of dx is written).  Cout % 32 == 0, Cin % 16 == 0. */
-int ee_conv3x3s2_bwd_data_f32(const float *dy, const float *weight, float *dx, int B, int Cin, int Cout, int H, int W,
-                              void *stream);
-
-/* Conv2d(3x3, stride 1, padding 1, bias=False) on 8x8 maps as Winograd F(2x2, 3x3) around the f32 matrix cores (ResNet-18 layer2 at
- * 64x64 inputs, resnet.py:26-31): x [B,KC,8,8], u [16][KC][RC] = the filters in the transform domain, u[4i+j][k][r] = (G g G^T)[i][j] with
- * g = weight[r][k] (forward: KC = Cin, RC = Cout) or g = weight[k][r] rotated by 180 degrees (backward-data: KC = Cout, RC = Cin;
- * x = dy) -> y [B,RC,8,8].  KC % 16 == 0, RC % 32 == 0 (else EE_ERR_UNSUPPORTED). */
-int ee_wino3x3_map8_f32(const float *x, const float *u, float *y, int B, int KC, int RC, void *stream);
-/* the same for H x H maps, H = 8 or 16 (layer1: 64 tiles per image, four accumulator blocks per wavefront) */
+/* Conv2d(3x3, stride 1, padding 1, bias=False) of the residual blocks (resnet.py:26-31) on H x H maps, H = 4, 8 or 16 (ResNet-18 layers 3, 2, 1
+ * at 64x64 inputs), forward and backward-data, as Winograd F(2x2, 3x3) around the f32 matrix cores: x [B,KC,H,H], u [16][KC][RC] = the filters
+ * in the transform domain, u[4i+j][k][r] = (G g G^T)[i][j] with g = weight[r][k] (forward: KC = Cin, RC = Cout) or g = weight[k][r] rotated by
+ * 180 degrees (backward-data: KC = Cout, RC = Cin; x = dy) -> y [B,RC,H,H].  KC % 16 == 0, RC % 32 == 0 (else EE_ERR_UNSUPPORTED).  The weight
+ * gradient is not provided.  (Round 3 removed the direct implicit-GEMM kernels ee_conv3x3s1_* / ee_conv3x3s2_* that these and the
+ * ee_conv3x3s2_small_* kernels below superseded on every shape of the BASELINE configs.) */
 int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int RC, int H, void *stream);
 
 /* Conv2d(3x3, stride 2, padding 1, bias=False) between SMALL maps - the first convolution of ResNet-18's layer2 / layer3 / layer4 at 64x64 inputs
@@ -414,10 +399,6 @@ int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, const flo
 #define EE_WPREP_S2P_B 5
 #define EE_WPREP_DENSE_MAP2 6
 int ee_conv_weight_prep_f32(int kind, const float *w, const float *w1, float *out, int Cout, int Cin, void *stream);
-/* every (weight, kind) of a model in ONE launch: table_dev = device array [n_items][8] of int64 {w, w1 or 0, out, kind, Cout, Cin, first
- * block, blocks}; blocks = ee_conv_weight_prep_blocks(kind, Cout, Cin), first block = their running sum, total_blocks = the sum */
-int ee_conv_weight_prep_blocks(int kind, int Cout, int Cin);
-int ee_conv_weight_prep_batched_f32(const void *table_dev, int n_items, int total_blocks, void *stream);
 
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.
@@ -514,10 +495,7 @@ int ee_chain_bwd_f32(const float *g_in, const uint8_t *gate, const float *gx, co
 #define EE_K_HFS_SQ_FWD 11  /* ee_hfs_f32, sq_mode 1 (Add_Square on load) */
 #define EE_K_HFS_SQ_BWD 12  /* ee_hfs_f32, sq_mode 2 (times d Add_Square / dx on store) */
 #define EE_K_SQUARE_DRAW 13 /* ee_square_draw_f32 */
-#define EE_K_CONV3_FWD 14   /* ee_conv3x3s1_fwd_f32, 4-wavefront kernel */
-#define EE_K_CONV3_BWD 15   /* ee_conv3x3s1_bwd_data_f32, 4-wavefront kernel */
-#define EE_K_CONV3P_FWD 16  /* ee_conv3x3s1_fwd_f32, pipelined kernel (256-channel 4x4 maps) */
-#define EE_K_CONV3P_BWD 17  /* ee_conv3x3s1_bwd_data_f32, pipelined kernel */
+/* 14 - 17: the direct 3x3 kernels removed in round 3 */
 #define EE_K_WINO 18        /* ee_wino3x3_f32 (forward and backward-data are the same kernel); work = the convolution's algorithmic flops */
 #define EE_K_CONV3S2_FWD 19 /* ee_conv3x3s2_small_fwd_f32; work = flops */
 #define EE_K_CONV3S2_BWD 20 /* ee_conv3x3s2_small_bwd_data_f32 */

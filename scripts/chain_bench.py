@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times ee_chain_fwd_f32 / ee_chain_bwd_f32 alone (graph-replayed back-to-back launches) next to the separate kernels they
-replace.  EEADV_CHAIN_DBG=<bits> skips phases of the fused kernels (see ee_chain.hip) to attribute their time."""
+replace."""
 import os
 import sys
 
@@ -41,7 +41,6 @@ def main():
     dev = "cuda:0"
     shapes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["100x3x64x64", "1600x3x64x64", "50x1x28x28"]
     wts = ops.EdgeWeights(1.0)
-    print("dbg =", os.environ.get("EEADV_CHAIN_DBG", "0"))
     for shp in shapes:
         B, C, H, W = map(int, shp.split("x"))
         r = 8 if H == 64 else 4
@@ -59,7 +58,7 @@ def main():
             ("chain_fwd nosq", lambda: ops.chain_fwd(x, op.chain, wts, 0.0, 76 / 255, 1.0), (9 * C + 8) * px),
             ("chain_bwd", lambda: ops.chain_bwd_(x, g, gate, gx, gy, x0, op.chain, wts, 0.0, 76 / 255, 1.0, 2 / 255, 16 / 255), (17 * C + 8) * px),
         ]
-        if not os.environ.get("EEADV_CHAIN_DBG"):
+        if True:
             d = dict(zip(("stripe", "sq_pos", "sq_sign"), ops.square_draw(B, C, H, sizes, state)))
             d["sq_size"] = sizes
             gate0 = (gate & 1).contiguous()

@@ -50,17 +50,3 @@ from eeadv import ops  # noqa: E402
 x = torch.randn(B, 3, 64, 64, device=dev)
 w = torch.randn(64, 3, 7, 7, device=dev)
 print("%-28s %10.1f   (MIOpen %.1f)" % ("stem fwd on ee_conv.hip", timeit(lambda: ops.stem7x7s2_fwd(x, w)), timeit(lambda: F.conv2d(x, w, None, 2, 3))))
-print("stride-2 3x3 on ee_conv.hip (forward, backward-data):")
-for name, ci, co, hw in (("l2.0 64->128 @16", 64, 128, 16), ("l3.0 128->256 @8", 128, 256, 8), ("l4.0 256->512 @4", 256, 512, 4)):
-    x = torch.randn(B, ci, hw, hw, device=dev)
-    w = torch.randn(co, ci, 3, 3, device=dev)
-    dy = torch.randn(B, co, hw // 2, hw // 2, device=dev)
-    try:
-        tf = timeit(lambda: ops.conv3x3s2_fwd(x, w))
-    except Exception as e:  # noqa: BLE001
-        tf = float("nan")
-    try:
-        tb = timeit(lambda: ops.conv3x3s2_bwd_data(dy, w, hw, hw))
-    except Exception as e:  # noqa: BLE001
-        tb = float("nan")
-    print("%-28s %10.1f %10.1f" % (name, tf, tb), flush=True)

@@ -26,8 +26,6 @@ FAMILIES = {
     "ee_chain_fwd": "chain_fwd_kernel", "ee_chain_bwd": "chain_bwd_kernel", "ee_frontend_fwd": "edge_fwd_kernel",
     "ee_frontend_bwd": "edge_bwd_saved_kernel", "ee_hfs": "hfs_*kernel<0", "ee_hfs_square_fwd": "hfs_*kernel<1", "ee_hfs_square_bwd": "hfs_*kernel<2",
     "ee_pgd_step": "map3_kernel*PgdStepOp", "ee_pgd_step_bcast": "pgd_step_bcast_kernel", "ee_square_draw": "square_draw_kernel",
-    "ee_conv3x3s1_fwd": "conv3x3s1_kernel<false, 16>", "ee_conv3x3s1_bwd_data": "conv3x3s1_kernel<true, 16>",
-    "ee_conv3x3s1_pipe_fwd": "conv3x3s1_pipe_kernel<false, 4,", "ee_conv3x3s1_pipe_bwd_data": "conv3x3s1_pipe_kernel<true, 4,",
     "ee_wino3x3": "wino3x3_", "ee_conv3x3s2_small_fwd": "conv3s2_fwd_mfma_kernel", "ee_conv3x3s2_small_bwd_data": "conv3s2_bwd_mfma_kernel",
 }
 

@@ -65,9 +65,6 @@ for cin, cout, hw in ((64, 128, 16), (128, 256, 8), (256, 512, 4)):
         print("   EEADV_S2_MT=%s: forward %6.1f us  backward-data %6.1f us" % (mt, timeit(lambda: ops.conv3x3s2_small_fwd(x, wf, cout)),
                                                                                timeit(lambda: ops.conv3x3s2_small_bwd_data(dy, wb, cin))), flush=True)
     os.environ.pop("EEADV_S2_MT")
-    if hw == 16:
-        print("   ee_conv.hip direct kernels: forward %6.1f us  backward-data %6.1f us" % (
-            timeit(lambda: ops.conv3x3s2_fwd(x, w)), timeit(lambda: ops.conv3x3s2_bwd_data(dy, w, hw, hw))), flush=True)
     mi_f = timeit(lambda: F.conv2d(x, w, None, 2, 1))
     mi_b = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
     print("%3d -> %3d ch %dx%d:  forward MIOpen %6.1f us  ee_s2 %6.1f us   backward-data MIOpen %6.1f us  ee_s2 %6.1f us" % (

@@ -45,7 +45,7 @@ for c, hw in SHAPES:
     w = torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5)
     u = EF._rearranged(w, "wino_f").contiguous()
     if os.environ.get("PROBE_EAGER"):
-        timeit(lambda: ops.wino3x3_map8(x, u))
+        timeit(lambda: ops.wino3x3(x, u))
         continue
-    print("%3d ch %2dx%-2d:  MIOpen %6.1f us   direct MFMA %6.1f us   Winograd MFMA %6.1f us" % (
-        c, hw, hw, timeit(lambda: F.conv2d(x, w, None, 1, 1)), timeit(lambda: ops.conv3x3s1_fwd(x, w)), timeit(lambda: ops.wino3x3_map8(x, u))), flush=True)
+    print("%3d ch %2dx%-2d:  MIOpen %6.1f us   Winograd MFMA %6.1f us" % (
+        c, hw, hw, timeit(lambda: F.conv2d(x, w, None, 1, 1)), timeit(lambda: ops.wino3x3(x, u))), flush=True)

@@ -776,31 +776,6 @@ def test_stem_conv_fwd_mfma_matches_aten(ops, B, K, H, W):
             torch.testing.assert_close(a, e, rtol=2e-6, atol=2e-6)
 
 
-@pytest.mark.parametrize("B,Cin,Cout", [(100, 256, 512), (3, 5, 7), (2, 64, 32)])
-def test_conv3x3s2_from_4x4_map_backward_as_dense_product(ops, B, Cin, Cout):
-    """Conv2d(3x3, stride 2, padding 1) from a 4x4 to a 2x2 map (layer4.0.conv1 at 64x64 inputs): backward-data as one dense product
-    vs ATen, the rearranged [16 Cin, 4 Cout] matrix follows in-place weight updates, forward and weight gradient are ATen's own."""
-    import torch.nn.functional as F
-    from eeadv import functional as EF
-    g = torch.Generator(device="cpu").manual_seed(B + Cin + 1)
-    x = torch.randn(B, Cin, 4, 4, generator=g).to(DEV).requires_grad_(True)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
-    dy = torch.randn(B, Cout, 2, 2, generator=g).to(DEV)
-    for round_ in range(2):
-        ref = F.conv2d(x, w, None, 2, 1)
-        got = EF.Conv3x3S2Map4Fn.apply(x, w)
-        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
-        (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
-        torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (4 * B) ** 0.5)
-        w2 = EF._dense_weight(w, "s2")
-        assert w2.shape == (16 * Cin, 4 * Cout) and float((w2 != 0).float().mean()) <= 9 / 16 + 1e-6
-        ptr = w2.data_ptr()
-        with torch.no_grad():
-            w.mul_(1.5)
-        assert EF._dense_weight(w, "s2").data_ptr() == ptr  # same buffer, new contents
-
-
 @pytest.mark.parametrize("B,Cin,Cout", [(100, 512, 512), (3, 5, 7), (1, 64, 32)])
 def test_conv3x3_on_2x2_map_as_dense_product(ops, B, Cin, Cout):
     """Conv2d(3x3, stride 1, padding 1) on a 2x2 map (ResNet layer4 at 64x64 inputs) as one GEMM vs ATen, and the rearranged
@@ -835,44 +810,6 @@ def test_conv3x3_on_2x2_map_as_dense_product(ops, B, Cin, Cout):
         EF.refresh_dense_weights()
         gph.replay()
         torch.testing.assert_close(out, F.conv2d(xs, w, None, 1, 1), rtol=1e-4, atol=1e-4)
-
-
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(100, 64, 64, 16, 16), (100, 128, 128, 8, 8), (100, 256, 256, 4, 4), (3, 64, 128, 5, 8),
-                                            (2, 128, 64, 3, 2), (1, 64, 64, 1, 1), (2, 64, 64, 56, 32), (5, 64, 192, 7, 64), (3, 64, 64, 5, 4),
-                                            (7, 192, 64, 4, 4)])
-def test_conv3x3s1_mfma_matches_aten(ops, B, Cin, Cout, H, W):
-    """The residual blocks' 3x3 convolution (resnet.py:26-31) as an implicit GEMM on the f32 matrix cores vs ATen: forward,
-    input gradient, and (through ATen) weight gradient; tiles that span image boundaries included (W = 4, 2, 1)."""
-    import torch.nn.functional as F
-    from eeadv.functional import Conv3x3Fn
-    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout + H)
-    x = torch.randn(B, Cin, H, W, generator=g).to(DEV).requires_grad_(True)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
-    ref = F.conv2d(x, w, None, 1, 1)
-    got = Conv3x3Fn.apply(x, w)
-    dy = torch.randn(ref.shape, generator=g).to(DEV)
-    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
-    (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
-    torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W) ** 0.5)
-
-
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(100, 64, 128, 16, 16), (100, 128, 256, 8, 8), (100, 256, 512, 4, 4), (3, 16, 64, 6, 8),
-                                            (2, 32, 128, 2, 2), (2, 64, 64, 56, 64), (5, 16, 192, 10, 128)])
-def test_conv3x3s2_mfma_matches_aten(ops, B, Cin, Cout, H, W):
-    """The stride-2 3x3 convolution opening ResNet layers 2-4 as an implicit GEMM on the f32 matrix cores vs ATen."""
-    import torch.nn.functional as F
-    from eeadv.functional import Conv3x3S2Fn
-    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout + H)
-    x = torch.randn(B, Cin, H, W, generator=g).to(DEV).requires_grad_(True)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV).requires_grad_(True)
-    ref = F.conv2d(x, w, None, 2, 1)
-    got = Conv3x3S2Fn.apply(x, w, True, Cout % 32 == 0 and Cin % 16 == 0)
-    dy = torch.randn(ref.shape, generator=g).to(DEV)
-    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
-    (gx, gw), (ex, ew) = torch.autograd.grad(got, [x, w], dy), torch.autograd.grad(ref, [x, w], dy)
-    torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (B * H * W / 4) ** 0.5)
 
 
 @pytest.mark.parametrize("shape", [(4, 3, 64, 64), (3, 1, 28, 28), (2, 3, 17, 23), (2, 2, 5, 4), (1, 3, 80, 72), (2, 4, 224, 224)])
@@ -1074,20 +1011,18 @@ def test_weight_preparation_kernels_match_their_torch_restatement(ops, monkeypat
     again = EF._dense_weight(p, "wino_f")
     assert again.data_ptr() == ptr
     torch.testing.assert_close(again, EF._rearranged(p, "wino_f").contiguous(), rtol=1e-6, atol=1e-6)
-    # the batched rebuild (one launch for every cached item of a model) gives the same bits as the per-item launches
+    # the in-place rebuild of every cached item of a model (what a captured optimiser step ends with) gives the per-item launches' bits
     m = torch.nn.Module()
     m.a, m.b = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w1.clone())
     bufs = {k: EF._dense_weight(m.a, k, m.b if k.startswith("s2p") else None) for k in ("wino_f", "wino_b", "s2p_f", "s2p_b", "s2m_f", "s1")}
-    for batched in (True, False):
-        monkeypatch.setattr(EF, "_WPREP_BATCH", batched)
-        with torch.no_grad():
-            m.a.mul_(0.5)
-            m.b.add_(1.0)
-        EF.rebuild_dense_weights(m)
-        for k, bufk in bufs.items():
-            want = torch.empty_like(bufk)
-            ops.conv_weight_prep(EF._NATIVE_KIND[k], m.a.detach(), m.b.detach() if k.startswith("s2p") else None, want)
-            assert torch.equal(bufk, want), (k, batched)
+    with torch.no_grad():
+        m.a.mul_(0.5)
+        m.b.add_(1.0)
+    assert set(EF.rebuild_dense_weights(m)) == {(id(m.a), k) for k in bufs}
+    for k, bufk in bufs.items():
+        want = torch.empty_like(bufk)
+        ops.conv_weight_prep(EF._NATIVE_KIND[k], m.a.detach(), m.b.detach() if k.startswith("s2p") else None, want)
+        assert torch.equal(bufk, want), k
 
 
 @pytest.mark.parametrize("H", [4, 8, 16])
@@ -1102,7 +1037,7 @@ def test_mfma_convs_with_an_odd_number_of_rounds(ops, H, KC):
     B = 5
     x = torch.randn(B, KC, H, H, generator=g).to(DEV)
     w = (torch.randn(32, KC, 3, 3, generator=g) / (3 * KC ** 0.5)).to(DEV)
-    got = ops.wino3x3_map8(x, EF._rearranged(w, "wino_f").contiguous())
+    got = ops.wino3x3(x, EF._rearranged(w, "wino_f").contiguous())
     ref = F.conv2d(x.double(), w.double(), None, 1, 1)
     assert float((got.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
     got = ops.conv3x3s2_small_fwd(x, EF._rearranged(w, "s2m_f").contiguous(), 32)

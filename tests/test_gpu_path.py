@@ -664,7 +664,7 @@ def test_fused_classifier_body_equals_stock_modules(monkeypatch, depth, B):
 @pytest.mark.parametrize("method", ["TRADES", "ALP"])
 def test_trades_alp_step_as_two_graphs_around_the_attack(monkeypatch, method):
     """trainer._GraphedPredsUpdate: preds = model(x) | attack | model(x_adv), .loss(), backward, SGD as two captured graphs sharing a
-    pool, the attack between them.  Against the eager step (EEADV_GRAPH_TRADES=0) on the same seeds: the same number of BatchNorm
+    pool, the attack between them.  Against the eager step (trainer._GRAPH_PREDS = False) on the same seeds: the same number of BatchNorm
     updates, the model back in train mode, the eager steps before the capture identical, the trajectory after it within a few per cent (the
     random starts differ from there on: the capturing step draws one extra 0.001 * randn; MIOpen's backward is not bit-reproducible
     either), the weights moving the same way."""
