@@ -583,6 +583,12 @@ def main():
         emit()
         os._exit(0)
 
+    t_start = time.perf_counter()
+
+    def leg(name):
+        sys.stderr.write("[bench] %7.1f s after the headline workload: %s\n" % (time.perf_counter() - t_start, name))
+        sys.stderr.flush()
+
     import threading
     timer = threading.Timer(a.extras_timeout, watchdog)
     timer.daemon = True
@@ -595,6 +601,7 @@ def main():
             if world > 1 and name != "imagenet_free_at":
                 continue
             try:
+                leg("other workload " + name)
                 others[name] = time_other_workload(name, dev, world, rank, a.other_steps, 2)
             except Exception as exc:  # noqa: BLE001 - reported on the line, the headline number stands
                 others[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
@@ -605,12 +612,14 @@ def main():
             out["other_workloads"] = others
         if world == 1 and not a.no_cpu_baseline:
             # all the cores this process may use AND n = 8 (the survey container's count), same step
+            leg("cpu baselines")
             out["cpu_baseline"] = cpu_baseline(cfg, 14.0)
             if out["cpu_baseline"]["cores"] != 8:
                 out["cpu_baseline_8_threads"] = cpu_baseline(cfg, 10.0, threads=8)
             if "imagenet_free_at" in others and "error" not in others["imagenet_free_at"]:
                 others["imagenet_free_at"]["cpu_baseline"] = cpu_baseline(dict(WORKLOADS["imagenet_free_at"]), 12.0)
     timer.cancel()
+    leg("done")
     emit()
     if world > 1:
         dist.barrier()
