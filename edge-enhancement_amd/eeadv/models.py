@@ -76,7 +76,8 @@ _CHAIN = os.environ.get("EEADV_CHAIN", "1") == "1"  # the front end of a PGD ite
 # ee_conv.hip's stride-2 1x1 shortcut kernel reads its operands straight from L2, one wavefront per 32x32 tile: built for the 16 / 8 / 4-wide
 # maps of the 64x64 configs (8 - 12 us against MIOpen's 25).  On ImageNet-size maps it is 4x SLOWER than MIOpen (profiles/
 # round3_c_resnet50_conv_probe.txt: 424 / 462 / 483 us against 102 / 91 / 91 on the three ResNet-50 shortcuts at batch 32), so those go to MIOpen.
-_CONV1X1S2_MAXW = 16
+# ... and so does ResNet-50's last shortcut (1024 -> 2048 channels on a 14x14 map: 480 us): the reduction is split over a workgroup's four wavefronts only
+_CONV1X1S2_MAXW, _CONV1X1S2_MAXC = 16, 256
 
 
 def _dense_f32(x):
@@ -149,7 +150,7 @@ def block_tail(block, bn, out, x, fork, sc=None):
         cv = ds[0]
         if ("conv" not in _STOCK and cv.kernel_size == (1, 1) and cv.stride == (2, 2) and cv.padding == (0, 0) and cv.bias is None and cv.groups == 1
                 and cv.in_channels % 2 == 0 and cv.out_channels % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-                and x.shape[3] <= _CONV1X1S2_MAXW and cv.weight.is_contiguous()):
+                and x.shape[3] <= _CONV1X1S2_MAXW and cv.in_channels <= _CONV1X1S2_MAXC and cv.weight.is_contiguous()):
             sc = Conv1x1S2Fn.apply(x, cv.weight)
             if sc.shape == out.shape:
                 b2 = ds[1]
@@ -169,7 +170,7 @@ def shortcut(block, x):
         cv = ds[0]
         if (cv.kernel_size == (1, 1) and cv.stride == (2, 2) and cv.padding == (0, 0) and cv.bias is None and cv.groups == 1
                 and cv.in_channels % 2 == 0 and cv.out_channels % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-                and x.shape[3] <= _CONV1X1S2_MAXW and cv.weight.is_contiguous()):
+                and x.shape[3] <= _CONV1X1S2_MAXW and cv.in_channels <= _CONV1X1S2_MAXC and cv.weight.is_contiguous()):
             return bn_act(ds[1], Conv1x1S2Fn.apply(x, cv.weight), relu=False)
     return ds(x)
 
