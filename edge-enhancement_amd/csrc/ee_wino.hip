@@ -21,6 +21,29 @@ using namespace ee;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -DEE_WINO_TIMING (scripts/wino_timing.py builds its own copy of this file with it; never the product): shader-clock stamps of one
+// multiplying and one producing lane per workgroup - entry, loop start, loop end, and the cycles spent inside the round bodies (the rest
+// of the loop being barrier waits); a second mode splits the producing lane's even rounds into U store | transform | pixel store + loads
+#ifdef EE_WINO_TIMING
+__device__ unsigned long long g_wino_stamps[8 * 2048];
+__device__ int g_wino_sub;
+#define WT_DECL unsigned long long wt_body = 0, wt_t = 0, wt_p[3] = {0, 0, 0}, wt_q = 0
+#define WT_STAMP(k) do { if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == PC_CW) && blockIdx.x < 2048) g_wino_stamps[blockIdx.x * 8 + (wave ? 4 : 0) + (k)] = (k) == 3 ? wt_body : clock64(); } while (0)
+#define WT_BEGIN wt_t = clock64()
+#define WT_END wt_body += clock64() - wt_t
+#define WT_P0 wt_q = clock64()
+#define WT_P(i) do { const unsigned long long n_ = clock64(); wt_p[i] += n_ - wt_q; wt_q = n_; } while (0)
+#define WT_DUMP do { if (g_wino_sub && (threadIdx.x & 63) == 0 && wave == PC_CW && blockIdx.x < 2048) { g_wino_stamps[blockIdx.x * 8 + 0] = wt_p[0]; g_wino_stamps[blockIdx.x * 8 + 1] = wt_p[1]; g_wino_stamps[blockIdx.x * 8 + 2] = wt_p[2]; } } while (0)
+#else
+#define WT_DECL
+#define WT_STAMP(k)
+#define WT_BEGIN
+#define WT_END
+#define WT_P0
+#define WT_P(i)
+#define WT_DUMP
+#endif
+
 constexpr int WN_CK = 16, WN_CO = 32;
 constexpr int WN_CP = 48;                      // U row stride in LDS: the four k of a wavefront on disjoint banks (32 + 16)
 constexpr int WN_US = WN_CK * WN_CP;           // one xi's [16 ci][48]
@@ -237,67 +260,84 @@ struct PcGeo {
     static constexpr int VT = T + 16, VS = CK * VT;                   // V row stride (the four k of a wavefront on disjoint banks), one xi's V
     static constexpr int XW = MAP + 4, XI = (MAP + 2) * XW, XP = IMG * XI, XS = CK * XP;  // pixel frames (zero ring)
     static constexpr int BUF = 16 * US + 16 * VS + XS;
-    static constexpr int XF4 = CK * IMG * MAP * MAP / 4 / 256;        // float4 of pixels per producer lane and round: 1 or 2
-    static constexpr int PPT = CK * T / 256;                          // patches per producer lane and round: 1 or 2
+    // producing wavefronts: the 16x16 kernel is bound by its producers (clock stamps, scripts/wino_timing.py: 3056 cycles of producer work per
+    // round against 1770 of the multiplying side with four of them) -> eight there, four on 8x8 (one patch per lane already)
+    static constexpr int PW = MAP == 16 ? 8 : 4, PL = PW * 64, NT = (8 + PW) * 64, WPE = NT / 256;
+    static constexpr int UPL = 1024 / PL;                             // float4 of the U slice per producer lane and round: 4 or 2
+    static constexpr int XF4 = CK * IMG * MAP * MAP / 4 / PL;         // float4 of pixels per producer lane and round: 1
+    static constexpr int PPT = CK * T / PL;                           // patches per producer lane and round: 1
     static constexpr size_t lds_bytes = 2 * BUF * sizeof(float);
 };
 
+// EIGHT multiplying wavefronts (two xi each) and four (8x8) or eight (16x16) producing ones: three or four wavefronts per SIMD (round 3;
+// round 2: four multiplying wavefronts with four xi each + four producing ones, two per SIMD).  Shader-clock stamps inside the round-2
+// kernel (scripts/wino_timing.py) showed the rounds bound by the PRODUCERS - 3056 cycles of producer work per 8-channel round on the 16x16
+// layer (2314 of them the two input-patch transforms of a lane, i.e. LDS latency), 1770 on the multiplying side, whose wavefronts spent
+// half of the loop waiting at the round barrier.  Twice the producing lanes halve a lane's share (one patch, two U rows, one pixel float4
+// per round); the 64 accumulator registers per multiplying wavefront (instead of 128) make room for the extra wavefronts.  Same products
+// in the same order per accumulator: bit-identical results.
+constexpr int PC_CW = 8, PC_XPW = 16 / PC_CW;
+
 template <int MAP>
-__global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino3x3_pc_kernel(const float *__restrict__ x, const float *__restrict__ u,
+__global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(PcGeo<MAP>::WPE, PcGeo<MAP>::WPE))) void wino3x3_pc_kernel(const float *__restrict__ x, const float *__restrict__ u,
                                                                                                      float *__restrict__ y, WinoDims d) {
     using G = PcGeo<MAP>;
-    static_assert(G::XF4 == G::PPT && (G::XF4 == 1 || G::XF4 == 2), "8x8 or 16x16 maps");
+    static_assert(G::XF4 == 1 && G::PPT == 1 && (G::UPL == 2 || G::UPL == 4), "8x8 or 16x16 maps");
     extern __shared__ __align__(16) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool producer = wave >= 4;
-    const int pt = threadIdx.x & 255;  // lane number inside its group of four wavefronts
+    const bool producer = wave >= PC_CW;
+    const int pt = (threadIdx.x - PC_CW * 64) & (G::PL - 1);  // producers: lane number inside their group of wavefronts
+    WT_DECL;
+    WT_STAMP(0);
     int bx, by;  // XCD-aware numbering (see the 4x4 kernel)
     if (!xcd_decode(blockIdx.x, d.RC / WN_CO, (d.B + G::IMG - 1) / G::IMG, d.wl, bx, by)) return;
     const int b = bx * G::IMG, co0 = by * WN_CO;
     const int l15 = lane & 15, lq = lane >> 4;
     const int rounds = d.KC / G::CK;
-    // U slice of a round: 16 xi x 8 ci rows of 32 floats = 1024 float4, four per producer lane: rows (xi0 + 4 j, ci_u)
+    // U slice of a round: 16 xi x 8 ci rows of 32 floats = 1024 float4, UPL per producer lane: rows (xi0 + PW j, ci_u)
     const int uq = pt & 7, ci_u = (pt >> 3) & 7, xi0 = pt >> 6;
     const float *ubase = u + (static_cast<size_t>(xi0) * d.KC + ci_u) * d.RC + co0 + 4 * uq;
-    const size_t uxi4 = 4 * static_cast<size_t>(d.KC) * d.RC, ustep = static_cast<size_t>(G::CK) * d.RC;
-    // pixels of a round: 16x16: the 8 planes are contiguous, float4 number pt + 256 k; 8x8: image pt >> 7, float4 pt & 127 of its 8 planes
+    const size_t uxi4 = G::PW * static_cast<size_t>(d.KC) * d.RC, ustep = static_cast<size_t>(G::CK) * d.RC;
+    // pixels of a round: 16x16: the 8 planes are contiguous, float4 number pt; 8x8: image pt >> 7, float4 pt & 127 of its 8 planes
     const int ximg = MAP == 8 ? pt >> 7 : 0, xbi = b + ximg < d.B ? b + ximg : d.B - 1;  // past the batch: a valid image, never stored
     const float *xsrc = x + static_cast<size_t>(xbi) * d.KC * (MAP * MAP) + 4 * (MAP == 8 ? pt & 127 : pt);
     const size_t xstep = static_cast<size_t>(G::CK) * (MAP * MAP);
-    for (int i = threadIdx.x; i < G::XS; i += W4_NT) lds[16 * G::US + 16 * G::VS + i] = lds[G::BUF + 16 * G::US + 16 * G::VS + i] = 0.0f;  // zero rings
-    float4 UA0, UA1, UA2, UA3, UB0, UB1, UB2, UB3, XA0, XA1, XB0, XB1;  // NAMED register sets (see the 4x4 kernel)
-    XA1 = XB1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 UA0, UA1, UA2, UA3, UB0, UB1, UB2, UB3, XA0, XB0;  // NAMED register sets (see the 4x4 kernel)
+    UA2 = UA3 = UB2 = UB3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #define PC_FETCH_U(S, round_)                                                                      \
     do {                                                                                           \
         const int r_ = (round_) < rounds ? (round_) : rounds - 1; /* always issued */              \
         const float *up_ = ubase + r_ * ustep;                                                     \
         S##0 = *reinterpret_cast<const float4 *>(up_);                                             \
         S##1 = *reinterpret_cast<const float4 *>(up_ + uxi4);                                      \
-        S##2 = *reinterpret_cast<const float4 *>(up_ + 2 * uxi4);                                  \
-        S##3 = *reinterpret_cast<const float4 *>(up_ + 3 * uxi4);                                  \
+        if (G::UPL > 2) {                                                                          \
+            S##2 = *reinterpret_cast<const float4 *>(up_ + 2 * uxi4);                              \
+            S##3 = *reinterpret_cast<const float4 *>(up_ + 3 * uxi4);                              \
+        }                                                                                          \
     } while (0)
 #define PC_FETCH_X(S, round_)                                                                      \
     do {                                                                                           \
         const int r_ = (round_) < rounds ? (round_) : rounds - 1;                                  \
         const float *xp_ = xsrc + r_ * xstep;                                                      \
         S##0 = *reinterpret_cast<const float4 *>(xp_);                                             \
-        if (G::XF4 > 1) S##1 = *reinterpret_cast<const float4 *>(xp_ + 4 * 256);                   \
     } while (0)
 #define PC_STORE_U(buf_, S)                                                                        \
     do {                                                                                           \
         float *ud_ = (buf_) + xi0 * G::US + ci_u * WN_CP + 4 * uq;                                 \
         *reinterpret_cast<float4 *>(ud_) = S##0;                                                   \
-        *reinterpret_cast<float4 *>(ud_ + 4 * G::US) = S##1;                                       \
-        *reinterpret_cast<float4 *>(ud_ + 8 * G::US) = S##2;                                       \
-        *reinterpret_cast<float4 *>(ud_ + 12 * G::US) = S##3;                                      \
+        *reinterpret_cast<float4 *>(ud_ + G::PW * G::US) = S##1;                                   \
+        if (G::UPL > 2) {                                                                          \
+            *reinterpret_cast<float4 *>(ud_ + 2 * G::PW * G::US) = S##2;                           \
+            *reinterpret_cast<float4 *>(ud_ + 3 * G::PW * G::US) = S##3;                           \
+        }                                                                                          \
     } while (0)
-    auto put_x = [&](float *xs, float4 v, int k) {  // float4 number k of this lane -> frame interior
+    auto put_x = [&](float *xs, float4 v) {  // this lane's float4 -> frame interior
         int ci, img, row, c4;
         if (MAP == 8) {
             const int w = pt & 127;
             img = pt >> 7, ci = w >> 4, row = (w & 15) >> 1, c4 = 4 * (w & 1);
         } else {
-            const int f = pt + 256 * k, q = f & 63;
+            const int f = pt, q = f & 63;
             img = 0, ci = f >> 6, row = q >> 2, c4 = 4 * (q & 3);
         }
         float *dst = xs + ci * G::XP + img * G::XI + (1 + row) * G::XW + 1 + c4;
@@ -305,16 +345,14 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     };
 #define PC_PUT_X(buf_, S)                                                                          \
     do {                                                                                           \
-        put_x((buf_) + 16 * G::US + 16 * G::VS, S##0, 0);                                          \
-        if (G::XF4 > 1) put_x((buf_) + 16 * G::US + 16 * G::VS, S##1, 1);                          \
+        put_x((buf_) + 16 * G::US + 16 * G::VS, S##0);                                             \
     } while (0)
     // V = B^T d B of this lane's patches, from the frames of `buf` into its V
     auto transform = [&](float *buf) {
         const float *xs = buf + 16 * G::US + 16 * G::VS;
         float *vs = buf + 16 * G::US;
-#pragma unroll
-        for (int k = 0; k < G::PPT; ++k) {
-            const int pr = pt + 256 * k, ci = pr / G::T, t = pr - ci * G::T, img = t / G::TI, ti = t - img * G::TI;
+        {
+            const int pr = pt, ci = pr / G::T, t = pr - ci * G::T, img = t / G::TI, ti = t - img * G::TI;
             const int ty = ti / G::TX, tx = ti - ty * G::TX;
             const float *p = xs + ci * G::XP + img * G::XI + (2 * ty) * G::XW + 2 * tx;  // patch rows 2ty-1 .. 2ty+2 = frame rows 2ty .. 2ty+3
             float dd[4][4];
@@ -340,19 +378,19 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             }
         }
     };
-    f32x4 acc[4][G::NB][2];
+    f32x4 acc[PC_XPW][G::NB][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < PC_XPW; ++a)
 #pragma unroll
         for (int nb = 0; nb < G::NB; ++nb)
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc[a][nb][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     // consumer: M_xi += U_xi V_xi for this wavefront's four xi; a round's operands first, then its products
     auto multiply = [&](const float *cur) {
-        float a0[4][2], a1[4][2], bv[4][2][G::NB];
+        float a0[PC_XPW][2], a1[PC_XPW][2], bv[PC_XPW][2][G::NB];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int xi = 4 * wave + a;
+        for (int a = 0; a < PC_XPW; ++a) {
+            const int xi = PC_XPW * wave + a;
             const float *up = cur + xi * G::US + lq * WN_CP + l15;
             const float *vp = cur + 16 * G::US + xi * G::VS + lq * G::VT + l15;
 #pragma unroll
@@ -365,7 +403,7 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < PC_XPW; ++a)
 #pragma unroll
                 for (int nb = 0; nb < G::NB; ++nb) {
                     acc[a][nb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[a][kq], bv[a][kq][nb], acc[a][nb][0], 0, 0, 0);
@@ -374,11 +412,12 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     };
     float *buf0 = lds, *buf1 = lds + G::BUF;
     // prologue: pixels of rounds 0 and 1 into their frames, U of round 0, V of round 0; sets: UA / XA hold even rounds, UB / XB odd ones
-    if (producer) {
+    if (producer) {  // the first loads are in flight while the rings are zeroed
         PC_FETCH_U(UA, 0);
         PC_FETCH_X(XA, 0);
         PC_FETCH_X(XB, 1);
     }
+    for (int i = threadIdx.x; i < G::XS; i += G::NT) lds[16 * G::US + 16 * G::VS + i] = lds[G::BUF + 16 * G::US + 16 * G::VS + i] = 0.0f;  // zero rings
     __syncthreads();  // the zero rings
     if (producer) {
         PC_PUT_X(buf0, XA);
@@ -392,19 +431,27 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     __syncthreads();
     if (producer) transform(buf0);
     __syncthreads();
+    WT_STAMP(1);
     for (int round = 0; round < rounds; round += 2) {
         // iteration `round` (even): multiply buffer 0; U and V of round + 1 -> buffer 1, pixels of round + 2 -> frames of buffer 0
+        WT_BEGIN;
         if (producer) {
+            WT_P0;
             PC_STORE_U(buf1, UB);
+            WT_P(0);
             transform(buf1);
+            WT_P(1);
             PC_PUT_X(buf0, XA);
             PC_FETCH_U(UB, round + 3);
             PC_FETCH_X(XA, round + 4);
+            WT_P(2);
         } else {
             multiply(buf0);
         }
+        WT_END;
         __syncthreads();
         if (round + 1 < rounds) {  // iteration round + 1: multiply buffer 1; U and V of round + 2 -> buffer 0, pixels of round + 3 -> frames of buffer 1
+            WT_BEGIN;
             if (producer) {
                 PC_STORE_U(buf0, UA);
                 transform(buf0);
@@ -414,35 +461,43 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             } else {
                 multiply(buf1);
             }
+            WT_END;
             __syncthreads();
         }
     }
+    WT_STAMP(2);
 #undef PC_FETCH_U
 #undef PC_FETCH_X
 #undef PC_STORE_U
 #undef PC_PUT_X
-    // ---- output transform Y = A^T M A, one N block (16 tiles) at a time.  D[row = 4 lq + reg][col = l15] -> ms[xi][co][tile] ---------------
+    // ---- output transform Y = A^T M A.  D[row = 4 lq + reg][col = l15] -> ms[nb][xi][co][tile]: the accumulators of ALL N blocks go to
+    // LDS at once (NB x 32 KB <= the two round buffers), ONE barrier, then every lane transforms its NB (co, tile) items back to back -
+    // 16 LDS reads and two 8-byte stores each, all independent (round 2 ran the blocks one at a time through one 32 KB area: two barriers
+    // and a serialised read -> store chain per block)
     float *ms = lds;
+    static_assert(static_cast<size_t>(G::NB) * 16 * WN_CO * 16 * sizeof(float) <= G::lds_bytes, "the accumulators of all N blocks fit the round buffers");
+    if (!producer) {
 #pragma unroll
-    for (int nb = 0; nb < G::NB; ++nb) {
-        if (nb > 0) __syncthreads();
-        if (!producer) {
+        for (int nb = 0; nb < G::NB; ++nb)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < PC_XPW; ++a)
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ms[((4 * wave + a) * WN_CO + 16 * m + 4 * lq + r) * 16 + l15] = acc[a][nb][m][r];
-        }
-        __syncthreads();
-        {
-            const int idx = threadIdx.x;  // (co, tile of this block)
-            const int co = idx >> 4, tl = idx & 15, t = 16 * nb + tl, img = t / G::TI, ti = t - img * G::TI, ty = ti / G::TX, tx = ti - ty * G::TX;
+                    for (int r = 0; r < 4; ++r) ms[((nb * 16 + PC_XPW * wave + a) * WN_CO + 16 * m + 4 * lq + r) * 16 + l15] = acc[a][nb][m][r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 512) {
+        const int idx = threadIdx.x;  // (co, tile of a block)
+        const int co = idx >> 4, tl = idx & 15;
+#pragma unroll
+        for (int nb = 0; nb < G::NB; ++nb) {
+            const int t = 16 * nb + tl, img = t / G::TI, ti = t - img * G::TI, ty = ti / G::TX, tx = ti - ty * G::TX;
             float mm[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mm[i][j] = ms[((4 * i + j) * WN_CO + co) * 16 + tl];
+                for (int j = 0; j < 4; ++j) mm[i][j] = ms[((nb * 16 + 4 * i + j) * WN_CO + co) * 16 + tl];
             float t0[4], t1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -456,6 +511,8 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             }
         }
     }
+    WT_STAMP(3);
+    WT_DUMP;
 }
 
 template <int MAP>
@@ -464,7 +521,7 @@ int wino_pc_launch(const float *x, const float *u, float *y, const WinoDims &d, 
     static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_pc_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(G::lds_bytes)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH(wino3x3_pc_kernel<MAP>, dim3(xcd_grid((d.B + G::IMG - 1) / G::IMG, d.RC / WN_CO, d.wl)), dim3(W4_NT), G::lds_bytes,
+    EE_LAUNCH(wino3x3_pc_kernel<MAP>, dim3(xcd_grid((d.B + G::IMG - 1) / G::IMG, d.RC / WN_CO, d.wl)), dim3(G::NT), G::lds_bytes,
               st, x, u, y, d);
     return launch_status();
 }
@@ -495,3 +552,10 @@ EE_API int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int K
     if (H == 8) return wino_pc_launch<8>(x, u, y, d, as_stream(stream));
     return wino_pc_launch<16>(x, u, y, d, as_stream(stream));
 }
+
+#ifdef EE_WINO_TIMING
+EE_API int ee_wino_timing_sub(int on) { return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(g_wino_sub), &on, sizeof(int))); }
+EE_API int ee_wino_timing_read(unsigned long long *host, int n) {
+    return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_stamps), sizeof(unsigned long long) * n));
+}
+#endif
