@@ -33,7 +33,7 @@ __device__ int g_wino_sub;
 #define WT_END wt_body += clock64() - wt_t
 #define WT_P0 wt_q = clock64()
 #define WT_P(i) do { const unsigned long long n_ = clock64(); wt_p[i] += n_ - wt_q; wt_q = n_; } while (0)
-#define WT_DUMP do { if (g_wino_sub && (threadIdx.x & 63) == 0 && wave == PC_CW && blockIdx.x < 2048) { g_wino_stamps[blockIdx.x * 8 + 0] = wt_p[0]; g_wino_stamps[blockIdx.x * 8 + 1] = wt_p[1]; g_wino_stamps[blockIdx.x * 8 + 2] = wt_p[2]; } } while (0)
+#define WT_DUMP do { if ((g_wino_sub & 1) && (threadIdx.x & 63) == 0 && wave == PC_CW && blockIdx.x < 2048) { g_wino_stamps[blockIdx.x * 8 + 0] = wt_p[0]; g_wino_stamps[blockIdx.x * 8 + 1] = wt_p[1]; g_wino_stamps[blockIdx.x * 8 + 2] = wt_p[2]; } } while (0)
 #else
 #define WT_DECL
 #define WT_STAMP(k)
