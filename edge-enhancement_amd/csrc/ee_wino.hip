@@ -258,7 +258,10 @@ struct PcGeo {
     static constexpr int CK = 8;
     static constexpr int US = CK * WN_CP;                             // one xi's U [8 ci][48]
     static constexpr int VT = T + 16, VS = CK * VT;                   // V row stride (the four k of a wavefront on disjoint banks), one xi's V
-    static constexpr int XW = MAP + 4, XI = (MAP + 2) * XW, XP = IMG * XI, XS = CK * XP;  // pixel frames (zero ring)
+    // pixel frames (zero ring).  Row stride and image stride are chosen so that a wavefront's patch reads - one ds_read_b64 per half row,
+    // lanes = tiles - fall on 64 distinct banks: 16x16: rows of 24 floats; 8x8: rows of 12, the second image 160 floats behind the first
+    static constexpr int XW = MAP == 16 ? 24 : 12, XI = MAP == 16 ? (MAP + 2) * XW : 160, XP = IMG * XI, XS = CK * XP;
+    static_assert(XI >= (MAP + 2) * XW && XW >= MAP + 2 && XW % 2 == 0, "frame fits");
     static constexpr int BUF = 16 * US + 16 * VS + XS;
     // producing wavefronts: the 16x16 kernel is bound by its producers (clock stamps, scripts/wino_timing.py: 3056 cycles of producer work per
     // round against 1770 of the multiplying side with four of them) -> eight there, four on 8x8 (one patch per lane already)
@@ -357,9 +360,10 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
             const float *p = xs + ci * G::XP + img * G::XI + (2 * ty) * G::XW + 2 * tx;  // patch rows 2ty-1 .. 2ty+2 = frame rows 2ty .. 2ty+3
             float dd[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dd[i][j] = p[i * G::XW + j];
+            for (int i = 0; i < 4; ++i) {  // an even column offset: two 8-byte reads per row (bank-conflict-free, see PcGeo)
+                const float2 lo = *reinterpret_cast<const float2 *>(p + i * G::XW), hi = *reinterpret_cast<const float2 *>(p + i * G::XW + 2);
+                dd[i][0] = lo.x, dd[i][1] = lo.y, dd[i][2] = hi.x, dd[i][3] = hi.y;
+            }
             float tt[4][4];  // B^T d
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -368,13 +372,13 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
                 tt[2][j] = dd[2][j] - dd[1][j];
                 tt[3][j] = dd[1][j] - dd[3][j];
             }
-            float *vp = vs + ci * G::VT + t;
+            // V as [8 xi pairs][8 ci][VT tiles][2]: a multiplying wavefront owns the pair (2 w, 2 w + 1) and reads both values of a (ci, tile)
+            // with one ds_read_b64; eight 8-byte stores here instead of sixteen 4-byte ones
+            float2 *vp = reinterpret_cast<float2 *>(vs) + ci * G::VT + t;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                vp[(4 * i + 0) * G::VS] = tt[i][0] - tt[i][2];
-                vp[(4 * i + 1) * G::VS] = tt[i][1] + tt[i][2];
-                vp[(4 * i + 2) * G::VS] = tt[i][2] - tt[i][1];
-                vp[(4 * i + 3) * G::VS] = tt[i][1] - tt[i][3];
+                vp[(2 * i + 0) * G::VS] = make_float2(tt[i][0] - tt[i][2], tt[i][1] + tt[i][2]);
+                vp[(2 * i + 1) * G::VS] = make_float2(tt[i][2] - tt[i][1], tt[i][1] - tt[i][3]);
             }
         }
     };
@@ -388,17 +392,21 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     // consumer: M_xi += U_xi V_xi for this wavefront's four xi; a round's operands first, then its products
     auto multiply = [&](const float *cur) {
         float a0[PC_XPW][2], a1[PC_XPW][2], bv[PC_XPW][2][G::NB];
+        static_assert(PC_XPW == 2, "one xi pair per multiplying wavefront");
+        const float2 *vp = reinterpret_cast<const float2 *>(cur + 16 * G::US) + (wave * G::CK + lq) * G::VT + l15;  // V[pair = wave][ci = 4 kq + lq][tile]
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+            for (int nb = 0; nb < G::NB; ++nb) {
+                const float2 v2 = vp[kq * 4 * G::VT + 16 * nb];
+                bv[0][kq][nb] = v2.x, bv[1][kq][nb] = v2.y;
+            }
 #pragma unroll
         for (int a = 0; a < PC_XPW; ++a) {
             const int xi = PC_XPW * wave + a;
             const float *up = cur + xi * G::US + lq * WN_CP + l15;
-            const float *vp = cur + 16 * G::US + xi * G::VS + lq * G::VT + l15;
 #pragma unroll
-            for (int kq = 0; kq < 2; ++kq) {
-                a0[a][kq] = up[kq * 4 * WN_CP], a1[a][kq] = up[kq * 4 * WN_CP + 16];
-#pragma unroll
-                for (int nb = 0; nb < G::NB; ++nb) bv[a][kq][nb] = vp[kq * 4 * G::VT + 16 * nb];
-            }
+            for (int kq = 0; kq < 2; ++kq) a0[a][kq] = up[kq * 4 * WN_CP], a1[a][kq] = up[kq * 4 * WN_CP + 16];
         }
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq)
