@@ -85,14 +85,31 @@ __global__ __launch_bounds__(N2_NT) void net2_conv1_fwd_kernel(const float *__re
 // ---- conv2 + bias -> dropout scale -> pool -> relu.  grid (B, 8): 8 output channels per workgroup; the 32 input channels are split
 // over the two halves of the workgroup (threads 0-127 / 128-255), partial sums meet in LDS and are added in that order ----------------
 constexpr int N2_WP = 28;  // weights of one (co, ci) padded 25 -> 28: 16-byte rows
+// RNG: Dropout2d's Bernoulli(keep) draw per (image, channel) is made HERE (Philox4x32-10 on the device-resident {seed, offset, ticket} state
+// that Add_Square's draws use, stream id 7): element e = b * 64 + co <-> component e % 4 of counter offset + e / 4; the mask (0 / 1) is also
+// written to drop_out [B,64] for the backward kernel.  The workgroup holding the last ticket advances the offset, so a replayed HIP graph
+// draws fresh masks - and torch's bernoulli_ launch (5 us, once per forward of the attack loop) disappears from the captured iteration.
+template <bool RNG>
 __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__restrict__ a1, const float *__restrict__ w, const float *__restrict__ bias,
                                                                const float *__restrict__ drop, float keep, float *__restrict__ a2,
-                                                               uint8_t *__restrict__ code2) {
+                                                               uint8_t *__restrict__ code2, unsigned long long *state, float *__restrict__ drop_out, int B) {
     __shared__ __align__(16) float as[N2_C1 * N2_H1 * N2_H1];      // 18 KB
     constexpr int CS = N2_C1 * N2_WP + 4;  // per-channel stride: the 8 channels of a wavefront on disjoint banks (32 * 28 floats apart they collide 8-fold)
     __shared__ __align__(16) float ws[8 * CS];                     // 28 KB
     __shared__ float part[128 * 4];
     const int b = blockIdx.x, c0 = blockIdx.y * 8;
+    unsigned long long seed = 0ull, base = 0ull;
+    if (RNG) {  // every lane reads the state; lane 0 then takes a ticket, the last ticket of the grid advances the offset (as ee_chain.hip does)
+        seed = state[0], base = state[1];
+        __threadfence();
+        if (threadIdx.x == 0) {
+            const unsigned long long done = atomicAdd(state + 2, 1ull);
+            if (done + 1ull == static_cast<unsigned long long>(B) * 8ull) {
+                state[1] = base + static_cast<unsigned long long>((static_cast<long long>(B) * N2_C2 + 3) >> 2);
+                state[2] = 0ull;
+            }
+        }
+    }
     const float4 *src = reinterpret_cast<const float4 *>(a1 + static_cast<size_t>(b) * N2_C1 * N2_H1 * N2_H1);
     for (int i = threadIdx.x; i < N2_C1 * N2_H1 * N2_H1 / 4; i += N2_NT) reinterpret_cast<float4 *>(as)[i] = src[i];
     for (int i = threadIdx.x; i < 8 * N2_C1 * 25; i += N2_NT) {  // w[c0 + co][ci][25] is one contiguous block of 8 * 32 * 25 floats
@@ -142,11 +159,22 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__re
     __syncthreads();
     if (half == 0) {
         const float bv = bias ? bias[c0 + co] : 0.0f;
-        const float dm = drop ? drop[static_cast<size_t>(b) * N2_C2 + c0 + co] / keep : 1.0f;  // Bernoulli(keep) draw (0 / 1) -> 0 or 1 / keep, as noise.div_(keep)
+        float mask = 1.0f;
+        if (RNG) {
+            const long long e = static_cast<long long>(b) * N2_C2 + c0 + co;
+            const uint4 r = Philox(seed)(base + static_cast<unsigned long long>(e >> 2), 7u);
+            const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+            mask = u01(rr[e & 3]) < keep ? 1.0f : 0.0f;  // bernoulli_(keep): 1 with probability keep
+            if (p == 0) drop_out[e] = mask;
+        } else if (drop) {
+            mask = drop[static_cast<size_t>(b) * N2_C2 + c0 + co];
+        }
+        const bool dropping = RNG || drop != nullptr;
+        const float dm = mask / keep;  // Bernoulli(keep) draw (0 / 1) -> 0 or 1 / keep, as noise.div_(keep)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float s = (v[k] + part[idx * 4 + k]) + bv;
-            v[k] = drop ? s * dm : s;
+            v[k] = dropping ? s * dm : s;
         }
         int code;
         const float best = pool4(v, code);
@@ -297,15 +325,22 @@ __global__ __launch_bounds__(N2_NT) void net2_conv1_bwd_kernel(const float *__re
 }  // namespace
 
 EE_API int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *drop, float keep,
-                                float *a1, uint8_t *code1, float *a2, uint8_t *code2, int B, void *stream) {
+                                uint64_t *draw_state, float *drop_out, float *a1, uint8_t *code1, float *a2, uint8_t *code2, int B, void *stream) {
     if (B < 0) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
     if (!x || !w1 || !w2 || !a1 || !code1 || !a2 || !code2) return EE_ERR_NULL;
-    if (drop && !(keep > 0.0f)) return EE_ERR_SHAPE;
+    const bool rng = !drop && draw_state;
+    if ((drop || rng) && !(keep > 0.0f)) return EE_ERR_SHAPE;
+    if (rng && !drop_out) return EE_ERR_NULL;
     if (!aligned16(x) || !aligned16(a1)) return EE_ERR_ALIGN;
     hipStream_t st = as_stream(stream);
     EE_LAUNCH(net2_conv1_fwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, x, w1, b1, a1, code1);
-    EE_LAUNCH(net2_conv2_fwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, a1, w2, b2, drop, keep, a2, code2);
+    if (rng)
+        EE_LAUNCH(net2_conv2_fwd_kernel<true>, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, a1, w2, b2, drop, keep, a2, code2,
+                  reinterpret_cast<unsigned long long *>(draw_state), drop_out, B);
+    else
+        EE_LAUNCH(net2_conv2_fwd_kernel<false>, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, a1, w2, b2, drop, keep, a2, code2,
+                  static_cast<unsigned long long *>(nullptr), static_cast<float *>(nullptr), B);
     return launch_status();
 }
 

@@ -586,9 +586,10 @@ class Net2ConvFn(torch.autograd.Function):
     ATen differentiate it."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, drop, keep=1.0):
-        """drop: the Bernoulli(keep) draw [B,64] of Dropout2d (0 / 1), or None; scaled by 1 / keep inside the kernels"""
-        a2, saved = ops.net2_conv_fwd(x, w1, b1, w2, b2, drop, keep)
+    def forward(ctx, x, w1, b1, w2, b2, drop, keep=1.0, draw_state=None):
+        """drop: the Bernoulli(keep) draw [B,64] of Dropout2d (0 / 1), or None; scaled by 1 / keep inside the kernels.  drop None with a
+        draw_state: the kernel draws the mask on the device (no random launch from the host: the captured attack iteration)"""
+        a2, saved, drop = ops.net2_conv_fwd(x, w1, b1, w2, b2, drop, keep, draw_state)
         ctx.save_for_backward(x, w1, b1, w2, b2, drop, a2, *saved)
         ctx.keep = keep
         return a2
@@ -608,9 +609,9 @@ class Net2ConvFn(torch.autograd.Function):
                 h = F.relu(F.max_pool2d(h, 2))
                 wanted = [t for t, n in zip((xx, w1, b1, w2, b2), need[:5]) if n and t is not None]
                 got = iter(torch.autograd.grad(h, wanted, da2))
-            return tuple(next(got) if (n and t is not None) else None for t, n in zip((xx, w1, b1, w2, b2), need[:5])) + (None, None)
+            return tuple(next(got) if (n and t is not None) else None for t, n in zip((xx, w1, b1, w2, b2), need[:5])) + (None, None, None)
         dx = ops.net2_conv_bwd(da2.contiguous(), a2, (a1, c1, c2), w1, w2, drop, ctx.keep) if need[0] else None
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class PoolLinearFn(torch.autograd.Function):

@@ -913,10 +913,11 @@ def net2_conv_supported(x, w1, w2):
             and x.data_ptr() % 16 == 0)
 
 
-def net2_conv_fwd(x, w1, b1, w2, b2, drop=None, keep=1.0):
+def net2_conv_fwd(x, w1, b1, w2, b2, drop=None, keep=1.0, draw_state=None):
     """a2 = relu(max_pool2d(drop * conv2(relu(max_pool2d(conv1(x), 2))), 2)) (MNIST/models_mnist/Net2.py:13-14), two launches.
-    Returns (a2 [B,64,4,4], saved) - `saved` = (a1, code1, code2) for net2_conv_bwd.  drop: Dropout2d's [B,64] Bernoulli(keep) draw (0 / 1) or None; the kernels scale by
-    drop / keep (what noise.div_(1 - p) does)."""
+    Returns (a2 [B,64,4,4], saved, drop) - `saved` = (a1, code1, code2) for net2_conv_bwd.  drop: Dropout2d's [B,64] Bernoulli(keep) draw (0 / 1) or None;
+    the kernels scale by drop / keep (what noise.div_(1 - p) does).  drop None + draw_state (runtime.draw_state): the kernel draws the mask itself and
+    the returned `drop` is what it drew."""
     B = x.shape[0]
     dev = x.device
     a1 = torch.empty((B, 32, 12, 12), dtype=torch.float32, device=dev)
@@ -924,12 +925,15 @@ def net2_conv_fwd(x, w1, b1, w2, b2, drop=None, keep=1.0):
     a2 = torch.empty((B, 64, 4, 4), dtype=torch.float32, device=dev)
     c2 = torch.empty((B, 64, 4, 4), dtype=torch.uint8, device=dev)
     ptr = lambda t: None if t is None else t.data_ptr()
+    rng = drop is None and draw_state is not None
+    drop_out = torch.empty((B, 64), dtype=torch.float32, device=dev) if rng else None
     N.check(N.lib.ee_net2_conv_fwd_f32(_chk(x, torch.float32, "x", (B, 1, 28, 28)), _chk(w1, torch.float32, "w1", (32, 1, 5, 5)),
                                        None if b1 is None else _chk(b1, torch.float32, "b1", (32,)), _chk(w2, torch.float32, "w2", (64, 32, 5, 5)),
                                        None if b2 is None else _chk(b2, torch.float32, "b2", (64,)),
-                                       None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)), float(keep), ptr(a1), ptr(c1), ptr(a2),
+                                       None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)), float(keep),
+                                       _chk(draw_state, torch.int64, "draw_state", (4,)) if rng else None, ptr(drop_out), ptr(a1), ptr(c1), ptr(a2),
                                        ptr(c2), B, _stream()), "ee_net2_conv_fwd_f32")
-    return a2, (a1, c1, c2)
+    return a2, (a1, c1, c2), (drop_out if rng else drop)
 
 
 def net2_conv_bwd(da2, a2, saved, w1, w2, drop=None, keep=1.0):

@@ -417,12 +417,15 @@ int ee_stem7x7s2_fwd_stats_f32(const float *x, const float *weight, float *y, fl
  * The convolutional half of the MNIST classifier Net_2 (MNIST/models_mnist/Net2.py:13-16), one launch per half each way:
  *   a1 = relu(max_pool2d(conv1(x), 2)),  a2 = relu(max_pool2d(dropmask * conv2(a1), 2))
  *   x [B,1,28,28], w1 [32,1,5,5], b1 [32] (nullable), w2 [64,32,5,5], b2 [64] (nullable), drop [B,64] (nullable: Dropout2d's per-(image,
- *   channel) Bernoulli(keep) draw, 0 or 1, drawn by the caller; the kernels scale by drop / keep, keep = 1 - p)
+ *   channel) Bernoulli(keep) draw, 0 or 1, drawn by the caller; the kernels scale by drop / keep, keep = 1 - p).  drop == NULL with
+ *   draw_state != NULL (the device-resident {seed, offset, ticket, -} state of ee_square_draw_f32 / ee_chain_fwd_f32): the second kernel makes
+ *   the draw itself (Philox4x32-10, stream id 7), writes the mask to drop_out [B,64] for the backward, and its last workgroup advances
+ *   the offset - no host-side random launch inside a captured attack iteration
  *   -> a1 [B,32,12,12], a2 [B,64,4,4] and the one-byte argmax codes of the two pools.
  * Backward (input gradient only): da2 [B,64,4,4] -> dx [B,1,28,28]; da1 [B,32,12,12] is scratch the caller provides.  ReLU backward
  * follows ATen's threshold rule (the gradient passes unless the output is <= 0); pool ties and NaNs follow ATen's max_pool2d. */
 int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *drop, float keep,
-                         float *a1, uint8_t *code1, float *a2, uint8_t *code2, int B, void *stream);
+                         uint64_t *draw_state, float *drop_out, float *a1, uint8_t *code1, float *a2, uint8_t *code2, int B, void *stream);
 int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t *code2, const float *drop, float keep, const float *w2,
                          const float *a1, const uint8_t *code1, const float *w1, float *da1, float *dx, int B, void *stream);
 

@@ -39,7 +39,7 @@ w1, b1 = torch.randn(32, 1, 5, 5, device=dev) * 0.2, torch.randn(32, device=dev)
 w2, b2 = torch.randn(64, 32, 5, 5, device=dev) * 0.05, torch.randn(64, device=dev) * 0.1
 draw = (torch.rand(B, 64, device=dev) < 0.5).float()
 drop = draw * 2
-a2, saved = ops.net2_conv_fwd(x, w1, b1, w2, b2, draw, 0.5)
+a2, saved, _ = ops.net2_conv_fwd(x, w1, b1, w2, b2, draw, 0.5)
 da2 = torch.randn_like(a2)
 
 

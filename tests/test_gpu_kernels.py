@@ -919,6 +919,42 @@ def test_net2_model_uses_the_fused_half_and_draws_the_stock_dropout_mask(ops):
                                rtol=1e-4, atol=1e-4)
 
 
+def test_net2_dropout_mask_drawn_on_the_device(ops):
+    """ee_net2_conv_fwd_f32 with drop = NULL and a draw state: the second kernel draws Dropout2d's Bernoulli(keep) mask itself (what a
+    captured attack iteration uses instead of torch's bernoulli_ launch).  The mask it reports reproduces its output when injected (bit for
+    bit), is 0 / 1 with mean ~ keep, differs from launch to launch (the last workgroup advanced the offset, the ticket is back at 0), and a
+    replayed HIP graph draws fresh masks too."""
+    from eeadv import runtime
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, keep = 50, 0.5
+    x = torch.rand(B, 1, 28, 28, generator=g).to(DEV)
+    w1, b1 = (torch.randn(32, 1, 5, 5, generator=g) * 0.2).to(DEV), (torch.randn(32, generator=g) * 0.1).to(DEV)
+    w2, b2 = (torch.randn(64, 32, 5, 5, generator=g) * 0.05).to(DEV), (torch.randn(64, generator=g) * 0.1).to(DEV)
+    torch.manual_seed(77)
+    runtime.reseed()
+    state = runtime.draw_state(torch.device(DEV))
+    off0 = int(state[1])
+    a2, saved, mask = ops.net2_conv_fwd(x, w1, b1, w2, b2, None, keep, state)
+    assert set(torch.unique(mask).tolist()) <= {0.0, 1.0} and 0.4 < float(mask.mean()) < 0.6
+    assert int(state[1]) == off0 + (B * 64 + 3) // 4 and int(state[2]) == 0
+    again, _, same = ops.net2_conv_fwd(x, w1, b1, w2, b2, mask, keep)
+    assert torch.equal(a2, again) and same is mask
+    zero = (mask == 0).view(B, 64, 1, 1).expand_as(a2)
+    assert float(a2[zero].abs().max()) == 0.0  # dropped channels: relu(max_pool(0)) = 0
+    _, _, mask2 = ops.net2_conv_fwd(x, w1, b1, w2, b2, None, keep, state)
+    assert not torch.equal(mask, mask2)
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph):
+        _, _, mg = ops.net2_conv_fwd(x, w1, b1, w2, b2, None, keep, state)
+    seen = []
+    for _ in range(3):
+        gph.replay()
+        seen.append(mg.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    total = torch.stack(seen + [mask, mask2]).mean()
+    assert 0.45 < float(total) < 0.55
+
+
 @pytest.mark.parametrize("mt", ["222222", "111111"])
 @pytest.mark.parametrize("B,Cin,Cout,H", [(100, 128, 256, 8), (100, 256, 512, 4), (100, 64, 128, 16), (3, 32, 32, 8), (1, 64, 96, 8), (7, 32, 64, 4), (9, 96, 32, 4), (8, 64, 64, 4),
                                           (2, 32, 32, 4), (3, 32, 64, 16), (1, 96, 32, 16)])
