@@ -131,6 +131,7 @@ class _GraphedStep:
         attack_step_(model, self.x, self.x0, self.spec, step_size, eps, direction, lo, hi)
 
     def capture(self, model, x_init, x0, payload):
+        runtime.draw_state(x0.device)  # the device-side draws of a captured iteration (Add_Square, Net_2's dropout) need their state to exist
         self.load(x_init, x0, payload)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -367,9 +367,10 @@ class Net_2(nn.Module):
             drop, keep, state = None, 1.0, None
             if self.training and self.conv2_drop.p > 0:
                 keep = 1.0 - self.conv2_drop.p
-                state = runtime.draw_state(x.device)  # (created on the first eager pass: a capture cannot read the generator)
-                if not torch.cuda.is_current_stream_capturing():
-                    state, drop = None, torch.empty((x.shape[0], 64), dtype=x.dtype, device=x.device).bernoulli_(keep)
+                if torch.cuda.is_current_stream_capturing():
+                    state = runtime.draw_state(x.device)  # (exists: whoever captures creates it first - engine / trainer)
+                else:
+                    drop = torch.empty((x.shape[0], 64), dtype=x.dtype, device=x.device).bernoulli_(keep)
             x = Net2ConvFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, drop, keep, state)
         else:
             x = F.relu(F.max_pool2d(self.conv1(x), 2))

@@ -212,6 +212,7 @@ class _GraphedUpdate:
         return out
 
     def _capture(self):
+        runtime.draw_state(self.x.device)  # device-side draws inside the captured forward need their state to exist
         torch.cuda.synchronize()
         mode = runtime.capture_mode()
         self.graph = torch.cuda.CUDAGraph()
@@ -345,6 +346,7 @@ class _GraphedPredsUpdate:
         if self.g1 is None:
             if not model.training:
                 raise RuntimeError("TRADES / ALP step: the model must be in train mode when the step starts (the .loss() methods leave it there)")
+            runtime.draw_state(self.x.device)
             torch.cuda.synchronize()
             mode = runtime.capture_mode()
             self.g1 = torch.cuda.CUDAGraph()
@@ -595,6 +597,7 @@ class FreeAtStep:
         from eeadv.functional import rebuild_dense_weights, refresh_dense_weights
         refresh_dense_weights()
         if self.graph is None:
+            runtime.draw_state(self.x.device)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode=runtime.capture_mode()):
