@@ -194,7 +194,10 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
                     sqp[k] = p.two_eps * sgn(2.0f * u - 1.0f);
                 }
             }
-            __threadfence();  // the state has been read by this wave ...
+            // the state has been read by this wave (its loads have RETURNED: s_waitcnt, not an agent-scope fence - a fence writes the XCD's
+            // dirty L2 lines back, and nothing here needs that: every read of the state precedes its workgroup's ticket, the tickets are
+            // device-scope atomics, and the new offset only has to be visible to the next launch) ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (tid == 0) {   // ... before its ticket is taken
                 const unsigned long long done = atomicAdd(p.state + 2, 1ull);
                 if (done + 1ull == static_cast<unsigned long long>(p.B)) {

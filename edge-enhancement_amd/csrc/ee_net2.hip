@@ -99,24 +99,24 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__re
     __shared__ float part[128 * 4];
     const int b = blockIdx.x, c0 = blockIdx.y * 8;
     unsigned long long seed = 0ull, base = 0ull;
-    if (RNG) {  // every lane reads the state; lane 0 then takes a ticket, the last ticket of the grid advances the offset (as ee_chain.hip does)
-        seed = state[0], base = state[1];
-        __threadfence();
-        if (threadIdx.x == 0) {
-            const unsigned long long done = atomicAdd(state + 2, 1ull);
-            if (done + 1ull == static_cast<unsigned long long>(B) * 8ull) {
-                state[1] = base + static_cast<unsigned long long>((static_cast<long long>(B) * N2_C2 + 3) >> 2);
-                state[2] = 0ull;
-            }
-        }
-    }
+    if (RNG) seed = state[0], base = state[1];  // every lane reads the state ...
     const float4 *src = reinterpret_cast<const float4 *>(a1 + static_cast<size_t>(b) * N2_C1 * N2_H1 * N2_H1);
     for (int i = threadIdx.x; i < N2_C1 * N2_H1 * N2_H1 / 4; i += N2_NT) reinterpret_cast<float4 *>(as)[i] = src[i];
     for (int i = threadIdx.x; i < 8 * N2_C1 * 25; i += N2_NT) {  // w[c0 + co][ci][25] is one contiguous block of 8 * 32 * 25 floats
         const int pair = i / 25, k = i - pair * 25;
         ws[(pair >> 5) * CS + (pair & 31) * N2_WP + k] = w[static_cast<size_t>(c0) * N2_C1 * 25 + i];
     }
-    __syncthreads();
+    __syncthreads();  // (waits for every outstanding load of the workgroup, the state's included)
+    if (RNG && threadIdx.x == 0) {
+        // ... and only then takes the workgroup's ticket: the last ticket of the grid advances the offset.  No fence: every read of the state
+        // precedes its workgroup's ticket, the tickets are device-scope atomics, and the new offset only has to be visible to the NEXT launch
+        // (an agent-scope fence here flushed the XCD's L2 in all 400 workgroups: +22 us per launch)
+        const unsigned long long done = atomicAdd(state + 2, 1ull);
+        if (done + 1ull == static_cast<unsigned long long>(B) * 8ull) {
+            state[1] = base + static_cast<unsigned long long>((static_cast<long long>(B) * N2_C2 + 3) >> 2);
+            state[2] = 0ull;
+        }
+    }
     const int half = threadIdx.x >> 7, idx = threadIdx.x & 127;
     const int co = idx >> 4, p = idx & 15, py = p >> 2, px = p & 3;
     float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
