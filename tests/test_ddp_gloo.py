@@ -37,7 +37,12 @@ def _worker(rank, world, port, out_dir):
     ddp.setup(device="cpu")
     assert ddp.world() == 2 and ddp.rank() == rank and ddp.rank_seed(5) == 5 + rank and ddp.per_rank_batch(8) == 4
     torch.manual_seed(0)  # same weights on every rank
-    model = ddp.wrap(TinyNet(2, 8, 10, 7), device="cpu")
+    os.environ["EEADV_GRAD_SYNC"] = "ddp"  # the stock multi-rank path, as the drivers / bench.py select it (ddp.make_grad_sync)
+    model, sync = ddp.make_grad_sync(TinyNet(2, 8, 10, 7), "cpu")
+    assert sync is None and type(model).__name__ == "DistributedDataParallel" and ddp.grad_sync_mode() == "ddp"
+    os.environ["EEADV_GRAD_SYNC"] = "flat"
+    assert ddp.grad_sync_mode() == "flat"
+    os.environ.pop("EEADV_GRAD_SYNC")
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     g = torch.Generator().manual_seed(123)
     X, Y = torch.rand(8, 2, 8, 8, generator=g), torch.randint(0, 10, (8,), generator=g)
