@@ -384,7 +384,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run every PGD iteration eagerly (no HIP graph)")
     ap.add_argument("--probe-iters", type=int, default=1,
                     help="PGD iterations per attack that run outside the HIP graph so their kernels can be event-timed")
-    ap.add_argument("--probe-every", type=int, default=4,
+    ap.add_argument("--probe-every", type=int, default=10,
                     help="steps between two probed attacks (the eager probe iteration costs ~1 %% of a step; its kernels are the "
                          "roofline samples, so at least one step of the timed region is always probed)")
     ap.add_argument("--large-batch", action="store_true",
