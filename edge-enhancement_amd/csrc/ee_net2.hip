@@ -264,39 +264,51 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__re
 }
 
 // ---- backward of the first half: d a1 -> d x.  G1[c][24][24] un-pooled (threshold rule, argmax), d x[y][x] = sum_c sum_k G1[c][y-ky][x-kx] w1[c][ky][kx].
-// grid (B, 4): 7 rows of one image per workgroup; a thread owns 4 neighbouring pixels of a row for a quarter of the channels in flight
-// (8 at a time in LDS, zero-padded frame [c][11][36]); the four quarters meet in LDS and are added in quarter order ----------------------
+// grid (B, 4): 7 rows of one image per workgroup; a thread owns 4 neighbouring pixels of a row for a quarter of the channels.  Round 3:
+// ALL 32 channels' zero-padded frames [c][11][36] sit in LDS at once (50 KB) - one zero pass, one scatter whose three global loads per element
+// are unconditional and all in flight together, one barrier - where round 2 ran four rounds of 8 channels with three barriers each and
+// the gradient / activation loads behind a predicate that depended on the code load (eight serialised memory round trips: 19.6 us for
+// 31 MFLOP).  The same fma chains in the same order per thread (channels c0 + 2 hc + cc for c0 = 0, 8, 16, 24): bit-identical results;
+// the four quarters meet in LDS and are added in quarter order ------------------------------------------------------------------------
 __global__ __launch_bounds__(N2_NT) void net2_conv1_bwd_kernel(const float *__restrict__ da1, const float *__restrict__ a1, const uint8_t *__restrict__ code1,
                                                                const float *__restrict__ w, float *__restrict__ dx) {
     constexpr int ROWS = 7, FR = ROWS + 4, FW = 36, NQ = ROWS * 7;  // 49 pixel quads
-    __shared__ __align__(16) float G[8 * FR * FW];  // 12.4 KB: [c][4 + (y - y0) - ky][4 + x - kx]
+    constexpr int NE = N2_C1 * N2_H1 * N2_H1, EPT = NE / N2_NT;     // 4608 pooled elements of the image, 18 per thread
+    static_assert(NE % N2_NT == 0, "elements per thread");
+    __shared__ __align__(16) float G[N2_C1 * FR * FW];  // 50.7 KB: [c][4 + (y - y0) - ky][4 + x - kx]
     __shared__ float ws[N2_C1 * 25];
     __shared__ __align__(16) float part[3 * NQ * 4];
     const int b = blockIdx.x, y0 = blockIdx.y * ROWS;
+    // every load of the scatter first (registers), the frame zeroed while they travel
+    float gv[EPT], av[EPT];
+    int cv[EPT];
+    const size_t base = static_cast<size_t>(b) * NE;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const size_t src = base + threadIdx.x + N2_NT * k;
+        cv[k] = code1[src];
+        gv[k] = da1[src];
+        av[k] = a1[src];
+    }
     for (int i = threadIdx.x; i < N2_C1 * 25; i += N2_NT) ws[i] = w[i];
+    for (int i = threadIdx.x; i < N2_C1 * FR * FW / 4; i += N2_NT) reinterpret_cast<float4 *>(G)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = threadIdx.x + N2_NT * k;
+        const int c = i / (N2_H1 * N2_H1), r = i - c * (N2_H1 * N2_H1), py = r / N2_H1, px = r - py * N2_H1;
+        const int lr = 2 * py + (cv[k] >> 1) - y0 + 4;  // frame row of the un-pooled position
+        if (lr >= 0 && lr < FR) G[(c * FR + lr) * FW + 4 + 2 * px + (cv[k] & 1)] = av[k] <= 0.0f ? 0.0f : gv[k];
+    }
+    __syncthreads();
     const int hc = threadIdx.x / NQ, quad = threadIdx.x - hc * NQ, ry = quad / 7, x0 = 4 * (quad - ry * 7);  // threads 0..195: (channel quarter, quad)
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int c0 = 0; c0 < N2_C1; c0 += 8) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 8 * FR * FW / 4; i += N2_NT) reinterpret_cast<float4 *>(G)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 8 * N2_H1 * N2_H1; i += N2_NT) {
-            const int c = i / (N2_H1 * N2_H1), r = i - c * (N2_H1 * N2_H1), py = r / N2_H1, px = r - py * N2_H1;
-            const size_t src = (static_cast<size_t>(b) * N2_C1 + c0 + c) * (N2_H1 * N2_H1) + r;
-            const int cd = code1[src];
-            const int lr = 2 * py + (cd >> 1) - y0 + 4;  // frame row of the un-pooled position
-            if (lr >= 0 && lr < FR) {
-                float g = da1[src];
-                if (a1[src] <= 0.0f) g = 0.0f;
-                G[(c * FR + lr) * FW + 4 + 2 * px + (cd & 1)] = g;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 4 * NQ) {
+    if (threadIdx.x < 4 * NQ) {
+        for (int c0 = 0; c0 < N2_C1; c0 += 8) {
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                const int c = hc * 2 + cc;
-                const float *wc = ws + (c0 + c) * 25;
+                const int c = c0 + hc * 2 + cc;
+                const float *wc = ws + c * 25;
 #pragma unroll
                 for (int ky = 0; ky < 5; ++ky) {
                     const float4 *gr = reinterpret_cast<const float4 *>(G + (c * FR + 4 + ry - ky) * FW + x0);
