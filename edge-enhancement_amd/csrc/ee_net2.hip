@@ -186,29 +186,34 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__re
 
 // ---- backward of the second half: d a2 -> d a1.  G[co][8][8] = the un-pooled gradient (threshold rule, argmax position, dropout scale),
 // then the transposed convolution d a1[ci][y][x] = sum_co sum_{ky,kx} G[co][y - ky][x - kx] * w[co][ci][ky][kx].
-// grid (B, 8): 4 input channels per workgroup; a thread owns one row y of one channel for a quarter of the output channels in flight
-// (192 threads work; 32 output channels at a time in LDS), the four partial rows meet in LDS and are added in quarter order --------
+// grid (B, 8): 4 input channels per workgroup; a thread owns one row y of one channel for an eighth of the output channels in flight
+// (384 of 512 threads work; 32 output channels at a time in LDS), the eight partial rows meet in LDS and are added in group order --
 constexpr int N2_GW = 20;  // G rows: 8 -> 16 columns (4 zeros either side) + 4 of padding (a wavefront's 12 rows on disjoint banks); 16 rows: [co][16][20]
-__global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__restrict__ da2, const float *__restrict__ a2, const uint8_t *__restrict__ code2,
+// Round 3: 512 lanes, EIGHT groups of 48 (channel, row) lanes, each taking an eighth of the output channels (round 2: 256 lanes, four
+// quarters).  The kernel is bound by the issue rate of its scalar FMAs, and a wavefront alone on a SIMD issues one vector instruction
+// per 4 cycles where two issue one per 2: with 3 active wavefronts per workgroup the SIMDs ran at half rate.
+constexpr int N2_BT = 512, N2_BG = 8;
+__global__ __launch_bounds__(N2_BT) void net2_conv2_bwd_kernel(const float *__restrict__ da2, const float *__restrict__ a2, const uint8_t *__restrict__ code2,
                                                                const float *__restrict__ drop, float keep, const float *__restrict__ w,
                                                                float *__restrict__ da1) {
     constexpr int GP = 16 * N2_GW;                             // one channel's frame
     __shared__ __align__(16) float G[32 * GP];                 // 40 KB
     __shared__ __align__(16) float ws[N2_C2 * 4 * N2_WP];      // w[co][ci0 .. ci0+3][25 -> 28]: 28 KB
     const int b = blockIdx.x, ci0 = blockIdx.y * 4;
-    for (int i = threadIdx.x; i < N2_C2 * 4 * 25; i += N2_NT) {
+    for (int i = threadIdx.x; i < N2_C2 * 4 * 25; i += N2_BT) {
         const int co = i / 100, rem = i - co * 100, cl = rem / 25, k = rem - cl * 25;
         ws[(co * 4 + cl) * N2_WP + k] = w[(static_cast<size_t>(co) * N2_C1 + ci0 + cl) * 25 + k];
     }
     float acc[N2_H1];
 #pragma unroll
     for (int xx = 0; xx < N2_H1; ++xx) acc[xx] = 0.0f;
-    const int q = threadIdx.x / 48, rem = threadIdx.x - q * 48, cl = rem / N2_H1, y = rem - cl * N2_H1;  // threads 0..191: (quarter, channel, row)
+    const int q = threadIdx.x / 48, rem = threadIdx.x - q * 48, cl = rem / N2_H1, y = rem - cl * N2_H1;  // threads 0..383: (group, channel, row)
+    constexpr int CPG = 32 / N2_BG;  // output channels per group and half
     for (int h = 0; h < 2; ++h) {
         __syncthreads();  // the previous half's rows have been read (and, first time round, nothing is pending)
-        for (int i = threadIdx.x; i < 32 * GP / 4; i += N2_NT) reinterpret_cast<float4 *>(G)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int i = threadIdx.x; i < 32 * GP / 4; i += N2_BT) reinterpret_cast<float4 *>(G)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         __syncthreads();
-        for (int i = threadIdx.x; i < 32 * 16; i += N2_NT) {
+        for (int i = threadIdx.x; i < 32 * 16; i += N2_BT) {
             const int cc = i >> 4, p = i & 15, wy = p >> 2, wx = p & 3, co = 32 * h + cc;
             const size_t src = (static_cast<size_t>(b) * N2_C2 + co) * 16 + p;
             float g = da2[src];
@@ -218,9 +223,9 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__re
             G[cc * GP + (4 + 2 * wy + (cd >> 1)) * N2_GW + 4 + 2 * wx + (cd & 1)] = g;
         }
         __syncthreads();
-        if (threadIdx.x < 192) {
-            for (int cc = 0; cc < 8; ++cc) {
-                const int gl = q * 8 + cc, co = 32 * h + gl;
+        if (threadIdx.x < 48 * N2_BG) {
+            for (int cc = 0; cc < CPG; ++cc) {
+                const int gl = q * CPG + cc, co = 32 * h + gl;
                 float wv[N2_WP];
                 const float4 *wr = reinterpret_cast<const float4 *>(ws + (co * 4 + cl) * N2_WP);
 #pragma unroll
@@ -248,18 +253,22 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_kernel(const float *__re
             }
         }
     }
-    __syncthreads();  // G is dead: the partial rows of quarters 1-3 go there
+    __syncthreads();  // G is dead: the partial rows of groups 1 .. 7 go there
     float *part = G;
-    if (threadIdx.x < 192 && q > 0) {
+    if (threadIdx.x < 48 * N2_BG && q > 0) {
 #pragma unroll
         for (int xx = 0; xx < N2_H1; ++xx) part[((q - 1) * 48 + rem) * N2_H1 + xx] = acc[xx];
     }
     __syncthreads();
-    if (threadIdx.x < 48) {
+    if (threadIdx.x < 48) {  // added in group order: a fixed summation order, reproducible run to run
         float *dst = da1 + ((static_cast<size_t>(b) * N2_C1 + ci0 + cl) * N2_H1 + y) * N2_H1;
 #pragma unroll
-        for (int xx = 0; xx < N2_H1; ++xx)
-            dst[xx] = ((acc[xx] + part[(0 * 48 + rem) * N2_H1 + xx]) + part[(1 * 48 + rem) * N2_H1 + xx]) + part[(2 * 48 + rem) * N2_H1 + xx];
+        for (int xx = 0; xx < N2_H1; ++xx) {
+            float sacc = acc[xx];
+#pragma unroll
+            for (int g = 0; g < N2_BG - 1; ++g) sacc += part[(g * 48 + rem) * N2_H1 + xx];
+            dst[xx] = sacc;
+        }
     }
 }
 
@@ -363,7 +372,7 @@ EE_API int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t
     if (!da2 || !a2 || !code2 || !w2 || !a1 || !code1 || !w1 || !da1 || !dx) return EE_ERR_NULL;
     if (!aligned16(dx)) return EE_ERR_ALIGN;
     hipStream_t st = as_stream(stream);
-    EE_LAUNCH(net2_conv2_bwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, da2, a2, code2, drop, keep, w2, da1);
+    EE_LAUNCH(net2_conv2_bwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_BT), 0, st, da2, a2, code2, drop, keep, w2, da1);
     EE_LAUNCH(net2_conv1_bwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, da1, a1, code1, w1, dx);
     return launch_status();
 }
