@@ -426,7 +426,6 @@ def main():
     os.environ["EEADV_GRAPH"] = "0" if a.no_graph else "1"
     engine.PROBE_ITERS = 0 if a.no_graph else a.probe_iters
     job = Job(a.workload, cfg, dev, world, rank, channels_last=a.channels_last)
-    sync = job.sync
     B = cfg["batch"]
     probe_iters = engine.PROBE_ITERS
 
