@@ -642,9 +642,9 @@ def test_fused_classifier_body_equals_stock_modules(monkeypatch, depth, B):
 
     def total_err(r):
         return sum(float((g.double() - g64).norm()) ** 2 for g, g64 in zip(r[1], grads64)) ** 0.5
-    fused = min((run("fused") for _ in range(5)), key=total_err)
-    stock = min((run("stock") for _ in range(5)), key=total_err)
-    a, b = fused, stock
+    fused_runs = [run("fused") for _ in range(5)]
+    stock_runs = [run("stock") for _ in range(5)]
+    a, b = min(fused_runs, key=total_err), min(stock_runs, key=total_err)
     ea, eb = float((a[0].double() - logits64).norm()), float((b[0].double() - logits64).norm())
     assert ea <= 2 * eb + 1e-6 * float(logits64.norm()), ("logits", ea, eb)
     np.testing.assert_allclose(a[0].cpu().numpy(), logits64.float().cpu().numpy(), atol=1e-4 if depth == 18 else 5e-4)
@@ -654,11 +654,16 @@ def test_fused_classifier_body_equals_stock_modules(monkeypatch, depth, B):
     den = sum(float(g.norm()) ** 2 for g in grads64) ** 0.5
     fa, fb = total_err(a), total_err(b)
     assert fa <= 2 * fb + 1e-6 * den, (fa, fb, den)
-    # per tensor: a guard against a wrong kernel, not a precision claim - the best-of-five run is chosen by its TOTAL error, and
-    # a single tensor of it may still carry MIOpen's bimodal implicit-GEMM error (0.4 - 0.9 % of its norm, scripts/stock_nondet.py)
-    for ga, gb, g64 in zip(a[1], b[1], grads64):
-        ta, tb, n64 = float((ga.double() - g64).norm()), float((gb.double() - g64).norm()), float(g64.norm())
-        assert ta <= 4 * tb + 1e-2 * n64, (tuple(ga.shape), ta, tb, n64)
+    # per tensor: a guard against a wrong kernel, not a precision claim.  A wrong kernel is wrong in every run; MIOpen's bimodal
+    # implicit-GEMM backward-data error (0.4 - 1.5 % of a tensor's norm, scripts/stock_nondet.py) shows up in some runs and not in others -
+    # and since round 3 the fused path of this model hands two more convolutions to MIOpen (the 512- and 1024-channel stride-2 1x1
+    # shortcuts, models._CONV1X1S2_MAXC) - so each tensor is judged by its BEST run on either side (round 2 judged the tensors of the run
+    # with the smallest total error, which one tensor's bad draw could fail)
+    for i, g64 in enumerate(grads64):
+        ta = min(float((r[1][i].double() - g64).norm()) for r in fused_runs)
+        tb = min(float((r[1][i].double() - g64).norm()) for r in stock_runs)
+        n64 = float(g64.norm())
+        assert ta <= 4 * tb + 1e-2 * n64, (tuple(g64.shape), ta, tb, n64)
 
 
 @pytest.mark.parametrize("method", ["TRADES", "ALP"])
