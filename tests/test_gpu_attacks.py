@@ -344,7 +344,7 @@ def test_free_at_repeat_vs_oracle(arch, B, size, K, batches):
             flip_g, flip_c = (np.sign(g_g) != np.sign(g_64)).mean(), (np.sign(g_c) != np.sign(g_64)).mean()
             # budget: twice the fp32 oracle's own distance from fp64 - or, where the oracle happens to land closer than fp32
             # convolution stacks usually do (resnet18_EE repeat 0: oracle 0.7 %, GPU 2 %, while on resnet50 the ORACLE sits at
-            # 3 - 6 %; MIOpen's backward-data solvers are bimodal, profiles/round2_c_stock_miopen_nondeterminism.txt), 5 % of the
+            # 3 - 6 %: ReLU masks of pre-activations within fp32 rounding of zero flip between any two implementations), 5 % of the
             # largest entry and 0.2 % of the signs
             assert err_g <= max(2 * err_c, 5e-2) + 1e-6, (what, err_g, err_c)
             assert flip_g <= 2 * flip_c + 2e-3, (what, flip_g, flip_c)

@@ -570,9 +570,8 @@ def test_parameter_update_graph_equals_eager(monkeypatch):
     def err(run):
         return (np.abs(np.array(run[0]) - ref_losses).max(), float((run[1].double() - ref_w).norm()), float((run[3].double() - ref_rm).norm()))
     e_graph, e_eager = err(runs["1"]), err(runs["0"])
-    # floor: MIOpen's implicit-GEMM backward-data kernel of the 256-channel 4x4 layers returns one of TWO results at random
-    # (scripts/stock_nondet.py: the all-stock backward of this network is 1.1e-3 or 4.1e-3 of |g| away from float64, run to run
-    # in one process; stable with MIOPEN_DEBUG_CONV_IMPLICIT_GEMM=0) - either run here may have drawn the bad one more often
+    # floor: one flipped ReLU mask of a late layer (a pre-activation within fp32 rounding of zero; replayed_body_gradients below) moves the
+    # gradient by 2e-3 ... 7e-3 of its norm, on either run, from MIOpen's run-to-run rounding differences alone (scripts/stock_nondet.py)
     floor = (2e-3 * np.abs(ref_losses).max(), 2e-3 * float(ref_w.norm()), 2e-3 * float(ref_rm.norm()))
     for a, b, f, what in zip(e_graph, e_eager, floor, ("losses", "fc.weight", "bn1.running_mean")):
         assert a <= 2 * b + f, (what, a, b)
@@ -611,59 +610,135 @@ def test_full_canny_module_and_ee_at_model_UNPINNED(Cm, golden):
     assert np.abs(g[fin] - gr[fin]).max() < 2e-4 * np.abs(gr[fin]).max() + 1e-7
 
 
+_ALL_STOCK = frozenset(("bn", "pool", "head", "conv", "stem", "dense", "conv3", "conv3s2"))
+
+
+def _body_run(models, depth, x, dl, stock, dt=torch.float32, wrap=None):
+    """one forward + backward of make_resnet(depth, 'tiny') from seed 21 in train mode -> (names, logits, gradients of input and parameters, net)"""
+    models._STOCK = stock
+    torch.manual_seed(21)
+    net = models.make_resnet(depth, "tiny").to(DEV).to(dt).train()
+    xi = x.to(dt).requires_grad_(True)
+    logits = net(xi)
+    grads = torch.autograd.grad(logits, [xi] + list(net.parameters()), dl.to(dt))
+    return ["input"] + [n for n, _ in net.named_parameters()], logits.detach(), grads, net
+
+
+def replayed_body_gradients(monkeypatch, depth, B, seed, fp32_stock=frozenset(("bnpool",))):
+    """The fused ResNet body in fp32, and the stock modules in float64 ON THE SAME PIECEWISE-LINEAR BRANCH: every ReLU mask and the stem
+    max-pool's argmax of the float64 run are the ones the fp32 run took.
+
+    Why: the gradient of a ReLU network is discontinuous in its pre-activations.  Of the ~3 M of them in ResNet-18 at batch 16 about one
+    lies within fp32 rounding of zero, its mask differs between ANY two implementations (fp32 stock against float64 too), and one flipped
+    mask on a 2x2 map of layer 4 moves the whole gradient by 0.2 - 0.7 % of its norm (scripts/fused_vs_stock_diag.py: the fused path is off
+    by 2.4e-6 of the norm on inputs without a flip and by 1.5e-3 ... 3.9e-3 on the others; the all-MIOpen path the same, at random from run
+    to run).  Holding the branch fixed leaves the arithmetic of the kernels, which is what this compares.
+    The stem runs as its two kernels here (BatchNorm+ReLU, then the max-pool): their one-pass fusion never materialises the ReLU output
+    that carries the mask (tests/test_gpu_kernels.py::test_bn_relu_pool_fused_equals_the_two_kernels pins it bit for bit to the pair)."""
+    from eeadv import models
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x, dl = torch.rand(B, 3, 64, 64, generator=g).to(DEV), torch.randn(B, 200, generator=g).to(DEV)
+    masks, nested = [], [0]
+    bn_act, block_tail, stem_pool = models.bn_act, models.block_tail, models.stem_pool
+    first = lambda t: t[0] if isinstance(t, tuple) else t
+
+    def rec_bn_act(bn, x, residual=None, relu=True, fork=False):
+        out = bn_act(bn, x, residual, relu, fork)
+        if relu and not nested[0]:
+            masks.append(first(out).detach().clone())
+        return out
+
+    def rec_tail(*a, **k):  # the last ReLU of a block, however block_tail gets there (BnDualFn, or bn_act around the shortcut)
+        nested[0] += 1
+        try:
+            out = block_tail(*a, **k)
+        finally:
+            nested[0] -= 1
+        masks.append(first(out).detach().clone())
+        return out
+    monkeypatch.setattr(models, "bn_act", rec_bn_act)
+    monkeypatch.setattr(models, "block_tail", rec_tail)
+    names, logits32, g32, _ = _body_run(models, depth, x, dl, fp32_stock)
+    n_relu = len(masks)
+    todo = list(masks)
+
+    def replay_bn_act(bn, x, residual=None, relu=True, fork=False):
+        out = bn(x)
+        if residual is not None:
+            out = out + residual
+        return out * (todo.pop(0) > 0).to(out.dtype) if relu else out
+
+    def replay_pool(pool, x64):  # ATen's first-maximum rule on the fp32 activations (ee_pool.hip is bit-identical to it), applied to the float64 ones
+        idx = F.max_pool2d(masks[0], 3, 2, 1, return_indices=True)[1]
+        return x64.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+    monkeypatch.setattr(models, "bn_act", replay_bn_act)
+    monkeypatch.setattr(models, "block_tail", block_tail)
+    monkeypatch.setattr(models, "stem_pool", replay_pool)
+    _, logits64, g64, _ = _body_run(models, depth, x, dl, _ALL_STOCK, torch.float64)
+    assert not todo and n_relu == {18: 17, 50: 49}[depth]
+    monkeypatch.setattr(models, "bn_act", bn_act)
+    monkeypatch.setattr(models, "stem_pool", stem_pool)
+    return names, logits32, g32, logits64, g64
+
+
+@pytest.mark.parametrize("depth,B", [(18, 16), (50, 8)])
+def test_fused_classifier_body_gradients_equal_float64_on_the_same_branch(monkeypatch, depth, B):
+    """Input and parameter gradients of the hand-written ResNet body (Winograd / dense / stride-2 / stem convolutions, BatchNorm+add+ReLU,
+    max-pool, head; weight gradients from MIOpen) against float64 autograd through the stock modules with the ReLU masks held fixed
+    (resnet.py:26-162), on three inputs.  Measured (scripts/fused_vs_stock_diag.py, error / norm of the float64 gradient):
+        ResNet-18, batch 16:  2.4e-6 over all tensors, 5.5e-6 on the worst tensor   (asserted: 1e-5, 3e-5)
+        ResNet-50, batch 8:   7.6e-5 over all tensors, 1.7e-4 on the worst tensor   (asserted: 3e-4, 6e-4) - the all-MIOpen fp32 path is at
+                              6.1e-5 / 1.3e-4 under the same procedure: 50 layers of batch statistics over 32 samples amplify fp32 rounding
+    and the fused path is required to stay within twice the stock fp32 path's own distance from float64."""
+    from eeadv import models
+    stock = models._STOCK
+    tol_total, tol_tensor = {18: (1e-5, 3e-5), 50: (3e-4, 6e-4)}[depth]
+
+    def distance(g32, g64):
+        errs = [float((a.double() - b).norm()) for a, b in zip(g32, g64)]
+        norms = [float(b.norm()) for b in g64]
+        return errs, norms, sum(e * e for e in errs) ** 0.5, sum(n * n for n in norms) ** 0.5
+    try:
+        for seed in (0, 1, 2):
+            names, l32, g32, l64, g64 = replayed_body_gradients(monkeypatch, depth, B, seed)
+            np.testing.assert_allclose(l32.cpu().numpy(), l64.float().cpu().numpy(), atol=1e-4 if depth == 18 else 5e-4)
+            errs, norms, tot, den = distance(g32, g64)
+            assert tot <= tol_total * den, (seed, tot, den)
+            for name, e, n in zip(names, errs, norms):
+                assert e <= tol_tensor * n + 1e-6 * den, (seed, name, e, n)
+            if seed == 0:
+                _, _, s32, _, s64 = replayed_body_gradients(monkeypatch, depth, B, seed, fp32_stock=_ALL_STOCK)
+                _, _, stock_tot, stock_den = distance(s32, s64)
+                assert tot / den <= 2 * stock_tot / stock_den + 1e-6, (tot / den, stock_tot / stock_den)
+    finally:
+        models._STOCK = stock
+
+
 @pytest.mark.parametrize("depth,B", [(18, 16), (50, 8)])
 def test_fused_classifier_body_equals_stock_modules(monkeypatch, depth, B):
-    """The hand-written CNN glue (BatchNorm+add+ReLU, max-pool, head, shortcut / stem / small-map convolutions) against the
-    stock ATen / MIOpen modules on the same weights, train mode: logits and BatchNorm running statistics tightly, input and
-    parameter gradients in the L2 sense (resnet.py:26-162)."""
+    """The fully fused body (the one-pass stem included) against float64 autograd through the stock ATen modules on the same weights, train
+    mode (resnet.py:26-162): logits and BatchNorm running statistics tightly.  The gradients here are a WIRING guard only - a wrong kernel
+    or a missing term is an O(1) error - because ReLU masks flip between any two implementations (replayed_body_gradients, which carries the
+    precision claim): every flipped mask of a late layer costs 0.2 - 0.7 % of the gradient's norm, ResNet-50 at batch 8 collects 1.4 - 1.9 %."""
     from eeadv import models
-    x = torch.rand(B, 3, 64, 64, device=DEV)
-    dl = torch.randn(B, 200, device=DEV)
-
-    def run(mode, dt=torch.float32):
-        monkeypatch.setattr(models, "_STOCK", frozenset() if mode == "fused" else frozenset(
-            ("bn", "pool", "head", "conv", "stem", "dense", "conv3", "conv3s2")))
-        torch.manual_seed(21)
-        net = models.make_resnet(depth, "tiny").to(DEV).to(dt).train()
-        xi = x.to(dt).requires_grad_(True)
-        logits = net(xi)
-        grads = torch.autograd.grad(logits, [xi] + list(net.parameters()), dl.to(dt))
-        return (logits.detach(), grads, net.bn1.running_mean.clone(), net.layer4[1].bn2.running_var.clone(),
-                int(net.layer3[0].bn1.num_batches_tracked), net)
-    # float64 reference of the same forward / backward (stock ATen ops, same seed -> same weights): fp32 gradients of a deep ReLU
-    # network are not reproducible across implementations at all (a pre-activation that rounds to +0 here and -1e-9 there flips
-    # a mask; scripts/freeat_diag.py: the fp32 CPU oracle is 15 % of the largest entry away from float64 on resnet50), so the
-    # hand-written glue is required to be no further from float64 than TWICE the stock MIOpen path is - per tensor in the L2
-    # sense with a factor 4 (one flipped mask in a small tensor is a big relative change), 2 over all tensors together.
-    # The stock path is itself not reproducible on this platform: MIOpen's implicit-GEMM backward-data kernel returns one of two
-    # results at random (scripts/stock_nondet.py), so every configuration runs five times and is judged by its best run.
-    r64 = run("stock", torch.float64)
-    logits64, grads64, ref = r64[0], r64[1], r64[5]
-
-    def total_err(r):
-        return sum(float((g.double() - g64).norm()) ** 2 for g, g64 in zip(r[1], grads64)) ** 0.5
-    fused_runs = [run("fused") for _ in range(5)]
-    stock_runs = [run("stock") for _ in range(5)]
-    a, b = min(fused_runs, key=total_err), min(stock_runs, key=total_err)
-    ea, eb = float((a[0].double() - logits64).norm()), float((b[0].double() - logits64).norm())
-    assert ea <= 2 * eb + 1e-6 * float(logits64.norm()), ("logits", ea, eb)
-    np.testing.assert_allclose(a[0].cpu().numpy(), logits64.float().cpu().numpy(), atol=1e-4 if depth == 18 else 5e-4)
-    torch.testing.assert_close(a[2].double(), ref.bn1.running_mean, rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(a[3].double(), ref.layer4[1].bn2.running_var, rtol=1e-4, atol=1e-6)
-    assert a[4] == b[4] == 1
-    den = sum(float(g.norm()) ** 2 for g in grads64) ** 0.5
-    fa, fb = total_err(a), total_err(b)
-    assert fa <= 2 * fb + 1e-6 * den, (fa, fb, den)
-    # per tensor: a guard against a wrong kernel, not a precision claim.  A wrong kernel is wrong in every run; MIOpen's bimodal
-    # implicit-GEMM backward-data error (0.4 - 1.5 % of a tensor's norm, scripts/stock_nondet.py) shows up in some runs and not in others -
-    # and since round 3 the fused path of this model hands two more convolutions to MIOpen (the 512- and 1024-channel stride-2 1x1
-    # shortcuts, models._CONV1X1S2_MAXC) - so each tensor is judged by its BEST run on either side (round 2 judged the tensors of the run
-    # with the smallest total error, which one tensor's bad draw could fail)
-    for i, g64 in enumerate(grads64):
-        ta = min(float((r[1][i].double() - g64).norm()) for r in fused_runs)
-        tb = min(float((r[1][i].double() - g64).norm()) for r in stock_runs)
-        n64 = float(g64.norm())
-        assert ta <= 4 * tb + 1e-2 * n64, (tuple(g64.shape), ta, tb, n64)
+    stock = models._STOCK
+    g = torch.Generator(device="cpu").manual_seed(1000 + depth)
+    x, dl = torch.rand(B, 3, 64, 64, generator=g).to(DEV), torch.randn(B, 200, generator=g).to(DEV)
+    try:
+        names, logits64, grads64, ref = _body_run(models, depth, x, dl, _ALL_STOCK, torch.float64)
+        _, logits, grads, net = _body_run(models, depth, x, dl, frozenset())
+    finally:
+        models._STOCK = stock
+    np.testing.assert_allclose(logits.cpu().numpy(), logits64.float().cpu().numpy(), atol=1e-4 if depth == 18 else 5e-4)
+    torch.testing.assert_close(net.bn1.running_mean.double(), ref.bn1.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(net.layer4[1].bn2.running_var.double(), ref.layer4[1].bn2.running_var, rtol=1e-4, atol=1e-6)
+    assert int(net.layer3[0].bn1.num_batches_tracked) == int(ref.layer3[0].bn1.num_batches_tracked) == 1
+    errs = [float((a.double() - b).norm()) for a, b in zip(grads, grads64)]
+    norms = [float(b.norm()) for b in grads64]
+    den = sum(n * n for n in norms) ** 0.5
+    assert sum(e * e for e in errs) ** 0.5 <= 5e-2 * den, (sum(e * e for e in errs) ** 0.5, den)
+    for name, e, n in zip(names, errs, norms):
+        assert e <= 0.15 * n + 1e-3 * den, (name, e, n)
 
 
 @pytest.mark.parametrize("method", ["TRADES", "ALP"])
