@@ -1,0 +1,300 @@
+// ee_wrw.hip - the WEIGHT gradient of Conv2d(3x3, stride 1, padding 1, bias=False) on 16x16 / 8x8 / 4x4 / 2x2 maps (every stride-1 3x3 layer
+// of ResNet-18 at 64x64 inputs, resnet.py:26-31; `loss.backward()` at experiments_tinyimagenet.py:304-306) as Winograd F(3x3, 2x2) around the
+// f32 matrix cores.
+//
+// Why: MIOpen's best solvers for these shapes are its NHWC implicit-GEMM kernels: per layer one 24 - 28 us product plus two to four layout
+// transposes and a zero fill, 0.65 ms of the 2.1 ms update of a training step (profiles/round3_h_trace_breakdown.txt), summed with atomics (not
+// reproducible from run to run).  Here, per 2x2 tile t of the output map (its 2x2 patch y of dy, the 4x4 input patch d around it):
+//     dW = sum_t A^T [ (G y G^T) (.) (B^T d B) ] A        G = [[1,0],[.5,.5],[.5,-.5],[0,1]]   A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]
+// (B^T as in ee_wino.hip), i.e. 16 products per tile instead of 36, and the sum over tiles is 16 small GEMMs
+//     M_xi[co][ci] = sum_t Yh_xi[co][t] * Xh_xi[ci][t]          on v_mfma_f32_16x16x4_f32
+// A workgroup owns a 32 x 32 block of (co, ci) and a contiguous range of 16-tile chunks (a quarter of a 16x16 image, one 8x8 image, four 4x4
+// images, sixteen 2x2 images): per chunk all 512 lanes transform one input patch and one dy patch each into LDS, then wavefront w multiplies
+// the xi pair (2w, 2w+1) (32 MFMAs); the next chunk's pixels are already on their way (registers -> a second raw buffer during the products).
+// The reduction over chunks is split over workgroups so that ~256 of them exist; their partial M go to a workspace and a second kernel adds
+// them IN A FIXED ORDER and applies A^T . A: the result is reproducible bit for bit.
+//
+// CNN-body glue, not a row of SURVEY.md section 8.
+#include "ee_common.hpp"
+
+namespace {
+
+using namespace ee;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WR_NT = 512;
+constexpr int WR_TS = 18;               // row stride of the transform-domain operands, in float2: rows 18 apart, the four k of a wavefront next to each other -> 32 distinct bank pairs per half wavefront
+constexpr int WR_T2 = 8 * 64 * WR_TS;   // [8 xi pairs][32 co rows + 32 ci rows][18] float2
+constexpr int WR_YS = 68;               // dy pixels of a chunk: 64 per channel, channels 68 apart
+
+template <int MAP>
+struct WrwGeo {
+    static constexpr int TX = MAP / 2, TI = TX * TX;
+    static constexpr int IMGS = TI >= 16 ? 1 : 16 / TI;  // images per chunk of 16 tiles
+    static constexpr int CPI = TI >= 16 ? TI / 16 : 1;   // chunks per image (16x16 maps: 4 bands of four rows)
+    // zero-ringed pixel frames of a chunk; the channel stride is 4 mod 64 floats so that a half wavefront's patch reads (16 channels x 2
+    // neighbouring tiles, 8 bytes each) fall on 32 distinct bank pairs
+    static constexpr int FW = MAP == 16 ? 20 : MAP == 8 ? 12 : MAP == 4 ? 6 : 4;                // row stride
+    static constexpr int FI = MAP == 16 ? 6 * 20 : MAP == 8 ? 10 * 12 : MAP == 4 ? 36 : 16;     // one image's frame (16x16: a band of 4 + 2 rows)
+    static constexpr int CS = MAP == 16 ? 132 : MAP == 8 ? 132 : MAP == 4 ? 196 : 260;
+    static_assert(IMGS * FI <= CS && CS % 64 == 4, "frames fit, channels on distinct banks");
+    static constexpr int RAW = 32 * CS + 32 * WR_YS;  // one raw buffer: x frames, dy pixels
+    static constexpr size_t lds_bytes = WR_T2 * sizeof(float2) + 2 * RAW * sizeof(float);
+};
+
+struct WrwDims {
+    int B, KC, RC;      // images, input channels (x), output channels (dy)
+    int chunks, cpw, S; // 16-tile chunks in all, per workgroup, number of splits
+    int grouped;        // workgroup numbering: the (co, ci) blocks of a split on ONE XCD (they read the same pixels)
+};
+
+template <int MAP>
+__global__ __launch_bounds__(WR_NT) void wrw_wino_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, WrwDims d) {
+    using G = WrwGeo<MAP>;
+    extern __shared__ __align__(16) float lds[];
+    float2 *tp = reinterpret_cast<float2 *>(lds);
+    float *raw0 = lds + 2 * WR_T2, *raw1 = raw0 + G::RAW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int ncb = d.RC / 32, nkb = d.KC / 32, ntile = ncb * nkb;
+    int s, tile;
+    if (d.grouped) {
+        const int g = blockIdx.x & 7, k = blockIdx.x >> 3;
+        s = g + 8 * (k / ntile), tile = k % ntile;
+        if (s >= d.S) return;
+    } else {
+        s = blockIdx.x / ntile, tile = blockIdx.x - s * ntile;
+    }
+    const int co0 = (tile / nkb) * 32, ci0 = (tile % nkb) * 32;
+    const int q0 = s * d.cpw, nq = d.chunks - q0 < d.cpw ? d.chunks - q0 : d.cpw;
+    // ---- this lane's share of a chunk's pixels: one float4 of x (channel pc, float4 number pf of its 64 pixels), one of dy, and on 16x16 maps
+    // one float4 of the two halo rows for the first 256 lanes
+    const int pc = threadIdx.x >> 4, pf = threadIdx.x & 15;
+    const int hc = (threadIdx.x >> 3) & 31, hh = threadIdx.x & 7;
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 xv = zero4, hv = zero4, yv = zero4;
+    auto load = [&](int q) {
+        if (MAP == 16) {
+            const int img = q >> 2, cc = q & 3;
+            xv = *reinterpret_cast<const float4 *>(x + (static_cast<size_t>(img) * d.KC + ci0 + pc) * 256 + cc * 64 + 4 * pf);
+            yv = *reinterpret_cast<const float4 *>(dy + (static_cast<size_t>(img) * d.RC + co0 + pc) * 256 + cc * 64 + 4 * pf);
+            if (threadIdx.x < 256) {
+                const bool up = hh < 4, ok = up ? cc > 0 : cc < 3;
+                const int off = up ? cc * 64 - 16 + 4 * hh : cc * 64 + 64 + 4 * (hh - 4);
+                hv = ok ? *reinterpret_cast<const float4 *>(x + (static_cast<size_t>(img) * d.KC + ci0 + hc) * 256 + off) : zero4;
+            }
+        } else if (MAP == 8) {
+            xv = *reinterpret_cast<const float4 *>(x + (static_cast<size_t>(q) * d.KC + ci0 + pc) * 64 + 4 * pf);
+            yv = *reinterpret_cast<const float4 *>(dy + (static_cast<size_t>(q) * d.RC + co0 + pc) * 64 + 4 * pf);
+        } else if (MAP == 4) {
+            const int img = 4 * q + (pf >> 2), r = pf & 3;
+            const bool ok = img < d.B;
+            xv = ok ? *reinterpret_cast<const float4 *>(x + (static_cast<size_t>(img) * d.KC + ci0 + pc) * 16 + 4 * r) : zero4;
+            yv = ok ? *reinterpret_cast<const float4 *>(dy + (static_cast<size_t>(img) * d.RC + co0 + pc) * 16 + 4 * r) : zero4;
+        } else {
+            const int img = 16 * q + pf;
+            const bool ok = img < d.B;
+            xv = ok ? *reinterpret_cast<const float4 *>(x + (static_cast<size_t>(img) * d.KC + ci0 + pc) * 4) : zero4;
+            yv = ok ? *reinterpret_cast<const float4 *>(dy + (static_cast<size_t>(img) * d.RC + co0 + pc) * 4) : zero4;
+        }
+    };
+    auto store = [&](float *buf) {  // the loaded pixels -> frame interiors (the rings stay zero) and the dy rows
+        float *xs = buf, *ys = buf + 32 * G::CS;
+        float *dst;
+        if (MAP == 16) dst = xs + pc * G::CS + (1 + (pf >> 2)) * G::FW + 1 + 4 * (pf & 3);
+        else if (MAP == 8) dst = xs + pc * G::CS + (1 + (pf >> 1)) * G::FW + 1 + 4 * (pf & 1);
+        else if (MAP == 4) dst = xs + pc * G::CS + (pf >> 2) * G::FI + (1 + (pf & 3)) * G::FW + 1;
+        else dst = xs + pc * G::CS + pf * G::FI;
+        if (MAP == 2) {
+            dst[5] = xv.x, dst[6] = xv.y, dst[9] = xv.z, dst[10] = xv.w;
+        } else {
+            dst[0] = xv.x, dst[1] = xv.y, dst[2] = xv.z, dst[3] = xv.w;
+        }
+        if (MAP == 16 && threadIdx.x < 256) {
+            float *h = xs + hc * G::CS + (hh < 4 ? 0 : 5) * G::FW + 1 + 4 * (hh & 3);
+            h[0] = hv.x, h[1] = hv.y, h[2] = hv.z, h[3] = hv.w;
+        }
+        *reinterpret_cast<float4 *>(ys + pc * WR_YS + 4 * pf) = yv;
+    };
+    // ---- this lane's two patches of a chunk: input patch (channel row, tile t) and dy patch (channel row, tile t)
+    const int row = l15 + 16 * (wave & 1), t = 4 * (wave >> 1) + lq;
+    int po, yo;
+    if (MAP == 16) po = 2 * (t >> 3) * G::FW + 2 * (t & 7), yo = 2 * (t >> 3) * 16 + 2 * (t & 7);
+    else if (MAP == 8) po = 2 * (t >> 2) * G::FW + 2 * (t & 3), yo = 2 * (t >> 2) * 8 + 2 * (t & 3);
+    else if (MAP == 4) po = (t >> 2) * G::FI + 2 * ((t >> 1) & 1) * G::FW + 2 * (t & 1), yo = (t >> 2) * 16 + 2 * ((t >> 1) & 1) * 4 + 2 * (t & 1);
+    else po = t * G::FI, yo = t * 4;
+    auto transform = [&](const float *buf) {
+        const float *p = buf + row * G::CS + po;
+        float dd[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 lo = *reinterpret_cast<const float2 *>(p + i * G::FW), hi = *reinterpret_cast<const float2 *>(p + i * G::FW + 2);
+            dd[i][0] = lo.x, dd[i][1] = lo.y, dd[i][2] = hi.x, dd[i][3] = hi.y;
+        }
+        float tt[4][4];  // B^T d
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tt[0][j] = dd[0][j] - dd[2][j];
+            tt[1][j] = dd[1][j] + dd[2][j];
+            tt[2][j] = dd[2][j] - dd[1][j];
+            tt[3][j] = dd[1][j] - dd[3][j];
+        }
+        float2 *xo = tp + (32 + row) * WR_TS + t;  // pair p = 2 a + b / 2 of xi = 4 a + b
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            xo[(2 * a + 0) * 64 * WR_TS] = make_float2(tt[a][0] - tt[a][2], tt[a][1] + tt[a][2]);
+            xo[(2 * a + 1) * 64 * WR_TS] = make_float2(tt[a][2] - tt[a][1], tt[a][1] - tt[a][3]);
+        }
+        const float *yp = buf + 32 * G::CS + row * WR_YS + yo;
+        const float2 y0 = *reinterpret_cast<const float2 *>(yp), y1 = *reinterpret_cast<const float2 *>(yp + (MAP == 2 ? 2 : MAP));
+        float gy[4][2];  // G y
+        gy[0][0] = y0.x, gy[0][1] = y0.y;
+        gy[1][0] = 0.5f * (y0.x + y1.x), gy[1][1] = 0.5f * (y0.y + y1.y);
+        gy[2][0] = 0.5f * (y0.x - y1.x), gy[2][1] = 0.5f * (y0.y - y1.y);
+        gy[3][0] = y1.x, gy[3][1] = y1.y;
+        float2 *yo2 = tp + row * WR_TS + t;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            yo2[(2 * a + 0) * 64 * WR_TS] = make_float2(gy[a][0], 0.5f * (gy[a][0] + gy[a][1]));
+            yo2[(2 * a + 1) * 64 * WR_TS] = make_float2(0.5f * (gy[a][0] - gy[a][1]), gy[a][1]);
+        }
+    };
+    f32x4 acc[2][2][2];  // [xi of the pair][co tile][ci tile]
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[e][m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    auto multiply = [&]() {  // M_xi += Yh_xi Xh_xi^T over the chunk's 16 tiles for xi = 2 wave, 2 wave + 1
+        const float2 *ap = tp + (wave * 64 + l15) * WR_TS + lq;
+        float2 av[2][4], bv[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) av[m][ks] = ap[16 * m * WR_TS + 4 * ks], bv[m][ks] = ap[(32 + 16 * m) * WR_TS + 4 * ks];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][ks].x, bv[n][ks].x, acc[0][m][n], 0, 0, 0);
+                    acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][ks].y, bv[n][ks].y, acc[1][m][n], 0, 0, 0);
+                }
+    };
+    // ---- pipeline: chunk r's pixels are in raw[r & 1] when round r starts; chunk r + 1's are in registers
+    load(q0);
+    for (int i = threadIdx.x; i < 2 * G::RAW; i += WR_NT) raw0[i] = 0.0f;  // the rings (and everything else) of both buffers
+    __syncthreads();
+    store(raw0);
+    if (nq > 1) load(q0 + 1);
+    __syncthreads();
+    for (int r = 0; r < nq; ++r) {
+        transform((r & 1) ? raw1 : raw0);
+        __syncthreads();
+        if (r + 1 < nq) {
+            store((r & 1) ? raw0 : raw1);
+            if (r + 2 < nq) load(q0 + r + 2);
+        }
+        multiply();
+        __syncthreads();
+    }
+    // ---- partial sums: part[s][xi][co][ci]; D[row = 4 lq + reg][col = l15]
+    const size_t plane = static_cast<size_t>(d.RC) * d.KC;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int xi = 4 * (wave >> 1) + 2 * (wave & 1) + e;
+        float *pp = part + (static_cast<size_t>(s) * 16 + xi) * plane;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) pp[static_cast<size_t>(co0 + 16 * m + 4 * lq + rg) * d.KC + ci0 + 16 * n + l15] = acc[e][m][n][rg];
+    }
+}
+
+// dW[co][ci] = A^T (sum_s M[s]) A for 16 (co, ci) pairs per workgroup: lane (xi, pair) adds the S partial values in order, then 144 lanes
+// apply A^T . A
+__global__ __launch_bounds__(256) void wrw_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int S, int plane) {
+    __shared__ float ms[16][17];
+    const int xi = threadIdx.x >> 4, e = threadIdx.x & 15;
+    const int elem = static_cast<int>(blockIdx.x) * 16 + e;
+    float sum = 0.0f;
+    if (elem < plane) {
+        const float *p = part + static_cast<size_t>(xi) * plane + elem;
+        for (int s = 0; s < S; ++s) sum += p[static_cast<size_t>(s) * 16 * plane];
+    }
+    ms[xi][e] = sum;
+    __syncthreads();
+    if (threadIdx.x < 144) {
+        const int pe = threadIdx.x / 9, k = threadIdx.x - 9 * pe, i = k / 3, j = k - 3 * i;
+        // A^T rows: (1,1,1,0), (0,1,-1,0), (0,1,1,-1)
+        float col[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float m0 = ms[4 * a + 0][pe], m1 = ms[4 * a + 1][pe], m2 = ms[4 * a + 2][pe], m3 = ms[4 * a + 3][pe];
+            col[a] = j == 0 ? (m0 + m1) + m2 : j == 1 ? m1 - m2 : (m1 + m2) - m3;
+        }
+        const float v = i == 0 ? (col[0] + col[1]) + col[2] : i == 1 ? col[1] - col[2] : (col[1] + col[2]) - col[3];
+        const int oe = static_cast<int>(blockIdx.x) * 16 + pe;
+        if (oe < plane) dw[static_cast<size_t>(oe) * 9 + k] = v;
+    }
+}
+
+// how the reduction over tiles is cut: about 256 workgroups in all, every one with the same number of 16-tile chunks (but the last)
+void wrw_plan(int B, int KC, int RC, int H, WrwDims &d) {
+    d.B = B, d.KC = KC, d.RC = RC;
+    d.chunks = H == 16 ? 4 * B : H == 8 ? B : H == 4 ? (B + 3) / 4 : (B + 15) / 16;
+    const int ntile = (KC / 32) * (RC / 32);
+    const int target = ntile >= 256 ? 1 : 256 / ntile;
+    d.cpw = (d.chunks + target - 1) / target;
+    d.S = (d.chunks + d.cpw - 1) / d.cpw;
+    d.grouped = d.S >= 8;
+}
+
+template <int MAP>
+int wrw_launch(const float *x, const float *dy, float *part, const WrwDims &d, hipStream_t st) {
+    using G = WrwGeo<MAP>;
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wrw_wino_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(G::lds_bytes)) == hipSuccess;
+    if (!ok) return EE_ERR_UNSUPPORTED;
+    const int ntile = (d.KC / 32) * (d.RC / 32);
+    const unsigned grid = static_cast<unsigned>(d.grouped ? 8 * ((d.S + 7) / 8) * ntile : d.S * ntile);
+    EE_LAUNCH(wrw_wino_kernel<MAP>, dim3(grid), dim3(WR_NT), G::lds_bytes, st, x, dy, part, d);
+    return launch_status();
+}
+
+}  // namespace
+
+EE_API int64_t ee_wrw3x3_workspace_floats(int B, int Cin, int Cout, int H) {
+    if (B < 1 || Cin < 32 || Cout < 32 || Cin % 32 != 0 || Cout % 32 != 0 || (H != 2 && H != 4 && H != 8 && H != 16)) return 0;
+    WrwDims d;
+    wrw_plan(B, Cin, Cout, H, d);
+    return static_cast<int64_t>(d.S) * 16 * Cin * Cout;
+}
+
+// dw [Cout][Cin][3][3] = d loss / d weight of y = conv3x3(x, weight) (stride 1, padding 1) given x [B][Cin][H][H] and dy [B][Cout][H][H];
+// workspace: ee_wrw3x3_workspace_floats(...) floats, overwritten
+EE_API int ee_wrw3x3_f32(const float *x, const float *dy, float *dw, float *workspace, int B, int Cin, int Cout, int H, void *stream) {
+    if (B < 0 || Cin < 1 || Cout < 1) return EE_ERR_SHAPE;
+    if (Cin % 32 != 0 || Cout % 32 != 0 || (H != 2 && H != 4 && H != 8 && H != 16)) return EE_ERR_UNSUPPORTED;
+    if (!dw) return EE_ERR_NULL;
+    if (B == 0) return static_cast<int>(hipMemsetAsync(dw, 0, sizeof(float) * 9 * Cin * Cout, as_stream(stream)));
+    if (!x || !dy || !workspace) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(workspace)) return EE_ERR_ALIGN;
+    if (static_cast<int64_t>(B) * (Cin > Cout ? Cin : Cout) * H * H > 0x7fffffffLL) return EE_ERR_SHAPE;
+    WrwDims d;
+    wrw_plan(B, Cin, Cout, H, d);
+    hipStream_t st = as_stream(stream);
+    int rc;
+    if (H == 16) rc = wrw_launch<16>(x, dy, workspace, d, st);
+    else if (H == 8) rc = wrw_launch<8>(x, dy, workspace, d, st);
+    else if (H == 4) rc = wrw_launch<4>(x, dy, workspace, d, st);
+    else rc = wrw_launch<2>(x, dy, workspace, d, st);
+    if (rc != EE_OK) return rc;
+    const int plane = Cin * Cout;
+    EE_LAUNCH(wrw_reduce_kernel, dim3((plane + 15) / 16), dim3(256), 0, st, workspace, dw, d.S, plane);
+    return launch_status();
+}

@@ -795,6 +795,26 @@ def wino3x3(x, u):
     return y
 
 
+def wrw3x3_supported(x, dy):
+    """ee_wrw.hip: weight gradient of a 3x3 / stride 1 / padding 1 convolution on 2x2, 4x4, 8x8 or 16x16 maps"""
+    return (x.dim() == 4 and dy.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (2, 4, 8, 16) and x.shape[2:] == dy.shape[2:]
+            and x.shape[0] == dy.shape[0] and x.shape[1] % 32 == 0 and dy.shape[1] % 32 == 0 and x.is_cuda and x.dtype == torch.float32
+            and dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous())
+
+
+def wrw3x3(x, dy):
+    """d loss / d weight [Cout,Cin,3,3] of conv3x3(x, weight) (stride 1, padding 1) from its input x [B,Cin,H,H] and output gradient dy [B,Cout,H,H]:
+    Winograd F(3x3, 2x2) on the matrix cores, partial sums added in a fixed order (bit-reproducible)."""
+    B, Cin, H = x.shape[0], x.shape[1], x.shape[2]
+    Cout = dy.shape[1]
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    n = int(N.lib.ee_wrw3x3_workspace_floats(B, Cin, Cout, H))
+    ws = torch.empty(max(n, 4), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_wrw3x3_f32(_chk(x, torch.float32, "x", (B, Cin, H, H)), _chk(dy, torch.float32, "dy", (B, Cout, H, H)), dw.data_ptr(), ws.data_ptr(),
+                                B, Cin, Cout, H, _stream()), "ee_wrw3x3_f32")
+    return dw
+
+
 def conv3x3s2_small_supported(x, cin, cout):
     """ee_s2.hip: 3x3 / stride 2 / padding 1 from a 16x16, 8x8 or 4x4 map"""
     return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8, 16) and cin % 32 == 0 and cout % 32 == 0

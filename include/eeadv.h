@@ -369,6 +369,14 @@ int ee_conv1x1s2_bwd_f32(const float *dy, const float *weight, float *dx, int B,
  * ee_conv3x3s2_small_* kernels below superseded on every shape of the BASELINE configs.) */
 int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int RC, int H, void *stream);
 
+/* The WEIGHT gradient of the same convolution (`loss.backward()` of the training step, experiments_tinyimagenet.py:304-306; resnet.py:26-31) on
+ * H x H maps, H = 2, 4, 8 or 16, as Winograd F(3x3, 2x2) around the f32 matrix cores: x [B,Cin,H,H] (the layer's input), dy [B,Cout,H,H] (the
+ * gradient of its output) -> dw [Cout,Cin,3,3] (overwritten).  The sum over images and tiles is split over ~256 workgroups whose partial results
+ * meet in `workspace` (ee_wrw3x3_workspace_floats(...) floats, contents undefined on entry and exit) and are added in a fixed order: the result
+ * is reproducible bit for bit.  Cin, Cout multiples of 32 (else EE_ERR_UNSUPPORTED; the workspace query then returns 0). */
+int64_t ee_wrw3x3_workspace_floats(int B, int Cin, int Cout, int H);
+int ee_wrw3x3_f32(const float *x, const float *dy, float *dw, float *workspace, int B, int Cin, int Cout, int H, void *stream);
+
 /* Conv2d(3x3, stride 2, padding 1, bias=False) between SMALL maps - the first convolution of ResNet-18's layer2 / layer3 / layer4 at 64x64 inputs
  * (resnet.py:26-31, :132-137): H = 16 (16x16 -> 8x8), 8 (8x8 -> 4x4) or 4 (4x4 -> 2x2) - on the f32 matrix cores with the reduction split over a
  * workgroup's wavefronts.  The filters arrive rearranged, w9 [R/32][K/16][9][4][2][16][4] with R = result and K = reduction channels:

@@ -1148,3 +1148,35 @@ def test_conv3x3_winograd_on_8x8_maps_matches_aten(ops, B, Cin, Cout, H):
         torch.testing.assert_close(gw, ew, rtol=1e-4, atol=1e-4 * (H * H * B) ** 0.5)
         with torch.no_grad():
             w.mul_(1.25)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(100, 64, 64, 16), (100, 128, 128, 8), (100, 256, 256, 4), (100, 512, 512, 2), (1, 32, 32, 16), (3, 32, 96, 16),
+                                          (7, 64, 32, 8), (5, 32, 64, 4), (37, 96, 32, 4), (17, 64, 96, 2), (1, 32, 32, 2), (33, 32, 32, 2)])
+def test_conv3x3_weight_gradient_winograd_matches_float64(ops, B, Cin, Cout, H):
+    """d loss / d weight of Conv2d(3x3, stride 1, padding 1) (`loss.backward()`, experiments_tinyimagenet.py:304-306; resnet.py:26-31) as Winograd
+    F(3x3, 2x2) on the f32 matrix cores with the reduction over images split over workgroups (ee_wrw.hip): against float64 direct
+    correlation (2e-6 of the largest entry per sqrt of the reduction length ... in practice below MIOpen's own error), against ATen, and
+    bit-identical from call to call (partial sums are added in a fixed order; MIOpen's solvers use atomics)."""
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=g).to(DEV)
+    dy = torch.randn(B, Cout, H, H, generator=g).to(DEV)
+    assert ops.wrw3x3_supported(x, dy)
+    got = ops.wrw3x3(x, dy)
+    w = torch.zeros(Cout, Cin, 3, 3, device=DEV)
+    ref = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    ref64 = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    scale = float(ref64.abs().max())
+    err, err_aten = float((got.double() - ref64).abs().max()), float((ref.double() - ref64).abs().max())
+    assert err < 3e-6 * scale, (err / scale, err_aten / scale)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4 * (H * H * B) ** 0.5)
+    again = ops.wrw3x3(x, dy)
+    assert torch.equal(got, again)
+    # structured inputs: a single bright pixel and a single gradient pixel give exactly one tap (exact in fp32: products with 0, 1, .5, .25)
+    x.zero_(), dy.zero_()
+    b, ci, co = B - 1, Cin - 1, Cout // 2
+    x[b, ci, H - 1, 0] = 1.0
+    dy[b, co, H - 2, 1] = 1.0  # output (H-2, 1) sees input (H-1, 0) through tap (2, 0)
+    one = ops.wrw3x3(x, dy)
+    exp = torch.zeros_like(one)
+    exp[co, ci, 2, 0] = 1.0
+    assert torch.equal(one, exp)
