@@ -11,8 +11,9 @@
 // A workgroup owns a 32 x 32 block of (co, ci) and a contiguous range of 16-tile chunks (a quarter of a 16x16 image, one 8x8 image, four 4x4
 // images, sixteen 2x2 images): per chunk all 512 lanes transform one input patch and one dy patch each into LDS, then wavefront w multiplies
 // the xi pair (2w, 2w+1) (32 MFMAs); the next chunk's pixels are already on their way (registers -> a second raw buffer during the products).
-// The reduction over chunks is split over workgroups so that ~256 of them exist; their partial M go to a workspace and a second kernel adds
-// them IN A FIXED ORDER and applies A^T . A: the result is reproducible bit for bit.
+// The reduction over chunks is split over workgroups so that ~256 of them exist; each applies A^T . A to its partial M and writes 3x3 partial
+// gradients to a workspace, which a second kernel adds IN A FIXED ORDER (one split - the 512-channel layers - writes the gradient itself):
+// the result is reproducible bit for bit.
 //
 // CNN-body glue, not a row of SURVEY.md section 8.
 #include "ee_common.hpp"
@@ -50,7 +51,7 @@ struct WrwDims {
 };
 
 template <int MAP>
-__global__ __launch_bounds__(WR_NT) void wrw_wino_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, WrwDims d) {
+__global__ __launch_bounds__(WR_NT) void wrw_wino_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ out, WrwDims d) {
     using G = WrwGeo<MAP>;
     extern __shared__ __align__(16) float lds[];
     float2 *tp = reinterpret_cast<float2 *>(lds);
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(WR_NT) void wrw_wino_kernel(const float *__restrict
     };
     // ---- pipeline: chunk r's pixels are in raw[r & 1] when round r starts; chunk r + 1's are in registers
     load(q0);
-    for (int i = threadIdx.x; i < 2 * G::RAW; i += WR_NT) raw0[i] = 0.0f;  // the rings (and everything else) of both buffers
+    for (int i = threadIdx.x; i < 2 * G::RAW / 4; i += WR_NT) reinterpret_cast<float4 *>(raw0)[i] = zero4;  // the rings (and everything else) of both buffers
     __syncthreads();
     store(raw0);
     if (nq > 1) load(q0 + 1);
@@ -200,46 +201,63 @@ __global__ __launch_bounds__(WR_NT) void wrw_wino_kernel(const float *__restrict
         multiply();
         __syncthreads();
     }
-    // ---- partial sums: part[s][xi][co][ci]; D[row = 4 lq + reg][col = l15]
-    const size_t plane = static_cast<size_t>(d.RC) * d.KC;
+    // ---- this workgroup's share of dW: the accumulators meet in LDS (D[row = 4 lq + reg][col = l15] -> ms[xi][co][ci], rows 33 apart), every lane
+    // applies A^T . A to two (co, ci) pairs and writes their nine taps: out[s][co][ci][3][3] - the weight gradient itself when there is one split
+    float *ms = lds;
+    constexpr int MS = 32 * 33;
+    static_assert(16 * MS * sizeof(float) <= 2 * WR_T2 * sizeof(float), "the accumulators fit the operand area");
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int xi = 4 * (wave >> 1) + 2 * (wave & 1) + e;
-        float *pp = part + (static_cast<size_t>(s) * 16 + xi) * plane;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) pp[static_cast<size_t>(co0 + 16 * m + 4 * lq + rg) * d.KC + ci0 + 16 * n + l15] = acc[e][m][n][rg];
+                for (int rg = 0; rg < 4; ++rg) ms[xi * MS + (16 * m + 4 * lq + rg) * 33 + 16 * n + l15] = acc[e][m][n][rg];
+    }
+    __syncthreads();
+    float *op = out + static_cast<size_t>(s) * 9 * d.RC * d.KC;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int co = (threadIdx.x >> 5) + 16 * h, ci = threadIdx.x & 31;
+        float col[4][3];  // M A
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float m0 = ms[(4 * a + 0) * MS + co * 33 + ci], m1 = ms[(4 * a + 1) * MS + co * 33 + ci], m2 = ms[(4 * a + 2) * MS + co * 33 + ci],
+                        m3 = ms[(4 * a + 3) * MS + co * 33 + ci];
+            col[a][0] = (m0 + m1) + m2, col[a][1] = m1 - m2, col[a][2] = (m1 + m2) - m3;
+        }
+        float *o = op + (static_cast<size_t>(co0 + co) * d.KC + ci0 + ci) * 9;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            o[j] = (col[0][j] + col[1][j]) + col[2][j];
+            o[3 + j] = col[1][j] - col[2][j];
+            o[6 + j] = (col[1][j] + col[2][j]) - col[3][j];
+        }
     }
 }
 
-// dW[co][ci] = A^T (sum_s M[s]) A for 16 (co, ci) pairs per workgroup: lane (xi, pair) adds the S partial values in order, then 144 lanes
-// apply A^T . A
-__global__ __launch_bounds__(256) void wrw_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int S, int plane) {
-    __shared__ float ms[16][17];
-    const int xi = threadIdx.x >> 4, e = threadIdx.x & 15;
-    const int elem = static_cast<int>(blockIdx.x) * 16 + e;
-    float sum = 0.0f;
-    if (elem < plane) {
-        const float *p = part + static_cast<size_t>(xi) * plane + elem;
-        for (int s = 0; s < S; ++s) sum += p[static_cast<size_t>(s) * 16 * plane];
-    }
-    ms[xi][e] = sum;
-    __syncthreads();
-    if (threadIdx.x < 144) {
-        const int pe = threadIdx.x / 9, k = threadIdx.x - 9 * pe, i = k / 3, j = k - 3 * i;
-        // A^T rows: (1,1,1,0), (0,1,-1,0), (0,1,1,-1)
-        float col[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float m0 = ms[4 * a + 0][pe], m1 = ms[4 * a + 1][pe], m2 = ms[4 * a + 2][pe], m3 = ms[4 * a + 3][pe];
-            col[a] = j == 0 ? (m0 + m1) + m2 : j == 1 ? m1 - m2 : (m1 + m2) - m3;
+// dw = sum_s part[s] (n4 float4 each), always in the same order: a workgroup takes 64 float4 columns, its four wavefronts the splits
+// s = 0, 4, 8 ... / 1, 5, 9 ... / ..., and wavefront 0 adds the four sums
+__global__ __launch_bounds__(256) void wrw_sum_kernel(const float4 *__restrict__ part, float4 *__restrict__ dw, int S, int n4) {
+    __shared__ float4 sm[3][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (col < n4)
+        for (int s = sg; s < S; s += 4) {
+            const float4 v = part[static_cast<size_t>(s) * n4 + col];
+            a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
         }
-        const float v = i == 0 ? (col[0] + col[1]) + col[2] : i == 1 ? col[1] - col[2] : (col[1] + col[2]) - col[3];
-        const int oe = static_cast<int>(blockIdx.x) * 16 + pe;
-        if (oe < plane) dw[static_cast<size_t>(oe) * 9 + k] = v;
+    if (sg) sm[sg - 1][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (sg == 0 && col < n4) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float4 v = sm[g][threadIdx.x];
+            a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+        }
+        dw[col] = a;
     }
 }
 
@@ -255,14 +273,14 @@ void wrw_plan(int B, int KC, int RC, int H, WrwDims &d) {
 }
 
 template <int MAP>
-int wrw_launch(const float *x, const float *dy, float *part, const WrwDims &d, hipStream_t st) {
+int wrw_launch(const float *x, const float *dy, float *out, const WrwDims &d, hipStream_t st) {
     using G = WrwGeo<MAP>;
     static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wrw_wino_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(G::lds_bytes)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
     const int ntile = (d.KC / 32) * (d.RC / 32);
     const unsigned grid = static_cast<unsigned>(d.grouped ? 8 * ((d.S + 7) / 8) * ntile : d.S * ntile);
-    EE_LAUNCH(wrw_wino_kernel<MAP>, dim3(grid), dim3(WR_NT), G::lds_bytes, st, x, dy, part, d);
+    EE_LAUNCH(wrw_wino_kernel<MAP>, dim3(grid), dim3(WR_NT), G::lds_bytes, st, x, dy, out, d);
     return launch_status();
 }
 
@@ -272,7 +290,7 @@ EE_API int64_t ee_wrw3x3_workspace_floats(int B, int Cin, int Cout, int H) {
     if (B < 1 || Cin < 32 || Cout < 32 || Cin % 32 != 0 || Cout % 32 != 0 || (H != 2 && H != 4 && H != 8 && H != 16)) return 0;
     WrwDims d;
     wrw_plan(B, Cin, Cout, H, d);
-    return static_cast<int64_t>(d.S) * 16 * Cin * Cout;
+    return d.S > 1 ? static_cast<int64_t>(d.S) * 9 * Cin * Cout : 0;
 }
 
 // dw [Cout][Cin][3][3] = d loss / d weight of y = conv3x3(x, weight) (stride 1, padding 1) given x [B][Cin][H][H] and dy [B][Cout][H][H];
@@ -282,19 +300,21 @@ EE_API int ee_wrw3x3_f32(const float *x, const float *dy, float *dw, float *work
     if (Cin % 32 != 0 || Cout % 32 != 0 || (H != 2 && H != 4 && H != 8 && H != 16)) return EE_ERR_UNSUPPORTED;
     if (!dw) return EE_ERR_NULL;
     if (B == 0) return static_cast<int>(hipMemsetAsync(dw, 0, sizeof(float) * 9 * Cin * Cout, as_stream(stream)));
-    if (!x || !dy || !workspace) return EE_ERR_NULL;
-    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(workspace)) return EE_ERR_ALIGN;
+    if (!x || !dy) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw)) return EE_ERR_ALIGN;
     if (static_cast<int64_t>(B) * (Cin > Cout ? Cin : Cout) * H * H > 0x7fffffffLL) return EE_ERR_SHAPE;
     WrwDims d;
     wrw_plan(B, Cin, Cout, H, d);
     hipStream_t st = as_stream(stream);
+    if (d.S > 1 && (!workspace || !aligned16(workspace))) return workspace ? EE_ERR_ALIGN : EE_ERR_NULL;
+    float *out = d.S > 1 ? workspace : dw;  // one split: the kernel's 3x3 results ARE the gradient
     int rc;
-    if (H == 16) rc = wrw_launch<16>(x, dy, workspace, d, st);
-    else if (H == 8) rc = wrw_launch<8>(x, dy, workspace, d, st);
-    else if (H == 4) rc = wrw_launch<4>(x, dy, workspace, d, st);
-    else rc = wrw_launch<2>(x, dy, workspace, d, st);
-    if (rc != EE_OK) return rc;
-    const int plane = Cin * Cout;
-    EE_LAUNCH(wrw_reduce_kernel, dim3((plane + 15) / 16), dim3(256), 0, st, workspace, dw, d.S, plane);
+    if (H == 16) rc = wrw_launch<16>(x, dy, out, d, st);
+    else if (H == 8) rc = wrw_launch<8>(x, dy, out, d, st);
+    else if (H == 4) rc = wrw_launch<4>(x, dy, out, d, st);
+    else rc = wrw_launch<2>(x, dy, out, d, st);
+    if (rc != EE_OK || d.S == 1) return rc;
+    const int n4 = 9 * Cin * Cout / 4;
+    EE_LAUNCH(wrw_sum_kernel, dim3((n4 + 63) / 64), dim3(256), 0, st, reinterpret_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(dw), d.S, n4);
     return launch_status();
 }

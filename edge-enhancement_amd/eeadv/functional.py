@@ -26,6 +26,18 @@ class input_grad_only:
         _INPUT_GRAD_ONLY = self._prev
 
 
+# EEADV_STOCK_WRW=1: the weight gradients of the stride-1 3x3 layers from ATen / MIOpen instead of ee_wrw.hip (an A/B switch for measurements)
+_STOCK_WRW = os.environ.get("EEADV_STOCK_WRW", "0") == "1"
+
+
+def conv3x3_weight_grad(x, dy, weight):
+    """d loss / d weight of conv3x3(x, weight) (stride 1, padding 1): ee_wrw.hip on the maps it takes (2 / 4 / 8 / 16 wide, channels % 32 == 0;
+    bit-reproducible), ATen's convolution_backward otherwise."""
+    if not _STOCK_WRW and ops.wrw3x3_supported(x, dy):
+        return ops.wrw3x3(x, dy)
+    return torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+
+
 class Edge125Fn(torch.autograd.Function):
     """CannyFilter_step125_1 forward/backward (utils/core.py:549-585, To_compare :329-358)."""
 
@@ -486,7 +498,7 @@ def refresh_dense_weights():
 class Conv3x3WinoFn(torch.autograd.Function):
     """Conv2d(3x3, stride 1, padding 1, bias=False) on 8x8 maps (ResNet-18 layer2 at 64x64 inputs, resnet.py:26-31): forward and
     backward-data as Winograd F(2x2, 3x3) around the f32 matrix cores (ee_wino.hip); the transformed filters follow the weight's version
-    counter like the dense matrices above (rebuilt inside a captured optimiser step); weight gradient on MIOpen."""
+    counter like the dense matrices above (rebuilt inside a captured optimiser step); weight gradient: ee_wrw.hip."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -502,7 +514,7 @@ class Conv3x3WinoFn(torch.autograd.Function):
         dx = ops.wino3x3(dy, _dense_weight(weight, "wino_b")) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            dw = conv3x3_weight_grad(x, dy, weight)
         return dx, dw
 
 
@@ -558,7 +570,7 @@ class Conv3x3S2PairFn(torch.autograd.Function):
 
 class Conv3x3Map2Fn(torch.autograd.Function):
     """Conv2d(Cin, Cout, 3, stride 1, padding 1, bias=False) on a 2x2 map (resnet.py:31, layer4 at 64x64 inputs) as one GEMM
-    each way; the weight gradient (once per training step) comes from ATen's convolution_backward."""
+    each way; the weight gradient (once per training step): ee_wrw.hip."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -575,7 +587,7 @@ class Conv3x3Map2Fn(torch.autograd.Function):
         dx = torch.mm(dy.reshape(B, -1), _dense_weight(weight).t()).view_as(x) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            dw = conv3x3_weight_grad(x, dy, weight)
         return dx, dw
 
 

@@ -372,8 +372,8 @@ int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int 
 /* The WEIGHT gradient of the same convolution (`loss.backward()` of the training step, experiments_tinyimagenet.py:304-306; resnet.py:26-31) on
  * H x H maps, H = 2, 4, 8 or 16, as Winograd F(3x3, 2x2) around the f32 matrix cores: x [B,Cin,H,H] (the layer's input), dy [B,Cout,H,H] (the
  * gradient of its output) -> dw [Cout,Cin,3,3] (overwritten).  The sum over images and tiles is split over ~256 workgroups whose partial results
- * meet in `workspace` (ee_wrw3x3_workspace_floats(...) floats, contents undefined on entry and exit) and are added in a fixed order: the result
- * is reproducible bit for bit.  Cin, Cout multiples of 32 (else EE_ERR_UNSUPPORTED; the workspace query then returns 0). */
+ * meet in `workspace` (ee_wrw3x3_workspace_floats(...) floats, contents undefined on entry and exit; 0 = none needed, NULL allowed) and are added
+ * in a fixed order: the result is reproducible bit for bit.  Cin, Cout multiples of 32 (else EE_ERR_UNSUPPORTED; the workspace query returns 0). */
 int64_t ee_wrw3x3_workspace_floats(int B, int Cin, int Cout, int H);
 int ee_wrw3x3_f32(const float *x, const float *dy, float *dw, float *workspace, int B, int Cin, int Cout, int H, void *stream);
 
