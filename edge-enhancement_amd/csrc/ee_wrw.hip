@@ -9,8 +9,9 @@
 // (B^T as in ee_wino.hip), i.e. 16 products per tile instead of 36, and the sum over tiles is 16 small GEMMs
 //     M_xi[co][ci] = sum_t Yh_xi[co][t] * Xh_xi[ci][t]          on v_mfma_f32_16x16x4_f32
 // A workgroup owns a 32 x 32 block of (co, ci) and a contiguous range of 16-tile chunks (a quarter of a 16x16 image, one 8x8 image, four 4x4
-// images, sixteen 2x2 images): per chunk all 512 lanes transform one input patch and one dy patch each into LDS, then wavefront w multiplies
-// the xi pair (2w, 2w+1) (32 MFMAs); the next chunk's pixels are already on their way (registers -> a second raw buffer during the products).
+// images, sixteen 2x2 images): per half chunk wavefronts 0-3 transform one input patch per lane and wavefronts 4-7 one dy patch into LDS while
+// wavefront w multiplies the xi pair (2w, 2w+1) of the previous half (16 MFMAs); the next chunk's pixels are already on their way (registers ->
+// a second raw buffer during the products).
 // The reduction over chunks is split over workgroups so that ~256 of them exist; each applies A^T . A to its partial M and writes 3x3 partial
 // gradients to a workspace, which a second kernel adds IN A FIXED ORDER (one split - the 512-channel layers - writes the gradient itself):
 // the result is reproducible bit for bit.
@@ -24,9 +25,15 @@ using namespace ee;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -DEE_WRW_SKIP=mask (scripts/native/wrw_bench.hip builds its own copies of this file with it; never the product): phase skipping inside the
+// loop - 1: no global loads, 2: no raw stores, 4: no transforms, 8: operand reads without products, 16: no operand reads and no products
+#ifndef EE_WRW_SKIP
+#define EE_WRW_SKIP 0
+#endif
+
 constexpr int WR_NT = 512;
-constexpr int WR_TS = 18;               // row stride of the transform-domain operands, in float2: rows 18 apart, the four k of a wavefront next to each other -> 32 distinct bank pairs per half wavefront
-constexpr int WR_T2 = 8 * 64 * WR_TS;   // [8 xi pairs][32 co rows + 32 ci rows][18] float2
+constexpr int WR_TS = 10;               // row stride of the transform-domain operands, in float2: rows 10 apart, the four k of a wavefront next to each other -> 32 distinct bank pairs per half wavefront
+constexpr int WR_T2 = 8 * 64 * WR_TS;   // one operand buffer = HALF a chunk: [8 xi pairs][32 co rows + 32 ci rows][8 tiles + 2] float2
 constexpr int WR_YS = 68;               // dy pixels of a chunk: 64 per channel, channels 68 apart
 
 template <int MAP>
@@ -37,11 +44,11 @@ struct WrwGeo {
     // zero-ringed pixel frames of a chunk; the channel stride is 4 mod 64 floats so that a half wavefront's patch reads (16 channels x 2
     // neighbouring tiles, 8 bytes each) fall on 32 distinct bank pairs
     static constexpr int FW = MAP == 16 ? 20 : MAP == 8 ? 12 : MAP == 4 ? 6 : 4;                // row stride
-    static constexpr int FI = MAP == 16 ? 6 * 20 : MAP == 8 ? 10 * 12 : MAP == 4 ? 36 : 16;     // one image's frame (16x16: a band of 4 + 2 rows)
-    static constexpr int CS = MAP == 16 ? 132 : MAP == 8 ? 132 : MAP == 4 ? 196 : 260;
+    static constexpr int FI = MAP == 16 ? 6 * 20 : MAP == 8 ? 10 * 12 : MAP == 4 ? 36 : 4;      // one image's frame (16x16: a band of 4 + 2 rows; 2x2: no ring, the four pixels)
+    static constexpr int CS = MAP == 16 ? 132 : MAP == 8 ? 132 : MAP == 4 ? 196 : WR_YS;
     static_assert(IMGS * FI <= CS && CS % 64 == 4, "frames fit, channels on distinct banks");
     static constexpr int RAW = 32 * CS + 32 * WR_YS;  // one raw buffer: x frames, dy pixels
-    static constexpr size_t lds_bytes = WR_T2 * sizeof(float2) + 2 * RAW * sizeof(float);
+    static constexpr size_t lds_bytes = 2 * WR_T2 * sizeof(float2) + 2 * RAW * sizeof(float);
 };
 
 struct WrwDims {
@@ -55,7 +62,8 @@ __global__ __launch_bounds__(WR_NT) void wrw_wino_kernel(const float *__restrict
     using G = WrwGeo<MAP>;
     extern __shared__ __align__(16) float lds[];
     float2 *tp = reinterpret_cast<float2 *>(lds);
-    float *raw0 = lds + 2 * WR_T2, *raw1 = raw0 + G::RAW;
+    float2 *tp1 = tp + WR_T2;
+    float *raw0 = lds + 4 * WR_T2, *raw1 = raw0 + G::RAW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
     const int ncb = d.RC / 32, nkb = d.KC / 32, ntile = ncb * nkb;
     int s, tile;
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(WR_NT) void wrw_wino_kernel(const float *__restrict
         else if (MAP == 4) dst = xs + pc * G::CS + (pf >> 2) * G::FI + (1 + (pf & 3)) * G::FW + 1;
         else dst = xs + pc * G::CS + pf * G::FI;
         if (MAP == 2) {
-            dst[5] = xv.x, dst[6] = xv.y, dst[9] = xv.z, dst[10] = xv.w;
+            *reinterpret_cast<float4 *>(dst) = xv;
         } else {
             dst[0] = xv.x, dst[1] = xv.y, dst[2] = xv.z, dst[3] = xv.w;
         }
@@ -117,47 +125,65 @@ __global__ __launch_bounds__(WR_NT) void wrw_wino_kernel(const float *__restrict
         }
         *reinterpret_cast<float4 *>(ys + pc * WR_YS + 4 * pf) = yv;
     };
-    // ---- this lane's two patches of a chunk: input patch (channel row, tile t) and dy patch (channel row, tile t)
-    const int row = l15 + 16 * (wave & 1), t = 4 * (wave >> 1) + lq;
-    int po, yo;
-    if (MAP == 16) po = 2 * (t >> 3) * G::FW + 2 * (t & 7), yo = 2 * (t >> 3) * 16 + 2 * (t & 7);
-    else if (MAP == 8) po = 2 * (t >> 2) * G::FW + 2 * (t & 3), yo = 2 * (t >> 2) * 8 + 2 * (t & 3);
-    else if (MAP == 4) po = (t >> 2) * G::FI + 2 * ((t >> 1) & 1) * G::FW + 2 * (t & 1), yo = (t >> 2) * 16 + 2 * ((t >> 1) & 1) * 4 + 2 * (t & 1);
-    else po = t * G::FI, yo = t * 4;
-    auto transform = [&](const float *buf) {
-        const float *p = buf + row * G::CS + po;
-        float dd[4][4];
+    // ---- this lane's patch of a HALF chunk (8 tiles): wavefronts 0-3 transform the input patches (channel row, tile), 4-7 the dy patches
+    const int row = l15 + 16 * (wave & 1), t8 = 4 * ((wave >> 1) & 1) + lq;
+    const bool xside = wave < 4;
+    auto transform = [&](const float *buf, int half, float2 *tq) {
+        const int t = 8 * half + t8;
+        if (xside) {
+            float dd[4][4];
+            if (MAP == 2) {  // the 4x4 patch of a 2x2 map is the map inside a ring of zeros
+                const float4 v = *reinterpret_cast<const float4 *>(buf + row * G::CS + 4 * t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float2 lo = *reinterpret_cast<const float2 *>(p + i * G::FW), hi = *reinterpret_cast<const float2 *>(p + i * G::FW + 2);
-            dd[i][0] = lo.x, dd[i][1] = lo.y, dd[i][2] = hi.x, dd[i][3] = hi.y;
-        }
-        float tt[4][4];  // B^T d
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tt[0][j] = dd[0][j] - dd[2][j];
-            tt[1][j] = dd[1][j] + dd[2][j];
-            tt[2][j] = dd[2][j] - dd[1][j];
-            tt[3][j] = dd[1][j] - dd[3][j];
-        }
-        float2 *xo = tp + (32 + row) * WR_TS + t;  // pair p = 2 a + b / 2 of xi = 4 a + b
+                    for (int j = 0; j < 4; ++j) dd[i][j] = 0.0f;
+                dd[1][1] = v.x, dd[1][2] = v.y, dd[2][1] = v.z, dd[2][2] = v.w;
+            } else {
+                int po;
+                if (MAP == 16) po = 2 * (t >> 3) * G::FW + 2 * (t & 7);
+                else if (MAP == 8) po = 2 * (t >> 2) * G::FW + 2 * (t & 3);
+                else po = (t >> 2) * G::FI + 2 * ((t >> 1) & 1) * G::FW + 2 * (t & 1);
+                const float *p = buf + row * G::CS + po;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            xo[(2 * a + 0) * 64 * WR_TS] = make_float2(tt[a][0] - tt[a][2], tt[a][1] + tt[a][2]);
-            xo[(2 * a + 1) * 64 * WR_TS] = make_float2(tt[a][2] - tt[a][1], tt[a][1] - tt[a][3]);
-        }
-        const float *yp = buf + 32 * G::CS + row * WR_YS + yo;
-        const float2 y0 = *reinterpret_cast<const float2 *>(yp), y1 = *reinterpret_cast<const float2 *>(yp + (MAP == 2 ? 2 : MAP));
-        float gy[4][2];  // G y
-        gy[0][0] = y0.x, gy[0][1] = y0.y;
-        gy[1][0] = 0.5f * (y0.x + y1.x), gy[1][1] = 0.5f * (y0.y + y1.y);
-        gy[2][0] = 0.5f * (y0.x - y1.x), gy[2][1] = 0.5f * (y0.y - y1.y);
-        gy[3][0] = y1.x, gy[3][1] = y1.y;
-        float2 *yo2 = tp + row * WR_TS + t;
+                for (int i = 0; i < 4; ++i) {
+                    const float2 lo = *reinterpret_cast<const float2 *>(p + i * G::FW), hi = *reinterpret_cast<const float2 *>(p + i * G::FW + 2);
+                    dd[i][0] = lo.x, dd[i][1] = lo.y, dd[i][2] = hi.x, dd[i][3] = hi.y;
+                }
+            }
+            float tt[4][4];  // B^T d
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            yo2[(2 * a + 0) * 64 * WR_TS] = make_float2(gy[a][0], 0.5f * (gy[a][0] + gy[a][1]));
-            yo2[(2 * a + 1) * 64 * WR_TS] = make_float2(0.5f * (gy[a][0] - gy[a][1]), gy[a][1]);
+            for (int j = 0; j < 4; ++j) {
+                tt[0][j] = dd[0][j] - dd[2][j];
+                tt[1][j] = dd[1][j] + dd[2][j];
+                tt[2][j] = dd[2][j] - dd[1][j];
+                tt[3][j] = dd[1][j] - dd[3][j];
+            }
+            float2 *xo = tq + (32 + row) * WR_TS + t8;  // pair p = 2 a + b / 2 of xi = 4 a + b
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                xo[(2 * a + 0) * 64 * WR_TS] = make_float2(tt[a][0] - tt[a][2], tt[a][1] + tt[a][2]);
+                xo[(2 * a + 1) * 64 * WR_TS] = make_float2(tt[a][2] - tt[a][1], tt[a][1] - tt[a][3]);
+            }
+        } else {
+            int yo;
+            if (MAP == 16) yo = 2 * (t >> 3) * 16 + 2 * (t & 7);
+            else if (MAP == 8) yo = 2 * (t >> 2) * 8 + 2 * (t & 3);
+            else if (MAP == 4) yo = (t >> 2) * 16 + 2 * ((t >> 1) & 1) * 4 + 2 * (t & 1);
+            else yo = t * 4;
+            const float *yp = buf + 32 * G::CS + row * WR_YS + yo;
+            const float2 y0 = *reinterpret_cast<const float2 *>(yp), y1 = *reinterpret_cast<const float2 *>(yp + (MAP == 2 ? 2 : MAP));
+            float gy[4][2];  // G y
+            gy[0][0] = y0.x, gy[0][1] = y0.y;
+            gy[1][0] = 0.5f * (y0.x + y1.x), gy[1][1] = 0.5f * (y0.y + y1.y);
+            gy[2][0] = 0.5f * (y0.x - y1.x), gy[2][1] = 0.5f * (y0.y - y1.y);
+            gy[3][0] = y1.x, gy[3][1] = y1.y;
+            float2 *yo2 = tq + row * WR_TS + t8;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                yo2[(2 * a + 0) * 64 * WR_TS] = make_float2(gy[a][0], 0.5f * (gy[a][0] + gy[a][1]));
+                yo2[(2 * a + 1) * 64 * WR_TS] = make_float2(0.5f * (gy[a][0] - gy[a][1]), gy[a][1]);
+            }
         }
     };
     f32x4 acc[2][2][2];  // [xi of the pair][co tile][ci tile]
@@ -167,45 +193,59 @@ __global__ __launch_bounds__(WR_NT) void wrw_wino_kernel(const float *__restrict
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) acc[e][m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    auto multiply = [&]() {  // M_xi += Yh_xi Xh_xi^T over the chunk's 16 tiles for xi = 2 wave, 2 wave + 1
-        const float2 *ap = tp + (wave * 64 + l15) * WR_TS + lq;
-        float2 av[2][4], bv[2][4];
+    auto multiply = [&](const float2 *tq) {  // M_xi += Yh_xi Xh_xi^T over the half chunk's 8 tiles for xi = 2 wave, 2 wave + 1
+        const float2 *ap = tq + (wave * 64 + l15) * WR_TS + lq;
+        float2 av[2][2], bv[2][2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) av[m][ks] = ap[16 * m * WR_TS + 4 * ks], bv[m][ks] = ap[(32 + 16 * m) * WR_TS + 4 * ks];
+            for (int ks = 0; ks < 2; ++ks) av[m][ks] = ap[16 * m * WR_TS + 4 * ks], bv[m][ks] = ap[(32 + 16 * m) * WR_TS + 4 * ks];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
+                    if (EE_WRW_SKIP & 8) {  // timing only: the operand reads without the products
+                        acc[0][m][n][0] += av[m][ks].x + bv[n][ks].x, acc[1][m][n][0] += av[m][ks].y + bv[n][ks].y;
+                        continue;
+                    }
                     acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][ks].x, bv[n][ks].x, acc[0][m][n], 0, 0, 0);
                     acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][ks].y, bv[n][ks].y, acc[1][m][n], 0, 0, 0);
                 }
     };
-    // ---- pipeline: chunk r's pixels are in raw[r & 1] when round r starts; chunk r + 1's are in registers
+    // ---- pipeline over HALF chunks h = 0 .. 2 nq - 1 (chunk h / 2, tiles 8 (h & 1) ..): during half round h every wavefront transforms its
+    // patch of half h + 1 into the other operand buffer, then multiplies half h - one barrier per half round, and the matrix pipe of a SIMD works
+    // for one of its two wavefronts while the other waits for LDS.  Chunk r's pixels sit in raw[r & 1]; chunk r + 1's go from registers into
+    // the other raw buffer during the first half of chunk r, and chunk r + 2's loads are issued right after.
     load(q0);
     for (int i = threadIdx.x; i < 2 * G::RAW / 4; i += WR_NT) reinterpret_cast<float4 *>(raw0)[i] = zero4;  // the rings (and everything else) of both buffers
     __syncthreads();
     store(raw0);
     if (nq > 1) load(q0 + 1);
     __syncthreads();
-    for (int r = 0; r < nq; ++r) {
-        transform((r & 1) ? raw1 : raw0);
-        __syncthreads();
-        if (r + 1 < nq) {
-            store((r & 1) ? raw0 : raw1);
-            if (r + 2 < nq) load(q0 + r + 2);
+    transform(raw0, 0, tp);
+    __syncthreads();
+    const int nh = 2 * nq;
+    for (int h = 0; h < nh; ++h) {
+        const int r = h >> 1;
+        // the two wavefronts of a SIMD (w and w + 4) take the half round's two jobs in OPPOSITE order: all eight running the same sequence
+        // between barriers meet in the LDS-bound transform, then in the matrix pipe, and the phases simply add up (phase skipping,
+        // scripts/native/wrw_bench.hip: 0.8 us transform + 1.2 us products + 0.2 us raw stores + 0.2 us barriers = the 2.5 us a chunk took)
+        if (!xside && !(EE_WRW_SKIP & 16)) multiply((h & 1) ? tp1 : tp);
+        if (h + 1 < nh && !(EE_WRW_SKIP & 4)) transform(((h + 1) >> 1) & 1 ? raw1 : raw0, (h + 1) & 1, (h & 1) ? tp : tp1);
+        if (!(h & 1) && r + 1 < nq) {
+            if (!(EE_WRW_SKIP & 2)) store((r & 1) ? raw0 : raw1);
+            if (r + 2 < nq && !(EE_WRW_SKIP & 1)) load(q0 + r + 2);
         }
-        multiply();
+        if (xside && !(EE_WRW_SKIP & 16)) multiply((h & 1) ? tp1 : tp);
         __syncthreads();
     }
     // ---- this workgroup's share of dW: the accumulators meet in LDS (D[row = 4 lq + reg][col = l15] -> ms[xi][co][ci], rows 33 apart), every lane
     // applies A^T . A to two (co, ci) pairs and writes their nine taps: out[s][co][ci][3][3] - the weight gradient itself when there is one split
     float *ms = lds;
     constexpr int MS = 32 * 33;
-    static_assert(16 * MS * sizeof(float) <= 2 * WR_T2 * sizeof(float), "the accumulators fit the operand area");
+    static_assert(16 * MS * sizeof(float) <= 2 * WR_T2 * sizeof(float2), "the accumulators fit the operand area");
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int xi = 4 * (wave >> 1) + 2 * (wave & 1) + e;
