@@ -239,10 +239,11 @@ def time_other_workload(name, dev, world, rank, steps, warmup):
     trainer.clear_update_graphs()
     engine.PROBE_ITERS = 0
     # MIOpen's solver search over ResNet-50's ~50 convolution shapes x 3 directions compiles kernels for four and a half minutes on a fresh
-    # box (measured: this leg 283 s with the search, ~40 s without); the search buys 7 % (553 vs 518 img/s).  As an extra leg of the default
-    # run the config therefore takes MIOpen's immediate-mode solvers; `--workload imagenet_free_at` on its own searches.
+    # box (measured: this leg 283 s with the search, ~40 s without); the search buys 7 % (553 vs 518 img/s).  With the recorded find-db
+    # (eeadv.runtime.use_shipped_miopen_db) the search is a lookup; without it (--no-miopen-db) this extra leg of the default run takes MIOpen's
+    # immediate-mode solvers, and `--workload imagenet_free_at` on its own searches.
     find_before = torch.backends.cudnn.benchmark
-    if name == "imagenet_free_at":
+    if name == "imagenet_free_at" and MIOPEN_DB is None:
         torch.backends.cudnn.benchmark = False
     job = Job(name, cfg, dev, world, rank)
     for i in range(SETUP_STEPS + warmup):
@@ -260,7 +261,7 @@ def time_other_workload(name, dev, world, rank, steps, warmup):
     res = {"value": round(world * cfg["batch"] * steps / dt, 2), "unit": "adversarial images/s", "ms_per_step": round(1e3 * dt / steps, 3),
            "steps": steps, "warmup": warmup, "final_loss": round(float(last[0].item()), 5),
            "config": {"workload": job.describe(), "global_batch": world * cfg["batch"], "grad_sync": job.grad_sync(),
-                      "miopen_find": bool(torch.backends.cudnn.benchmark)}}
+                      "miopen_find": bool(torch.backends.cudnn.benchmark), "miopen_db": "recorded" if MIOPEN_DB else None}}
     torch.backends.cudnn.benchmark = find_before
     del job, last
     engine.clear_graphs()
@@ -270,6 +271,7 @@ def time_other_workload(name, dev, world, rank, steps, warmup):
 
 
 SETUP_STEPS = 3
+MIOPEN_DB = None  # the private copy of the recorded MIOpen find-db this process uses (main sets it)
 
 
 def calibrate_bracket(ops, N, cfg, dev, n=200):
@@ -396,6 +398,8 @@ def main():
     ap.add_argument("--extras-timeout", type=int, default=420, help="seconds after which the headline line is printed without the extra legs")
     ap.add_argument("--dry-launch", action="store_true", help="only prove that --gpus N starts N ranks (gloo, no GPU needed)")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-miopen-db", action="store_true",
+                    help="do not use the recorded MIOpen find-db (edge-enhancement_amd/miopen_db): MIOpen then searches its solvers itself")
     ap.add_argument("--no-miopen-benchmark", action="store_true",
                     help="leave torch.backends.cudnn.benchmark off (default: on, MIOpen searches its solvers once per shape)")
     a = ap.parse_args()
@@ -423,6 +427,8 @@ def main():
 
     from eeadv import engine, ops, runtime, trainer, _native as N
 
+    global MIOPEN_DB
+    MIOPEN_DB = None if a.no_miopen_db else runtime.use_shipped_miopen_db()  # before the first convolution
     os.environ["EEADV_GRAPH"] = "0" if a.no_graph else "1"
     engine.PROBE_ITERS = 0 if a.no_graph else a.probe_iters
     job = Job(a.workload, cfg, dev, world, rank, channels_last=a.channels_last)
@@ -562,7 +568,7 @@ def main():
                 "global_batch": world * B, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
                 "backend": dist.get_backend() if world > 1 else None, "grad_sync": grad_sync_text,
                 "switches": non_default_switches,
-                "rank0_phase_ms": phases, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "probe_iters": probe_iters, "probe_every": a.probe_every,
+                "rank0_phase_ms": phases, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "miopen_db": "recorded" if MIOPEN_DB else None, "probe_iters": probe_iters, "probe_every": a.probe_every,
                 "device": (N.lib.ee_device_name() or b"?").decode()},
             "roofline": roofline, "roofline_front_end": roofline_hbm, "kernels": kernels, "final_loss": round(loss_val, 5),
             "note": "throughput is bounded by the classifier's fp32 convolutions (hand-written MFMA kernels + MIOpen) and BatchNorm launches, "

@@ -1,5 +1,7 @@
 """Process-wide switches of the host layer."""
 import os
+import shutil
+import tempfile
 
 import torch
 
@@ -82,3 +84,24 @@ def non_default_switches():
     """Every EEADV_* environment switch that is set in this process, for the bench line's `config.switches`: a number measured with
     an A/B switch thrown says so.  EEADV_GRAPH is left out (bench.py sets it itself and reports `hip_graph`)."""
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith("EEADV_") and k != "EEADV_GRAPH"}
+
+
+# ---- MIOpen's solver choices for the convolutions that stay on MIOpen --------------------------------------------------------------------
+# torch.backends.cudnn.benchmark = True makes MIOpen time every applicable solver once per convolution shape and direction: 4.5 minutes of
+# kernel compilation for ResNet-50's ~50 shapes on a fresh machine, for 7 % throughput on BASELINE config 5 (bench.py: 553 against 518 img/s).
+# The outcome of that search is a 70 KB text file (MIOpen's "user find-db").  `miopen_db/` holds the one recorded on an MI355X with this
+# image's MIOpen for the convolution shapes of the BASELINE configs (scripts/r3_finddb.sh); with it in place the search is a lookup.
+_MIOPEN_DB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miopen_db")
+
+
+def use_shipped_miopen_db():
+    """Point MIOpen's user find-db at a PRIVATE copy of `miopen_db/` (every process its own: MIOpen appends to the files, and eight ranks must
+    not share them).  Call before the first convolution.  A MIOPEN_USER_DB_PATH the caller has set wins; shapes the recorded db does not
+    know are searched as usual.  Returns the directory, or None when nothing was done."""
+    if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(_MIOPEN_DB):
+        return None
+    dst = tempfile.mkdtemp(prefix="eeadv_miopen_")
+    for name in os.listdir(_MIOPEN_DB):
+        shutil.copy(os.path.join(_MIOPEN_DB, name), dst)
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return dst
