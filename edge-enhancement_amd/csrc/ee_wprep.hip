@@ -82,6 +82,66 @@ __device__ __forceinline__ void dense_map2_body(const float *__restrict__ w, flo
     out[idx] = w[(static_cast<size_t>(co) * Cin + ci) * 9 + (iy - oy + 1) * 3 + (ix - ox + 1)];
 }
 
+// EE_WPREP_WINO_FB: both Winograd sets of a weight in one pass over it.  wino_filter_body gathers its nine taps with the lanes along the RESULT
+// channel - forward that is a stride of 9 Cin floats between lanes (one 4-byte use per fetched sector), and every weight is read twice (forward,
+// backward-data).  Here a workgroup reads a 16 x 16 tile of (co, ci) filters ONCE, row by row (16 x 9 contiguous floats per output channel),
+// into LDS and writes both sets with the lanes along each set's fastest index.  Same sums in the same order: the same bits.
+constexpr int FB_T = 16;               // the tile: 16 x 16 (co, ci) filters per workgroup - (C / 16)^2 workgroups, 256 for the 256-channel layers
+constexpr int FB_ROW = FB_T * 9 + 1;   // LDS row of an output channel's 16 filters (+1: lanes along co on distinct banks)
+
+__device__ __forceinline__ void wino_transform_store(const float (&gg)[3][3], float *o, size_t xs) {
+    float t[4][3];  // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float s = gg[0][b] + gg[2][b];
+        t[0][b] = gg[0][b];
+        t[1][b] = 0.5f * (s + gg[1][b]);
+        t[2][b] = 0.5f * (s - gg[1][b]);
+        t[3][b] = gg[2][b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float s = t[i][0] + t[i][2];
+        o[(4 * i + 0) * xs] = t[i][0];
+        o[(4 * i + 1) * xs] = 0.5f * (s + t[i][1]);
+        o[(4 * i + 2) * xs] = 0.5f * (s - t[i][1]);
+        o[(4 * i + 3) * xs] = t[i][2];
+    }
+}
+
+__global__ __launch_bounds__(256) void wino_filter_fb_kernel(const float *__restrict__ w, float *__restrict__ uf, float *__restrict__ ub, int Cout, int Cin) {
+    __shared__ float g[FB_T * FB_ROW];
+    const int nci = Cin / FB_T;
+    const int co0 = (blockIdx.x / nci) * FB_T, ci0 = (blockIdx.x % nci) * FB_T;
+    for (int i = threadIdx.x; i < FB_T * FB_T * 9; i += 256) {
+        const int r = i / (FB_T * 9), c = i - r * (FB_T * 9);
+        g[r * FB_ROW + c] = w[(static_cast<size_t>(co0 + r) * Cin + ci0) * 9 + c];
+    }
+    __syncthreads();
+    const size_t xs = static_cast<size_t>(Cout) * Cin;
+    const int lo = threadIdx.x & (FB_T - 1), hi = threadIdx.x / FB_T;
+    {  // forward set u[xi][ci][co]: lanes along co
+        const int co = lo, ci = hi;
+        const float *p = g + co * FB_ROW + ci * 9;
+        float gg[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) gg[a][b] = p[a * 3 + b];
+        wino_transform_store(gg, uf + static_cast<size_t>(ci0 + ci) * Cout + co0 + co, xs);
+    }
+    {  // backward-data set u[xi][co][ci] of the filters rotated by 180 degrees: lanes along ci
+        const int ci = lo, co = hi;
+        const float *p = g + co * FB_ROW + ci * 9;
+        float gg[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) gg[a][b] = p[(2 - a) * 3 + (2 - b)];
+        wino_transform_store(gg, ub + static_cast<size_t>(co0 + co) * Cin + ci0 + ci, xs);
+    }
+}
+
 __device__ __forceinline__ void wprep_dispatch(int kind, const float *w, const float *w1, float *out, int Cout, int Cin, unsigned block) {
     if (kind == EE_WPREP_WINO_F || kind == EE_WPREP_WINO_B)
         wino_filter_body(w, out, Cout, Cin, kind == EE_WPREP_WINO_B ? 1 : 0, block);
@@ -111,6 +171,11 @@ EE_API int ee_conv_weight_prep_f32(int kind, const float *w, const float *w1, fl
     if (static_cast<int64_t>(Cout) * Cin > (1LL << 26)) return EE_ERR_SHAPE;
     hipStream_t st = as_stream(stream);
     const size_t pairs = static_cast<size_t>(Cout) * Cin;
+    if (kind == EE_WPREP_WINO_FB) {
+        if (Cout % 32 != 0 || Cin % 32 != 0) return EE_ERR_UNSUPPORTED;
+        EE_LAUNCH(wino_filter_fb_kernel, dim3(static_cast<unsigned>((Cout / FB_T) * (Cin / FB_T))), dim3(256), 0, st, w, out, out + 16 * pairs, Cout, Cin);
+        return launch_status();
+    }
     if (kind < EE_WPREP_WINO_F || kind > EE_WPREP_DENSE_MAP2) return EE_ERR_UNSUPPORTED;
     if (kind >= EE_WPREP_S2M_F && kind <= EE_WPREP_S2P_B) {
         const bool backward = kind == EE_WPREP_S2M_B || kind == EE_WPREP_S2P_B;

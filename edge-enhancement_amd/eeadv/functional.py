@@ -340,6 +340,8 @@ def _rearranged(weight, kind="s1", extra=None):
     """kind "s1": 3x3 / stride 1 / padding 1 on a 2x2 map -> [4 Cin, 4 Cout]; kind "s2": 3x3 / stride 2 / padding 1 from a 4x4 map to
     a 2x2 map -> [16 Cin, 4 Cout] (tap ky = iy - 2 oy + 1, zero where it leaves the 3x3 window)."""
     co, ci = weight.shape[0], weight.shape[1]
+    if kind == "wino_fb":
+        return torch.stack([_rearranged(weight, "wino_f").reshape(-1), _rearranged(weight, "wino_b").reshape(-1)])
     if kind in ("wino_f", "wino_b"):
         # Winograd F(2x2, 3x3) filter transform U = G g G^T, laid out [16][KC][RC] for ee_wino.hip: forward g = w[r][k] (k = input channel),
         # backward-data g = w[k][r] rotated by 180 degrees (k = output channel)
@@ -382,13 +384,15 @@ def _versions(weight, extra):
 
 # kinds ee_wprep.hip builds in one launch (EE_WPREP_* of eeadv.h); _rearranged's torch expressions are their restatement (tests) and the
 # path of anything the kernel does not take
-_NATIVE_KIND = {"wino_f": 0, "wino_b": 1, "s2m_f": 2, "s2m_b": 3, "s2p_f": 4, "s2p_b": 5, "s1": 6}
+_NATIVE_KIND = {"wino_f": 0, "wino_b": 1, "s2m_f": 2, "s2m_b": 3, "s2p_f": 4, "s2p_b": 5, "s1": 6, "wino_fb": 7}
 
 
 def _rearranged_shape(weight, kind):
     co, ci = weight.shape[0], weight.shape[1]
     if kind in ("wino_f", "wino_b"):
         return (16, ci, co) if kind == "wino_f" else (16, co, ci)
+    if kind == "wino_fb":  # [forward set | backward-data set], each 16 * ci * co floats (wino_sets() hands out the two views)
+        return (2, 16 * ci * co)
     if kind in ("s2m_f", "s2p_f"):
         return (co // 32, ci // 16, 10 if kind == "s2p_f" else 9, 4, 2, 16, 4)
     if kind in ("s2m_b", "s2p_b"):
@@ -398,15 +402,27 @@ def _rearranged_shape(weight, kind):
 
 def _fill_rearranged(buf, weight, kind, extra):
     """buf <- the rearranged copy, in place (capturable): one hand-written launch where ee_wprep.hip knows the kind"""
-    if (kind in _NATIVE_KIND and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
-            and (extra is None or (extra.is_contiguous() and extra.dtype == torch.float32))):
+    if (_native_kind(weight, kind) and (extra is None or (extra.is_contiguous() and extra.dtype == torch.float32))):
         ops.conv_weight_prep(_NATIVE_KIND[kind], weight.detach(), None if extra is None else extra.detach(), buf)
     else:
         buf.copy_(_rearranged(weight, kind, extra))
 
 
+def _native_kind(weight, kind):
+    return (kind in _NATIVE_KIND and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
+            and (kind != "wino_fb" or (weight.shape[0] % 32 == 0 and weight.shape[1] % 32 == 0)))
+
+
+def wino_sets(weight):
+    """(u forward [16, Cin, Cout], u backward-data [16, Cout, Cin]) of a 3x3 weight: the two halves of ONE cached buffer that one ee_wprep.hip
+    launch rebuilds (round 3; two entries and two launches before)"""
+    co, ci = weight.shape[0], weight.shape[1]
+    both = _dense_weight(weight, "wino_fb")
+    return both[0].view(16, ci, co), both[1].view(16, co, ci)
+
+
 def _new_rearranged(weight, kind, extra):
-    if kind in _NATIVE_KIND and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous():
+    if _native_kind(weight, kind):
         buf = torch.empty(_rearranged_shape(weight, kind), dtype=torch.float32, device=weight.device)
         _fill_rearranged(buf, weight, kind, extra)
         return buf
@@ -502,8 +518,7 @@ class Conv3x3WinoFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight):
-        u = _dense_weight(weight, "wino_f")
-        _dense_weight(weight, "wino_b")  # created outside any capture; the backward only reads it
+        u = wino_sets(weight)[0]  # (both sets are created here, outside any capture; the backward only reads its half)
         ctx.save_for_backward(x, weight)
         return ops.wino3x3(x, u)
 
@@ -511,7 +526,7 @@ class Conv3x3WinoFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = ops.wino3x3(dy, _dense_weight(weight, "wino_b")) if ctx.needs_input_grad[0] else None
+        dx = ops.wino3x3(dy, wino_sets(weight)[1]) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
             dw = conv3x3_weight_grad(x, dy, weight)

@@ -398,7 +398,9 @@ int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, const flo
  *   EE_WPREP_WINO_F / _B   u [16][K][R] for ee_wino3x3_f32, forward (K = Cin, R = Cout) / backward-data (K = Cout, R = Cin, rotated filters)
  *   EE_WPREP_S2M_F / _B    w9 [R/32][K/16][9][4][2][16][4] for ee_conv3x3s2_small_*; EE_WPREP_S2P_F / _B: w10 (10 taps) for ee_conv3x3s2_pair_*,
  *                          w1 [Cout,Cin] = the shortcut's 1x1 filters
- *   EE_WPREP_DENSE_MAP2    [4 Cin][4 Cout]: a 3x3 / stride 1 / padding 1 convolution on a 2x2 map as one dense product (layer 4) */
+ *   EE_WPREP_DENSE_MAP2    [4 Cin][4 Cout]: a 3x3 / stride 1 / padding 1 convolution on a 2x2 map as one dense product (layer 4)
+ *   EE_WPREP_WINO_FB       both Winograd sets in one pass over the weight: out = [ u forward [16][Cin][Cout] | u backward-data [16][Cout][Cin] ]
+ *                          (2 * 16 * Cin * Cout floats; Cin, Cout multiples of 32), the same values as EE_WPREP_WINO_F / _B */
 #define EE_WPREP_WINO_F 0
 #define EE_WPREP_WINO_B 1
 #define EE_WPREP_S2M_F 2
@@ -406,6 +408,7 @@ int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, const flo
 #define EE_WPREP_S2P_F 4
 #define EE_WPREP_S2P_B 5
 #define EE_WPREP_DENSE_MAP2 6
+#define EE_WPREP_WINO_FB 7
 int ee_conv_weight_prep_f32(int kind, const float *w, const float *w1, float *out, int Cout, int Cin, void *stream);
 
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient

@@ -1039,6 +1039,16 @@ def test_weight_preparation_kernels_match_their_torch_restatement(ops, monkeypat
         w64 = w.double() if kind == "wino_f" else w.double().flip(2, 3)
         want = torch.einsum("ia,jb,rkab->ijkr" if kind == "wino_f" else "ia,jb,krab->ijkr", G, G, w64).reshape(got.shape)
         assert float((got.double() - want).abs().max()) < 1e-6 * float(want.abs().max())
+    if co % 32 == 0 and ci % 32 == 0:  # both sets in one launch (what Conv3x3WinoFn's cache uses): the per-set launches' bits
+        both = torch.empty(EF._rearranged_shape(w, "wino_fb"), device=DEV)
+        ops.conv_weight_prep(EF._NATIVE_KIND["wino_fb"], w, None, both)
+        for half, kind in enumerate(("wino_f", "wino_b")):
+            one = torch.empty(EF._rearranged_shape(w, kind), device=DEV)
+            ops.conv_weight_prep(EF._NATIVE_KIND[kind], w, None, one)
+            assert torch.equal(both[half].view(one.shape), one), kind
+        pf = torch.nn.Parameter(w.clone())
+        uf, ub = EF.wino_sets(pf)
+        assert uf.data_ptr() + 4 * uf.numel() == ub.data_ptr() and torch.equal(uf, both[0].view(uf.shape))
     p = torch.nn.Parameter(w.clone())
     buf = EF._dense_weight(p, "wino_f")
     ptr = buf.data_ptr()
