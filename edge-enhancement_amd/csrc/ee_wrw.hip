@@ -324,6 +324,186 @@ int wrw_launch(const float *x, const float *dy, float *out, const WrwDims &d, hi
     return launch_status();
 }
 
+// ---- stride 2: the first convolution of a down-sampling block (3x3 / stride 2 / padding 1, H x H -> H/2 x H/2, H = 16, 8 or 4) and, optionally,
+// the block's shortcut Conv2d(1x1, stride 2) of the SAME input (resnet.py:50-59, :132-142) in one launch ---------------------------------------
+// No Winograd at stride 2: per tap (kh, kw) a plain product dW_t[co][ci] = sum over (image, oh, ow) dy[co][oh][ow] * x[ci][2 oh + kh - 1][2 ow + kw - 1]
+// on v_mfma_f32_16x16x4_f32, the MFMA operands read straight from the chunk's raw pixels in LDS (dy rows; zero-ringed x frames, the tap a constant
+// offset).  A workgroup owns 32 x 32 (co, ci) and a range of 16-output-pixel chunks (two output rows of a 16x16 input's 8x8 result, one 8x8 input
+// image, four 4x4 ones); wavefront w multiplies (co, ci) quarter w & 3 for five of the ten taps (w >> 2: taps 0-4 / 5-8 and the shortcut's 1x1,
+// whose input pixel is the centre tap's).  Same split over ~256 workgroups, same fixed-order sum kernel as above.
+constexpr int S2W_YS = 18;  // dy pixels of a chunk: 16 per channel, channels 18 apart (the A operand's 32 lanes of a group on 32 banks)
+
+template <int H>
+struct WrwS2Geo {
+    static constexpr int OH = H / 2, OP = OH * OH;
+    static constexpr int IMGS = OP >= 16 ? 1 : 16 / OP;      // images per chunk of 16 output pixels
+    static constexpr int FR = H == 16 ? 5 : H == 8 ? 9 : 5;  // frame rows: input rows 4c-1 .. 4c+3 of a band / -1 .. 7 / -1 .. 3
+    static constexpr int FW = H == 16 ? 20 : H == 8 ? 10 : 6; // frame row stride: columns -1 .. H-1 (no right or bottom padding is ever read)
+    static constexpr int FI = FR * FW;
+    static constexpr int CS = IMGS * FI + 1 + ((IMGS * FI) & 1);  // odd channel stride
+    static constexpr int RAW = 32 * CS + 2 * 32 * S2W_YS;         // x frames, dy3 rows, dy1 rows
+    static constexpr int MSF = 10 * 32 * 33;                      // the epilogue's accumulator exchange
+    static constexpr size_t lds_bytes = (2 * RAW > MSF ? 2 * RAW : MSF) * sizeof(float);
+};
+
+template <int H>
+__global__ __launch_bounds__(WR_NT) void wrw_s2_kernel(const float *__restrict__ x, const float *__restrict__ dy3, const float *__restrict__ dy1,
+                                                       float *__restrict__ out, WrwDims d) {
+    using G = WrwS2Geo<H>;
+    extern __shared__ __align__(16) float lds[];
+    float *raw0 = lds, *raw1 = lds + G::RAW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int ncb = d.RC / 32, nkb = d.KC / 32, ntile = ncb * nkb;
+    int s, tile;
+    if (d.grouped) {
+        const int g = blockIdx.x & 7, k = blockIdx.x >> 3;
+        s = g + 8 * (k / ntile), tile = k % ntile;
+        if (s >= d.S) return;
+    } else {
+        s = blockIdx.x / ntile, tile = blockIdx.x - s * ntile;
+    }
+    const int co0 = (tile / nkb) * 32, ci0 = (tile % nkb) * 32;
+    const int q0 = s * d.cpw, nq = d.chunks - q0 < d.cpw ? d.chunks - q0 : d.cpw;
+    const bool pair = dy1 != nullptr;
+    // ---- a lane's share of a chunk's pixels: one float4 of x (channel pc, float4 pf of its 64 pixels); lanes < 128 one float4 of dy3 and of dy1
+    // (channel threadIdx.x >> 2, float4 threadIdx.x & 3 of its 16 pixels); 16x16 inputs: lanes 128 .. 255 one float4 of the halo row above the band
+    const int pc = threadIdx.x >> 4, pf = threadIdx.x & 15;
+    const int yc = (threadIdx.x >> 2) & 31, yf = threadIdx.x & 3;
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 xv = zero4, hv = zero4, y3v = zero4, y1v = zero4;
+    auto load = [&](int q) {
+        if (H == 16) {
+            const int img = q >> 2, c = q & 3;
+            xv = *reinterpret_cast<const float4 *>(x + (static_cast<size_t>(img) * d.KC + ci0 + pc) * 256 + c * 64 + 4 * pf);
+            if (threadIdx.x < 128) {
+                y3v = *reinterpret_cast<const float4 *>(dy3 + (static_cast<size_t>(img) * d.RC + co0 + yc) * 64 + c * 16 + 4 * yf);
+                if (pair) y1v = *reinterpret_cast<const float4 *>(dy1 + (static_cast<size_t>(img) * d.RC + co0 + yc) * 64 + c * 16 + 4 * yf);
+            } else if (threadIdx.x < 256) {
+                hv = c > 0 ? *reinterpret_cast<const float4 *>(x + (static_cast<size_t>(img) * d.KC + ci0 + yc) * 256 + c * 64 - 16 + 4 * yf) : zero4;
+            }
+        } else if (H == 8) {
+            xv = *reinterpret_cast<const float4 *>(x + (static_cast<size_t>(q) * d.KC + ci0 + pc) * 64 + 4 * pf);
+            if (threadIdx.x < 128) {
+                y3v = *reinterpret_cast<const float4 *>(dy3 + (static_cast<size_t>(q) * d.RC + co0 + yc) * 16 + 4 * yf);
+                if (pair) y1v = *reinterpret_cast<const float4 *>(dy1 + (static_cast<size_t>(q) * d.RC + co0 + yc) * 16 + 4 * yf);
+            }
+        } else {
+            const int img = 4 * q + (pf >> 2);
+            xv = img < d.B ? *reinterpret_cast<const float4 *>(x + (static_cast<size_t>(img) * d.KC + ci0 + pc) * 16 + 4 * (pf & 3)) : zero4;
+            if (threadIdx.x < 128) {
+                const int im2 = 4 * q + yf;  // float4 yf of a channel's 16 dy pixels = the 2x2 result of image yf
+                const bool ok = im2 < d.B;
+                y3v = ok ? *reinterpret_cast<const float4 *>(dy3 + (static_cast<size_t>(im2) * d.RC + co0 + yc) * 4) : zero4;
+                if (pair) y1v = ok ? *reinterpret_cast<const float4 *>(dy1 + (static_cast<size_t>(im2) * d.RC + co0 + yc) * 4) : zero4;
+            }
+        }
+    };
+    auto store = [&](float *buf) {  // frame row 0 / column 0 = input row (band start - 1) / column -1: the ring stays zero
+        float *dst;
+        if (H == 16) dst = buf + pc * G::CS + (1 + (pf >> 2)) * G::FW + 1 + 4 * (pf & 3);
+        else if (H == 8) dst = buf + pc * G::CS + (1 + (pf >> 1)) * G::FW + 1 + 4 * (pf & 1);
+        else dst = buf + pc * G::CS + (pf >> 2) * G::FI + (1 + (pf & 3)) * G::FW + 1;
+        dst[0] = xv.x, dst[1] = xv.y, dst[2] = xv.z, dst[3] = xv.w;
+        if (threadIdx.x < 128) {
+            float *y3 = buf + 32 * G::CS + yc * S2W_YS + 4 * yf;
+            y3[0] = y3v.x, y3[1] = y3v.y, y3[2] = y3v.z, y3[3] = y3v.w;
+            if (pair) {
+                float *y1 = y3 + 32 * S2W_YS;
+                y1[0] = y1v.x, y1[1] = y1v.y, y1[2] = y1v.z, y1[3] = y1v.w;
+            }
+        } else if (H == 16 && threadIdx.x < 256) {
+            float *h = buf + yc * G::CS + 1 + 4 * yf;
+            h[0] = hv.x, h[1] = hv.y, h[2] = hv.z, h[3] = hv.w;
+        }
+    };
+    // ---- this wavefront's products: quarter (m, n) of the (co, ci) block, taps t0 .. t0 + 4 (tap 9 = the shortcut's 1x1: dy1, centre pixel)
+    const int m = (wave >> 1) & 1, n = wave & 1, t0 = 5 * (wave >> 2);
+    int pos[4];  // frame offset of output pixel k = lq + 4 ks at tap (0, 0)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int p = lq + 4 * ks;
+        if (H == 16) pos[ks] = 2 * (p >> 3) * G::FW + 2 * (p & 7);
+        else if (H == 8) pos[ks] = 2 * (p >> 2) * G::FW + 2 * (p & 3);
+        else pos[ks] = (p >> 2) * G::FI + 2 * ((p >> 1) & 1) * G::FW + 2 * (p & 1);
+    }
+    f32x4 acc[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    auto multiply = [&](const float *buf) {
+        const float *ap = buf + 32 * G::CS + (16 * m + l15) * S2W_YS + lq;
+        const float *bp = buf + (16 * n + l15) * G::CS;
+        float av[4], a1[4], bv[5][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            av[ks] = ap[4 * ks];
+            a1[ks] = ap[32 * S2W_YS + 4 * ks];
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                const int t = t0 + a, tt = t == 9 ? 4 : t;
+                bv[a][ks] = bp[pos[ks] + (tt / 3) * G::FW + tt % 3];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int a = 0; a < 5; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(t0 + a == 9 ? a1[ks] : av[ks], bv[a][ks], acc[a], 0, 0, 0);
+    };
+    // ---- pipeline: chunk r's pixels are in raw[r & 1] when round r starts; chunk r + 1's go from registers into the other buffer during round r
+    load(q0);
+    for (int i = threadIdx.x; i < 2 * G::RAW; i += WR_NT) raw0[i] = 0.0f;
+    __syncthreads();
+    store(raw0);
+    if (nq > 1) load(q0 + 1);
+    __syncthreads();
+    for (int r = 0; r < nq; ++r) {
+        if (r + 1 < nq) {
+            store((r & 1) ? raw0 : raw1);
+            if (r + 2 < nq) load(q0 + r + 2);
+        }
+        multiply((r & 1) ? raw1 : raw0);
+        __syncthreads();
+    }
+    // ---- this workgroup's share: ms[tap][co][ci] in LDS, then rows of [co][ci][9] (and [co][ci] for the shortcut) written whole
+    float *ms = lds;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) ms[((t0 + a) * 32 + 16 * m + 4 * lq + rg) * 33 + 16 * n + l15] = acc[a][rg];
+    __syncthreads();
+    const size_t plane = static_cast<size_t>(d.RC) * d.KC;
+    float *o3 = out + static_cast<size_t>(s) * (pair ? 10 : 9) * plane, *o1 = o3 + 9 * plane;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int co = (threadIdx.x >> 5) + 16 * h, ci = threadIdx.x & 31;
+        const size_t e = static_cast<size_t>(co0 + co) * d.KC + ci0 + ci;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o3[e * 9 + t] = ms[(t * 32 + co) * 33 + ci];
+        if (pair) o1[e] = ms[(9 * 32 + co) * 33 + ci];
+    }
+}
+
+void wrw_s2_plan(int B, int KC, int RC, int H, WrwDims &d) {
+    d.B = B, d.KC = KC, d.RC = RC;
+    d.chunks = H == 16 ? 4 * B : H == 8 ? B : (B + 3) / 4;
+    const int ntile = (KC / 32) * (RC / 32);
+    const int target = ntile >= 256 ? 1 : 256 / ntile;
+    d.cpw = (d.chunks + target - 1) / target;
+    d.S = (d.chunks + d.cpw - 1) / d.cpw;
+    d.grouped = d.S >= 8;
+}
+
+template <int H>
+int wrw_s2_launch(const float *x, const float *dy3, const float *dy1, float *out, const WrwDims &d, hipStream_t st) {
+    using G = WrwS2Geo<H>;
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wrw_s2_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(G::lds_bytes)) == hipSuccess;
+    if (!ok) return EE_ERR_UNSUPPORTED;
+    const int ntile = (d.KC / 32) * (d.RC / 32);
+    const unsigned grid = static_cast<unsigned>(d.grouped ? 8 * ((d.S + 7) / 8) * ntile : d.S * ntile);
+    EE_LAUNCH(wrw_s2_kernel<H>, dim3(grid), dim3(WR_NT), G::lds_bytes, st, x, dy3, dy1, out, d);
+    return launch_status();
+}
+
 }  // namespace
 
 EE_API int64_t ee_wrw3x3_workspace_floats(int B, int Cin, int Cout, int H) {
@@ -355,6 +535,39 @@ EE_API int ee_wrw3x3_f32(const float *x, const float *dy, float *dw, float *work
     else rc = wrw_launch<2>(x, dy, out, d, st);
     if (rc != EE_OK || d.S == 1) return rc;
     const int n4 = 9 * Cin * Cout / 4;
+    EE_LAUNCH(wrw_sum_kernel, dim3((n4 + 63) / 64), dim3(256), 0, st, reinterpret_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(dw), d.S, n4);
+    return launch_status();
+}
+
+EE_API int64_t ee_wrw3x3s2_workspace_floats(int B, int Cin, int Cout, int H, int with_shortcut) {
+    if (B < 1 || Cin < 32 || Cout < 32 || Cin % 32 != 0 || Cout % 32 != 0 || (H != 4 && H != 8 && H != 16)) return 0;
+    WrwDims d;
+    wrw_s2_plan(B, Cin, Cout, H, d);
+    return d.S > 1 ? static_cast<int64_t>(d.S) * (with_shortcut ? 10 : 9) * Cin * Cout : 0;
+}
+
+// dw = [ d loss / d w3 [Cout][Cin][3][3] | d loss / d w1 [Cout][Cin] (only with dy1) ] of y3 = conv3x3(x, w3) (stride 2, padding 1) and
+// y1 = conv1x1(x, w1) (stride 2): x [B][Cin][H][H], dy3 / dy1 [B][Cout][H/2][H/2] (dy1 NULL: the 3x3 alone); workspace as above
+EE_API int ee_wrw3x3s2_f32(const float *x, const float *dy3, const float *dy1, float *dw, float *workspace, int B, int Cin, int Cout, int H, void *stream) {
+    if (B < 0 || Cin < 1 || Cout < 1) return EE_ERR_SHAPE;
+    if (Cin % 32 != 0 || Cout % 32 != 0 || (H != 4 && H != 8 && H != 16)) return EE_ERR_UNSUPPORTED;
+    if (!dw) return EE_ERR_NULL;
+    const int taps = dy1 ? 10 : 9;
+    if (B == 0) return static_cast<int>(hipMemsetAsync(dw, 0, sizeof(float) * taps * Cin * Cout, as_stream(stream)));
+    if (!x || !dy3) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(dy3) || (dy1 && !aligned16(dy1)) || !aligned16(dw)) return EE_ERR_ALIGN;
+    if (static_cast<int64_t>(B) * (Cin > Cout ? Cin : Cout) * H * H > 0x7fffffffLL) return EE_ERR_SHAPE;
+    WrwDims d;
+    wrw_s2_plan(B, Cin, Cout, H, d);
+    hipStream_t st = as_stream(stream);
+    if (d.S > 1 && (!workspace || !aligned16(workspace))) return workspace ? EE_ERR_ALIGN : EE_ERR_NULL;
+    float *out = d.S > 1 ? workspace : dw;
+    int rc;
+    if (H == 16) rc = wrw_s2_launch<16>(x, dy3, dy1, out, d, st);
+    else if (H == 8) rc = wrw_s2_launch<8>(x, dy3, dy1, out, d, st);
+    else rc = wrw_s2_launch<4>(x, dy3, dy1, out, d, st);
+    if (rc != EE_OK || d.S == 1) return rc;
+    const int n4 = taps * Cin * Cout / 4;
     EE_LAUNCH(wrw_sum_kernel, dim3((n4 + 63) / 64), dim3(256), 0, st, reinterpret_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(dw), d.S, n4);
     return launch_status();
 }

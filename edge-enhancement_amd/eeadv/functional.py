@@ -26,7 +26,7 @@ class input_grad_only:
         _INPUT_GRAD_ONLY = self._prev
 
 
-# EEADV_STOCK_WRW=1: the weight gradients of the stride-1 3x3 layers from ATen / MIOpen instead of ee_wrw.hip (an A/B switch for measurements)
+# EEADV_STOCK_WRW=1: the weight gradients of the 3x3 layers (and the stride-2 shortcuts) from ATen / MIOpen instead of ee_wrw.hip (an A/B switch for measurements)
 _STOCK_WRW = os.environ.get("EEADV_STOCK_WRW", "0") == "1"
 
 
@@ -536,7 +536,7 @@ class Conv3x3WinoFn(torch.autograd.Function):
 class Conv3x3S2SmallFn(torch.autograd.Function):
     """Conv2d(3x3, stride 2, padding 1, bias=False) from an 8x8 or a 4x4 map (ResNet-18 layer3.0 / layer4.0 conv1 at 64x64 inputs,
     resnet.py:26-31): forward and backward-data on ee_s2.hip (reduction split over the wavefronts, backward by parity classes); the
-    rearranged filters follow the weight's version counter like the Winograd ones; weight gradient on MIOpen."""
+    rearranged filters follow the weight's version counter like the Winograd ones; weight gradient: ee_wrw.hip."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -552,14 +552,17 @@ class Conv3x3S2SmallFn(torch.autograd.Function):
         dx = ops.conv3x3s2_small_bwd_data(dy, _dense_weight(weight, "s2m_b"), weight.shape[1]) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            if not _STOCK_WRW and ops.wrw3x3s2_supported(x, dy):
+                dw = ops.wrw3x3s2(x, dy)[0]
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw
 
 
 class Conv3x3S2PairFn(torch.autograd.Function):
     """(conv1(x), downsample[0](x)) of a down-sampling BasicBlock (resnet.py:50-59, :137-142) - Conv2d(3x3, stride 2, padding 1) and
     Conv2d(1x1, stride 2) of the same input - as ONE launch each way on ee_s2.hip: the 1x1 filter rides along as a tenth tap over the 3x3's
-    centre plane, and the backward pass returns the block's input gradient already summed.  Weight gradients on MIOpen."""
+    centre plane, and the backward pass returns the block's input gradient already summed.  Weight gradients: one launch of ee_wrw.hip."""
 
     @staticmethod
     def forward(ctx, x, w3, w1):
@@ -575,7 +578,10 @@ class Conv3x3S2PairFn(torch.autograd.Function):
         dy1 = torch.zeros_like(dy3) if dy1 is None else dy1.contiguous()
         dx = ops.conv3x3s2_pair_bwd_data(dy3, dy1, _dense_weight(w3, "s2p_b", w1), w3.shape[1]) if ctx.needs_input_grad[0] else None
         dw3 = dw1 = None
-        if not _INPUT_GRAD_ONLY:
+        if not _INPUT_GRAD_ONLY and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            if not _STOCK_WRW and ops.wrw3x3s2_supported(x, dy3, dy1):  # both weight gradients in one launch (ee_wrw.hip)
+                dw3, dw1 = ops.wrw3x3s2(x, dy3, dy1)
+                return dx, (dw3 if ctx.needs_input_grad[1] else None), (dw1 if ctx.needs_input_grad[2] else None)
             if ctx.needs_input_grad[1]:
                 dw3 = torch.ops.aten.convolution_backward(dy3, x, w3, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
             if ctx.needs_input_grad[2]:

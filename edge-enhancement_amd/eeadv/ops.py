@@ -815,6 +815,30 @@ def wrw3x3(x, dy):
     return dw
 
 
+def wrw3x3s2_supported(x, dy3, dy1=None):
+    """ee_wrw.hip: weight gradient of a 3x3 / stride 2 / padding 1 convolution from a 16x16, 8x8 or 4x4 map (and of the 1x1 / stride 2 shortcut)"""
+    ok = (x.dim() == 4 and dy3.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8, 16) and dy3.shape[2] == dy3.shape[3] == x.shape[2] // 2
+          and x.shape[0] == dy3.shape[0] and x.shape[1] % 32 == 0 and dy3.shape[1] % 32 == 0 and x.is_cuda and x.dtype == torch.float32
+          and dy3.dtype == torch.float32 and x.is_contiguous() and dy3.is_contiguous())
+    return ok and (dy1 is None or (dy1.shape == dy3.shape and dy1.dtype == torch.float32 and dy1.is_contiguous()))
+
+
+def wrw3x3s2(x, dy3, dy1=None):
+    """(dw3 [Cout,Cin,3,3], dw1 [Cout,Cin,1,1] or None): weight gradients of conv3x3(x) (stride 2, padding 1) and, with dy1, of the 1x1 / stride 2
+    shortcut of the same x, in one launch + the fixed-order sum (two views of one buffer)"""
+    B, Cin, H = x.shape[0], x.shape[1], x.shape[2]
+    Cout = dy3.shape[1]
+    taps = 9 if dy1 is None else 10
+    dw = torch.empty(taps * Cout * Cin, dtype=torch.float32, device=x.device)
+    n = int(N.lib.ee_wrw3x3s2_workspace_floats(B, Cin, Cout, H, 0 if dy1 is None else 1))
+    ws = torch.empty(max(n, 4), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_wrw3x3s2_f32(_chk(x, torch.float32, "x", (B, Cin, H, H)), _chk(dy3, torch.float32, "dy3", (B, Cout, H // 2, H // 2)),
+                                  None if dy1 is None else _chk(dy1, torch.float32, "dy1", (B, Cout, H // 2, H // 2)), dw.data_ptr(), ws.data_ptr(),
+                                  B, Cin, Cout, H, _stream()), "ee_wrw3x3s2_f32")
+    dw3 = dw[:9 * Cout * Cin].view(Cout, Cin, 3, 3)
+    return dw3, (None if dy1 is None else dw[9 * Cout * Cin:].view(Cout, Cin, 1, 1))
+
+
 def conv3x3s2_small_supported(x, cin, cout):
     """ee_s2.hip: 3x3 / stride 2 / padding 1 from a 16x16, 8x8 or 4x4 map"""
     return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8, 16) and cin % 32 == 0 and cout % 32 == 0

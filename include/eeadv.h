@@ -377,6 +377,13 @@ int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int 
 int64_t ee_wrw3x3_workspace_floats(int B, int Cin, int Cout, int H);
 int ee_wrw3x3_f32(const float *x, const float *dy, float *dw, float *workspace, int B, int Cin, int Cout, int H, void *stream);
 
+/* ... and of the down-sampling blocks' first convolution (3x3 / stride 2 / padding 1 from an H x H map, H = 16, 8 or 4; resnet.py:26-31, :132-137),
+ * optionally together with the block's shortcut Conv2d(1x1, stride 2) of the same input (resnet.py:137-142): plain per-tap products on the f32
+ * matrix cores, same split + fixed-order sum.  x [B,Cin,H,H], dy3 (and dy1, or NULL) [B,Cout,H/2,H/2] -> dw = [ dw3 [Cout,Cin,3,3] | dw1 [Cout,Cin]
+ * (only with dy1) ], overwritten.  Cin, Cout multiples of 32 (else EE_ERR_UNSUPPORTED). */
+int64_t ee_wrw3x3s2_workspace_floats(int B, int Cin, int Cout, int H, int with_shortcut);
+int ee_wrw3x3s2_f32(const float *x, const float *dy3, const float *dy1, float *dw, float *workspace, int B, int Cin, int Cout, int H, void *stream);
+
 /* Conv2d(3x3, stride 2, padding 1, bias=False) between SMALL maps - the first convolution of ResNet-18's layer2 / layer3 / layer4 at 64x64 inputs
  * (resnet.py:26-31, :132-137): H = 16 (16x16 -> 8x8), 8 (8x8 -> 4x4) or 4 (4x4 -> 2x2) - on the f32 matrix cores with the reduction split over a
  * workgroup's wavefronts.  The filters arrive rearranged, w9 [R/32][K/16][9][4][2][16][4] with R = result and K = reduction channels:

@@ -1190,3 +1190,45 @@ def test_conv3x3_weight_gradient_winograd_matches_float64(ops, B, Cin, Cout, H):
     exp = torch.zeros_like(one)
     exp[co, ci, 2, 0] = 1.0
     assert torch.equal(one, exp)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(100, 64, 128, 16), (100, 128, 256, 8), (100, 256, 512, 4), (1, 32, 32, 16), (3, 32, 64, 16), (7, 64, 32, 8),
+                                          (5, 32, 96, 4), (37, 96, 32, 4), (2, 32, 32, 8)])
+@pytest.mark.parametrize("pair", [True, False])
+def test_conv3x3s2_weight_gradient_matches_float64(ops, B, Cin, Cout, H, pair):
+    """Weight gradients of a down-sampling block's Conv2d(3x3, stride 2, padding 1) and of its shortcut Conv2d(1x1, stride 2) of the same input
+    (resnet.py:50-59, :132-142) in one launch of ee_wrw.hip: against float64, against ATen, bit-identical from call to call, and exact on a
+    one-pixel input."""
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=g).to(DEV)
+    dy3 = torch.randn(B, Cout, H // 2, H // 2, generator=g).to(DEV)
+    dy1 = torch.randn(B, Cout, H // 2, H // 2, generator=g).to(DEV) if pair else None
+    assert ops.wrw3x3s2_supported(x, dy3, dy1)
+    dw3, dw1 = ops.wrw3x3s2(x, dy3, dy1)
+    assert (dw1 is None) == (not pair)
+    w3, w1 = torch.zeros(Cout, Cin, 3, 3, device=DEV), torch.zeros(Cout, Cin, 1, 1, device=DEV)
+
+    def ref(dy, w, pad, dt):
+        return torch.ops.aten.convolution_backward(dy.to(dt), x.to(dt), w.to(dt), None, [2, 2], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    for got, dy, w, pad in ((dw3, dy3, w3, 1),) + (((dw1, dy1, w1, 0),) if pair else ()):
+        r64 = ref(dy, w, pad, torch.float64)
+        assert float((got.double() - r64).abs().max()) < 3e-6 * float(r64.abs().max())
+        torch.testing.assert_close(got, ref(dy, w, pad, torch.float32), rtol=1e-4, atol=1e-4 * (H * H * B) ** 0.5)
+    a3, a1 = ops.wrw3x3s2(x, dy3, dy1)
+    assert torch.equal(a3, dw3) and (not pair or torch.equal(a1, dw1))
+    x.zero_(), dy3.zero_()
+    b, ci, co = B - 1, Cin - 1, Cout // 2
+    x[b, ci, H - 1, 0] = 1.0
+    dy3[b, co, H // 2 - 1, 0] = 1.0  # output (H/2-1, 0) sees input (H-1, 0) = (2 oh + 1, 2 ow + 0) through tap (2, 1)
+    if pair:
+        dy1.zero_()
+        x[b, 0, 2, 2] = 1.0
+        dy1[b, 1, 1, 1] = 1.0  # the shortcut's pixel (1, 1) is input (2, 2)
+    o3, o1 = ops.wrw3x3s2(x, dy3, dy1)
+    e3 = torch.zeros_like(o3)
+    e3[co, ci, 2, 1] = 1.0
+    assert torch.equal(o3, e3)
+    if pair:
+        e1 = torch.zeros_like(o1)
+        e1[1, 0, 0, 0] = 1.0
+        assert torch.equal(o1, e1)
