@@ -504,6 +504,105 @@ int wrw_s2_launch(const float *x, const float *dy3, const float *dy1, float *out
     return launch_status();
 }
 
+// ---- the stem: Conv2d(3, 64, 7, stride 2, padding 3) (resnet.py:112) ------------------------------------------------------------------------
+// dW[co][j] with j = (ci, kh, kw) flattened (147, padded to 160) = sum over output pixels dy[co][pixel] * x[ci][2 oh + kh - 3][2 ow + kw - 3]: a
+// [64] x [160] x [B OH OW] product.  A workgroup owns ALL of dW for a range of 16-pixel chunks (16 consecutive output pixels of a row): per chunk
+// the 7 input rows x 40 columns around them (3 channels: 840 floats, zero outside the image) and the 64 x 16 dy values go global -> registers ->
+// LDS; wavefront w multiplies output-channel tile w & 3 against five of the ten 16-wide tap tiles (w >> 2), the B operand of lane (tap j, pixel k)
+// being frame[ci][kh][2 k + kw + 1].  Split over ~256 workgroups, the same fixed-order sum.
+constexpr int ST_FW = 40, ST_FI = 7 * ST_FW, ST_XF = 3 * ST_FI;   // one chunk's x frames
+constexpr int ST_RAW = ST_XF + 64 * S2W_YS;                       // + its dy rows
+constexpr int ST_J = 147, ST_JP = 160;
+constexpr int ST_MS = ST_JP * 65;                                 // the epilogue's accumulator exchange [j][co], rows 65 apart
+
+__global__ __launch_bounds__(WR_NT) void wrw_stem_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ out, int B, int H, int W,
+                                                        int chunks, int cpw) {
+    extern __shared__ __align__(16) float lds[];
+    float *raw0 = lds, *raw1 = lds + ST_RAW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int OH = H / 2, OW = W / 2, cpr = OW / 16;  // chunks per output row
+    const int s = blockIdx.x;
+    const int q0 = s * cpw, nq = chunks - q0 < cpw ? chunks - q0 : cpw;
+    // ---- a lane's share of a chunk: lanes 0 .. 209 one float4 of x (channel, frame row, float4 column), lanes 256 .. 511 one float4 of dy
+    const int xc = threadIdx.x / 70, xr = (threadIdx.x % 70) / 10, xq = threadIdx.x % 10;
+    const int yc = (threadIdx.x >> 2) & 63, yf = threadIdx.x & 3;
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 xv = zero4, yv = zero4;
+    auto load = [&](int q) {
+        const int row = q / cpr, half = q - row * cpr;  // row = (image, oh)
+        const int img = row / OH, oh = row - img * OH, ow0 = 16 * half;
+        if (threadIdx.x < 210) {
+            const int ih = 2 * oh - 3 + xr, iw = 2 * ow0 - 4 + 4 * xq;  // a float4 of the image or wholly outside it (W is a multiple of 4)
+            xv = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? *reinterpret_cast<const float4 *>(x + ((static_cast<size_t>(img) * 3 + xc) * H + ih) * W + iw) : zero4;
+        } else if (threadIdx.x >= 256) {
+            yv = *reinterpret_cast<const float4 *>(dy + ((static_cast<size_t>(img) * 64 + yc) * OH + oh) * OW + ow0 + 4 * yf);
+        }
+    };
+    auto store = [&](float *buf) {
+        if (threadIdx.x < 210) {
+            *reinterpret_cast<float4 *>(buf + xc * ST_FI + xr * ST_FW + 4 * xq) = xv;
+        } else if (threadIdx.x >= 256) {
+            float *y = buf + ST_XF + yc * S2W_YS + 4 * yf;
+            y[0] = yv.x, y[1] = yv.y, y[2] = yv.z, y[3] = yv.w;
+        }
+    };
+    const int m = wave & 3, n0 = 5 * (wave >> 2);
+    int toff[5];  // frame offset of this lane's tap j = 16 (n0 + a) + l15 at pixel 0; the padding taps (j >= 147) read tap 0 and are never stored
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+        const int j = 16 * (n0 + a) + l15, jj = j < ST_J ? j : 0;
+        const int ci = jj / 49, kh = (jj % 49) / 7, kw = jj % 7;
+        toff[a] = ci * ST_FI + kh * ST_FW + kw + 1 + 2 * lq;
+    }
+    f32x4 acc[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    auto multiply = [&](const float *buf) {
+        const float *ap = buf + ST_XF + (16 * m + l15) * S2W_YS + lq;
+        float av[4], bv[5][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            av[ks] = ap[4 * ks];
+#pragma unroll
+            for (int a = 0; a < 5; ++a) bv[a][ks] = buf[toff[a] + 8 * ks];  // pixel k = lq + 4 ks -> column 2 k
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int a = 0; a < 5; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[a][ks], acc[a], 0, 0, 0);
+    };
+    load(q0);
+    __syncthreads();
+    store(raw0);
+    if (nq > 1) load(q0 + 1);
+    __syncthreads();
+    for (int r = 0; r < nq; ++r) {
+        if (r + 1 < nq) {
+            store((r & 1) ? raw0 : raw1);
+            if (r + 2 < nq) load(q0 + r + 2);
+        }
+        multiply((r & 1) ? raw1 : raw0);
+        __syncthreads();
+    }
+    float *ms = lds;  // D[row = co = 4 lq + reg][col = tap l15]
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) ms[(16 * (n0 + a) + l15) * 65 + 16 * m + 4 * lq + rg] = acc[a][rg];
+    __syncthreads();
+    float *o = out + static_cast<size_t>(s) * 64 * ST_J;
+    for (int i = threadIdx.x; i < 64 * ST_J; i += WR_NT) {
+        const int co = i / ST_J, j = i - co * ST_J;
+        o[i] = ms[j * 65 + co];
+    }
+}
+
+void wrw_stem_plan(int B, int H, int W, int &chunks, int &cpw, int &S) {
+    chunks = B * (H / 2) * (W / 32);
+    cpw = (chunks + 255) / 256;
+    S = (chunks + cpw - 1) / cpw;
+}
+
 }  // namespace
 
 EE_API int64_t ee_wrw3x3_workspace_floats(int B, int Cin, int Cout, int H) {
@@ -569,5 +668,36 @@ EE_API int ee_wrw3x3s2_f32(const float *x, const float *dy3, const float *dy1, f
     if (rc != EE_OK || d.S == 1) return rc;
     const int n4 = taps * Cin * Cout / 4;
     EE_LAUNCH(wrw_sum_kernel, dim3((n4 + 63) / 64), dim3(256), 0, st, reinterpret_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(dw), d.S, n4);
+    return launch_status();
+}
+
+EE_API int64_t ee_wrw_stem7x7s2_workspace_floats(int B, int H, int W) {
+    if (B < 1 || H < 2 || W < 32 || H % 2 != 0 || W % 32 != 0) return 0;
+    int chunks, cpw, S;
+    wrw_stem_plan(B, H, W, chunks, cpw, S);
+    return S > 1 ? static_cast<int64_t>(S) * 64 * ST_J : 0;
+}
+
+// dw [64][3][7][7] = d loss / d weight of the stem Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (resnet.py:112): x [B][3][H][W],
+// dy [B][64][H/2][W/2]; H even, W a multiple of 32 (else EE_ERR_UNSUPPORTED); workspace: ee_wrw_stem7x7s2_workspace_floats(B, H, W) floats
+EE_API int ee_wrw_stem7x7s2_f32(const float *x, const float *dy, float *dw, float *workspace, int B, int H, int W, void *stream) {
+    if (B < 0 || H < 2 || W < 2) return EE_ERR_SHAPE;
+    if (H % 2 != 0 || W % 32 != 0) return EE_ERR_UNSUPPORTED;
+    if (!dw) return EE_ERR_NULL;
+    if (B == 0) return static_cast<int>(hipMemsetAsync(dw, 0, sizeof(float) * 64 * ST_J, as_stream(stream)));
+    if (!x || !dy) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw)) return EE_ERR_ALIGN;
+    if (static_cast<int64_t>(B) * 64 * (H / 2) * (W / 2) > 0x7fffffffLL) return EE_ERR_SHAPE;
+    int chunks, cpw, S;
+    wrw_stem_plan(B, H, W, chunks, cpw, S);
+    if (S > 1 && (!workspace || !aligned16(workspace))) return workspace ? EE_ERR_ALIGN : EE_ERR_NULL;
+    hipStream_t st = as_stream(stream);
+    constexpr size_t lds_bytes = (2 * ST_RAW > ST_MS ? 2 * ST_RAW : ST_MS) * sizeof(float);
+    static_assert(lds_bytes <= 64 * 1024, "the stem kernel's LDS fits the default limit");
+    EE_LAUNCH(wrw_stem_kernel, dim3(static_cast<unsigned>(S)), dim3(WR_NT), lds_bytes, st, x, dy, S > 1 ? workspace : dw, B, H, W, chunks, cpw);
+    int rc = launch_status();
+    if (rc != EE_OK || S == 1) return rc;
+    const int n4 = 64 * ST_J / 4;
+    EE_LAUNCH(wrw_sum_kernel, dim3((n4 + 63) / 64), dim3(256), 0, st, reinterpret_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(dw), S, n4);
     return launch_status();
 }

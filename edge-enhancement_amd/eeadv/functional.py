@@ -291,7 +291,7 @@ class Conv1x1S2Fn(torch.autograd.Function):
 
 class StemConvFn(torch.autograd.Function):
     """The stem Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (resnet.py:112-113): the forward (maps whose width is a multiple
-    of 64) and the gradient with respect to the image - what the attack loop is after - on ee_conv.hip; the weight gradient on MIOpen."""
+    of 64) and the gradient with respect to the image - what the attack loop is after - on ee_conv.hip; the weight gradient: ee_wrw.hip."""
 
     @staticmethod
     def forward(ctx, x, weight, want_stats=False):
@@ -322,7 +322,10 @@ class StemConvFn(torch.autograd.Function):
         dx = ops.stem7x7s2_bwd_data(dy, weight, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            if not _STOCK_WRW and ops.wrw_stem7x7s2_supported(x, dy):
+                dw = ops.wrw_stem7x7s2(x, dy)
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw, None
 
 

@@ -839,6 +839,24 @@ def wrw3x3s2(x, dy3, dy1=None):
     return dw3, (None if dy1 is None else dw[9 * Cout * Cin:].view(Cout, Cin, 1, 1))
 
 
+def wrw_stem7x7s2_supported(x, dy):
+    """ee_wrw.hip: weight gradient of the stem Conv2d(3, 64, 7, stride 2, padding 3)"""
+    return (x.dim() == 4 and dy.dim() == 4 and x.shape[1] == 3 and dy.shape[1] == 64 and x.shape[2] % 2 == 0 and x.shape[3] % 32 == 0
+            and tuple(dy.shape[2:]) == (x.shape[2] // 2, x.shape[3] // 2) and x.shape[0] == dy.shape[0] and x.is_cuda and x.dtype == torch.float32
+            and dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous())
+
+
+def wrw_stem7x7s2(x, dy):
+    """d loss / d weight [64,3,7,7] of the stem convolution from its input x [B,3,H,W] and output gradient dy [B,64,H/2,W/2] (bit-reproducible)"""
+    B, H, W = x.shape[0], x.shape[2], x.shape[3]
+    dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x.device)
+    n = int(N.lib.ee_wrw_stem7x7s2_workspace_floats(B, H, W))
+    ws = torch.empty(max(n, 4), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_wrw_stem7x7s2_f32(_chk(x, torch.float32, "x", (B, 3, H, W)), _chk(dy, torch.float32, "dy", (B, 64, H // 2, W // 2)), dw.data_ptr(),
+                                       ws.data_ptr(), B, H, W, _stream()), "ee_wrw_stem7x7s2_f32")
+    return dw
+
+
 def conv3x3s2_small_supported(x, cin, cout):
     """ee_s2.hip: 3x3 / stride 2 / padding 1 from a 16x16, 8x8 or 4x4 map"""
     return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8, 16) and cin % 32 == 0 and cout % 32 == 0

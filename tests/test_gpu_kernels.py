@@ -1232,3 +1232,26 @@ def test_conv3x3s2_weight_gradient_matches_float64(ops, B, Cin, Cout, H, pair):
         e1 = torch.zeros_like(o1)
         e1[1, 0, 0, 0] = 1.0
         assert torch.equal(o1, e1)
+
+
+@pytest.mark.parametrize("B,H,W", [(100, 64, 64), (3, 64, 64), (1, 32, 32), (5, 34, 96), (2, 224, 224)])
+def test_stem_weight_gradient_matches_float64(ops, B, H, W):
+    """d loss / d weight of the stem Conv2d(3, 64, 7, stride 2, padding 3) (resnet.py:112) on ee_wrw.hip: against float64 and ATen, bit-identical
+    from call to call, exact on a one-pixel input at the image border (the zero padding)."""
+    g = torch.Generator(device="cpu").manual_seed(B + H + W)
+    x = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    dy = torch.randn(B, 64, H // 2, W // 2, generator=g).to(DEV)
+    assert ops.wrw_stem7x7s2_supported(x, dy)
+    got = ops.wrw_stem7x7s2(x, dy)
+    w = torch.zeros(64, 3, 7, 7, device=DEV)
+    ref = lambda dt: torch.ops.aten.convolution_backward(dy.to(dt), x.to(dt), w.to(dt), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    r64 = ref(torch.float64)
+    assert float((got.double() - r64).abs().max()) < 3e-6 * float(r64.abs().max())
+    torch.testing.assert_close(got, ref(torch.float32), rtol=1e-4, atol=1e-4 * (H * W * B) ** 0.5)
+    assert torch.equal(got, ops.wrw_stem7x7s2(x, dy))
+    x.zero_(), dy.zero_()
+    x[B - 1, 2, H - 1, 0] = 1.0
+    dy[B - 1, 5, H // 2 - 1, 1] = 1.0  # output (H/2-1, 1) sees input (H-1, 0) = (2 oh - 3 + kh, 2 ow - 3 + kw) through tap (4, 1)
+    exp = torch.zeros_like(got)
+    exp[5, 2, 4, 1] = 1.0
+    assert torch.equal(ops.wrw_stem7x7s2(x, dy), exp)
