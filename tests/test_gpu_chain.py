@@ -296,3 +296,37 @@ def test_imagenet_ee_square_front_end_runs_on_the_band_kernel():
     assert np.array_equal(np.isnan(g), np.isnan(gr))
     fin = ~np.isnan(gr)
     assert np.abs(g[fin] - gr[fin]).max() < 2e-5 * np.abs(gr[fin]).max() + 1e-6
+
+
+def test_whole_training_step_is_reproducible_bit_for_bit(monkeypatch):
+    """Five adversarial-training steps of resnet18_EE_square (random start, PGD-4 in train mode, the update: two eager steps, the captures,
+    graph replays) twice from the same seeds: since round 3 every weight gradient of this network comes from ee_wrw.hip, whose partial sums
+    are added in a fixed order - MIOpen's weight-gradient solvers used atomics, so two runs of the same step differed in the last bits and a
+    deep ReLU network amplified that from step to step.  Now the parameters, the BatchNorm buffers and the losses come out IDENTICAL."""
+    from eeadv import engine, models, runtime, trainer
+    from tiny_models import Args
+    monkeypatch.setenv("EEADV_GRAPH", "1")
+    g = torch.Generator().manual_seed(17)
+    batches = [(torch.rand(16, 3, 64, 64, generator=g).to(DEV), torch.randint(0, 200, (16,), generator=g).to(DEV)) for _ in range(5)]
+    args = Args(method_name="EE_BPDA3_AT_square", random=True, epsilon=16 / 255, num_steps_1=4, step_size_1=2 / 255, num_classes=200, beta=6.0)
+    runs = []
+    for _ in range(2):
+        engine.clear_graphs()
+        trainer.clear_update_graphs()
+        torch.manual_seed(23)
+        runtime.reseed()
+        model = models.make_resnet_ee(18, "tiny", True, cize=64, r=8, w=1.0, with_gf=False, low=38.0, high=76.0, alpha=0.0, sigma=1.0,
+                                      type_canny="CannyFilter_step125_1", epsilon=16 / 255, n_queries=1).to(DEV).train()
+        opt = trainer.make_sgd(model.parameters(), lr=0.05, momentum=0.9, weight_decay=2e-4)
+        crit = trainer.make_criterion(args)
+        losses = []
+        for x, y in batches:
+            loss, _ = trainer.train_batch(model, crit, opt, args, x, y, torch.device(DEV))
+            losses.append(float(loss))
+        state = torch.cat([t.detach().flatten().float() for t in list(model.parameters()) + [b for n, b in model.named_buffers() if "running" in n]])
+        runs.append((losses, state.clone()))
+    engine.clear_graphs()
+    trainer.clear_update_graphs()
+    assert len(set(runs[0][0])) > 1 and all(np.isfinite(runs[0][0]))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])
