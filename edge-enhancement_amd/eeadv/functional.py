@@ -30,6 +30,11 @@ class input_grad_only:
 _STOCK_WRW = os.environ.get("EEADV_STOCK_WRW", "0") == "1"
 
 
+# ee_wrw.hip's stem kernel wins on the 64x64 inputs of the Tiny-ImageNet configs (46 us against MIOpen's 63); on 224x224 (ResNet-50 free-AT, batch
+# 32) MIOpen's searched solver is the faster one (559 against 557 img/s end to end), so wider images keep it
+_STEM_WRW_MAXW = 64
+
+
 def conv3x3_weight_grad(x, dy, weight):
     """d loss / d weight of conv3x3(x, weight) (stride 1, padding 1): ee_wrw.hip on the maps it takes (2 / 4 / 8 / 16 wide, channels % 32 == 0;
     bit-reproducible), ATen's convolution_backward otherwise."""
@@ -322,7 +327,7 @@ class StemConvFn(torch.autograd.Function):
         dx = ops.stem7x7s2_bwd_data(dy, weight, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
-            if not _STOCK_WRW and ops.wrw_stem7x7s2_supported(x, dy):
+            if not _STOCK_WRW and ops.wrw_stem7x7s2_supported(x, dy) and x.shape[3] <= _STEM_WRW_MAXW:
                 dw = ops.wrw_stem7x7s2(x, dy)
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
