@@ -90,7 +90,7 @@ def non_default_switches():
 # torch.backends.cudnn.benchmark = True makes MIOpen time every applicable solver once per convolution shape and direction: 4.5 minutes of
 # kernel compilation for ResNet-50's ~50 shapes on a fresh machine, for 7 % throughput on BASELINE config 5 (bench.py: 553 against 518 img/s).
 # The outcome of that search is a 70 KB text file (MIOpen's "user find-db").  `miopen_db/` holds the one recorded on an MI355X with this
-# image's MIOpen for the convolution shapes of the BASELINE configs (scripts/r3_finddb.sh); with it in place the search is a lookup.
+# image's MIOpen for the convolution shapes of the BASELINE configs (scripts/record_miopen_db.sh); with it in place the search is a lookup.
 _MIOPEN_DB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miopen_db")
 
 
