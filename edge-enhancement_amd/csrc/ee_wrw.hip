@@ -603,6 +603,100 @@ void wrw_stem_plan(int B, int H, int W, int &chunks, int &cpw, int &S) {
     S = (chunks + cpw - 1) / cpw;
 }
 
+// ---- 1x1 / stride 1 (ResNet-50's bottleneck convolutions at ImageNet size, resnet.py:75-100; BASELINE config 5) --------------------------------------
+// dW[co][ci] = sum over images and pixels dy[b][co][p] * x[b][ci][p]: a product whose two operands are both contiguous along the reduction (NCHW rows).
+// MIOpen's searched solvers for it are NHWC implicit-GEMM kernels behind layout transposes and zero fills - 31 % of a free-AT repeat on ResNet-50
+// (profiles/round3_m_free_at_trace_breakdown.txt).  Here a workgroup of four wavefronts owns a 64 x 64 block of (co, ci) and a range of 32-pixel
+// chunks (32 consecutive pixels of one image); a chunk's 64 + 64 rows arrive as float4 (8 lanes per row: coalesced), go to LDS transposed -
+// [pixel][channel], pixels 65 floats apart, so that both these stores and the MFMA operand reads (32 lanes along the channel) fall on 32 distinct
+// banks - and wavefront w multiplies quarter w of the block with sixteen v_mfma_f32_32x32x2_f32.  33 KB of LDS and 256 lanes per workgroup:
+// four workgroups per CU hide each other's latencies.  Same split over workgroups, same fixed-order sum.
+constexpr int P1_NT = 256, P1_KC = 32, P1_CS = 65;
+constexpr int P1_OP = P1_KC * P1_CS;   // one operand of one buffer
+constexpr size_t P1_LDS = 4 * P1_OP * sizeof(float);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct P1Dims {
+    int B, KC, RC, HW;   // images, input channels (x), output channels (dy), pixels per image (a multiple of 4)
+    int cpi, chunks, cpw, S, grouped;
+};
+
+__global__ __launch_bounds__(P1_NT) void wrw1x1_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ out, P1Dims d) {
+    extern __shared__ __align__(16) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncb = d.RC / 64, nkb = d.KC / 64, ntile = ncb * nkb;
+    int s, tile;
+    if (d.grouped) {
+        const int g = blockIdx.x & 7, k = blockIdx.x >> 3;
+        s = g + 8 * (k / ntile), tile = k % ntile;
+        if (s >= d.S) return;
+    } else {
+        s = blockIdx.x / ntile, tile = blockIdx.x - s * ntile;
+    }
+    const int co0 = (tile / nkb) * 64, ci0 = (tile % nkb) * 64;
+    const int q0 = s * d.cpw, nq = d.chunks - q0 < d.cpw ? d.chunks - q0 : d.cpw;
+    // a lane's four float4 of a chunk: number i = threadIdx.x + 256 j -> operand i >> 9 (0: dy, 1: x), channel row (i >> 3) & 63, float4 i & 7 of the 32 pixels
+    const int row = (threadIdx.x >> 3) & 31, k4 = threadIdx.x & 7;
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 v0 = zero4, v1 = zero4, v2 = zero4, v3 = zero4;  // dy rows `row`, `row + 32`; x rows `row`, `row + 32`
+    auto load = [&](int q) {
+        const int b = q / d.cpi, p = (q - b * d.cpi) * P1_KC + 4 * k4;
+        if (p < d.HW) {
+            const float *yp = dy + (static_cast<size_t>(b) * d.RC + co0 + row) * d.HW + p;
+            const float *xp = x + (static_cast<size_t>(b) * d.KC + ci0 + row) * d.HW + p;
+            v0 = *reinterpret_cast<const float4 *>(yp);
+            v1 = *reinterpret_cast<const float4 *>(yp + static_cast<size_t>(32) * d.HW);
+            v2 = *reinterpret_cast<const float4 *>(xp);
+            v3 = *reinterpret_cast<const float4 *>(xp + static_cast<size_t>(32) * d.HW);
+        } else {
+            v0 = v1 = v2 = v3 = zero4;
+        }
+    };
+    auto store = [&](float *buf) {
+        float *a = buf + 4 * k4 * P1_CS + row, *b = a + P1_OP;
+        a[0] = v0.x, a[P1_CS] = v0.y, a[2 * P1_CS] = v0.z, a[3 * P1_CS] = v0.w;
+        a[32] = v1.x, a[P1_CS + 32] = v1.y, a[2 * P1_CS + 32] = v1.z, a[3 * P1_CS + 32] = v1.w;
+        b[0] = v2.x, b[P1_CS] = v2.y, b[2 * P1_CS] = v2.z, b[3 * P1_CS] = v2.w;
+        b[32] = v3.x, b[P1_CS + 32] = v3.y, b[2 * P1_CS + 32] = v3.z, b[3 * P1_CS + 32] = v3.w;
+    };
+    const int m = wave >> 1, n = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    auto multiply = [&](const float *buf) {
+        const float *ap = buf + lh * P1_CS + 32 * m + l31, *bp = buf + P1_OP + lh * P1_CS + 32 * n + l31;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks * P1_CS], bp[2 * ks * P1_CS], acc, 0, 0, 0);
+    };
+    float *buf0 = lds, *buf1 = lds + 2 * P1_OP;
+    load(q0);
+    store(buf0);
+    __syncthreads();
+    for (int r = 0; r < nq; ++r) {
+        if (r + 1 < nq) load(q0 + r + 1);
+        multiply((r & 1) ? buf1 : buf0);
+        if (r + 1 < nq) store((r & 1) ? buf0 : buf1);
+        __syncthreads();
+    }
+    // D[row = 8 (reg / 4) + 4 (lane / 32) + reg % 4][col = lane % 32] of the wavefront's 32 x 32 quarter
+    float *o = out + static_cast<size_t>(s) * d.RC * d.KC + static_cast<size_t>(co0 + 32 * m) * d.KC + ci0 + 32 * n + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[static_cast<size_t>(8 * (r >> 2) + 4 * lh + (r & 3)) * d.KC] = acc[r];
+}
+
+void wrw1x1_plan(int B, int KC, int RC, int HW, P1Dims &d) {
+    d.B = B, d.KC = KC, d.RC = RC, d.HW = HW;
+    d.cpi = (HW + P1_KC - 1) / P1_KC;
+    d.chunks = B * d.cpi;
+    const int ntile = (KC / 64) * (RC / 64);
+    const int target = ntile >= 1024 ? 1 : 1024 / ntile;  // about four workgroups per CU
+    d.cpw = (d.chunks + target - 1) / target;
+    if (d.cpw < 8) d.cpw = d.chunks < 8 ? d.chunks : 8;   // ... but never so few chunks that the prologue and the partial sums dominate
+    d.S = (d.chunks + d.cpw - 1) / d.cpw;
+    d.grouped = d.S >= 8;
+}
+
 }  // namespace
 
 EE_API int64_t ee_wrw3x3_workspace_floats(int B, int Cin, int Cout, int H) {
@@ -699,5 +793,36 @@ EE_API int ee_wrw_stem7x7s2_f32(const float *x, const float *dy, float *dw, floa
     if (rc != EE_OK || S == 1) return rc;
     const int n4 = 64 * ST_J / 4;
     EE_LAUNCH(wrw_sum_kernel, dim3((n4 + 63) / 64), dim3(256), 0, st, reinterpret_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(dw), S, n4);
+    return launch_status();
+}
+
+EE_API int64_t ee_wrw1x1_workspace_floats(int B, int Cin, int Cout, int HW) {
+    if (B < 1 || Cin < 64 || Cout < 64 || Cin % 64 != 0 || Cout % 64 != 0 || HW < 4 || HW % 4 != 0) return 0;
+    P1Dims d;
+    wrw1x1_plan(B, Cin, Cout, HW, d);
+    return d.S > 1 ? static_cast<int64_t>(d.S) * Cin * Cout : 0;
+}
+
+// dw [Cout][Cin] = d loss / d weight of y = conv1x1(x, weight) (stride 1, no padding): x [B][Cin][HW], dy [B][Cout][HW] (HW = H * W pixels, a
+// multiple of 4); Cin, Cout multiples of 64 (else EE_ERR_UNSUPPORTED); workspace: ee_wrw1x1_workspace_floats(...) floats
+EE_API int ee_wrw1x1_f32(const float *x, const float *dy, float *dw, float *workspace, int B, int Cin, int Cout, int HW, void *stream) {
+    if (B < 0 || Cin < 1 || Cout < 1 || HW < 1) return EE_ERR_SHAPE;
+    if (Cin % 64 != 0 || Cout % 64 != 0 || HW % 4 != 0) return EE_ERR_UNSUPPORTED;
+    if (!dw) return EE_ERR_NULL;
+    if (B == 0) return static_cast<int>(hipMemsetAsync(dw, 0, sizeof(float) * Cin * Cout, as_stream(stream)));
+    if (!x || !dy) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw)) return EE_ERR_ALIGN;
+    if (static_cast<int64_t>(B) * (Cin > Cout ? Cin : Cout) * HW > 0x7fffffffLL) return EE_ERR_SHAPE;
+    P1Dims d;
+    wrw1x1_plan(B, Cin, Cout, HW, d);
+    if (d.S > 1 && (!workspace || !aligned16(workspace))) return workspace ? EE_ERR_ALIGN : EE_ERR_NULL;
+    hipStream_t st = as_stream(stream);
+    const int ntile = (Cin / 64) * (Cout / 64);
+    const unsigned grid = static_cast<unsigned>(d.grouped ? 8 * ((d.S + 7) / 8) * ntile : d.S * ntile);
+    EE_LAUNCH(wrw1x1_kernel, dim3(grid), dim3(P1_NT), P1_LDS, st, x, dy, d.S > 1 ? workspace : dw, d);
+    int rc = launch_status();
+    if (rc != EE_OK || d.S == 1) return rc;
+    const int n4 = Cin * Cout / 4;
+    EE_LAUNCH(wrw_sum_kernel, dim3((n4 + 63) / 64), dim3(256), 0, st, reinterpret_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(dw), d.S, n4);
     return launch_status();
 }

@@ -519,6 +519,29 @@ def refresh_dense_weights():
             _dense_weight(w, ent[3], e)
 
 
+class Conv1x1Fn(torch.autograd.Function):
+    """Conv2d(1x1, stride 1, bias=False) of the bottleneck blocks (resnet.py:75-100): forward and backward-data stay ATen's (MIOpen / rocBLAS run
+    them as plain GEMMs), the WEIGHT gradient is ee_wrw.hip's NCHW product (MIOpen's searched solvers for it are NHWC kernels behind layout
+    transposes and zero fills: 31 % of a free-AT repeat on ResNet-50)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.ops.aten.convolution(x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        want_w = ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY
+        own = want_w and not _STOCK_WRW and ops.wrw1x1_supported(x, dy)
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], want_w and not own, False])
+        if own:
+            dw = ops.wrw1x1(x, dy)
+        return dx, dw
+
+
 class Conv3x3WinoFn(torch.autograd.Function):
     """Conv2d(3x3, stride 1, padding 1, bias=False) on 8x8 maps (ResNet-18 layer2 at 64x64 inputs, resnet.py:26-31): forward and
     backward-data as Winograd F(2x2, 3x3) around the f32 matrix cores (ee_wino.hip); the transformed filters follow the weight's version

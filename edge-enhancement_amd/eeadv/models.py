@@ -22,7 +22,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime, syncbn as _syncbn
-from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1S2Fn, Conv3x3Map2Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1Fn, Conv1x1S2Fn, Conv3x3Map2Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -191,6 +191,16 @@ def conv3(conv, x):
             return Conv3x3WinoFn.apply(x, conv.weight)
     elif conv.stride == (2, 2) and hw in (4, 8, 16) and by32 and "conv3" not in _STOCK and "s2small" not in _STOCK:
         return Conv3x3S2SmallFn.apply(x, conv.weight)
+    return conv(x)
+
+
+def conv1(conv, x):
+    """A bottleneck block's 1x1 / stride 1 convolution (resnet.py:75-100): ATen's forward and backward-data, ee_wrw.hip's weight gradient where it
+    takes the shape (channels % 64 == 0, H * W % 4 == 0 - every 1x1 of ResNet-50 at 224x224 but the 7x7 maps of layer 4)."""
+    if ("conv" not in _STOCK and "wrw1x1" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 64 == 0
+            and conv.out_channels % 64 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and conv.weight.is_contiguous()):
+        return Conv1x1Fn.apply(x, conv.weight)
     return conv(x)
 
 
@@ -456,9 +466,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x, fork=False):
         xm, xs = _pair(x)
-        out = bn_act(self.bn1, self.conv1(xm))
+        out = bn_act(self.bn1, conv1(self.conv1, xm))
         out = bn_act(self.bn2, conv3(self.conv2, out))
-        return block_tail(self, self.bn3, self.conv3(out), xs, fork)
+        return block_tail(self, self.bn3, conv1(self.conv3, out), xs, fork)
 
 
 class ResNet(nn.Module):

@@ -857,6 +857,25 @@ def wrw_stem7x7s2(x, dy):
     return dw
 
 
+def wrw1x1_supported(x, dy):
+    """ee_wrw.hip: weight gradient of a 1x1 / stride 1 convolution, NCHW operands"""
+    return (x.dim() == 4 and dy.dim() == 4 and x.shape[0] == dy.shape[0] and x.shape[2:] == dy.shape[2:] and x.shape[1] % 64 == 0 and dy.shape[1] % 64 == 0
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and x.is_cuda and x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous()
+            and dy.is_contiguous())
+
+
+def wrw1x1(x, dy):
+    """d loss / d weight [Cout,Cin,1,1] of conv1x1(x, weight) (stride 1) from its input x [B,Cin,H,W] and output gradient dy [B,Cout,H,W] (bit-reproducible)"""
+    B, Cin, HW = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+    Cout = dy.shape[1]
+    dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
+    n = int(N.lib.ee_wrw1x1_workspace_floats(B, Cin, Cout, HW))
+    ws = torch.empty(max(n, 4), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_wrw1x1_f32(_chk(x, torch.float32, "x"), _chk(dy, torch.float32, "dy"), dw.data_ptr(), ws.data_ptr(), B, Cin, Cout, HW, _stream()),
+            "ee_wrw1x1_f32")
+    return dw
+
+
 def conv3x3s2_small_supported(x, cin, cout):
     """ee_s2.hip: 3x3 / stride 2 / padding 1 from a 16x16, 8x8 or 4x4 map"""
     return x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (4, 8, 16) and cin % 32 == 0 and cout % 32 == 0

@@ -389,6 +389,12 @@ int ee_wrw3x3s2_f32(const float *x, const float *dy3, const float *dy1, float *d
 int64_t ee_wrw_stem7x7s2_workspace_floats(int B, int H, int W);
 int ee_wrw_stem7x7s2_f32(const float *x, const float *dy, float *dw, float *workspace, int B, int H, int W, void *stream);
 
+/* ... and of the 1x1 / stride 1 convolutions of the bottleneck blocks (resnet.py:75-100; ResNet-50 at ImageNet size, BASELINE config 5): both operands
+ * are read in their NCHW layout (rows contiguous along the reduction) - x [B,Cin,HW], dy [B,Cout,HW] with HW = H * W pixels, a multiple of 4 ->
+ * dw [Cout,Cin], overwritten; Cin, Cout multiples of 64 (else EE_ERR_UNSUPPORTED); same split + fixed-order sum. */
+int64_t ee_wrw1x1_workspace_floats(int B, int Cin, int Cout, int HW);
+int ee_wrw1x1_f32(const float *x, const float *dy, float *dw, float *workspace, int B, int Cin, int Cout, int HW, void *stream);
+
 /* Conv2d(3x3, stride 2, padding 1, bias=False) between SMALL maps - the first convolution of ResNet-18's layer2 / layer3 / layer4 at 64x64 inputs
  * (resnet.py:26-31, :132-137): H = 16 (16x16 -> 8x8), 8 (8x8 -> 4x4) or 4 (4x4 -> 2x2) - on the f32 matrix cores with the reduction split over a
  * workgroup's wavefronts.  The filters arrive rearranged, w9 [R/32][K/16][9][4][2][16][4] with R = result and K = reduction channels:

@@ -1255,3 +1255,27 @@ def test_stem_weight_gradient_matches_float64(ops, B, H, W):
     exp = torch.zeros_like(got)
     exp[5, 2, 4, 1] = 1.0
     assert torch.equal(ops.wrw_stem7x7s2(x, dy), exp)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(32, 64, 256, 56, 56), (32, 256, 64, 56, 56), (32, 512, 128, 28, 28), (32, 256, 1024, 14, 14), (3, 64, 64, 6, 6),
+                                            (1, 128, 64, 2, 2), (5, 64, 192, 10, 14), (2, 64, 64, 30, 34)])
+def test_conv1x1_weight_gradient_matches_float64(ops, B, Cin, Cout, H, W):
+    """d loss / d weight of the bottleneck blocks' Conv2d(1x1, stride 1) (resnet.py:75-100) as an NCHW product on the f32 matrix cores (ee_wrw.hip):
+    against float64 (reduction lengths up to 100 352), against ATen, bit-identical from call to call, exact on a one-pixel input."""
+    g = torch.Generator(device="cpu").manual_seed(B + Cin + Cout + H * W)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    dy = torch.randn(B, Cout, H, W, generator=g).to(DEV)
+    assert ops.wrw1x1_supported(x, dy)
+    got = ops.wrw1x1(x, dy)
+    r64 = torch.einsum("bohw,bihw->oi", dy.double(), x.double())
+    assert float((got[:, :, 0, 0].double() - r64).abs().max()) < 3e-6 * float(r64.abs().max())
+    w = torch.zeros(Cout, Cin, 1, 1, device=DEV)
+    ref = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4 * (H * W * B) ** 0.5)
+    assert torch.equal(got, ops.wrw1x1(x, dy))
+    x.zero_(), dy.zero_()
+    x[B - 1, Cin - 1, H - 1, W - 1] = 1.0
+    dy[B - 1, 3, H - 1, W - 1] = 1.0
+    exp = torch.zeros_like(got)
+    exp[3, Cin - 1, 0, 0] = 1.0
+    assert torch.equal(ops.wrw1x1(x, dy), exp)
