@@ -612,6 +612,7 @@ void wrw_stem_plan(int B, int H, int W, int &chunks, int &cpw, int &S) {
 // banks - and wavefront w multiplies quarter w of the block with sixteen v_mfma_f32_32x32x2_f32.  33 KB of LDS and 256 lanes per workgroup:
 // four workgroups per CU hide each other's latencies.  Same split over workgroups, same fixed-order sum.
 constexpr int P1_NT = 256, P1_KC = 32, P1_CS = 65;
+constexpr int P1_WGS = 1024;  // workgroups aimed at (512: the same times; 2048: 13 % slower - scripts/wrw1x1_probe.py)
 constexpr int P1_OP = P1_KC * P1_CS;   // one operand of one buffer
 constexpr size_t P1_LDS = 4 * P1_OP * sizeof(float);
 
@@ -690,7 +691,7 @@ void wrw1x1_plan(int B, int KC, int RC, int HW, P1Dims &d) {
     d.cpi = (HW + P1_KC - 1) / P1_KC;
     d.chunks = B * d.cpi;
     const int ntile = (KC / 64) * (RC / 64);
-    const int target = ntile >= 1024 ? 1 : 1024 / ntile;  // about four workgroups per CU
+    const int target = ntile >= P1_WGS ? 1 : P1_WGS / ntile;  // about P1_WGS / 256 workgroups per CU
     d.cpw = (d.chunks + target - 1) / target;
     if (d.cpw < 8) d.cpw = d.chunks < 8 ? d.chunks : 8;   // ... but never so few chunks that the prologue and the partial sums dominate
     d.S = (d.chunks + d.cpw - 1) / d.cpw;
