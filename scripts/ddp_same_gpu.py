@@ -85,10 +85,10 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     one = run_config(rank, world, dev, "EE_BPDA3_AT_square", segmented=False)
     seg = run_config(rank, world, dev, "EE_BPDA3_AT_square", segmented=True)
-    # the backward cut at the layer boundaries is the same arithmetic: the two forms agree to the run-to-run noise of MIOpen's weight-gradient kernels
+    # the backward cut at the layer boundaries is the same arithmetic, and since every weight gradient has a fixed summation order (ee_wrw.hip) the two forms agree EXACTLY
     rel = float((one - seg).abs().max() / one.abs().max())
     print("rank %d: segmented vs one-piece update, max relative parameter difference after 6 steps: %.3e" % (rank, rel), flush=True)
-    # (a free-running comparison: six SGD steps at lr 0.05 on batch 16 amplify rounding-level differences; tests/test_gpu_ddp.py compares step by step)
+    # (with MIOpen's weight gradients - EEADV_STOCK_WRW=1 - six free-running steps at lr 0.05 amplify its atomics' rounding noise to 1e-1; tests/test_gpu_ddp.py compares step by step)
     run_config(rank, world, dev, "TRADES", segmented=True, steps=5)
     if os.environ.get("DDP_TIMING", "0") == "1":  # what cutting the backward into three graphs + three collectives costs per step (batch 100, replays only)
         for segmented in (False, True, False, True):
