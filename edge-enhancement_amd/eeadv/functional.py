@@ -645,9 +645,9 @@ class Conv3x3Map2Fn(torch.autograd.Function):
 
 class Net2ConvFn(torch.autograd.Function):
     """relu(max_pool2d(conv2_drop(conv2(relu(max_pool2d(conv1(x), 2)))), 2)) of Net_2 (MNIST/models_mnist/Net2.py:13-14) in two launches
-    each way (ee_net2.hip).  The kernels give the gradient w.r.t. the image - what the attack loop asks for, 40 times per training step;
-    a backward that needs PARAMETER gradients (the update, once per step) recomputes the stock sequence with the same dropout mask and lets
-    ATen differentiate it."""
+    each way (ee_net2.hip): the gradient w.r.t. the image - what the attack loop asks for, 40 times per training step - and, for a backward
+    that needs PARAMETER gradients (the update, once per step), two more launches (net2_conv*_wrw_kernel; before round 3 that pass re-ran the
+    stock sequence through ATen)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, drop, keep=1.0, draw_state=None):
@@ -662,7 +662,16 @@ class Net2ConvFn(torch.autograd.Function):
     def backward(ctx, da2):
         x, w1, b1, w2, b2, drop, a2, a1, c1, c2 = ctx.saved_tensors
         need = ctx.needs_input_grad
-        if any(need[1:5]) and not _INPUT_GRAD_ONLY:
+        if any(need[1:5]) and not _INPUT_GRAD_ONLY and not _STOCK_WRW:
+            # the training step's backward: the input gradient as in the attack loop (its scratch da1 kept), then the parameter gradients in
+            # two launches of ee_net2.hip (images added in order: bit-reproducible)
+            da2 = da2.contiguous()
+            da1 = torch.empty_like(a1)
+            dx = ops.net2_conv_bwd(da2, a2, (a1, c1, c2), w1, w2, drop, ctx.keep, da1_out=da1)
+            dw1, db1, dw2, db2 = ops.net2_conv_wrw(x, da2, a2, (a1, c1, c2), da1, drop, ctx.keep, bias=(b1 is not None or b2 is not None))
+            return ((dx if need[0] else None), (dw1 if need[1] else None), (db1 if need[2] and b1 is not None else None), (dw2 if need[3] else None),
+                    (db2 if need[4] and b2 is not None else None), None, None, None)
+        if any(need[1:5]) and not _INPUT_GRAD_ONLY:  # EEADV_STOCK_WRW=1: recompute the stock sequence with the same dropout mask and let ATen differentiate it
             import torch.nn.functional as F
             with torch.enable_grad():
                 xx = x.detach().requires_grad_(need[0])

@@ -1017,17 +1017,35 @@ def net2_conv_fwd(x, w1, b1, w2, b2, drop=None, keep=1.0, draw_state=None):
     return a2, (a1, c1, c2), (drop_out if rng else drop)
 
 
-def net2_conv_bwd(da2, a2, saved, w1, w2, drop=None, keep=1.0):
-    """d loss / d x [B,1,28,28] of net2_conv_fwd (input gradient only), two launches."""
+def net2_conv_bwd(da2, a2, saved, w1, w2, drop=None, keep=1.0, da1_out=None):
+    """d loss / d x [B,1,28,28] of net2_conv_fwd (input gradient only), two launches; da1_out: keeps the gradient of a1 for net2_conv_wrw."""
     a1, c1, c2 = saved
     B = a2.shape[0]
-    da1 = torch.empty_like(a1)
+    da1 = torch.empty_like(a1) if da1_out is None else da1_out
     dx = torch.empty((B, 1, 28, 28), dtype=torch.float32, device=a2.device)
     N.check(N.lib.ee_net2_conv_bwd_f32(_chk(da2, torch.float32, "da2", (B, 64, 4, 4)), _chk(a2, torch.float32, "a2"), _chk(c2, torch.uint8, "code2"),
                                        None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)), float(keep), _chk(w2, torch.float32, "w2"),
                                        _chk(a1, torch.float32, "a1"), _chk(c1, torch.uint8, "code1"), _chk(w1, torch.float32, "w1"),
                                        da1.data_ptr(), dx.data_ptr(), B, _stream()), "ee_net2_conv_bwd_f32")
     return dx
+
+
+def net2_conv_wrw(x, da2, a2, saved, da1, drop=None, keep=1.0, bias=True):
+    """(dw1 [32,1,5,5], db1 [32], dw2 [64,32,5,5], db2 [64]) of net2_conv_fwd: two launches, the images added in order (bit-reproducible).
+    da1 = the gradient of a1 (net2_conv_bwd's da1_out)."""
+    a1, c1, c2 = saved
+    B = a2.shape[0]
+    dev = a2.device
+    dw1 = torch.empty((32, 1, 5, 5), dtype=torch.float32, device=dev)
+    dw2 = torch.empty((64, 32, 5, 5), dtype=torch.float32, device=dev)
+    db1 = torch.empty(32, dtype=torch.float32, device=dev) if bias else None
+    db2 = torch.empty(64, dtype=torch.float32, device=dev) if bias else None
+    N.check(N.lib.ee_net2_conv_wrw_f32(_chk(x, torch.float32, "x", (B, 1, 28, 28)), _chk(a1, torch.float32, "a1", (B, 32, 12, 12)), _chk(c1, torch.uint8, "code1"),
+                                       _chk(da1, torch.float32, "da1", (B, 32, 12, 12)), _chk(a2, torch.float32, "a2", (B, 64, 4, 4)), _chk(c2, torch.uint8, "code2"),
+                                       _chk(da2, torch.float32, "da2", (B, 64, 4, 4)), None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)),
+                                       float(keep), dw1.data_ptr(), None if db1 is None else db1.data_ptr(), dw2.data_ptr(), None if db2 is None else db2.data_ptr(),
+                                       B, _stream()), "ee_net2_conv_wrw_f32")
+    return dw1, db1, dw2, db2
 
 
 # ---- timing hooks ------------------------------------------------------------------------------------------------------

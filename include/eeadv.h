@@ -457,6 +457,10 @@ int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1, const
                          uint64_t *draw_state, float *drop_out, float *a1, uint8_t *code1, float *a2, uint8_t *code2, int B, void *stream);
 int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t *code2, const float *drop, float keep, const float *w2,
                          const float *a1, const uint8_t *code1, const float *w1, float *da1, float *dx, int B, void *stream);
+/* Parameter gradients of the two halves (a training step's backward): da2 as above, da1 = what ee_net2_conv_bwd_f32 left in its scratch argument
+ * -> dw1 [32,1,5,5], db1 [32] (nullable), dw2 [64,32,5,5], db2 [64] (nullable), overwritten; the images are added in order (bit-reproducible). */
+int ee_net2_conv_wrw_f32(const float *x, const float *a1, const uint8_t *code1, const float *da1, const float *a2, const uint8_t *code2, const float *da2,
+                         const float *drop, float keep, float *dw1, float *db1, float *dw2, float *db2, int B, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Classifier head: logits = fc(avgpool(feat).view(B,-1)) for a global average pool

@@ -841,8 +841,8 @@ def test_frontend_bwd_from_saved_responses_is_bit_identical(ops, shape):
 @pytest.mark.parametrize("B,with_drop", [(50, False), (50, True), (3, True), (1, False)])
 def test_net2_conv_half_matches_aten(ops, B, with_drop):
     """relu(max_pool2d(drop * conv2(relu(max_pool2d(conv1(x), 2))), 2)): values within 1e-5 of ATen's sequence, the input gradient within
-    1e-5 of autograd's (the same pool winners and ReLU masks - compared on inputs without ties), parameter gradients through the
-    recomputing branch, NaN / inf inputs keep ATen's footprint."""
+    1e-5 of autograd's (the same pool winners and ReLU masks - compared on inputs without ties), parameter gradients on the hand-written
+    kernels too, NaN / inf inputs keep ATen's footprint."""
     import torch.nn.functional as F
     from eeadv.functional import Net2ConvFn
     g = torch.Generator(device="cpu").manual_seed(B + 7 * with_drop)
@@ -873,9 +873,21 @@ def test_net2_conv_half_matches_aten(ops, B, with_drop):
         (gx,) = torch.autograd.grad(got, [x], dy, retain_graph=True)
     (ex,) = torch.autograd.grad(ref, [x], dy, retain_graph=True)
     torch.testing.assert_close(gx, ex, rtol=1e-4, atol=1e-5 * float(ex.abs().max()))
-    # the update: parameter gradients (and x's) through the recomputing branch
-    for a, e in zip(torch.autograd.grad(got, [x, w1, b1, w2, b2], dy), torch.autograd.grad(ref, [x, w1, b1, w2, b2], dy)):
+    # the update: parameter gradients (and x's) - ee_net2.hip's net2_conv*_wrw kernels - against autograd through the stock sequence, against its
+    # float64 twin, and bit-identical from call to call (the images are added in order)
+    mine = torch.autograd.grad(got, [x, w1, b1, w2, b2], dy, retain_graph=True)
+    for a, e in zip(mine, torch.autograd.grad(ref, [x, w1, b1, w2, b2], dy)):
         torch.testing.assert_close(a, e, rtol=1e-4, atol=1e-5 * float(e.abs().max()))
+    p64 = [t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    h64 = F.relu(F.max_pool2d(F.conv2d(p64[0], p64[1], p64[2]), 2))
+    h64 = F.conv2d(h64, p64[3], p64[4])
+    if drop is not None:
+        h64 = h64 * drop.double().view(B, 64, 1, 1)
+    h64 = F.relu(F.max_pool2d(h64, 2))
+    for a, e in zip(mine, torch.autograd.grad(h64, p64, dy.double())):
+        assert float((a.double() - e).abs().max()) <= 2e-5 * float(e.abs().max()) + 1e-7
+    for a, e in zip(mine, torch.autograd.grad(got, [x, w1, b1, w2, b2], dy)):
+        assert torch.equal(a, e)
     # NaN / inf in the image: the NaN footprint of a direct convolution (float64 on the host - MIOpen's Winograd spreads a NaN over its
     # whole transform tile and turns inf - inf into NaN, so the stock GPU sequence is no yardstick here), forward and backward
     xn = x.detach().clone()
