@@ -347,94 +347,99 @@ __global__ __launch_bounds__(N2_NT) void net2_conv1_bwd_kernel(const float *__re
 // Through the pools only one position of every 2x2 window carries a gradient (the argmax the forward recorded), so
 //     dW2[co][ci][ky][kx] = sum over images and the 16 windows of  g2 * a1[ci][oy + ky][ox + kx],   g2 = da2 (0 where a2 <= 0) * drop / keep,
 //     (oy, ox) = the window's argmax position in conv2's 8x8 output;       db2[co] = sum g2;        dW1 / db1 likewise from da1, a1's mask, code1, x.
-// The gather position depends on the OUTPUT channel, so this is no GEMM: plain fma chains, one workgroup per (co, 8 input channels) for conv2
-// and per co for conv1, the images in order - a fixed summation order, bit-reproducible.  (Before round 3 a pass that needed these gradients
-// re-ran the stock ATen / MIOpen sequence: 25 launches and 0.27 ms of the MNIST training step.)
+// The gather position depends on the OUTPUT channel, so this is no GEMM: plain fma chains.  A workgroup takes ten images at once (one round of
+// loads, one barrier) for one output channel (and 8 input channels of conv2) and adds them in order; the groups of ten meet in a partial buffer
+// that net2_sum_kernel adds in order: a fixed summation order, bit-reproducible.  (Before round 3 a pass that needed these gradients re-ran the
+// stock ATen / MIOpen sequence: 25 launches and 0.27 ms of the MNIST training step.)
+constexpr int N2_WI = 10;                                   // images per workgroup
+constexpr int N2_PG = 64 * 32 * 25 + 32 * 25 + 64 + 32;     // one group's partials / the result: [dw2 | dw1 | db2 | db1] = 52096 floats
+
 __global__ __launch_bounds__(N2_NT) void net2_conv2_wrw_kernel(const float *__restrict__ da2, const float *__restrict__ a2, const uint8_t *__restrict__ code2,
                                                                const float *__restrict__ drop, float keep, const float *__restrict__ a1,
-                                                               float *__restrict__ dw2, float *__restrict__ db2, int B) {
-    __shared__ float A[2][8 * 144];
-    __shared__ float gs[2][16];
-    __shared__ int off[2][16];
-    const int co = blockIdx.x, ci0 = blockIdx.y * 8;
-    const int cl = threadIdx.x / 25, k = threadIdx.x - 25 * cl, tap = (k / 5) * 12 + k % 5;  // threads 0 .. 199: (input channel, tap)
-    auto stage = [&](int b, int buf) {
-        for (int i = threadIdx.x; i < 8 * 144 / 4; i += N2_NT)
-            reinterpret_cast<float4 *>(A[buf])[i] = reinterpret_cast<const float4 *>(a1 + (static_cast<size_t>(b) * N2_C1 + ci0) * 144)[i];
-        if (threadIdx.x < 16) {
-            const int p = threadIdx.x;
-            const size_t src = (static_cast<size_t>(b) * N2_C2 + co) * 16 + p;
-            float g = da2[src];
-            if (a2[src] <= 0.0f) g = 0.0f;
-            if (drop) g *= drop[static_cast<size_t>(b) * N2_C2 + co] / keep;
-            const int cd = code2[src];
-            gs[buf][p] = g;
-            off[buf][p] = (2 * (p >> 2) + (cd >> 1)) * 12 + 2 * (p & 3) + (cd & 1);
-        }
-    };
-    float acc = 0.0f, bsum = 0.0f;
-    if (B > 0) stage(0, 0);
-    __syncthreads();
-    for (int b = 0; b < B; ++b) {
-        const int cur = b & 1;
-        if (b + 1 < B) stage(b + 1, cur ^ 1);
-        if (threadIdx.x < 200) {
-            const float *ap = A[cur] + cl * 144 + tap;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) acc = fmaf(gs[cur][p], ap[off[cur][p]], acc);
-        } else if (threadIdx.x == 200 && blockIdx.y == 0) {
-#pragma unroll
-            for (int p = 0; p < 16; ++p) bsum += gs[cur][p];
-        }
-        __syncthreads();
+                                                               float *__restrict__ out, int B) {
+    __shared__ __align__(16) float A[N2_WI * 8 * 144];  // 46 KB
+    __shared__ float gs[N2_WI * 16];
+    __shared__ int off[N2_WI * 16];
+    const int co = blockIdx.x, ci0 = blockIdx.y * 8, b0 = blockIdx.z * N2_WI;
+    const int nb = B - b0 < N2_WI ? B - b0 : N2_WI;
+    for (int i = threadIdx.x; i < nb * 288; i += N2_NT) {
+        const int img = i / 288, f = i - img * 288;
+        reinterpret_cast<float4 *>(A)[i] = reinterpret_cast<const float4 *>(a1 + (static_cast<size_t>(b0 + img) * N2_C1 + ci0) * 144)[f];
     }
-    if (threadIdx.x < 200) dw2[(static_cast<size_t>(co) * N2_C1 + ci0 + cl) * 25 + k] = acc;
-    if (threadIdx.x == 200 && blockIdx.y == 0 && db2) db2[co] = bsum;
+    if (static_cast<int>(threadIdx.x) < nb * 16) {
+        const int img = threadIdx.x >> 4, p = threadIdx.x & 15;
+        const size_t src = (static_cast<size_t>(b0 + img) * N2_C2 + co) * 16 + p;
+        float g = da2[src];
+        if (a2[src] <= 0.0f) g = 0.0f;  // ATen's threshold_backward
+        if (drop) g *= drop[static_cast<size_t>(b0 + img) * N2_C2 + co] / keep;
+        const int cd = code2[src];
+        gs[threadIdx.x] = g;
+        off[threadIdx.x] = img * (8 * 144) + (2 * (p >> 2) + (cd >> 1)) * 12 + 2 * (p & 3) + (cd & 1);
+    }
+    __syncthreads();
+    float *o = out + static_cast<size_t>(blockIdx.z) * N2_PG;
+    if (threadIdx.x < 200) {
+        const int cl = threadIdx.x / 25, k = threadIdx.x - 25 * cl;
+        const float *ap = A + cl * 144 + (k / 5) * 12 + k % 5;
+        float acc = 0.0f;
+        for (int i = 0; i < nb * 16; ++i) acc = fmaf(gs[i], ap[off[i]], acc);
+        o[(static_cast<size_t>(co) * N2_C1 + ci0 + cl) * 25 + k] = acc;
+    } else if (threadIdx.x == 200 && blockIdx.y == 0) {
+        float bsum = 0.0f;
+        for (int i = 0; i < nb * 16; ++i) bsum += gs[i];
+        o[64 * 32 * 25 + 32 * 25 + co] = bsum;
+    }
 }
 
-// one workgroup per output channel of conv1; lane (tap k, slice j of the 144 windows: j, j + 10, ...); the ten slices meet in LDS in order
+// (output channel of conv1, group of ten images); lane (tap k, slice j of the 144 windows: j, j + 10, ...); the ten slices meet in LDS in order
 __global__ __launch_bounds__(N2_NT) void net2_conv1_wrw_kernel(const float *__restrict__ da1, const float *__restrict__ a1, const uint8_t *__restrict__ code1,
-                                                               const float *__restrict__ x, float *__restrict__ dw1, float *__restrict__ db1, int B) {
-    __shared__ __align__(16) float xs[2][N2_H0 * N2_H0];
-    __shared__ float gs[2][144];
-    __shared__ int off[2][144];
+                                                               const float *__restrict__ x, float *__restrict__ out, int B) {
+    __shared__ __align__(16) float xs[N2_WI * N2_H0 * N2_H0];  // 31 KB
+    __shared__ float gs[N2_WI * 144];
+    __shared__ int off[N2_WI * 144];
     __shared__ float red[10][26];
-    const int co = blockIdx.x;
-    const int j = threadIdx.x / 25, k = threadIdx.x - 25 * j, tap = (k / 5) * N2_H0 + k % 5;  // threads 0 .. 249
-    auto stage = [&](int b, int buf) {
-        for (int i = threadIdx.x; i < N2_H0 * N2_H0 / 4; i += N2_NT)
-            reinterpret_cast<float4 *>(xs[buf])[i] = reinterpret_cast<const float4 *>(x + static_cast<size_t>(b) * N2_H0 * N2_H0)[i];
-        if (threadIdx.x < 144) {
-            const int p = threadIdx.x, py = p / N2_H1, px = p - py * N2_H1;
-            const size_t src = (static_cast<size_t>(b) * N2_C1 + co) * 144 + p;
-            const int cd = code1[src];
-            gs[buf][p] = a1[src] <= 0.0f ? 0.0f : da1[src];
-            off[buf][p] = (2 * py + (cd >> 1)) * N2_H0 + 2 * px + (cd & 1);
-        }
-    };
-    float acc = 0.0f, bsum = 0.0f;
-    if (B > 0) stage(0, 0);
-    __syncthreads();
-    for (int b = 0; b < B; ++b) {
-        const int cur = b & 1;
-        if (b + 1 < B) stage(b + 1, cur ^ 1);
-        if (threadIdx.x < 250) {
-            const float *xp = xs[cur] + tap;
-            for (int p = j; p < 144; p += 10) acc = fmaf(gs[cur][p], xp[off[cur][p]], acc);
-        } else if (threadIdx.x == 250) {
-            for (int p = 0; p < 144; ++p) bsum += gs[cur][p];
-        }
-        __syncthreads();
+    const int co = blockIdx.x, b0 = blockIdx.y * N2_WI;
+    const int nb = B - b0 < N2_WI ? B - b0 : N2_WI;
+    for (int i = threadIdx.x; i < nb * 196; i += N2_NT) reinterpret_cast<float4 *>(xs)[i] = reinterpret_cast<const float4 *>(x + static_cast<size_t>(b0) * 784)[i];
+    for (int i = threadIdx.x; i < nb * 144; i += N2_NT) {
+        const int img = i / 144, p = i - img * 144, py = p / N2_H1, px = p - py * N2_H1;
+        const size_t src = (static_cast<size_t>(b0 + img) * N2_C1 + co) * 144 + p;
+        const int cd = code1[src];
+        gs[i] = a1[src] <= 0.0f ? 0.0f : da1[src];
+        off[i] = img * 784 + (2 * py + (cd >> 1)) * N2_H0 + 2 * px + (cd & 1);
     }
-    if (threadIdx.x < 250) red[j][k] = acc;
     __syncthreads();
+    const int j = threadIdx.x / 25, k = threadIdx.x - 25 * j;
+    if (threadIdx.x < 250) {
+        const float *xp = xs + (k / 5) * N2_H0 + k % 5;
+        float acc = 0.0f;
+        for (int img = 0; img < nb; ++img)
+            for (int p = j; p < 144; p += 10) acc = fmaf(gs[img * 144 + p], xp[off[img * 144 + p]], acc);
+        red[j][k] = acc;
+    }
+    __syncthreads();
+    float *o = out + static_cast<size_t>(blockIdx.y) * N2_PG + 64 * 32 * 25;
     if (threadIdx.x < 25) {
         float t = red[0][threadIdx.x];
 #pragma unroll
         for (int jj = 1; jj < 10; ++jj) t += red[jj][threadIdx.x];
-        dw1[co * 25 + threadIdx.x] = t;
+        o[co * 25 + threadIdx.x] = t;
+    } else if (threadIdx.x == 250) {
+        float bsum = 0.0f;
+        for (int i = 0; i < nb * 144; ++i) bsum += gs[i];
+        o[32 * 25 + 64 + co] = bsum;
     }
-    if (threadIdx.x == 250 && db1) db1[co] = bsum;
+}
+
+__global__ __launch_bounds__(N2_NT) void net2_sum_kernel(const float4 *__restrict__ part, float4 *__restrict__ out, int G) {
+    const int i = blockIdx.x * N2_NT + threadIdx.x;
+    if (i >= N2_PG / 4) return;
+    float4 a = part[i];
+    for (int g = 1; g < G; ++g) {
+        const float4 v = part[static_cast<size_t>(g) * (N2_PG / 4) + i];
+        a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+    }
+    out[i] = a;
 }
 
 }  // namespace
@@ -472,17 +477,27 @@ EE_API int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t
 }
 
 // Parameter gradients of the same two halves: da2 [B,64,4,4] (the gradient of a2) and da1 [B,32,12,12] (the gradient of a1: what
-// ee_net2_conv_bwd_f32 left in its scratch argument) -> dw1 [32,1,5,5], db1 [32] (nullable), dw2 [64,32,5,5], db2 [64] (nullable), all overwritten.
-// Images are added in order: bit-reproducible.
+// ee_net2_conv_bwd_f32 left in its scratch argument) -> out = [ dw2 [64,32,5,5] | dw1 [32,1,5,5] | db2 [64] | db1 [32] ] = 52096 floats, overwritten;
+// workspace: ee_net2_conv_wrw_workspace_floats(B) floats (0: none needed).  Images are added in order: bit-reproducible.
+EE_API int64_t ee_net2_conv_wrw_workspace_floats(int B) {
+    const int G = (B + N2_WI - 1) / N2_WI;
+    return G > 1 ? static_cast<int64_t>(G) * N2_PG : 0;
+}
+
 EE_API int ee_net2_conv_wrw_f32(const float *x, const float *a1, const uint8_t *code1, const float *da1, const float *a2, const uint8_t *code2,
-                                const float *da2, const float *drop, float keep, float *dw1, float *db1, float *dw2, float *db2, int B, void *stream) {
+                                const float *da2, const float *drop, float keep, float *out, float *workspace, int B, void *stream) {
     if (B < 0) return EE_ERR_SHAPE;
-    if (!dw1 || !dw2) return EE_ERR_NULL;
-    if (B > 0 && (!x || !a1 || !code1 || !da1 || !a2 || !code2 || !da2)) return EE_ERR_NULL;
-    if (drop && !(keep > 0.0f)) return EE_ERR_SHAPE;
-    if (B > 0 && (!aligned16(x) || !aligned16(a1))) return EE_ERR_ALIGN;
+    if (!out) return EE_ERR_NULL;
     hipStream_t st = as_stream(stream);
-    EE_LAUNCH(net2_conv2_wrw_kernel, dim3(N2_C2, N2_C1 / 8), dim3(N2_NT), 0, st, da2, a2, code2, drop, keep, a1, dw2, db2, B);
-    EE_LAUNCH(net2_conv1_wrw_kernel, dim3(N2_C1), dim3(N2_NT), 0, st, da1, a1, code1, x, dw1, db1, B);
+    if (B == 0) return static_cast<int>(hipMemsetAsync(out, 0, sizeof(float) * N2_PG, st));
+    if (!x || !a1 || !code1 || !da1 || !a2 || !code2 || !da2) return EE_ERR_NULL;
+    if (drop && !(keep > 0.0f)) return EE_ERR_SHAPE;
+    const int G = (B + N2_WI - 1) / N2_WI;
+    if (G > 1 && !workspace) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(a1) || !aligned16(out) || (G > 1 && !aligned16(workspace))) return EE_ERR_ALIGN;
+    float *dst = G > 1 ? workspace : out;
+    EE_LAUNCH(net2_conv2_wrw_kernel, dim3(N2_C2, N2_C1 / 8, static_cast<unsigned>(G)), dim3(N2_NT), 0, st, da2, a2, code2, drop, keep, a1, dst, B);
+    EE_LAUNCH(net2_conv1_wrw_kernel, dim3(N2_C1, static_cast<unsigned>(G)), dim3(N2_NT), 0, st, da1, a1, code1, x, dst, B);
+    if (G > 1) EE_LAUNCH(net2_sum_kernel, dim3((N2_PG / 4 + N2_NT - 1) / N2_NT), dim3(N2_NT), 0, st, reinterpret_cast<const float4 *>(workspace), reinterpret_cast<float4 *>(out), G);
     return launch_status();
 }

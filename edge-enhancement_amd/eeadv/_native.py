@@ -97,7 +97,8 @@ SIGNATURES = {
     "ee_conv_weight_prep_f32": [c_i, c_p, c_p, c_p, c_i, c_i, c_p],
     "ee_conv3x3s2_pair_fwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_pair_bwd_data_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "ee_net2_conv_wrw_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p],
+    "ee_net2_conv_wrw_workspace_floats": [c_i],
+    "ee_net2_conv_wrw_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p],
     "ee_net2_conv_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "ee_net2_conv_bwd_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "ee_maxpool3s2_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -116,7 +117,7 @@ SIGNATURES = {
     "ee_prof_read_work": [c_i, c_p],
     "ee_prof_reset": [],
 }
-_RESTYPE = {"ee_strerror": ctypes.c_char_p, "ee_device_name": ctypes.c_char_p, "ee_mse_num_partials": c_l, "ee_wrw3x3_workspace_floats": c_l, "ee_wrw3x3s2_workspace_floats": c_l, "ee_wrw_stem7x7s2_workspace_floats": c_l, "ee_wrw1x1_workspace_floats": c_l}
+_RESTYPE = {"ee_strerror": ctypes.c_char_p, "ee_device_name": ctypes.c_char_p, "ee_mse_num_partials": c_l, "ee_wrw3x3_workspace_floats": c_l, "ee_wrw3x3s2_workspace_floats": c_l, "ee_wrw_stem7x7s2_workspace_floats": c_l, "ee_wrw1x1_workspace_floats": c_l, "ee_net2_conv_wrw_workspace_floats": c_l}
 
 # kernel-family ids of include/eeadv.h (ee_prof_*)
 (K_PGD_STEP, K_FRONTEND_FWD, K_FRONTEND_BWD, K_EDGE_FWD, K_EDGE_BWD, K_CE, K_PGD_STEP_BCAST, K_EMPTY, K_HFS, K_CHAIN_FWD, K_CHAIN_BWD,

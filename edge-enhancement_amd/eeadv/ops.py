@@ -1030,22 +1030,20 @@ def net2_conv_bwd(da2, a2, saved, w1, w2, drop=None, keep=1.0, da1_out=None):
     return dx
 
 
-def net2_conv_wrw(x, da2, a2, saved, da1, drop=None, keep=1.0, bias=True):
-    """(dw1 [32,1,5,5], db1 [32], dw2 [64,32,5,5], db2 [64]) of net2_conv_fwd: two launches, the images added in order (bit-reproducible).
-    da1 = the gradient of a1 (net2_conv_bwd's da1_out)."""
+def net2_conv_wrw(x, da2, a2, saved, da1, drop=None, keep=1.0):
+    """(dw1 [32,1,5,5], db1 [32], dw2 [64,32,5,5], db2 [64]) of net2_conv_fwd - views of one buffer: two launches + the fixed-order sum over the
+    groups of ten images (bit-reproducible).  da1 = the gradient of a1 (net2_conv_bwd's da1_out)."""
     a1, c1, c2 = saved
     B = a2.shape[0]
-    dev = a2.device
-    dw1 = torch.empty((32, 1, 5, 5), dtype=torch.float32, device=dev)
-    dw2 = torch.empty((64, 32, 5, 5), dtype=torch.float32, device=dev)
-    db1 = torch.empty(32, dtype=torch.float32, device=dev) if bias else None
-    db2 = torch.empty(64, dtype=torch.float32, device=dev) if bias else None
+    out = torch.empty(64 * 32 * 25 + 32 * 25 + 64 + 32, dtype=torch.float32, device=a2.device)
+    n = int(N.lib.ee_net2_conv_wrw_workspace_floats(B))
+    ws = torch.empty(max(n, 4), dtype=torch.float32, device=a2.device)
     N.check(N.lib.ee_net2_conv_wrw_f32(_chk(x, torch.float32, "x", (B, 1, 28, 28)), _chk(a1, torch.float32, "a1", (B, 32, 12, 12)), _chk(c1, torch.uint8, "code1"),
                                        _chk(da1, torch.float32, "da1", (B, 32, 12, 12)), _chk(a2, torch.float32, "a2", (B, 64, 4, 4)), _chk(c2, torch.uint8, "code2"),
                                        _chk(da2, torch.float32, "da2", (B, 64, 4, 4)), None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)),
-                                       float(keep), dw1.data_ptr(), None if db1 is None else db1.data_ptr(), dw2.data_ptr(), None if db2 is None else db2.data_ptr(),
-                                       B, _stream()), "ee_net2_conv_wrw_f32")
-    return dw1, db1, dw2, db2
+                                       float(keep), out.data_ptr(), ws.data_ptr(), B, _stream()), "ee_net2_conv_wrw_f32")
+    n2, n1 = 64 * 32 * 25, 32 * 25
+    return out[n2:n2 + n1].view(32, 1, 5, 5), out[n2 + n1 + 64:], out[:n2].view(64, 32, 5, 5), out[n2 + n1:n2 + n1 + 64]
 
 
 # ---- timing hooks ------------------------------------------------------------------------------------------------------

@@ -458,9 +458,11 @@ int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1, const
 int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t *code2, const float *drop, float keep, const float *w2,
                          const float *a1, const uint8_t *code1, const float *w1, float *da1, float *dx, int B, void *stream);
 /* Parameter gradients of the two halves (a training step's backward): da2 as above, da1 = what ee_net2_conv_bwd_f32 left in its scratch argument
- * -> dw1 [32,1,5,5], db1 [32] (nullable), dw2 [64,32,5,5], db2 [64] (nullable), overwritten; the images are added in order (bit-reproducible). */
+ * -> out = [ dw2 [64,32,5,5] | dw1 [32,1,5,5] | db2 [64] | db1 [32] ] (52096 floats), overwritten; workspace: ee_net2_conv_wrw_workspace_floats(B)
+ * floats (0: none needed, NULL allowed).  Groups of ten images are added in order (bit-reproducible). */
+int64_t ee_net2_conv_wrw_workspace_floats(int B);
 int ee_net2_conv_wrw_f32(const float *x, const float *a1, const uint8_t *code1, const float *da1, const float *a2, const uint8_t *code2, const float *da2,
-                         const float *drop, float keep, float *dw1, float *db1, float *dw2, float *db2, int B, void *stream);
+                         const float *drop, float keep, float *out, float *workspace, int B, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Classifier head: logits = fc(avgpool(feat).view(B,-1)) for a global average pool
