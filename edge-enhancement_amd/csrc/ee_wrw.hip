@@ -1,6 +1,11 @@
-// ee_wrw.hip - the WEIGHT gradient of Conv2d(3x3, stride 1, padding 1, bias=False) on 16x16 / 8x8 / 4x4 / 2x2 maps (every stride-1 3x3 layer
-// of ResNet-18 at 64x64 inputs, resnet.py:26-31; `loss.backward()` at experiments_tinyimagenet.py:304-306) as Winograd F(3x3, 2x2) around the
-// f32 matrix cores.
+// ee_wrw.hip - the WEIGHT gradients of the classifiers' convolutions (`loss.backward()` of a training step, experiments_tinyimagenet.py:304-306),
+// four kernel families with one scheme - the reduction over images and pixels is cut over a few hundred workgroups, their partial gradients meet
+// in a workspace, and wrw_sum_kernel adds them IN A FIXED ORDER (MIOpen's solvers use atomics: not reproducible from run to run):
+//   wrw_wino_kernel<MAP>  Conv2d(3x3, stride 1, padding 1) on 16x16 / 8x8 / 4x4 / 2x2 maps (resnet.py:26-31 at 64x64 inputs): Winograd F(3x3, 2x2)
+//   wrw_s2_kernel<H>      Conv2d(3x3, stride 2, padding 1) from 16x16 / 8x8 / 4x4 maps together with the block's 1x1 / stride 2 shortcut (:50-59, :132-142)
+//   wrw_stem_kernel       the stem Conv2d(3, 64, 7, stride 2, padding 3) (:112)
+//   wrw1x1_kernel         Conv2d(1x1, stride 1) of the bottleneck blocks (:75-100; ResNet-50 at ImageNet size), operands in their NCHW layout
+// The first one in detail:
 //
 // Why: MIOpen's best solvers for these shapes are its NHWC implicit-GEMM kernels: per layer one 24 - 28 us product plus two to four layout
 // transposes and a zero fill, 0.65 ms of the 2.1 ms update of a training step (profiles/round3_h_trace_breakdown.txt), summed with atomics (not
