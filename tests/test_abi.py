@@ -64,6 +64,22 @@ def test_argument_checks_happen_before_any_launch(native):
     assert L.ee_mse_num_partials(0) == 0 and L.ee_mse_num_partials(4097) == 2
     assert b"NULL" in L.ee_strerror(-1) and b"not supported" in L.ee_strerror(-3)
     assert L.ee_prof_read(99, None, None) == -2
+    # the weight-gradient entry points (round 3): shapes they do not take, missing pointers and workspaces, the workspace queries
+    q = ctypes.c_void_p(4096)
+    assert L.ee_wrw3x3_f32(q, q, q, q, 4, 48, 64, 8, None) == -3 and L.ee_wrw3x3_f32(q, q, q, q, 4, 64, 64, 6, None) == -3
+    assert L.ee_wrw3x3_f32(q, q, None, q, 4, 64, 64, 8, None) == -1 and L.ee_wrw3x3_f32(None, q, q, q, 4, 64, 64, 8, None) == -1
+    assert L.ee_wrw3x3_f32(q, q, q, None, 100, 64, 64, 16, None) == -1  # 58 splits need the workspace
+    assert L.ee_wrw3x3_workspace_floats(100, 64, 64, 16) == 58 * 9 * 64 * 64 and L.ee_wrw3x3_workspace_floats(100, 512, 512, 2) == 0
+    assert L.ee_wrw3x3_workspace_floats(100, 48, 64, 16) == 0
+    assert L.ee_wrw3x3s2_f32(q, q, None, q, q, 4, 64, 128, 2, None) == -3 and L.ee_wrw3x3s2_f32(q, None, None, q, q, 4, 64, 128, 8, None) == -1
+    assert L.ee_wrw3x3s2_workspace_floats(100, 64, 128, 16, 1) == 10 * L.ee_wrw3x3s2_workspace_floats(100, 64, 128, 16, 0) // 9 > 0
+    assert L.ee_wrw_stem7x7s2_f32(q, q, q, q, 4, 64, 48, None) == -3 and L.ee_wrw_stem7x7s2_f32(q, q, None, q, 4, 64, 64, None) == -1
+    assert L.ee_wrw_stem7x7s2_workspace_floats(100, 64, 64) == 256 * 64 * 147
+    assert L.ee_wrw1x1_f32(q, q, q, q, 4, 64, 64, 49, None) == -3 and L.ee_wrw1x1_f32(q, q, q, q, 4, 96, 64, 16, None) == -3
+    assert L.ee_wrw1x1_f32(ctypes.c_void_p(4100), q, q, q, 4, 64, 64, 16, None) == -4  # EE_ERR_ALIGN
+    assert L.ee_net2_conv_wrw_workspace_floats(50) == 5 * 52096 and L.ee_net2_conv_wrw_workspace_floats(10) == 0
+    assert L.ee_net2_conv_wrw_f32(q, q, q, q, q, q, q, None, 1.0, None, None, 4, None) == -1
+    assert L.ee_conv_weight_prep_f32(7, q, None, q, 48, 64, None) == -3  # EE_WPREP_WINO_FB wants channels % 32 == 0
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
