@@ -8,7 +8,7 @@
 // global memory (everything is L2-resident), output channels on the accumulator rows so that stores run along pixels.
 //   forward : Y[co][p] = sum_ci W[co][ci] * X[ci][p@stride2]
 //   backward: dX[ci][p@stride2] = sum_co W[co][ci] * dY[co][p];  the other three pixels of every 2x2 cell are zero.
-// The weight gradient (once per training step) stays on MIOpen.
+// The weight gradient: ee_wrw.hip (together with the 3x3 / stride 2 convolution of the same block; a shortcut on its own keeps ATen's).
 //
 // CNN-body glue, not a row of SURVEY.md section 8: parity is "logits within 1e-4" through the model tests.
 #include <stdlib.h>
