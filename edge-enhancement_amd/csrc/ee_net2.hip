@@ -468,11 +468,12 @@ EE_API int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t
                                 const float *a1, const uint8_t *code1, const float *w1, float *da1, float *dx, int B, void *stream) {
     if (B < 0) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
-    if (!da2 || !a2 || !code2 || !w2 || !a1 || !code1 || !w1 || !da1 || !dx) return EE_ERR_NULL;
-    if (!aligned16(dx)) return EE_ERR_ALIGN;
+    if (!da2 || !a2 || !code2 || !w2 || !a1 || !code1 || !w1 || !da1) return EE_ERR_NULL;
+    if (dx && !aligned16(dx)) return EE_ERR_ALIGN;
     hipStream_t st = as_stream(stream);
     EE_LAUNCH(net2_conv2_bwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_BT), 0, st, da2, a2, code2, drop, keep, w2, da1);
-    EE_LAUNCH(net2_conv1_bwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, da1, a1, code1, w1, dx);
+    if (dx)  // NULL: only da1 is wanted (a training step whose input needs no gradient; ee_net2_conv_wrw_f32 reads da1)
+        EE_LAUNCH(net2_conv1_bwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, da1, a1, code1, w1, dx);
     return launch_status();
 }
 

@@ -667,7 +667,7 @@ class Net2ConvFn(torch.autograd.Function):
             # two launches of ee_net2.hip (images added in order: bit-reproducible)
             da2 = da2.contiguous()
             da1 = torch.empty_like(a1)
-            dx = ops.net2_conv_bwd(da2, a2, (a1, c1, c2), w1, w2, drop, ctx.keep, da1_out=da1)
+            dx = ops.net2_conv_bwd(da2, a2, (a1, c1, c2), w1, w2, drop, ctx.keep, da1_out=da1, need_dx=need[0])
             dw1, db1, dw2, db2 = ops.net2_conv_wrw(x, da2, a2, (a1, c1, c2), da1, drop, ctx.keep)
             return ((dx if need[0] else None), (dw1 if need[1] else None), (db1 if need[2] and b1 is not None else None), (dw2 if need[3] else None),
                     (db2 if need[4] and b2 is not None else None), None, None, None)

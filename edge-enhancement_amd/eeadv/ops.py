@@ -1017,16 +1017,16 @@ def net2_conv_fwd(x, w1, b1, w2, b2, drop=None, keep=1.0, draw_state=None):
     return a2, (a1, c1, c2), (drop_out if rng else drop)
 
 
-def net2_conv_bwd(da2, a2, saved, w1, w2, drop=None, keep=1.0, da1_out=None):
+def net2_conv_bwd(da2, a2, saved, w1, w2, drop=None, keep=1.0, da1_out=None, need_dx=True):
     """d loss / d x [B,1,28,28] of net2_conv_fwd (input gradient only), two launches; da1_out: keeps the gradient of a1 for net2_conv_wrw."""
     a1, c1, c2 = saved
     B = a2.shape[0]
     da1 = torch.empty_like(a1) if da1_out is None else da1_out
-    dx = torch.empty((B, 1, 28, 28), dtype=torch.float32, device=a2.device)
+    dx = torch.empty((B, 1, 28, 28), dtype=torch.float32, device=a2.device) if need_dx else None
     N.check(N.lib.ee_net2_conv_bwd_f32(_chk(da2, torch.float32, "da2", (B, 64, 4, 4)), _chk(a2, torch.float32, "a2"), _chk(c2, torch.uint8, "code2"),
                                        None if drop is None else _chk(drop, torch.float32, "drop", (B, 64)), float(keep), _chk(w2, torch.float32, "w2"),
                                        _chk(a1, torch.float32, "a1"), _chk(c1, torch.uint8, "code1"), _chk(w1, torch.float32, "w1"),
-                                       da1.data_ptr(), dx.data_ptr(), B, _stream()), "ee_net2_conv_bwd_f32")
+                                       da1.data_ptr(), None if dx is None else dx.data_ptr(), B, _stream()), "ee_net2_conv_bwd_f32")
     return dx
 
 

@@ -451,7 +451,7 @@ int ee_stem7x7s2_fwd_stats_f32(const float *x, const float *weight, float *y, fl
  *   the draw itself (Philox4x32-10, stream id 7), writes the mask to drop_out [B,64] for the backward, and its last workgroup advances
  *   the offset - no host-side random launch inside a captured attack iteration
  *   -> a1 [B,32,12,12], a2 [B,64,4,4] and the one-byte argmax codes of the two pools.
- * Backward (input gradient only): da2 [B,64,4,4] -> dx [B,1,28,28]; da1 [B,32,12,12] is scratch the caller provides.  ReLU backward
+ * Backward (input gradient only): da2 [B,64,4,4] -> dx [B,1,28,28] (NULL: skipped); da1 [B,32,12,12] = the gradient of a1, scratch the caller provides.  ReLU backward
  * follows ATen's threshold rule (the gradient passes unless the output is <= 0); pool ties and NaNs follow ATen's max_pool2d. */
 int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *drop, float keep,
                          uint64_t *draw_state, float *drop_out, float *a1, uint8_t *code1, float *a2, uint8_t *code2, int B, void *stream);
