@@ -261,13 +261,27 @@ def time_other_workload(name, dev, world, rank, steps, warmup):
     res = {"value": round(world * cfg["batch"] * steps / dt, 2), "unit": "adversarial images/s", "ms_per_step": round(1e3 * dt / steps, 3),
            "steps": steps, "warmup": warmup, "final_loss": round(float(last[0].item()), 5),
            "config": {"workload": job.describe(), "global_batch": world * cfg["batch"], "grad_sync": job.grad_sync(),
-                      "miopen_find": bool(torch.backends.cudnn.benchmark), "miopen_db": "recorded" if MIOPEN_DB else None}}
+                      "miopen_find": bool(torch.backends.cudnn.benchmark), "miopen_db": "recorded" if MIOPEN_DB else None,
+                      "miopen_db_matched": _db_matched(), "fallback_layers": _fallback_layers(job.model)}}
     torch.backends.cudnn.benchmark = find_before
     del job, last
     engine.clear_graphs()
     trainer.clear_update_graphs()
     torch.cuda.empty_cache()
     return res
+
+
+def _db_matched():
+    """config.miopen_db_matched: did MIOpen actually take the shipped find-db (eeadv.runtime.shipped_miopen_db_matched)"""
+    from eeadv import runtime
+    return runtime.shipped_miopen_db_matched(MIOPEN_DB)
+
+
+def _fallback_layers(model):
+    """config.fallback_layers: the convolutions of `model` that ran on MIOpen / Tensile instead of a hand-written kernel in the steps
+    just timed ({"count", "of", "layers": [...]}; eeadv.models records the route every convolution takes)."""
+    from eeadv import models as M
+    return M.fallback_report(model)
 
 
 SETUP_STEPS = 3
@@ -568,7 +582,8 @@ def main():
                 "global_batch": world * B, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
                 "backend": dist.get_backend() if world > 1 else None, "grad_sync": grad_sync_text,
                 "switches": non_default_switches,
-                "rank0_phase_ms": phases, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "miopen_db": "recorded" if MIOPEN_DB else None, "probe_iters": probe_iters, "probe_every": a.probe_every,
+                "rank0_phase_ms": phases, "setup_steps": SETUP_STEPS, "hip_graph": not a.no_graph, "miopen_db": "recorded" if MIOPEN_DB else None, "miopen_db_matched": _db_matched(),
+                "fallback_layers": _fallback_layers(job.model), "probe_iters": probe_iters, "probe_every": a.probe_every,
                 "device": (N.lib.ee_device_name() or b"?").decode()},
             "roofline": roofline, "roofline_front_end": roofline_hbm, "kernels": kernels, "final_loss": round(loss_val, 5),
             "note": "throughput is bounded by the classifier's fp32 convolutions (hand-written MFMA kernels + MIOpen) and BatchNorm launches, "
@@ -594,7 +609,7 @@ def main():
         if rank == 0:
             out["other_workloads_error"] = "timed out after %d s" % a.extras_timeout
         emit()
-        os._exit(0)
+        os._exit(3)  # non-zero: a stuck extra leg (a collective that never returns) must not read as a clean run
 
     t_start = time.perf_counter()
 

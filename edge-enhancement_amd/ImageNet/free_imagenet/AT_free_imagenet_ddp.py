@@ -174,7 +174,7 @@ def main(argv=None, parser=None, build=build_model, dirs_of=output_dirs, eval_at
     os.environ.setdefault("EEADV_GRAPH", "0" if ddp.world() > 1 else "1")
     # :149-152: SyncBatchNorm, and instead of DistributedDataParallel one flat gradient buffer all-reduced per repeat (ddp.FlatGradSync)
     if ddp.world() > 1:
-        model = convert_sync_batchnorm(model)
+        model = ddp.convert_sync_batchnorm(model)
     # (EEADV_GRAD_SYNC=ddp: DistributedDataParallel as in the reference, :151-152)
     net, sync = ddp.make_grad_sync(model, device, find_unused_parameters=True)
     criterion = trainer.Criterion()

@@ -3,8 +3,10 @@ ROCm) across the xGMI links of one node; gloo on CPU for the multi-process tests
 
 What is sharded: the batch dimension only: every kernel of the path is per-sample, so a
 rank attacks its own shard with NO collective inside the PGD loop.  The single data-path exchange is the
-gradient all-reduce of the outer training step (45.1 MB fp32 for ResNet-18/200), issued by DDP in 16 MB
-buckets while the backward is still running.  Replaces the reference's nn.DataParallel (MNIST / Tiny
+gradient all-reduce of the outer training step (45.1 MB fp32 for ResNet-18/200): by default FlatGradSync
+below - one flat buffer in backward order, one all-reduce per model segment issued while the remaining
+segments' backward runs (the update stays a replay of captured graphs); EEADV_GRAD_SYNC=ddp selects
+DistributedDataParallel (16 MB buckets, eager update).  Replaces the reference's nn.DataParallel (MNIST / Tiny
 drivers, which re-broadcast the weights K+1 times per batch) and mirrors its ImageNet DDP scripts
 (ImageNet/experiments_imagenet.py:56,125-129,154-161,369-384).
 """
@@ -23,6 +25,10 @@ def rank():
 
 
 def local_rank():
+    """LOCAL_RANK; 0 on every rank under EEADV_SHARE_GPU=1 (rehearsals and tests of the N > 1 path on a one-GPU box: the ranks
+    time-share cuda:0 and exchange over gloo, see EEADV_DIST_BACKEND)"""
+    if os.environ.get("EEADV_SHARE_GPU", "0") == "1":
+        return 0
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
@@ -33,7 +39,7 @@ def setup(device=None, backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
-        backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+        backend = os.environ.get("EEADV_DIST_BACKEND") or ("nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo")
     kw = {"device_id": torch.device(device)} if backend == "nccl" else {}
     dist.init_process_group(backend, rank=rank(), world_size=world(), **kw)
 

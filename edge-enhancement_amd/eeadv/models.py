@@ -84,6 +84,30 @@ def _dense_f32(x):
     return x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
 
 
+def _route(conv, how):
+    """remember which implementation the last forward of this convolution took (bench.py: config.fallback_layers)"""
+    conv.__dict__["_ee_route"] = how
+    return conv
+
+
+# routes whose forward / backward-data run on a vendor library (MIOpen solvers, Tensile GEMMs) rather than on a kernel of csrc/
+_VENDOR_ROUTES = ("miopen", "tensile")
+
+
+def fallback_report(model):
+    """{"count", "of", "layers"}: the convolutions of `model` whose last forward went to MIOpen / Tensile, by module name and route
+    ("miopen": ATen's convolution both ways; "miopen+ee_wrw": only the weight gradient is ours; "tensile-dense2x2": the 3x3 on a 2x2 map
+    as one BLAS product).  A convolution that never ran is not counted."""
+    layers, total = [], 0
+    for name, m in model.named_modules():
+        if isinstance(m, nn.Conv2d) and "_ee_route" in m.__dict__:
+            total += 1
+            how = m.__dict__["_ee_route"]
+            if how.startswith(_VENDOR_ROUTES):
+                layers.append("%s:%s" % (name, how))
+    return {"count": len(layers), "of": total, "layers": layers}
+
+
 def stem_bn_pool(bn, pool, x, fork=False, conv_stats=None):
     """maxpool(relu(bn1(x))) of the ResNet stem (resnet.py:113-117): one fused pass each way when the shapes allow (ee_bn.hip, bn_pool_*),
     the two separate kernels - or the stock modules - otherwise."""
@@ -128,6 +152,7 @@ def s2_pair(block, x):
             or c1.in_channels != c3.in_channels or c1.out_channels != c3.out_channels or c3.in_channels % 32 or c3.out_channels % 32
             or not c3.weight.is_contiguous() or not c1.weight.is_contiguous()):
         return None
+    _route(c3, "ee_s2.pair"), _route(c1, "ee_s2.pair")
     return Conv3x3S2PairFn.apply(x, c3.weight, c1.weight)
 
 
@@ -151,6 +176,7 @@ def block_tail(block, bn, out, x, fork, sc=None):
         if ("conv" not in _STOCK and cv.kernel_size == (1, 1) and cv.stride == (2, 2) and cv.padding == (0, 0) and cv.bias is None and cv.groups == 1
                 and cv.in_channels % 2 == 0 and cv.out_channels % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                 and x.shape[3] <= _CONV1X1S2_MAXW and cv.in_channels <= _CONV1X1S2_MAXC and cv.weight.is_contiguous()):
+            _route(cv, "ee_conv.1x1s2")
             sc = Conv1x1S2Fn.apply(x, cv.weight)
             if sc.shape == out.shape:
                 b2 = ds[1]
@@ -171,7 +197,10 @@ def shortcut(block, x):
         if (cv.kernel_size == (1, 1) and cv.stride == (2, 2) and cv.padding == (0, 0) and cv.bias is None and cv.groups == 1
                 and cv.in_channels % 2 == 0 and cv.out_channels % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                 and x.shape[3] <= _CONV1X1S2_MAXW and cv.in_channels <= _CONV1X1S2_MAXC and cv.weight.is_contiguous()):
+            _route(cv, "ee_conv.1x1s2")
             return bn_act(ds[1], Conv1x1S2Fn.apply(x, cv.weight), relu=False)
+    if isinstance(ds, nn.Sequential) and len(ds) and isinstance(ds[0], nn.Conv2d):
+        _route(ds[0], "miopen")
     return ds(x)
 
 
@@ -182,16 +211,19 @@ def conv3(conv, x):
     plain = (type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1)
              and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros" and x.shape[2] == x.shape[3] and conv.weight.is_contiguous())
     if not plain:
-        return conv(x)
+        return _route(conv, "miopen")(x)
     hw, by32 = x.shape[2], conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
     if conv.stride == (1, 1):
         if hw == 2 and "dense" not in _STOCK:
+            _route(conv, "tensile-dense2x2")
             return Conv3x3Map2Fn.apply(x, conv.weight)
         if hw in (4, 8, 16) and by32 and "conv3" not in _STOCK and "wino" not in _STOCK:
+            _route(conv, "ee_wino")
             return Conv3x3WinoFn.apply(x, conv.weight)
     elif conv.stride == (2, 2) and hw in (4, 8, 16) and by32 and "conv3" not in _STOCK and "s2small" not in _STOCK:
+        _route(conv, "ee_s2.small")
         return Conv3x3S2SmallFn.apply(x, conv.weight)
-    return conv(x)
+    return _route(conv, "miopen")(x)
 
 
 def conv1(conv, x):
@@ -200,8 +232,9 @@ def conv1(conv, x):
     if ("conv" not in _STOCK and "wrw1x1" not in _STOCK and type(conv) is nn.Conv2d and _dense_f32(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 64 == 0
             and conv.out_channels % 64 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and conv.weight.is_contiguous()):
+        _route(conv, "miopen+ee_wrw")
         return Conv1x1Fn.apply(x, conv.weight)
-    return conv(x)
+    return _route(conv, "miopen")(x)
 
 
 def stem_conv(conv, x, want_stats=False):
@@ -211,7 +244,9 @@ def stem_conv(conv, x, want_stats=False):
             and (x.requires_grad or ops.stem7x7s2_fwd_supported(x, conv.weight))
             and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.bias is None and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and conv.weight.is_contiguous()):
+        _route(conv, "ee_conv.stem" if ops.stem7x7s2_fwd_supported(x, conv.weight) else "miopen(forward)+ee_conv.stem(backward-data)")
         return StemConvFn.apply(x, conv.weight, want_stats)
+    _route(conv, "miopen")
     return (conv(x), None) if want_stats else conv(x)
 
 
@@ -381,8 +416,10 @@ class Net_2(nn.Module):
                     state = runtime.draw_state(x.device)  # (exists: whoever captures creates it first - engine / trainer)
                 else:
                     drop = torch.empty((x.shape[0], 64), dtype=x.dtype, device=x.device).bernoulli_(keep)
+            _route(self.conv1, "ee_net2"), _route(self.conv2, "ee_net2")
             x = Net2ConvFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, drop, keep, state)
         else:
+            _route(self.conv1, "miopen"), _route(self.conv2, "miopen")
             x = F.relu(F.max_pool2d(self.conv1(x), 2))
             x = F.relu(F.max_pool2d(self.conv2_drop(self.conv2(x)), 2))
         x = x.view(-1, 4 * 4 * 64)

@@ -1,4 +1,5 @@
 """Process-wide switches of the host layer."""
+import atexit
 import os
 import shutil
 import tempfile
@@ -96,12 +97,33 @@ _MIOPEN_DB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file
 
 def use_shipped_miopen_db():
     """Point MIOpen's user find-db at a PRIVATE copy of `miopen_db/` (every process its own: MIOpen appends to the files, and eight ranks must
-    not share them).  Call before the first convolution.  A MIOPEN_USER_DB_PATH the caller has set wins; shapes the recorded db does not
-    know are searched as usual.  Returns the directory, or None when nothing was done."""
+    not share them; removed again when the process exits).  Call before the first convolution.  A MIOPEN_USER_DB_PATH the caller has set
+    wins; shapes the recorded db does not know are searched as usual.  Returns the directory, or None when nothing was done."""
     if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(_MIOPEN_DB):
         return None
     dst = tempfile.mkdtemp(prefix="eeadv_miopen_")
+    atexit.register(shutil.rmtree, dst, ignore_errors=True)
     for name in os.listdir(_MIOPEN_DB):
         shutil.copy(os.path.join(_MIOPEN_DB, name), dst)
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     return dst
+
+
+def shipped_miopen_db_matched(db_dir, device=None):
+    """Did MIOpen take the recorded find-db?  The shipped files are named after ONE MIOpen build and device
+    (`<arch><CU count in hex>.HIP.<major>_<minor>_<patch>_<build>.ufdb.txt`); any other build or device opens files of ITS name in the
+    same directory and finds them empty: it searches, or (without the search) takes its immediate-mode solvers - silently.  True when a
+    shipped file carries this process's MIOpen version, architecture and CU count AND MIOpen created no file of another name in the
+    private copy; False otherwise; None when there is no private copy."""
+    if not db_dir or not os.path.isdir(db_dir):
+        return None
+    shipped = set(os.listdir(_MIOPEN_DB))
+    try:
+        v = int(torch.backends.cudnn.version())  # MIOpen: major * 1e6 + minor * 1e3 + patch
+        props = torch.cuda.get_device_properties(torch.cuda.current_device() if device is None else device)
+        head = "%s%x.HIP.%d_%d_%d_" % (props.gcnArchName.split(":")[0], props.multi_processor_count, v // 1000000, (v // 1000) % 1000, v % 1000)
+    except Exception:  # noqa: BLE001 - no device / no MIOpen: nothing can have matched
+        return False
+    named = any(n.startswith(head) for n in shipped)
+    foreign = any(n not in shipped and (n.endswith(".ufdb.txt") or n.endswith(".udb.txt")) for n in os.listdir(db_dir))
+    return named and not foreign

@@ -211,3 +211,31 @@ def test_free_at_ee_script_runs_on_one_rank(tmp_path):
     state = torch.load(os.path.join(root, "model_pth", name), weights_only=True)
     assert state["arch"] == "resnet50_EE_square" and "module.layer4.1.bn2.running_var" in state["state_dict"]  # two blocks: resnet18
     assert "module.layer4.2.bn1.weight" not in state["state_dict"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grad_sync", ["flat", "ddp"])
+def test_free_at_script_two_ranks_share_one_gpu(tmp_path, grad_sync):
+    """`main()` of the free-AT script itself at world size 2 - the branch that converts to SyncBatchNorm and builds the gradient
+    exchange, which the one-rank test never enters.  Two ranks time-share cuda:0 and exchange over gloo (EEADV_SHARE_GPU /
+    EEADV_DIST_BACKEND); small shapes (resnet18, 224 x 224, 10 classes, global batch 8), one batch x 4 repeats, the PGD evaluation, the
+    checkpoint; both gradient-exchange modes."""
+    script = os.path.join(PKG, "ImageNet", "free_imagenet", "AT_free_imagenet_ddp.py")
+    env = dict(os.environ, EEADV_SHARE_GPU="1", EEADV_DIST_BACKEND="gloo", EEADV_GRAD_SYNC=grad_sync, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() % 300) + (0 if grad_sync == "flat" else 301)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           script, "-a", "resnet18", "-b", "8", "--num-classes", "10", "--data", "synthetic:1:1", "--print-freq", "1",
+           "--num-steps-1", "1", "--max-epochs", "1", "--output-root", str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    out = r.stdout
+    assert "n-repeats:4,world:2" in out
+    ep = [l for l in out.splitlines() if l.startswith("Epoch: [0]")]
+    assert len(ep) == 1  # rank 0 prints
+    loss = float(re.search(r"Loss ([\d.]+) ", ep[0]).group(1))
+    assert 0.5 < loss < 6.0  # ln(10) = 2.3 at initialisation
+    assert any(l.startswith(" * Adv Prec@1") for l in out.splitlines())
+    ck = [os.path.join(d, f) for d, _, fs in os.walk(str(tmp_path)) for f in fs if f.endswith("_0.pth")]
+    assert len(ck) == 1, ck
+    state = torch.load(ck[0], weights_only=True)
+    assert "module.layer4.1.bn2.running_var" in state["state_dict"] and state["epoch"] == 1
