@@ -25,6 +25,7 @@
 #include <cstring>
 
 #include "ee_common.hpp"
+#include "ee_fuse.hpp"
 
 namespace {
 
@@ -34,6 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int S2_NT = 512, S2_CK = 16, S2_RB = 32;  // 256 consumer + 256 producer lanes
 constexpr int S2_RS = 36;              // row stride of the partial-sum exchange: the four k of a wavefront on disjoint banks
+constexpr int S2_MAX_KC = 512;         // backward-data with PRE: reduction channels whose gamma * invstd table fits (2 x 2 KB of LDS)
 
 struct S2Dims {
     int B, KC, RC;  // reduction channels (Cin forward, Cout backward), result channels
@@ -108,9 +110,10 @@ constexpr int S2_XS = 9 * 4 * 2 * 64;  // forward: a round's inputs [tap][quad][
 // ---- forward: x [B][KC][H][H] -> y [B][RC][H/2][H/2].  1-D grid of (ceil(B / IMG) or 2 B) x RC / (16 MT) workgroups ------------------------------------
 // DS: the block's shortcut Conv2d(1x1, stride 2) of the SAME input (resnet.py:137-142) rides along as a tenth tap - its B operand is the centre
 // tap's plane - into accumulators of its own -> y1
-template <int H, int MT, bool DS>
+// POST (eval-mode BatchNorm folded in, ee_fuse.hpp): y = relu(bn(conv3x3s2(x))) by `post`, y1 = bn_ds(conv1x1s2(x)) by `post1`
+template <int H, int MT, bool DS, bool POST>
 __global__ __launch_bounds__(S2_NT, 4) void conv3s2_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w9, float *__restrict__ y,
-                                                                 float *__restrict__ y1, S2Dims d) {
+                                                                 float *__restrict__ y1, S2Dims d, FusePost post, FusePost post1) {
     using G = S2Geo<H>;
     constexpr int OH = G::OH, PX = G::PX, IMG = G::IMG, TAPS = DS ? 10 : 9;
     constexpr int WFM = TAPS * 4 * MT * 64, BUF = WFM + S2_XS, RB = 16 * MT;
@@ -287,6 +290,14 @@ __global__ __launch_bounds__(S2_NT, 4) void conv3s2_fwd_mfma_kernel(const float 
                 const float4 v = *reinterpret_cast<const float4 *>(rp + w * (RB * S2_RS));
                 s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
             }
+            if constexpr (POST) {
+                const FusePost &pp = set == 0 ? post : post1;
+                if (pp.mean) {
+                    const PostConst k = post_const(pp, co0 + co);
+                    s.x = post_apply(s.x, k), s.y = post_apply(s.y, k), s.z = post_apply(s.z, k), s.w = post_apply(s.w, k);
+                }
+                if (pp.relu) s.x = relu_keep_nan(s.x), s.y = relu_keep_nan(s.y), s.z = relu_keep_nan(s.z), s.w = relu_keep_nan(s.w);
+            }
             if (b0 + img < d.B) *reinterpret_cast<float4 *>((set == 0 ? y : y1) + dst) = s;
         }
     }
@@ -299,13 +310,16 @@ constexpr int S2_OS = 20;              // row stride of the interleave exchange 
 
 // DS: plus the backward-data of the block's shortcut Conv2d(1x1, stride 2): dy1 (same shape as dy) under the transposed 1x1 filters (the
 // tenth tap) lands on the even-even parity class only
-template <int H, int MT, bool DS>
+// PRE (eval-mode BatchNorm backward folded in, ee_fuse.hpp): the staged dy is (pre.mask > 0 ? dy : 0) * gamma / sqrt(var + eps) of `pre`
+// (the block's first BatchNorm + ReLU), the staged dy1 is dy1 * gamma / sqrt(var + eps) of `pre1` (the shortcut's BatchNorm)
+template <int H, int MT, bool DS, bool PRE>
 __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__restrict__ dy, const float *__restrict__ dy1, const float *__restrict__ w9,
-                                                                 float *__restrict__ dx, S2Dims d) {
+                                                                 float *__restrict__ dx, S2Dims d, FusePre pre, FusePre pre1) {
     using G = S2Geo<H>;
     constexpr int OH = G::OH, PX = G::PX, IMG = G::IMG, TAPS = DS ? 10 : 9;
     constexpr int WFM = TAPS * 4 * MT * 64, D1 = WFM + S2_DS, BUF = D1 + (DS ? 512 : 0), RB = 16 * MT, OW = 4 * 2 * RB * S2_OS;  // OW: one accumulator set in the exchange
     __shared__ __align__(16) float lds[2 * BUF];  // rounds: two buffers of {filters, dy shifts}; afterwards: two accumulator sets
+    __shared__ float wtab[PRE ? 2 * S2_MAX_KC : 1];  // PRE: gamma * invstd per reduction channel, of `pre` and of `pre1`
     static_assert(BUF >= OW, "the exchange fits the staging buffers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
     const bool producer = wave >= 4;
@@ -314,6 +328,11 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     if (!xcd_decode(blockIdx.x, d.RC / RB, H == 16 ? 2 * d.B : (d.B + IMG - 1) / IMG, d.wl, bx, by)) return;
     const int b0 = H == 16 ? bx >> 1 : bx * IMG, hh = H == 16 ? bx & 1 : 0, ci0 = by * RB;
     for (int i = threadIdx.x; i < S2_DS; i += S2_NT) lds[WFM + i] = lds[BUF + WFM + i] = 0.0f;  // shifted-out slots stay zero
+    if constexpr (PRE)
+        for (int c = threadIdx.x; c < d.KC; c += S2_NT) {
+            wtab[c] = bn_scale(pre.var, pre.gamma, pre.eps, c);
+            if (DS) wtab[S2_MAX_KC + c] = bn_scale(pre1.var, pre1.gamma, pre1.eps, c);
+        }
     const int rounds = d.KC / S2_CK;
     S2_W_SETUP();
     // dy of a round, one float4 per thread (the idle threads repeat a valid address and skip the write):
@@ -328,10 +347,10 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     const bool live = (H == 16 ? pt < 160 : pt < 128) && oy_s < OH;
     const int bi = b0 + img_s < d.B ? b0 + img_s : d.B - 1;
     const size_t doff = (static_cast<size_t>(bi) * d.KC + co_s) * PX + (H == 4 ? 0 : (oy_s < OH ? oy_s : OH - 1) * OH + 4 * half_s);
-    const float *dsrc = dy + doff, *dsrc1 = DS ? dy1 + doff : dy + doff;
+    const float *dsrc = dy + doff, *dsrc1 = DS ? dy1 + doff : dy + doff, *dsrcm = PRE ? pre.mask + doff : dy + doff;
     const bool live1 = DS && live && row_s < 4;  // the shortcut's gradient needs no shifted row
-    float4 Ada, Adb, Bda, Bdb;  // two NAMED register sets (A holds even rounds, B odd ones)
-    Adb = Bdb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 Ada, Adb, Bda, Bdb, Adm, Bdm;  // two NAMED register sets (A holds even rounds, B odd ones); dm: the mask of da (PRE)
+    Adb = Bdb = Adm = Bdm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     auto put1 = [&](float *d1, float4 v) {  // dy1 unshifted: [quad][column block][16 n][4 k]
         float *p = d1 + (co_s >> 2) * 128 + (co_s & 3) + s2_slot<H>(img_s, row_s) + 16 * half_s;
         p[0] = v.x, p[4] = v.y, p[8] = v.z, p[12] = v.w;
@@ -370,9 +389,15 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
         const size_t do_ = static_cast<size_t>((round_) < rounds ? (round_) : rounds - 1) * dstep; \
         S##da = *reinterpret_cast<const float4 *>(dsrc + do_);                                 \
         if (DS) S##db = *reinterpret_cast<const float4 *>(dsrc1 + do_);                        \
+        if constexpr (PRE) S##dm = *reinterpret_cast<const float4 *>(dsrcm + do_);             \
     } while (0)
-#define S2_PUT_D(buf_, S)                                                                      \
+#define S2_PUT_D(buf_, S, round_)                                                              \
     do {                                                                                       \
+        if constexpr (PRE) {                                                                   \
+            const int c_ = ((round_) < rounds ? (round_) : rounds - 1) * S2_CK + co_s;         \
+            S##da = scale4(wtab[c_], mask4(S##da, S##dm));                                     \
+            if (DS) S##db = scale4(wtab[S2_MAX_KC + c_], S##db);                               \
+        }                                                                                      \
         if (live) put((buf_) + WFM, S##da);                                                    \
         if (live1) put1((buf_) + D1, S##db);                                                   \
     } while (0)
@@ -413,7 +438,7 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     __syncthreads();  // the zero fill
     if (producer) {
         S2_STORE_W(buf0, A);
-        S2_PUT_D(buf0, A);
+        S2_PUT_D(buf0, A, 0);
         S2_LOAD_W(B, 1);
         S2_LOAD_D(B, 1);
         S2_LOAD_W(A, 2);
@@ -423,7 +448,7 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
     for (int round = 0; round < rounds; round += 2) {
         if (producer) {  // round + 1 (set B) -> buffer 1 while buffer 0 is multiplied
             S2_STORE_W(buf1, B);
-            S2_PUT_D(buf1, B);
+            S2_PUT_D(buf1, B, round + 1);
             S2_LOAD_W(B, round + 3);
             S2_LOAD_D(B, round + 3);
         } else {
@@ -433,7 +458,7 @@ __global__ __launch_bounds__(S2_NT) void conv3s2_bwd_mfma_kernel(const float *__
         if (round + 1 < rounds) {
             if (producer) {  // round + 2 (set A) -> buffer 0 while buffer 1 is multiplied
                 S2_STORE_W(buf0, A);
-                S2_PUT_D(buf0, A);
+                S2_PUT_D(buf0, A, round + 2);
                 S2_LOAD_W(A, round + 4);
                 S2_LOAD_D(A, round + 4);
             } else {
@@ -503,27 +528,35 @@ int s2_mt(bool bwd, int H) {
     return bwd ? 1 : 2;
 }
 
-template <int H, int MT, bool DS>
-int s2_launch(bool bwd, const float *in, const float *in1, const float *w9, float *out, float *out1, const S2Dims &d, hipStream_t st) {
+template <int H, int MT, bool DS, bool FUSED>
+int s2_launch(bool bwd, const float *in, const float *in1, const float *w9, float *out, float *out1, const S2Dims &d, hipStream_t st, const void *f0, const void *f1) {
     const dim3 grid(xcd_grid(H == 16 ? 2 * d.B : (d.B + S2Geo<H>::IMG - 1) / S2Geo<H>::IMG, d.RC / (16 * MT), d.wl));
     if (bwd) {
-        EE_LAUNCH((conv3s2_bwd_mfma_kernel<H, MT, DS>), grid, dim3(S2_NT), 0, st, in, in1, w9, out, d);
+        const FusePre pre = FUSED ? *static_cast<const FusePre *>(f0) : FusePre{}, pre1 = FUSED && f1 ? *static_cast<const FusePre *>(f1) : FusePre{};
+        EE_LAUNCH((conv3s2_bwd_mfma_kernel<H, MT, DS, FUSED>), grid, dim3(S2_NT), 0, st, in, in1, w9, out, d, pre, pre1);
     } else {
+        const FusePost post = FUSED ? *static_cast<const FusePost *>(f0) : FusePost{}, post1 = FUSED && f1 ? *static_cast<const FusePost *>(f1) : FusePost{};
         constexpr size_t bytes = 2 * ((DS ? 10 : 9) * 4 * MT * 64 + S2_XS) * sizeof(float);  // 54-76 KB: above the static limit
-        static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3s2_fwd_mfma_kernel<H, MT, DS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3s2_fwd_mfma_kernel<H, MT, DS, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             static_cast<int>(bytes)) == hipSuccess;
         if (!ok) return EE_ERR_UNSUPPORTED;
-        EE_LAUNCH((conv3s2_fwd_mfma_kernel<H, MT, DS>), grid, dim3(S2_NT), bytes, st, in, w9, out, out1, d);
+        EE_LAUNCH((conv3s2_fwd_mfma_kernel<H, MT, DS, FUSED>), grid, dim3(S2_NT), bytes, st, in, w9, out, out1, d, post, post1);
     }
     return launch_status();
 }
 
+// f0 / f1: null (the plain convolutions) or the two FusePost (forward) / FusePre (backward-data) of the eval-mode BatchNorms folded in
+template <bool DS, bool FUSED>
+int s2_dispatch_f(bool bwd, const float *in, const float *in1, const float *w9, float *out, float *out1, const S2Dims &d, int H, hipStream_t st, const void *f0, const void *f1) {
+    const int mt = s2_mt(bwd, H);
+    if (H == 16) return mt == 2 ? s2_launch<16, 2, DS, FUSED>(bwd, in, in1, w9, out, out1, d, st, f0, f1) : s2_launch<16, 1, DS, FUSED>(bwd, in, in1, w9, out, out1, d, st, f0, f1);
+    if (H == 8) return mt == 2 ? s2_launch<8, 2, DS, FUSED>(bwd, in, in1, w9, out, out1, d, st, f0, f1) : s2_launch<8, 1, DS, FUSED>(bwd, in, in1, w9, out, out1, d, st, f0, f1);
+    return mt == 2 ? s2_launch<4, 2, DS, FUSED>(bwd, in, in1, w9, out, out1, d, st, f0, f1) : s2_launch<4, 1, DS, FUSED>(bwd, in, in1, w9, out, out1, d, st, f0, f1);
+}
+
 template <bool DS>
 int s2_dispatch(bool bwd, const float *in, const float *in1, const float *w9, float *out, float *out1, const S2Dims &d, int H, hipStream_t st) {
-    const int mt = s2_mt(bwd, H);
-    if (H == 16) return mt == 2 ? s2_launch<16, 2, DS>(bwd, in, in1, w9, out, out1, d, st) : s2_launch<16, 1, DS>(bwd, in, in1, w9, out, out1, d, st);
-    if (H == 8) return mt == 2 ? s2_launch<8, 2, DS>(bwd, in, in1, w9, out, out1, d, st) : s2_launch<8, 1, DS>(bwd, in, in1, w9, out, out1, d, st);
-    return mt == 2 ? s2_launch<4, 2, DS>(bwd, in, in1, w9, out, out1, d, st) : s2_launch<4, 1, DS>(bwd, in, in1, w9, out, out1, d, st);
+    return s2_dispatch_f<DS, false>(bwd, in, in1, w9, out, out1, d, H, st, nullptr, nullptr);
 }
 
 int s2_check(const void *a, const void *b, const void *c, int B, int KC, int RC, int H) {
@@ -582,4 +615,37 @@ EE_API int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, co
     const S2Dims d{B, Cout, Cin, xcd_weights_local(2.0 * B * Cout * H * H, 40.0 * Cin * Cout, Cin / 32) ? 1 : 0};
     ProfScope prof(EE_K_CONV3S2_BWD, as_stream(stream), 2.0 * 10.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
     return s2_dispatch<true>(true, dy3, dy1, w10, dx, nullptr, d, H, as_stream(stream));
+}
+
+// The pair above with the eval-mode BatchNorms behind the two convolutions (running statistics) and the ReLU folded into the output stage:
+//     y3 = relu( bn1(conv3x3s2(x)) ),   y1 = bn_ds(conv1x1s2(x))                               resnet.py:50-59, :137-142 under model.eval()
+// - ee_conv3x3s2_pair_fwd_f32 followed by ee_bn_act_fwd_f32(training = 0) on each output, bit for bit, in one launch.  mean / var / gamma / beta: [Cout].
+EE_API int ee_conv3x3s2_pair_bn_eval_fwd_f32(const float *x, const float *w10, const float *mean3, const float *var3, const float *gamma3, const float *beta3,
+                                             float eps3, const float *mean1, const float *var1, const float *gamma1, const float *beta1, float eps1, float *y3,
+                                             float *y1, int B, int Cin, int Cout, int H, void *stream) {
+    const int rc = s2_check(x, w10, y3, B, Cin, Cout, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (!y1 || !mean3 || !var3 || !mean1 || !var1) return EE_ERR_NULL;
+    if (!aligned16(y1)) return EE_ERR_ALIGN;
+    const FusePost p3{mean3, var3, gamma3, beta3, eps3, nullptr, 1}, p1{mean1, var1, gamma1, beta1, eps1, nullptr, 0};
+    const S2Dims d{B, Cin, Cout, xcd_weights_local(4.0 * B * Cin * H * H, 40.0 * Cin * Cout, Cout / 32) ? 1 : 0};
+    ProfScope prof(EE_K_CONV3S2_FWD, as_stream(stream), 2.0 * 10.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
+    return s2_dispatch_f<true, true>(false, x, nullptr, w10, y3, y1, d, H, as_stream(stream), &p3, &p1);
+}
+
+// ... and its backward-data, given the gradients of y3 and y1 and y3 itself (the ReLU mask):
+//     dx = conv3x3s2^T( gamma3 / sqrt(var3 + eps3) * (y3 > 0) * dy3 ) + conv1x1s2^T( gamma1 / sqrt(var1 + eps1) * dy1 )
+// - two ee_bn_act_bwd_f32(training = 0) and ee_conv3x3s2_pair_bwd_data_f32 in one launch.  var / gamma: [Cout] (<= 512).
+EE_API int ee_conv3x3s2_pair_bn_eval_bwd_f32(const float *dy3, const float *y3, const float *dy1, const float *w10, const float *var3, const float *gamma3,
+                                             float eps3, const float *var1, const float *gamma1, float eps1, float *dx, int B, int Cin, int Cout, int H,
+                                             void *stream) {
+    const int rc = s2_check(dy3, w10, dx, B, Cout, Cin, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (!dy1 || !y3 || !var3 || !var1) return EE_ERR_NULL;
+    if (!aligned16(dy1) || !aligned16(y3)) return EE_ERR_ALIGN;
+    if (Cout > S2_MAX_KC) return EE_ERR_UNSUPPORTED;
+    const FusePre p3{nullptr, y3, nullptr, var3, gamma3, eps3}, p1{nullptr, nullptr, nullptr, var1, gamma1, eps1};
+    const S2Dims d{B, Cout, Cin, xcd_weights_local(2.0 * B * Cout * H * H, 40.0 * Cin * Cout, Cin / 32) ? 1 : 0};
+    ProfScope prof(EE_K_CONV3S2_BWD, as_stream(stream), 2.0 * 10.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
+    return s2_dispatch_f<true, true>(true, dy3, dy1, w10, dx, nullptr, d, H, as_stream(stream), &p3, &p1);
 }

@@ -14,6 +14,7 @@
 //
 // CNN-body glue, not a row of SURVEY.md section 8.
 #include "ee_common.hpp"
+#include "ee_fuse.hpp"
 
 namespace {
 
@@ -67,7 +68,13 @@ constexpr int W4_BUF = 16 * WN_US + 16 * W4_VS;   // U [16][16][48] + V [16][16]
 constexpr size_t W4_LDS = 2 * W4_BUF * sizeof(float);
 constexpr int W4_NT = 512;
 
-__global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino3x3_map4_kernel(const float *__restrict__ x, const float *__restrict__ u, float *__restrict__ y, WinoDims d) {
+// PRE / POST: eval-mode BatchNorm folded in (ee_fuse.hpp).  PRE 1: the staged input is mask > 0 ? x : 0 times the channel's gamma * invstd
+// (BatchNorm + ReLU backward with running statistics), PRE 2: with a second input piece added first; both write the masked sum to pre.store
+// (one workgroup per image) when it is given.  POST: the output transform applies (c - mean) * invstd * gamma + beta, the residual, the ReLU.
+// PRE = 0, POST = false is the plain convolution, instruction for instruction what it was.
+template <int PRE, bool POST>
+__global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino3x3_map4_kernel(const float *__restrict__ x, const float *__restrict__ u, float *__restrict__ y, WinoDims d,
+                                                                                                        FusePre pre, FusePost post) {
     extern __shared__ __align__(16) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave >= 4;
@@ -85,12 +92,21 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // patch of this producer lane: channel ci_x of the round, tile t_x = (image, ty, tx) of the workgroup's 16
     const int ci_x = pt >> 4, t_x = pt & 15, ty = (t_x >> 1) & 1, tx = t_x & 1;
     const int xb = b + (t_x >> 2) < d.B ? b + (t_x >> 2) : d.B - 1;  // past the batch: a valid image, never stored
-    const float *xsrc = x + (static_cast<size_t>(xb) * d.KC + ci_x) * 16 + 4 * ty;  // rows ty .. ty+2 of the plane (patch rows 2ty-1 .. 2ty+2 minus the padding one)
+    const size_t xo = (static_cast<size_t>(xb) * d.KC + ci_x) * 16 + 4 * ty;
+    const float *xsrc = x + xo;  // rows ty .. ty+2 of the plane (patch rows 2ty-1 .. 2ty+2 minus the padding one)
     const size_t ustep = static_cast<size_t>(WN_CK) * d.RC, xstep = static_cast<size_t>(WN_CK) * 16;
     const int rounds = d.KC / WN_CK;
+    float *wtab = lds + 2 * W4_BUF;  // PRE: gamma * invstd of every reduction channel
+    if constexpr (PRE != 0) {
+        for (int c = threadIdx.x; c < d.KC; c += W4_NT) wtab[c] = bn_scale(pre.var, pre.gamma, pre.eps, c);
+        __syncthreads();
+    }
+    const bool pre_store = PRE != 0 && pre.store != nullptr && by == 0 && tx == 0 && b + (t_x >> 2) < d.B;
     // one round's prefetch of a producer lane: 8 float4 of U, 3 rows of its input plane - two sets (A, B) of NAMED registers filled by
     // straight-line code (as a struct handed to a lambda they lived in scratch memory)
     float4 Au0, Au1, Au2, Au3, Au4, Au5, Au6, Au7, Ax0, Ax1, Ax2, Bu0, Bu1, Bu2, Bu3, Bu4, Bu5, Bu6, Bu7, Bx0, Bx1, Bx2;
+    float4 Am0, Am1, Am2, Bm0, Bm1, Bm2, Ay0, Ay1, Ay2, By0, By1, By2;  // PRE: the mask rows and the second piece's rows
+    Am0 = Am1 = Am2 = Bm0 = Bm1 = Bm2 = Ay0 = Ay1 = Ay2 = By0 = By1 = By2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #define W4_FETCH(S, round_)                                                                        \
     do {                                                                                           \
         const int r_ = (round_) < rounds ? (round_) : rounds - 1; /* always issued */              \
@@ -107,7 +123,32 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         S##x0 = *reinterpret_cast<const float4 *>(xp_);                                            \
         S##x1 = *reinterpret_cast<const float4 *>(xp_ + 4);                                        \
         S##x2 = *reinterpret_cast<const float4 *>(xp_ + 8);                                        \
+        if constexpr (PRE >= 1) {                                                                  \
+            const float *mp_ = pre.mask + xo + r_ * xstep;                                         \
+            S##m0 = *reinterpret_cast<const float4 *>(mp_);                                        \
+            S##m1 = *reinterpret_cast<const float4 *>(mp_ + 4);                                    \
+            S##m2 = *reinterpret_cast<const float4 *>(mp_ + 8);                                    \
+        }                                                                                          \
+        if constexpr (PRE >= 2) {                                                                  \
+            const float *yp_ = pre.add + xo + r_ * xstep;                                          \
+            S##y0 = *reinterpret_cast<const float4 *>(yp_);                                        \
+            S##y1 = *reinterpret_cast<const float4 *>(yp_ + 4);                                    \
+            S##y2 = *reinterpret_cast<const float4 *>(yp_ + 8);                                    \
+        }                                                                                          \
     } while (0)
+    // PRE: dz = mask > 0 ? (x + add) : 0 of the three rows, written out by the lanes that own them (tx = 0: rows 0-2 with ty = 0, row 3
+    // with ty = 1), then times the channel's gamma * invstd
+    auto pre_rows = [&](float4 &p0, float4 &p1, float4 &p2, float4 y0, float4 y1, float4 y2, float4 m0, float4 m1, float4 m2, int round_) {
+        if constexpr (PRE >= 2) p0 = sum4(p0, y0), p1 = sum4(p1, y1), p2 = sum4(p2, y2);
+        p0 = mask4(p0, m0), p1 = mask4(p1, m1), p2 = mask4(p2, m2);
+        if (pre_store && round_ < rounds) {
+            float *sp = pre.store + xo + round_ * xstep;
+            if (ty == 0) *reinterpret_cast<float4 *>(sp) = p0, *reinterpret_cast<float4 *>(sp + 4) = p1;
+            *reinterpret_cast<float4 *>(sp + 8) = p2;
+        }
+        const float w = wtab[(round_ < rounds ? round_ : rounds - 1) * WN_CK + ci_x];
+        p0 = scale4(w, p0), p1 = scale4(w, p1), p2 = scale4(w, p2);
+    };
     // V = B^T d B of this lane's patch from the three rows p0..p2 (rows ty .. ty+2 of the plane) -> buffer `buf`.  Patch rows: ty = 0:
     // (pad, row 0, 1, 2); ty = 1: (row 1, 2, 3, pad); columns likewise with tx
     auto transform = [&](float *buf, float4 p0, float4 p1, float4 p2) {
@@ -145,7 +186,7 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }
     };
     // U slice and V of a fetched round -> buffer `buf_`
-#define W4_STAGE(buf_, S)                                                                          \
+#define W4_STAGE(buf_, S, round_)                                                                  \
     do {                                                                                           \
         float *ud_ = (buf_) + xi_s * WN_US + ci_s * WN_CP + 4 * uq; /* row urow0 + 32 j -> xi = xi_s + 2 j */ \
         *reinterpret_cast<float4 *>(ud_) = S##u0;                                                  \
@@ -156,6 +197,7 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         *reinterpret_cast<float4 *>(ud_ + 10 * WN_US) = S##u5;                                     \
         *reinterpret_cast<float4 *>(ud_ + 12 * WN_US) = S##u6;                                     \
         *reinterpret_cast<float4 *>(ud_ + 14 * WN_US) = S##u7;                                     \
+        if constexpr (PRE != 0) pre_rows(S##x0, S##x1, S##x2, S##y0, S##y1, S##y2, S##m0, S##m1, S##m2, round_); \
         transform(buf_, S##x0, S##x1, S##x2);                                                      \
     } while (0)
     f32x4 acc[4][2];
@@ -185,7 +227,7 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // producers: set B holds round r + 1 when iteration r starts (r even), set A round r + 2; the set just staged is refilled with round r + 3
     if (producer) {
         W4_FETCH(A, 0);
-        W4_STAGE(lds, A);
+        W4_STAGE(lds, A, 0);
         W4_FETCH(B, 1);
         W4_FETCH(A, 2);
     }
@@ -193,7 +235,7 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     for (int round = 0; round < rounds; round += 2) {
         // iteration `round` (even): current buffer 0, next buffer 1
         if (producer) {
-            W4_STAGE(lds + W4_BUF, B);  // round + 1 (past the end: the last slice again, nobody reads it)
+            W4_STAGE(lds + W4_BUF, B, round + 1);  // round + 1 (past the end: the last slice again, nobody reads it)
             W4_FETCH(B, round + 3);
         } else {
             multiply(lds);
@@ -201,7 +243,7 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         __syncthreads();
         if (round + 1 < rounds) {  // iteration round + 1: current buffer 1, next buffer 0
             if (producer) {
-                W4_STAGE(lds, A);  // round + 2
+                W4_STAGE(lds, A, round + 2);  // round + 2
                 W4_FETCH(A, round + 4);
             } else {
                 multiply(lds + W4_BUF);
@@ -237,9 +279,21 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             t1[j] = (mm[1][j] - mm[2][j]) - mm[3][j];
         }
         if (b + img < d.B) {
-            float *o = y + ((static_cast<size_t>(b + img) * d.RC + co0 + co) * 4 + 2 * oy) * 4 + 2 * ox;
-            *reinterpret_cast<float2 *>(o) = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]);
-            *reinterpret_cast<float2 *>(o + 4) = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
+            const size_t oo = ((static_cast<size_t>(b + img) * d.RC + co0 + co) * 4 + 2 * oy) * 4 + 2 * ox;
+            float2 r0 = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]), r1 = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
+            if constexpr (POST) {
+                if (post.mean) {
+                    const PostConst k = post_const(post, co0 + co);
+                    r0.x = post_apply(r0.x, k), r0.y = post_apply(r0.y, k), r1.x = post_apply(r1.x, k), r1.y = post_apply(r1.y, k);
+                }
+                if (post.res) {
+                    const float2 q0 = *reinterpret_cast<const float2 *>(post.res + oo), q1 = *reinterpret_cast<const float2 *>(post.res + oo + 4);
+                    r0.x += q0.x, r0.y += q0.y, r1.x += q1.x, r1.y += q1.y;
+                }
+                if (post.relu) r0.x = relu_keep_nan(r0.x), r0.y = relu_keep_nan(r0.y), r1.x = relu_keep_nan(r1.x), r1.y = relu_keep_nan(r1.y);
+            }
+            *reinterpret_cast<float2 *>(y + oo) = r0;
+            *reinterpret_cast<float2 *>(y + oo + 4) = r1;
         }
     }
 }
@@ -281,9 +335,10 @@ struct PcGeo {
 // in the same order per accumulator: bit-identical results.
 constexpr int PC_CW = 8, PC_XPW = 16 / PC_CW;
 
-template <int MAP>
+// PRE / POST: see wino3x3_map4_kernel
+template <int MAP, int PRE, bool POST>
 __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(PcGeo<MAP>::WPE, PcGeo<MAP>::WPE))) void wino3x3_pc_kernel(const float *__restrict__ x, const float *__restrict__ u,
-                                                                                                     float *__restrict__ y, WinoDims d) {
+                                                                                                     float *__restrict__ y, WinoDims d, FusePre pre, FusePost post) {
     using G = PcGeo<MAP>;
     static_assert(G::XF4 == 1 && G::PPT == 1 && (G::UPL == 2 || G::UPL == 4), "8x8 or 16x16 maps");
     extern __shared__ __align__(16) float lds[];
@@ -303,10 +358,20 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     const size_t uxi4 = G::PW * static_cast<size_t>(d.KC) * d.RC, ustep = static_cast<size_t>(G::CK) * d.RC;
     // pixels of a round: 16x16: the 8 planes are contiguous, float4 number pt; 8x8: image pt >> 7, float4 pt & 127 of its 8 planes
     const int ximg = MAP == 8 ? pt >> 7 : 0, xbi = b + ximg < d.B ? b + ximg : d.B - 1;  // past the batch: a valid image, never stored
-    const float *xsrc = x + static_cast<size_t>(xbi) * d.KC * (MAP * MAP) + 4 * (MAP == 8 ? pt & 127 : pt);
+    // (element offsets fit 31 bits: wino_check) a 32-bit lane offset under a per-round uniform base = the scalar-base form of the global load
+    const unsigned xo = static_cast<unsigned>(xbi) * static_cast<unsigned>(d.KC * (MAP * MAP)) + 4u * (MAP == 8 ? pt & 127 : pt);
+    const float *xsrc = x + xo;
     const size_t xstep = static_cast<size_t>(G::CK) * (MAP * MAP);
     float4 UA0, UA1, UA2, UA3, UB0, UB1, UB2, UB3, XA0, XB0;  // NAMED register sets (see the 4x4 kernel)
     UA2 = UA3 = UB2 = UB3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 XA1, XB1, XA2, XB2;  // PRE: the second piece (1) and the mask (2) of the same pixels
+    XA1 = XB1 = XA2 = XB2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float *wtab = lds + 2 * G::BUF;  // PRE: gamma * invstd of every reduction channel (filled before the prologue's first barrier)
+    const int ci_p = MAP == 8 ? (pt & 127) >> 4 : pt >> 6;  // this producer lane's channel inside a round
+    // 16x16 with PRE: the plain kernel sits at the 128 registers four wavefronts per SIMD leave; three pixel streams in two prefetch sets
+    // spilled (54 registers).  There pixels and filters travel ONE round ahead in one set (a round is ~1.3 us: enough for an L2 hit) instead of two
+    constexpr bool ONE_X = MAP == 16 && PRE != 0;
+    const bool pre_store = PRE != 0 && pre.store != nullptr && by == 0 && b + ximg < d.B;
 #define PC_FETCH_U(S, round_)                                                                      \
     do {                                                                                           \
         const int r_ = (round_) < rounds ? (round_) : rounds - 1; /* always issued */              \
@@ -323,6 +388,8 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
         const int r_ = (round_) < rounds ? (round_) : rounds - 1;                                  \
         const float *xp_ = xsrc + r_ * xstep;                                                      \
         S##0 = *reinterpret_cast<const float4 *>(xp_);                                             \
+        if constexpr (PRE >= 1) S##2 = *reinterpret_cast<const float4 *>((pre.mask + r_ * xstep) + xo); \
+        if constexpr (PRE >= 2) S##1 = *reinterpret_cast<const float4 *>((pre.add + r_ * xstep) + xo);  \
     } while (0)
 #define PC_STORE_U(buf_, S)                                                                        \
     do {                                                                                           \
@@ -346,8 +413,16 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
         float *dst = xs + ci * G::XP + img * G::XI + (1 + row) * G::XW + 1 + c4;
         dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
     };
-#define PC_PUT_X(buf_, S)                                                                          \
+    // PRE: dz = mask > 0 ? (x + add) : 0, written out by the by = 0 workgroup of the image, then times the channel's gamma * invstd
+    auto pre_px = [&](float4 v, float4 a, float4 m, int round_) {
+        if constexpr (PRE >= 2) v = sum4(v, a);
+        v = mask4(v, m);
+        if (pre_store && round_ < rounds) *reinterpret_cast<float4 *>((pre.store + round_ * xstep) + xo) = v;
+        return scale4(wtab[(round_ < rounds ? round_ : rounds - 1) * G::CK + ci_p], v);
+    };
+#define PC_PUT_X(buf_, S, round_)                                                                  \
     do {                                                                                           \
+        if constexpr (PRE != 0) S##0 = pre_px(S##0, S##1, S##2, round_);                           \
         put_x((buf_) + 16 * G::US + 16 * G::VS, S##0);                                             \
     } while (0)
     // V = B^T d B of this lane's patches, from the frames of `buf` into its V
@@ -426,15 +501,21 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
         PC_FETCH_X(XB, 1);
     }
     for (int i = threadIdx.x; i < G::XS; i += G::NT) lds[16 * G::US + 16 * G::VS + i] = lds[G::BUF + 16 * G::US + 16 * G::VS + i] = 0.0f;  // zero rings
+    if constexpr (PRE != 0)
+        for (int c = threadIdx.x; c < d.KC; c += G::NT) wtab[c] = bn_scale(pre.var, pre.gamma, pre.eps, c);
     __syncthreads();  // the zero rings
     if (producer) {
-        PC_PUT_X(buf0, XA);
-        PC_PUT_X(buf1, XB);
+        PC_PUT_X(buf0, XA, 0);
+        PC_PUT_X(buf1, XB, 1);
         PC_STORE_U(buf0, UA);
-        PC_FETCH_U(UB, 1);
-        PC_FETCH_U(UA, 2);
+        if constexpr (ONE_X) {
+            PC_FETCH_U(UA, 1);
+        } else {
+            PC_FETCH_U(UB, 1);
+            PC_FETCH_U(UA, 2);
+        }
         PC_FETCH_X(XA, 2);
-        PC_FETCH_X(XB, 3);
+        if constexpr (!ONE_X) PC_FETCH_X(XB, 3);
     }
     __syncthreads();
     if (producer) transform(buf0);
@@ -445,13 +526,19 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
         WT_BEGIN;
         if (producer) {
             WT_P0;
-            PC_STORE_U(buf1, UB);
+            if constexpr (ONE_X) PC_STORE_U(buf1, UA);
+            else PC_STORE_U(buf1, UB);
             WT_P(0);
             transform(buf1);
             WT_P(1);
-            PC_PUT_X(buf0, XA);
-            PC_FETCH_U(UB, round + 3);
-            PC_FETCH_X(XA, round + 4);
+            PC_PUT_X(buf0, XA, round + 2);
+            if constexpr (ONE_X) {
+                PC_FETCH_U(UA, round + 2);
+                PC_FETCH_X(XA, round + 3);
+            } else {
+                PC_FETCH_U(UB, round + 3);
+                PC_FETCH_X(XA, round + 4);
+            }
             WT_P(2);
         } else {
             multiply(buf0);
@@ -463,9 +550,15 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
             if (producer) {
                 PC_STORE_U(buf0, UA);
                 transform(buf0);
-                PC_PUT_X(buf1, XB);
-                PC_FETCH_U(UA, round + 4);
-                PC_FETCH_X(XB, round + 5);
+                if constexpr (ONE_X) {
+                    PC_PUT_X(buf1, XA, round + 3);
+                    PC_FETCH_U(UA, round + 3);
+                    PC_FETCH_X(XA, round + 4);
+                } else {
+                    PC_PUT_X(buf1, XB, round + 3);
+                    PC_FETCH_U(UA, round + 4);
+                    PC_FETCH_X(XB, round + 5);
+                }
             } else {
                 multiply(buf1);
             }
@@ -494,6 +587,24 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ms[((nb * 16 + PC_XPW * wave + a) * WN_CO + 16 * m + 4 * lq + r) * 16 + l15] = acc[a][nb][m][r];
     }
+    // POST: the lane's channel constants and its residual values are fetched while the accumulators settle in LDS
+    PostConst pk{0.0f, 1.0f, 0.0f};
+    float2 q0[G::NB], q1[G::NB];
+    if constexpr (POST) {
+        if (threadIdx.x < 512) {
+            const int co = threadIdx.x >> 4, tl = threadIdx.x & 15;
+            pk = post_const(post, co0 + co);
+            if (post.res) {
+#pragma unroll
+                for (int nb = 0; nb < G::NB; ++nb) {
+                    const int t = 16 * nb + tl, img = t / G::TI, ti = t - img * G::TI, ty = ti / G::TX, tx = ti - ty * G::TX;
+                    const int bi = b + img < d.B ? b + img : d.B - 1;
+                    const float *rp = post.res + ((static_cast<size_t>(bi) * d.RC + co0 + co) * MAP + 2 * ty) * MAP + 2 * tx;
+                    q0[nb] = *reinterpret_cast<const float2 *>(rp), q1[nb] = *reinterpret_cast<const float2 *>(rp + MAP);
+                }
+            }
+        }
+    }
     __syncthreads();
     if (threadIdx.x < 512) {
         const int idx = threadIdx.x;  // (co, tile of a block)
@@ -513,9 +624,15 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
                 t1[j] = (mm[1][j] - mm[2][j]) - mm[3][j];
             }
             if (b + img < d.B) {
-                float *o = y + ((static_cast<size_t>(b + img) * d.RC + co0 + co) * MAP + 2 * ty) * MAP + 2 * tx;
-                *reinterpret_cast<float2 *>(o) = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]);
-                *reinterpret_cast<float2 *>(o + MAP) = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
+                const size_t oo = ((static_cast<size_t>(b + img) * d.RC + co0 + co) * MAP + 2 * ty) * MAP + 2 * tx;
+                float2 r0 = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]), r1 = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
+                if constexpr (POST) {
+                    if (post.mean) r0.x = post_apply(r0.x, pk), r0.y = post_apply(r0.y, pk), r1.x = post_apply(r1.x, pk), r1.y = post_apply(r1.y, pk);
+                    if (post.res) r0.x += q0[nb].x, r0.y += q0[nb].y, r1.x += q1[nb].x, r1.y += q1[nb].y;
+                    if (post.relu) r0.x = relu_keep_nan(r0.x), r0.y = relu_keep_nan(r0.y), r1.x = relu_keep_nan(r1.x), r1.y = relu_keep_nan(r1.y);
+                }
+                *reinterpret_cast<float2 *>(y + oo) = r0;
+                *reinterpret_cast<float2 *>(y + oo + MAP) = r1;
             }
         }
     }
@@ -523,23 +640,46 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     WT_DUMP;
 }
 
-template <int MAP>
-int wino_pc_launch(const float *x, const float *u, float *y, const WinoDims &d, hipStream_t st) {
+constexpr int WN_MAX_KC = 512;  // PRE: the channel-scale table behind the two round buffers (2 KB; the 16x16 kernel has 5 KB to spare)
+
+template <int MAP, int PRE, bool POST>
+int wino_pc_launch(const float *x, const float *u, float *y, const WinoDims &d, const FusePre &pre, const FusePost &post, hipStream_t st) {
     using G = PcGeo<MAP>;
-    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_pc_kernel<MAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(G::lds_bytes)) == hipSuccess;
+    constexpr size_t bytes = G::lds_bytes + (PRE ? WN_MAX_KC * sizeof(float) : 0);
+    static_assert(bytes <= 160 * 1024, "fits the LDS of a CU");
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_pc_kernel<MAP, PRE, POST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(bytes)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH(wino3x3_pc_kernel<MAP>, dim3(xcd_grid((d.B + G::IMG - 1) / G::IMG, d.RC / WN_CO, d.wl)), dim3(G::NT), G::lds_bytes,
-              st, x, u, y, d);
+    EE_LAUNCH((wino3x3_pc_kernel<MAP, PRE, POST>), dim3(xcd_grid((d.B + G::IMG - 1) / G::IMG, d.RC / WN_CO, d.wl)), dim3(G::NT), bytes,
+              st, x, u, y, d, pre, post);
     return launch_status();
 }
 
-int wino_map4_launch(const float *x, const float *u, float *y, const WinoDims &d, hipStream_t st) {
-    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_map4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(W4_LDS)) == hipSuccess;
+template <int PRE, bool POST>
+int wino_map4_launch(const float *x, const float *u, float *y, const WinoDims &d, const FusePre &pre, const FusePost &post, hipStream_t st) {
+    constexpr size_t bytes = W4_LDS + (PRE ? WN_MAX_KC * sizeof(float) : 0);
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_map4_kernel<PRE, POST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(bytes)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH(wino3x3_map4_kernel, dim3(xcd_grid((d.B + 3) / 4, d.RC / WN_CO, d.wl)), dim3(W4_NT), W4_LDS, st, x, u, y, d);
+    EE_LAUNCH((wino3x3_map4_kernel<PRE, POST>), dim3(xcd_grid((d.B + 3) / 4, d.RC / WN_CO, d.wl)), dim3(W4_NT), bytes, st, x, u, y, d, pre, post);
     return launch_status();
+}
+
+template <int PRE, bool POST>
+int wino_dispatch(const float *x, const float *u, float *y, const WinoDims &d, int H, const FusePre &pre, const FusePost &post, hipStream_t st) {
+    if (H == 4) return wino_map4_launch<PRE, POST>(x, u, y, d, pre, post, st);
+    if (H == 8) return wino_pc_launch<8, PRE, POST>(x, u, y, d, pre, post, st);
+    return wino_pc_launch<16, PRE, POST>(x, u, y, d, pre, post, st);
+}
+
+int wino_check(const float *x, const float *u, const float *y, int B, int KC, int RC, int H) {
+    if (B < 0 || KC < 1 || RC < 1) return EE_ERR_SHAPE;
+    if (KC % WN_CK != 0 || RC % WN_CO != 0 || (H != 4 && H != 8 && H != 16)) return EE_ERR_UNSUPPORTED;
+    if (B == 0) return EE_OK;
+    if (!x || !u || !y) return EE_ERR_NULL;
+    if (!aligned16(x) || !aligned16(u) || !aligned16(y)) return EE_ERR_ALIGN;
+    if (static_cast<int64_t>(B) * (KC > RC ? KC : RC) * H * H > 0x7fffffffLL) return EE_ERR_SHAPE;
+    return EE_OK;
 }
 
 }  // namespace
@@ -547,18 +687,55 @@ int wino_map4_launch(const float *x, const float *u, float *y, const WinoDims &d
 // y = conv3x3(x) for H x H maps (H = 4, 8 or 16) with the filters given in the transform domain: u [16][KC][RC], u[4i+j][k][r] =
 // (G g G^T)[i][j] of the (r, k) filter pair the product needs (forward: g = w[r][k]; backward-data: g = w[k][r] rotated by 180 degrees).
 EE_API int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int RC, int H, void *stream) {
-    if (B < 0 || KC < 1 || RC < 1) return EE_ERR_SHAPE;
-    if (KC % WN_CK != 0 || RC % WN_CO != 0 || (H != 4 && H != 8 && H != 16)) return EE_ERR_UNSUPPORTED;
-    if (B == 0) return EE_OK;
-    if (!x || !u || !y) return EE_ERR_NULL;
-    if (!aligned16(x) || !aligned16(u) || !aligned16(y)) return EE_ERR_ALIGN;
-    if (static_cast<int64_t>(B) * (KC > RC ? KC : RC) * H * H > 0x7fffffffLL) return EE_ERR_SHAPE;
+    const int rc = wino_check(x, u, y, B, KC, RC, H);
+    if (rc != EE_OK || B == 0) return rc;
     const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
     // the convolution's ALGORITHMIC flops (2 * 9 * KC * RC per output pixel); the kernel executes 4/9 of them (16 multiplies per 2x2 tile)
     ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
-    if (H == 4) return wino_map4_launch(x, u, y, d, as_stream(stream));
-    if (H == 8) return wino_pc_launch<8>(x, u, y, d, as_stream(stream));
-    return wino_pc_launch<16>(x, u, y, d, as_stream(stream));
+    return wino_dispatch<0, false>(x, u, y, d, H, FusePre{}, FusePost{}, as_stream(stream));
+}
+
+// The same convolution with an eval-mode BatchNorm (running statistics), the block's residual and the ReLU in its output transform:
+//     y = [relu]( (conv3x3(x) - mean) * (gamma / sqrt(var + eps)) + beta [+ res] )          resnet.py:44-59 under model.eval()
+// - what ee_wino3x3_f32 followed by ee_bn_act_fwd_f32(training = 0) computes, bit for bit, in one launch and without the round trip of the
+// convolution's output through memory.  mean / var / gamma / beta: [Cout] (gamma, beta may be null: 1, 0); res: [B][Cout][H][H] or null.
+EE_API int ee_wino3x3_bn_eval_fwd_f32(const float *x, const float *u, const float *mean, const float *var, const float *gamma, const float *beta,
+                                      float eps, const float *res, int relu, float *y, int B, int Cin, int Cout, int H, void *stream) {
+    const int rc = wino_check(x, u, y, B, Cin, Cout, H);
+    if (rc != EE_OK || B == 0) return rc;
+    const FusePost post{mean, var, gamma, beta, eps, res, relu};
+    const int pc = check_post(post);
+    if (pc != EE_OK) return pc;
+    const WinoDims d{B, Cin, Cout, xcd_weights_local(4.0 * B * Cin * H * H, 64.0 * Cin * Cout, Cout / WN_CO) ? 1 : 0};
+    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
+    return wino_dispatch<0, true>(x, u, y, d, H, FusePre{}, post, as_stream(stream));
+}
+
+// ... and its backward with respect to x, given the gradient of y in one or two pieces (dy2 may be null) and y itself (the ReLU mask):
+//     dz = (y > 0) * (dy + dy2),   dx = conv3x3^T( gamma / sqrt(var + eps) * dz ),   dres = dz (optional: the residual branch's gradient)
+// - ee_bn_act_bwd2_f32(training = 0, relu = 1) followed by ee_wino3x3_f32 on the backward filter set `u_b` ([16][Cout][Cin]), in one launch.
+// var / gamma: [Cout] of the BatchNorm behind the convolution.  dx_add (optional, [B][Cin][H][H]): added to dx in the output transform - the
+// gradient that reaches the block's input through its identity branch, so that ONE summed gradient leaves the block (dx + dx_add in the
+// order ee_bn.hip's backward adds the two pieces of a forked output).
+EE_API int ee_wino3x3_bn_eval_bwd_f32(const float *dy, const float *dy2, const float *y, const float *u_b, const float *var, const float *gamma, float eps,
+                                      float *dres, const float *dx_add, float *dx, int B, int Cin, int Cout, int H, void *stream) {
+    const int rc = wino_check(dy, u_b, dx, B, Cout, Cin, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (!y) return EE_ERR_NULL;
+    if (Cout > WN_MAX_KC) return EE_ERR_UNSUPPORTED;
+    const FusePre pre{dy2, y, dres, var, gamma, eps};
+    const int pc = check_pre(pre);
+    if (pc != EE_OK) return pc;
+    const WinoDims d{B, Cout, Cin, xcd_weights_local(4.0 * B * Cout * H * H, 64.0 * Cin * Cout, Cin / WN_CO) ? 1 : 0};
+    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
+    if (dx_add) {
+        const FusePost post{nullptr, nullptr, nullptr, nullptr, 0.0f, dx_add, 0};
+        if (!aligned16(dx_add)) return EE_ERR_ALIGN;
+        if (dy2) return wino_dispatch<2, true>(dy, u_b, dx, d, H, pre, post, as_stream(stream));
+        return wino_dispatch<1, true>(dy, u_b, dx, d, H, pre, post, as_stream(stream));
+    }
+    if (dy2) return wino_dispatch<2, false>(dy, u_b, dx, d, H, pre, FusePost{}, as_stream(stream));
+    return wino_dispatch<1, false>(dy, u_b, dx, d, H, pre, FusePost{}, as_stream(stream));
 }
 
 #ifdef EE_WINO_TIMING

@@ -84,6 +84,10 @@ SIGNATURES = {
     # dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, rm, rv, eps, training, dx, dgamma, dbeta, workspace, B, C, H, W, stream
     "ee_bn_relu_pool_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wino3x3_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    # x, u, mean, var, gamma, beta, eps, res, relu, y, B, Cin, Cout, H, stream
+    "ee_wino3x3_bn_eval_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    # dy, dy2, y, u_b, var, gamma, eps, dres, dx_add, dx, B, Cin, Cout, H, stream
+    "ee_wino3x3_bn_eval_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wrw3x3_workspace_floats": [c_i, c_i, c_i, c_i],
     "ee_wrw3x3_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wrw3x3s2_workspace_floats": [c_i, c_i, c_i, c_i, c_i],
@@ -97,6 +101,10 @@ SIGNATURES = {
     "ee_conv_weight_prep_f32": [c_i, c_p, c_p, c_p, c_i, c_i, c_p],
     "ee_conv3x3s2_pair_fwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_pair_bwd_data_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    # x, w10, mean3, var3, gamma3, beta3, eps3, mean1, var1, gamma1, beta1, eps1, y3, y1, B, Cin, Cout, H, stream
+    "ee_conv3x3s2_pair_bn_eval_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    # dy3, y3, dy1, w10, var3, gamma3, eps3, var1, gamma1, eps1, dx, B, Cin, Cout, H, stream
+    "ee_conv3x3s2_pair_bn_eval_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_net2_conv_wrw_workspace_floats": [c_i],
     "ee_net2_conv_wrw_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p],
     "ee_net2_conv_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],

@@ -16,7 +16,7 @@ import weakref
 import torch
 
 from . import ops, runtime
-from .functional import input_grad_only, refresh_dense_weights
+from .functional import attack_forward, input_grad_only, refresh_dense_weights
 
 CE_SUM, CE_MEAN, KL, SOFTCE = "ce_sum", "ce_mean", "kl", "softce"
 # the input-gradient pass runs on the calling thread: handing it to autograd's device thread puts cross-thread stream
@@ -53,7 +53,7 @@ def _body_input_grad(model, x_in, spec, through_body):
     the cross-entropy and the way back as ONE launch (ops.fc_ce_grad) instead of five; the ResNets' head_grad declines (measured slower)."""
     pre = getattr(model, "body_pre", None) if _FC_HEAD and (through_body or not hasattr(model, "front_chain")) else None
     if pre is not None and spec.kind in (CE_SUM, CE_MEAN) and x_in.is_cuda and hasattr(model, "head_grad"):
-        with torch.enable_grad():
+        with torch.enable_grad(), attack_forward():
             z = pre(x_in)
         dz = model.head_grad(z.detach(), spec.payload, "mean" if spec.kind == CE_MEAN else "sum")
         if dz is not None:
@@ -63,7 +63,7 @@ def _body_input_grad(model, x_in, spec, through_body):
         with torch.enable_grad():
             logits = model.head_from_pre(z)
     else:
-        with torch.enable_grad():
+        with torch.enable_grad(), attack_forward():
             logits = model.body(x_in) if through_body else model(x_in)
     d = spec.dlogits(logits.contiguous())
     with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):

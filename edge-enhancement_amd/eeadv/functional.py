@@ -26,6 +26,27 @@ class input_grad_only:
         _INPUT_GRAD_ONLY = self._prev
 
 
+# The attack loop's forward passes (engine._body_input_grad) are differentiated with respect to the INPUT only.  Inside attack_forward()
+# an eval-mode residual block may therefore take the kernels with BatchNorm folded in (EvalBasicBlockFn / EvalDownBlockFn below), which
+# produce no parameter gradients at all; any other eval-mode forward with autograd on keeps the per-layer Functions.
+_ATTACK_FORWARD = False
+
+
+class attack_forward:
+    def __enter__(self):
+        global _ATTACK_FORWARD
+        self._prev, _ATTACK_FORWARD = _ATTACK_FORWARD, True
+
+    def __exit__(self, *exc):
+        global _ATTACK_FORWARD
+        _ATTACK_FORWARD = self._prev
+
+
+def input_only_forward():
+    """True where a forward pass will never be asked for parameter gradients: inside the attack loop, or with autograd off"""
+    return _ATTACK_FORWARD or not torch.is_grad_enabled()
+
+
 # EEADV_STOCK_WRW=1: the weight gradients of the 3x3 layers (and the stride-2 shortcuts) from ATen / MIOpen instead of ee_wrw.hip (an A/B switch for measurements)
 _STOCK_WRW = os.environ.get("EEADV_STOCK_WRW", "0") == "1"
 
@@ -562,6 +583,67 @@ class Conv3x3WinoFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
             dw = conv3x3_weight_grad(x, dy, weight)
         return dx, dw
+
+
+def _bn_fwd_consts(g, b, rm, rv, eps):
+    return (rm, rv, g, b, eps)
+
+
+class EvalBasicBlockFn(torch.autograd.Function):
+    """relu(bn2(conv2(relu(bn1(conv1(x))))) + x): a BasicBlock without shortcut convolution (resnet.py:44-59) under model.eval(), TWO launches
+    each way - the Winograd kernels with the running-statistics BatchNorm, the residual and the ReLU in their output transform (forward)
+    and the BatchNorm / ReLU backward in their input staging (backward-data): ee_wino3x3_bn_eval_*.  Bit-identical to the per-layer
+    sequence (Conv3x3WinoFn, BnActFn) it replaces: four launches each way.  Input gradient only: the parameters get None
+    (models.BasicBlock takes this path where functional.input_only_forward() holds).  x arrives as the two tensors of a forked output;
+    ONE summed gradient goes back (to the first)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, w1, w2, g1, b1, rm1, rv1, eps1, g2, b2, rm2, rv2, eps2, fork):
+        out1 = ops.wino3x3_bn_eval_fwd(xa, wino_sets(w1)[0], _bn_fwd_consts(g1, b1, rm1, rv1, eps1), None, True)
+        out2 = ops.wino3x3_bn_eval_fwd(out1, wino_sets(w2)[0], _bn_fwd_consts(g2, b2, rm2, rv2, eps2), xa, True)
+        ctx.save_for_backward(out1, out2, w1, w2, g1, rv1, g2, rv2)
+        ctx.eps = (eps1, eps2)
+        ctx.set_materialize_grads(False)
+        return (out2, out2.view_as(out2)) if fork else out2
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out1, out2, w1, w2, g1, rv1, g2, rv2 = ctx.saved_tensors
+        none = (None,) * 15
+        dy, dy2 = _two_pieces(grads)
+        if dy is None or not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return none
+        d1, dres = ops.wino3x3_bn_eval_bwd(dy, dy2, out2, wino_sets(w2)[1], (rv2, g2, ctx.eps[1]), True)
+        dx, _ = ops.wino3x3_bn_eval_bwd(d1, None, out1, wino_sets(w1)[1], (rv1, g1, ctx.eps[0]), False, dx_add=dres)
+        return (dx,) + none[1:]
+
+
+class EvalDownBlockFn(torch.autograd.Function):
+    """relu(bn2(conv2(relu(bn1(conv1(x))))) + bn_ds(conv_ds(x))): a down-sampling BasicBlock (resnet.py:44-59, :137-142) under model.eval(),
+    TWO launches each way: ee_conv3x3s2_pair_bn_eval_* (both stride-2 convolutions with their BatchNorms) and ee_wino3x3_bn_eval_* (conv2,
+    bn2, the shortcut's sum, the ReLU).  Bit-identical to Conv3x3S2PairFn, BnActFn, Conv3x3WinoFn, BnDualFn - four launches each way."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, w3, wd, w2, g1, b1, rm1, rv1, eps1, gd, bd, rmd, rvd, epsd, g2, b2, rm2, rv2, eps2, fork):
+        w10 = _dense_weight(w3, "s2p_f", wd)
+        _dense_weight(w3, "s2p_b", wd)  # created outside any capture; the backward only reads it
+        out1, sc = ops.conv3x3s2_pair_bn_eval_fwd(xa, w10, w3.shape[0], _bn_fwd_consts(g1, b1, rm1, rv1, eps1), _bn_fwd_consts(gd, bd, rmd, rvd, epsd))
+        out2 = ops.wino3x3_bn_eval_fwd(out1, wino_sets(w2)[0], _bn_fwd_consts(g2, b2, rm2, rv2, eps2), sc, True)
+        ctx.save_for_backward(out1, out2, w3, wd, w2, g1, rv1, gd, rvd, g2, rv2)
+        ctx.eps = (eps1, epsd, eps2)
+        ctx.set_materialize_grads(False)
+        return (out2, out2.view_as(out2)) if fork else out2
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out1, out2, w3, wd, w2, g1, rv1, gd, rvd, g2, rv2 = ctx.saved_tensors
+        none = (None,) * 21
+        dy, dy2 = _two_pieces(grads)
+        if dy is None or not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return none
+        d1, dsc = ops.wino3x3_bn_eval_bwd(dy, dy2, out2, wino_sets(w2)[1], (rv2, g2, ctx.eps[2]), True)
+        dx = ops.conv3x3s2_pair_bn_eval_bwd(d1, out1, dsc, _dense_weight(w3, "s2p_b", wd), w3.shape[1], (rv1, g1, ctx.eps[0]), (rvd, gd, ctx.eps[1]))
+        return (dx,) + none[1:]
 
 
 class Conv3x3S2SmallFn(torch.autograd.Function):

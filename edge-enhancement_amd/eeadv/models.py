@@ -22,7 +22,8 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
                         get_gaussian_kernel)
 
 from . import hfs as _hfs, ops, runtime, syncbn as _syncbn
-from .functional import Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1Fn, Conv1x1S2Fn, Conv3x3Map2Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from . import functional as _fn
+from .functional import EvalBasicBlockFn, EvalDownBlockFn, Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1Fn, Conv1x1S2Fn, Conv3x3Map2Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -463,6 +464,47 @@ def conv3x3(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
+def _plain_bn(bn):
+    return type(bn) is BatchNorm2d and not bn.training and bn.affine and bn.track_running_stats and bn.weight.dtype == torch.float32
+
+
+def _plain_conv3(cv, stride):
+    return (type(cv) is nn.Conv2d and cv.kernel_size == (3, 3) and cv.stride == (stride, stride) and cv.padding == (1, 1) and cv.dilation == (1, 1)
+            and cv.groups == 1 and cv.bias is None and cv.padding_mode == "zeros" and cv.in_channels % 32 == 0 and cv.out_channels % 32 == 0
+            and cv.weight.is_contiguous())
+
+
+def _bn_args(bn):
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+def eval_block(block, xm, xs, fork):
+    """A BasicBlock under model.eval() where only the input gradient can be asked for (the attack loop, or autograd off): BatchNorm with
+    running statistics is folded into the convolution kernels - two launches each way instead of four (functional.EvalBasicBlockFn /
+    EvalDownBlockFn; EEADV_STOCK_GLUE=evalfuse switches it off).  Returns None where it does not apply (train mode, SyncBatchNorm, maps
+    other than 4 / 8 / 16 wide after the block's stride, channel counts the kernels do not take, parameter gradients wanted)."""
+    if ("evalfuse" in _STOCK or "bn" in _STOCK or "conv3" in _STOCK or "wino" in _STOCK or block.training or not _fn.input_only_forward()
+            or not _dense_f32(xm) or xm.dim() != 4 or xm.shape[2] != xm.shape[3] or not _plain_bn(block.bn1) or not _plain_bn(block.bn2)
+            or not _plain_conv3(block.conv2, 1) or block.conv2.out_channels > 512):
+        return None
+    ds, hw = block.downsample, xm.shape[2]
+    if ds is None:
+        if hw not in (4, 8, 16) or not _plain_conv3(block.conv1, 1) or block.conv1.in_channels != block.conv2.out_channels:
+            return None
+        _route(block.conv1, "ee_wino+bn"), _route(block.conv2, "ee_wino+bn")
+        return EvalBasicBlockFn.apply(xm, xs, block.conv1.weight, block.conv2.weight, *_bn_args(block.bn1), *_bn_args(block.bn2), fork and _FORK)
+    if ("s2pair" in _STOCK or "s2small" in _STOCK or hw not in (8, 16) or not _plain_conv3(block.conv1, 2) or not isinstance(ds, nn.Sequential) or len(ds) != 2
+            or type(ds[0]) is not nn.Conv2d or not _plain_bn(ds[1])):
+        return None
+    c1 = ds[0]
+    if (c1.kernel_size != (1, 1) or c1.stride != (2, 2) or c1.padding != (0, 0) or c1.groups != 1 or c1.bias is not None or c1.in_channels != block.conv1.in_channels
+            or c1.out_channels != block.conv1.out_channels or not c1.weight.is_contiguous()):
+        return None
+    _route(block.conv1, "ee_s2.pair+bn"), _route(c1, "ee_s2.pair+bn"), _route(block.conv2, "ee_wino+bn")
+    return EvalDownBlockFn.apply(xm, xs, block.conv1.weight, c1.weight, block.conv2.weight, *_bn_args(block.bn1), *_bn_args(ds[1]), *_bn_args(block.bn2),
+                                 fork and _FORK)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -479,6 +521,10 @@ class BasicBlock(nn.Module):
     def forward(self, x, fork=False):
         """x: a tensor, or the two tensors of the previous block's forked output; fork: hand this block's output on the same way"""
         xm, xs = _pair(x)
+        if not self.training:
+            out = eval_block(self, xm, xs, fork)
+            if out is not None:
+                return out
         both = s2_pair(self, xm) if self.downsample is not None else None
         if both is not None:  # conv1 and the shortcut's convolution in one launch; the identity piece xs gets no gradient of its own
             return block_tail(self, self.bn2, conv3(self.conv2, bn_act(self.bn1, both[0])), xs, fork, sc=both[1])

@@ -795,6 +795,64 @@ def wino3x3(x, u):
     return y
 
 
+def _optf(t, name, shape=None):
+    return None if t is None else _chk(t, torch.float32, name, shape)
+
+
+def wino3x3_bn_eval_fwd(x, u, bn, res, relu):
+    """[relu]( bn(conv3x3(x)) [+ res] ) with bn in eval mode (running statistics) in ONE launch: bn = (mean, var, gamma, beta, eps)"""
+    B, KC, H = x.shape[0], x.shape[1], x.shape[2]
+    RC = u.shape[2]
+    mean, var, gamma, beta, eps = bn
+    y = torch.empty((B, RC, H, H), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_wino3x3_bn_eval_fwd_f32(_chk(x, torch.float32, "x", (B, KC, H, H)), _chk(u, torch.float32, "u", (16, KC, RC)),
+                                             _chk(mean, torch.float32, "running_mean", (RC,)), _chk(var, torch.float32, "running_var", (RC,)),
+                                             _optf(gamma, "gamma", (RC,)), _optf(beta, "beta", (RC,)), float(eps), _optf(res, "res", (B, RC, H, H)),
+                                             1 if relu else 0, y.data_ptr(), B, KC, RC, H, _stream()), "ee_wino3x3_bn_eval_fwd_f32")
+    return y
+
+
+def wino3x3_bn_eval_bwd(dy, dy2, y, u_b, bn, want_dres, dx_add=None):
+    """dz = (y > 0) * (dy [+ dy2]); dx = conv3x3^T(gamma / sqrt(var + eps) * dz) [+ dx_add] in ONE launch -> (dx, dz or None).
+    bn = (var, gamma, eps) of the BatchNorm behind the convolution; u_b [16, Cout, Cin]."""
+    B, Cout, H = dy.shape[0], dy.shape[1], dy.shape[2]
+    Cin = u_b.shape[2]
+    var, gamma, eps = bn
+    dx = torch.empty((B, Cin, H, H), dtype=torch.float32, device=dy.device)
+    dres = torch.empty_like(dy) if want_dres else None
+    N.check(N.lib.ee_wino3x3_bn_eval_bwd_f32(_chk(dy, torch.float32, "dy", (B, Cout, H, H)), _optf(dy2, "dy2", (B, Cout, H, H)),
+                                             _chk(y, torch.float32, "y", (B, Cout, H, H)), _chk(u_b, torch.float32, "u_b", (16, Cout, Cin)),
+                                             _chk(var, torch.float32, "running_var", (Cout,)), _optf(gamma, "gamma", (Cout,)), float(eps),
+                                             None if dres is None else dres.data_ptr(), _optf(dx_add, "dx_add", (B, Cin, H, H)), dx.data_ptr(),
+                                             B, Cin, Cout, H, _stream()), "ee_wino3x3_bn_eval_bwd_f32")
+    return dx, dres
+
+
+def conv3x3s2_pair_bn_eval_fwd(x, w10, cout, bn3, bn1):
+    """(relu(bn3(conv3x3s2(x))), bn1(conv1x1s2(x))) with both BatchNorms in eval mode, ONE launch: bn = (mean, var, gamma, beta, eps)"""
+    B, Cin, H = x.shape[0], x.shape[1], x.shape[2]
+    y3 = torch.empty((B, cout, H // 2, H // 2), dtype=torch.float32, device=x.device)
+    y1 = torch.empty_like(y3)
+    N.check(N.lib.ee_conv3x3s2_pair_bn_eval_fwd_f32(
+        _chk(x, torch.float32, "x", (B, Cin, H, H)), _chk(w10, torch.float32, "w10", (cout // 32, Cin // 16, 10, 4, 2, 16, 4)),
+        _chk(bn3[0], torch.float32, "mean3", (cout,)), _chk(bn3[1], torch.float32, "var3", (cout,)), _optf(bn3[2], "gamma3", (cout,)), _optf(bn3[3], "beta3", (cout,)), float(bn3[4]),
+        _chk(bn1[0], torch.float32, "mean1", (cout,)), _chk(bn1[1], torch.float32, "var1", (cout,)), _optf(bn1[2], "gamma1", (cout,)), _optf(bn1[3], "beta1", (cout,)), float(bn1[4]),
+        y3.data_ptr(), y1.data_ptr(), B, Cin, cout, H, _stream()), "ee_conv3x3s2_pair_bn_eval_fwd_f32")
+    return y3, y1
+
+
+def conv3x3s2_pair_bn_eval_bwd(dy3, y3, dy1, w10, cin, bn3, bn1):
+    """dx = conv3x3s2^T(gamma3 / sqrt(var3 + eps3) * (y3 > 0) * dy3) + conv1x1s2^T(gamma1 / sqrt(var1 + eps1) * dy1); bn = (var, gamma, eps)"""
+    B, Cout, OH = dy3.shape[0], dy3.shape[1], dy3.shape[2]
+    dx = torch.empty((B, cin, 2 * OH, 2 * OH), dtype=torch.float32, device=dy3.device)
+    N.check(N.lib.ee_conv3x3s2_pair_bn_eval_bwd_f32(
+        _chk(dy3, torch.float32, "dy3", (B, Cout, OH, OH)), _chk(y3, torch.float32, "y3", (B, Cout, OH, OH)), _chk(dy1, torch.float32, "dy1", (B, Cout, OH, OH)),
+        _chk(w10, torch.float32, "w10", (cin // 32, Cout // 16, 10, 4, 2, 16, 4)), _chk(bn3[0], torch.float32, "var3", (Cout,)), _optf(bn3[1], "gamma3", (Cout,)),
+        float(bn3[2]), _chk(bn1[0], torch.float32, "var1", (Cout,)), _optf(bn1[1], "gamma1", (Cout,)), float(bn1[2]), dx.data_ptr(), B, cin, Cout, 2 * OH,
+        _stream()), "ee_conv3x3s2_pair_bn_eval_bwd_f32")
+    return dx
+
+
 def wrw3x3_supported(x, dy):
     """ee_wrw.hip: weight gradient of a 3x3 / stride 1 / padding 1 convolution on 2x2, 4x4, 8x8 or 16x16 maps"""
     return (x.dim() == 4 and dy.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (2, 4, 8, 16) and x.shape[2:] == dy.shape[2:]

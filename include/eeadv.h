@@ -369,6 +369,24 @@ int ee_conv1x1s2_bwd_f32(const float *dy, const float *weight, float *dx, int B,
  * ee_conv3x3s2_small_* kernels below superseded on every shape of the BASELINE configs.) */
 int ee_wino3x3_f32(const float *x, const float *u, float *y, int B, int KC, int RC, int H, void *stream);
 
+/* ---- eval-mode BatchNorm folded into the convolutions (round 4) ---------------------------------------------------------------------------
+ * Every validate() pass (experiments_tinyimagenet.py:337 `model.eval()`, then PGD-10/50/100 at :354-358) and the inner loops of ALP / TRADES
+ * (utils/attacks.py:249, :405) differentiate the classifier in eval mode: BatchNorm reads its RUNNING statistics and is the per-channel
+ * constant map (x - mean) * gamma / sqrt(var + eps) + beta - nothing crosses workgroups, so it needs no launch of its own.  These entry
+ * points replace [convolution, BatchNorm(+ residual)(+ ReLU)] (forward) and [BatchNorm/ReLU backward, backward-data convolution] of
+ * resnet.py:44-59 by ONE launch each; the expressions and their order are those of ee_bn_act_fwd_f32 / ee_bn_act_bwd2_f32 with
+ * training = 0, so the results equal the unfused sequence bit for bit.  mean / var / gamma / beta are [channels] device arrays (gamma / beta
+ * may be NULL: 1 / 0).
+ *   forward   y = [relu]( (conv3x3(x) - mean) * gamma / sqrt(var + eps) + beta [+ res] )           x [B,Cin,H,H], u = EE_WPREP_WINO_F, res / y [B,Cout,H,H]
+ *   backward  dz = (y > 0) * (dy [+ dy2]);  dres <- dz (optional);  dx = conv3x3^T( gamma / sqrt(var + eps) * dz ) [+ dx_add]
+ *             dy, dy2, y, dres [B,Cout,H,H]; u_b = EE_WPREP_WINO_B; var / gamma [Cout] (Cout <= 512); dx_add / dx [B,Cin,H,H].  dy2 = the second
+ *             piece of a forked output's gradient; dres = the gradient of the block's residual input; dx_add = what reaches the block's input
+ *             through the identity branch (one summed gradient then leaves the block). */
+int ee_wino3x3_bn_eval_fwd_f32(const float *x, const float *u, const float *mean, const float *var, const float *gamma, const float *beta, float eps,
+                               const float *res, int relu, float *y, int B, int Cin, int Cout, int H, void *stream);
+int ee_wino3x3_bn_eval_bwd_f32(const float *dy, const float *dy2, const float *y, const float *u_b, const float *var, const float *gamma, float eps,
+                               float *dres, const float *dx_add, float *dx, int B, int Cin, int Cout, int H, void *stream);
+
 /* The WEIGHT gradient of the same convolution (`loss.backward()` of the training step, experiments_tinyimagenet.py:304-306; resnet.py:26-31) on
  * H x H maps, H = 2, 4, 8 or 16, as Winograd F(3x3, 2x2) around the f32 matrix cores: x [B,Cin,H,H] (the layer's input), dy [B,Cout,H,H] (the
  * gradient of its output) -> dw [Cout,Cin,3,3] (overwritten).  The sum over images and tiles is split over ~256 workgroups whose partial results
@@ -410,6 +428,15 @@ int ee_conv3x3s2_small_bwd_data_f32(const float *dy, const float *w9, float *dx,
  * conv1x1s2^T(dy1) in one pass (the block's input gradient arrives summed). */
 int ee_conv3x3s2_pair_fwd_f32(const float *x, const float *w10, float *y3, float *y1, int B, int Cin, int Cout, int H, void *stream);
 int ee_conv3x3s2_pair_bwd_data_f32(const float *dy3, const float *dy1, const float *w10, float *dx, int B, int Cin, int Cout, int H, void *stream);
+/* ... with the eval-mode BatchNorms behind the two convolutions folded in (see ee_wino3x3_bn_eval_*; resnet.py:50-59, :137-142 under model.eval()):
+ *   forward   y3 = relu( bn1(conv3x3s2(x)) ),  y1 = bn_ds(conv1x1s2(x))       (mean3 .. eps3: the block's bn1; mean1 .. eps1: downsample[1])
+ *   backward  dx = conv3x3s2^T( gamma3 / sqrt(var3 + eps3) * (y3 > 0) * dy3 ) + conv1x1s2^T( gamma1 / sqrt(var1 + eps1) * dy1 )     (Cout <= 512) */
+int ee_conv3x3s2_pair_bn_eval_fwd_f32(const float *x, const float *w10, const float *mean3, const float *var3, const float *gamma3, const float *beta3,
+                                      float eps3, const float *mean1, const float *var1, const float *gamma1, const float *beta1, float eps1, float *y3,
+                                      float *y1, int B, int Cin, int Cout, int H, void *stream);
+int ee_conv3x3s2_pair_bn_eval_bwd_f32(const float *dy3, const float *y3, const float *dy1, const float *w10, const float *var3, const float *gamma3,
+                                      float eps3, const float *var1, const float *gamma1, float eps1, float *dx, int B, int Cin, int Cout, int H,
+                                      void *stream);
 
 /* The filters of the convolution kernels above in the order those kernels read them, from the Conv2d weight [Cout,Cin,3,3] (one launch;
  * the host rebuilds them once per optimiser step, inside the captured update graph):
