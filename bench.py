@@ -58,8 +58,13 @@ WORKLOADS = {
     # gradient) + noise update + SGD step.
     "imagenet_free_at": dict(arch="resnet50", method="free_AT", batch=32, shape=(3, 224, 224), classes=1000,
                              eps=4.0 / 255, alpha=4.0 / 255, steps=4, lr=0.1, momentum=0.9, wd=1e-4),
+    # One batch of validate() (Tiny_ImageNet/experiments_tinyimagenet.py:326-397) for the headline model: model.eval() (:337), PGD with
+    # num_steps_2 = 50 / step_size_2 = 1/255 (ee_at_bpda3_square.yml), then the clean and the adversarial forward under no_grad and the
+    # two cross-entropies / top-k (:376-395).  The reference's log: 3.076 s per batch of 100 (LOG_B3:1310).  No optimiser.
+    "tiny_ee_eval_pgd50": dict(arch="resnet18_EE_square", method="EE_BPDA3_AT_square", batch=100, shape=(3, 64, 64), classes=200,
+                               eps=0.062745098039216, alpha=0.003921568627451, steps=50, lr=0.1, momentum=0.9, wd=2e-4, eval_only=True),
 }
-OTHER_WORKLOADS = ("tiny_trades", "mnist_ee_at", "imagenet_free_at")  # the other BASELINE configs, timed briefly behind the headline one
+OTHER_WORKLOADS = ("tiny_trades", "mnist_ee_at", "imagenet_free_at", "tiny_ee_eval_pgd50")  # the other BASELINE configs, timed briefly behind the headline one
 
 
 class Args:
@@ -130,7 +135,15 @@ def cpu_baseline(cfg, seconds_target=25.0, threads=None):
     args = Args(random=True, epsilon=cfg["eps"])
     noise = torch.zeros(B, *cfg["shape"]) if cfg["method"] == "free_AT" else None
 
+    if cfg.get("eval_only"):
+        model.eval()
+
     def step():
+        if cfg.get("eval_only"):  # one batch of validate(): attack, clean and adversarial forward, the two losses
+            adv = R.PGD(model, args, x, y, cfg["steps"], cfg["alpha"])
+            with torch.no_grad():
+                F.cross_entropy(model(x), y), F.cross_entropy(model(adv), y)
+            return
         if cfg["method"] == "free_AT":
             for _ in range(cfg["steps"]):
                 R.free_at_repeat(model, F.cross_entropy, opt, x, y, noise, cfg["alpha"], cfg["eps"])
@@ -177,6 +190,9 @@ class Job:
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
         self.free_at = cfg["method"] == "free_AT"
+        self.eval_only = bool(cfg.get("eval_only"))
+        if self.eval_only:
+            model.eval()  # experiments_tinyimagenet.py:337
         if self.free_at and world > 1:  # AT_free_imagenet_ddp.py:149
             model = ddp.convert_sync_batchnorm(model)
         self.model = model
@@ -203,6 +219,8 @@ class Job:
         x, y = self.batches[i % len(self.batches)]
         if self.free_at:
             return self.free_step(x, y)
+        if self.eval_only:  # one batch of validate(): attack in eval mode + clean and adversarial forward + losses + top-k
+            return trainer.validate_batch(self.run_model, self.criterion, self.dargs, x, y, self.dev, self.cfg["steps"], self.cfg["alpha"], self.cfg["classes"])
         return trainer.train_batch(self.run_model, self.criterion, self.optimizer, self.dargs, x, y, self.dev, sync=self.sync)
 
     def describe(self):
@@ -211,6 +229,9 @@ class Job:
             return "%s: %s free-AT, per-rank batch %d x %s, %d repeats per batch, clip_eps %.4f fgsm_step %.4f, each repeat = fwd + bwd (weights and input) + noise update + SGD%s" % (
                 self.name, cfg["arch"], cfg["batch"], "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"],
                 ", SyncBatchNorm + gradient all-reduce (RCCL)" if self.world > 1 else "")
+        if self.eval_only:
+            return "%s: %s %s, one batch of validate(): model.eval(), per-rank batch %d x %s, PGD-%d eps %.4f alpha %.4f + clean and adversarial forward, CE, top-k" % (
+                self.name, cfg["arch"], cfg["method"], cfg["batch"], "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"])
         return "%s: %s %s, per-rank batch %d x %s, PGD-%d eps %.4f alpha %.4f, train step incl. SGD%s" % (
             self.name, cfg["arch"], cfg["method"], cfg["batch"], "x".join(map(str, cfg["shape"])), cfg["steps"], cfg["eps"], cfg["alpha"],
             ", DDP all-reduce (RCCL)" if self.world > 1 else "")

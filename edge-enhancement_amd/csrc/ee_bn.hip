@@ -808,6 +808,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_apply_kernel(const floa
 // (the gradient sums are taken over a different partition, so dgamma / dbeta / dx agree to rounding).
 struct PoolShape {
     int B, C, H, W, OH, OW, IPW, G;  // IPW images per workgroup, G = ceil(B / IPW) groups
+    int nosums;                      // backward, eval mode, no parameter gradients wanted: pass 1 did not run, pass 2 needs no sums
 };
 
 // Statistics handed over by the producing convolution (ee_conv.hip: the stem forward writes, per output channel and workgroup,
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_pool_bwd_kernel(const float *__re
     const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
     const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
     float m1 = 0.0f, m2 = 0.0f;
-    if (APPLY) {
+    if (APPLY && !p.nosums) {
         __shared__ float parts[2 * SPLIT_MAX];  // the G partial sums, one parallel load (a loop of dependent global loads cost 8 us)
         for (int i = threadIdx.x; i < 2 * p.G; i += SPLIT_NT) parts[i] = ws[static_cast<size_t>(c) * p.G * 2 + i];
         __syncthreads();
@@ -1028,7 +1029,7 @@ inline bool pool_shape(int B, int C, int H, int W, PoolShape &p) {
     if (B < 1 || C < 1 || H < 1 || W < 4 || W % 4 || static_cast<int64_t>(H) * W > 16000) return false;  // one plane in 64 KB of LDS (ImageNet: 112 x 112)
     if (static_cast<int64_t>(B) * C * H * W / 4 > 0x7fffffffLL) return false;
     const int ipw = (B + SPLIT_MAX - 1) / SPLIT_MAX;
-    p = PoolShape{B, C, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, ipw, (B + ipw - 1) / ipw};
+    p = PoolShape{B, C, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, ipw, (B + ipw - 1) / ipw, 0};
     return true;
 }
 
@@ -1311,8 +1312,12 @@ EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, 
     hipStream_t st = as_stream(stream);
     const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(p.G)), block(SPLIT_NT);
     const size_t lds = (static_cast<size_t>(p.OH) * p.OW * 5 + 15) / 16 * 16;  // floats + bytes
-    EE_LAUNCH((bn_pool_bwd_kernel<false>), grid, block, lds, st, dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
-              training, dx, dgamma, dbeta, workspace, p);
+    // eval mode (running statistics) and no parameter gradients wanted - every iteration of an eval-mode attack: dx = a * dz needs no sums
+    p.nosums = (!training && !dgamma && !dbeta) ? 1 : 0;
+    if (p.nosums && !dx) return EE_OK;
+    if (!p.nosums)
+        EE_LAUNCH((bn_pool_bwd_kernel<false>), grid, block, lds, st, dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
+                  training, dx, dgamma, dbeta, workspace, p);
     EE_LAUNCH((bn_pool_bwd_kernel<true>), grid, block, lds, st, dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
               training, dx, dgamma, dbeta, workspace, p);
     return launch_status();

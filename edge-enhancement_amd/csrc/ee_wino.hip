@@ -45,6 +45,13 @@ __device__ int g_wino_sub;
 #define WT_DUMP
 #endif
 
+// the float4 held by another lane of the same quad: DPP quad_perm CTRL = p0 | p1 << 2 | p2 << 4 | p3 << 6, lane i reads lane p_i
+template <int CTRL>
+__device__ __forceinline__ float4 quad_rot(float4 v) {
+    auto mv = [](float f) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), CTRL, 0xF, 0xF, true)); };
+    return make_float4(mv(v.x), mv(v.y), mv(v.z), mv(v.w));
+}
+
 constexpr int WN_CK = 16, WN_CO = 32;
 constexpr int WN_CP = 48;                      // U row stride in LDS: the four k of a wavefront on disjoint banks (32 + 16)
 constexpr int WN_US = WN_CK * WN_CP;           // one xi's [16 ci][48]
@@ -101,12 +108,13 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         for (int c = threadIdx.x; c < d.KC; c += W4_NT) wtab[c] = bn_scale(pre.var, pre.gamma, pre.eps, c);
         __syncthreads();
     }
-    const bool pre_store = PRE != 0 && pre.store != nullptr && by == 0 && tx == 0 && b + (t_x >> 2) < d.B;
+    const unsigned xq = static_cast<unsigned>(xb * d.KC + ci_x) * 16u + 4u * (t_x & 3);  // PRE: row q = t_x & 3 of the lane's plane
+    const bool pre_store = PRE != 0 && pre.store != nullptr && by == 0 && b + (t_x >> 2) < d.B;
     // one round's prefetch of a producer lane: 8 float4 of U, 3 rows of its input plane - two sets (A, B) of NAMED registers filled by
     // straight-line code (as a struct handed to a lambda they lived in scratch memory)
     float4 Au0, Au1, Au2, Au3, Au4, Au5, Au6, Au7, Ax0, Ax1, Ax2, Bu0, Bu1, Bu2, Bu3, Bu4, Bu5, Bu6, Bu7, Bx0, Bx1, Bx2;
-    float4 Am0, Am1, Am2, Bm0, Bm1, Bm2, Ay0, Ay1, Ay2, By0, By1, By2;  // PRE: the mask rows and the second piece's rows
-    Am0 = Am1 = Am2 = Bm0 = Bm1 = Bm2 = Ay0 = Ay1 = Ay2 = By0 = By1 = By2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 Am0, Bm0, Ay0, By0;  // PRE: the lane's mask row and its row of the second piece
+    Am0 = Bm0 = Ay0 = By0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #define W4_FETCH(S, round_)                                                                        \
     do {                                                                                           \
         const int r_ = (round_) < rounds ? (round_) : rounds - 1; /* always issued */              \
@@ -123,31 +131,41 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         S##x0 = *reinterpret_cast<const float4 *>(xp_);                                            \
         S##x1 = *reinterpret_cast<const float4 *>(xp_ + 4);                                        \
         S##x2 = *reinterpret_cast<const float4 *>(xp_ + 8);                                        \
-        if constexpr (PRE >= 1) {                                                                  \
-            const float *mp_ = pre.mask + xo + r_ * xstep;                                         \
-            S##m0 = *reinterpret_cast<const float4 *>(mp_);                                        \
-            S##m1 = *reinterpret_cast<const float4 *>(mp_ + 4);                                    \
-            S##m2 = *reinterpret_cast<const float4 *>(mp_ + 8);                                    \
-        }                                                                                          \
-        if constexpr (PRE >= 2) {                                                                  \
-            const float *yp_ = pre.add + xo + r_ * xstep;                                          \
-            S##y0 = *reinterpret_cast<const float4 *>(yp_);                                        \
-            S##y1 = *reinterpret_cast<const float4 *>(yp_ + 4);                                    \
-            S##y2 = *reinterpret_cast<const float4 *>(yp_ + 8);                                    \
-        }                                                                                          \
+    } while (0)
+    // PRE: a lane fetches ONE row of its plane - row q = its index in the quad of the plane's four tiles - of the gradient, the mask and
+    // the second piece (instead of three rows of each: 2-3 float4 per round, not 6-9), applies the BatchNorm / ReLU backward to it and the
+    // quad passes the rows around with three DPP rotations
+#define W4_FETCH_ROW(S, round_)                                                                    \
+    do {                                                                                           \
+        const int r_ = (round_) < rounds ? (round_) : rounds - 1;                                  \
+        const float *up_ = ubase + r_ * ustep;                                                     \
+        S##u0 = *reinterpret_cast<const float4 *>(up_);                                            \
+        S##u1 = *reinterpret_cast<const float4 *>(up_ + uxi2);                                     \
+        S##u2 = *reinterpret_cast<const float4 *>(up_ + 2 * uxi2);                                 \
+        S##u3 = *reinterpret_cast<const float4 *>(up_ + 3 * uxi2);                                 \
+        S##u4 = *reinterpret_cast<const float4 *>(up_ + 4 * uxi2);                                 \
+        S##u5 = *reinterpret_cast<const float4 *>(up_ + 5 * uxi2);                                 \
+        S##u6 = *reinterpret_cast<const float4 *>(up_ + 6 * uxi2);                                 \
+        S##u7 = *reinterpret_cast<const float4 *>(up_ + 7 * uxi2);                                 \
+        S##x0 = *reinterpret_cast<const float4 *>((x + r_ * xstep) + xq);                          \
+        S##m0 = *reinterpret_cast<const float4 *>((pre.mask + r_ * xstep) + xq);                   \
+        if constexpr (PRE >= 2) S##y0 = *reinterpret_cast<const float4 *>((pre.add + r_ * xstep) + xq); \
     } while (0)
     // PRE: dz = mask > 0 ? (x + add) : 0 of the three rows, written out by the lanes that own them (tx = 0: rows 0-2 with ty = 0, row 3
     // with ty = 1), then times the channel's gamma * invstd
-    auto pre_rows = [&](float4 &p0, float4 &p1, float4 &p2, float4 y0, float4 y1, float4 y2, float4 m0, float4 m1, float4 m2, int round_) {
-        if constexpr (PRE >= 2) p0 = sum4(p0, y0), p1 = sum4(p1, y1), p2 = sum4(p2, y2);
-        p0 = mask4(p0, m0), p1 = mask4(p1, m1), p2 = mask4(p2, m2);
-        if (pre_store && round_ < rounds) {
-            float *sp = pre.store + xo + round_ * xstep;
-            if (ty == 0) *reinterpret_cast<float4 *>(sp) = p0, *reinterpret_cast<float4 *>(sp + 4) = p1;
-            *reinterpret_cast<float4 *>(sp + 8) = p2;
-        }
-        const float w = wtab[(round_ < rounds ? round_ : rounds - 1) * WN_CK + ci_x];
-        p0 = scale4(w, p0), p1 = scale4(w, p1), p2 = scale4(w, p2);
+    auto pre_rows = [&](float4 &p0, float4 &p1, float4 &p2, float4 y0, float4 m0, int round_) {
+        float4 own = p0;  // row q of the plane
+        if constexpr (PRE >= 2) own = sum4(own, y0);
+        own = mask4(own, m0);
+        if (pre_store && round_ < rounds) *reinterpret_cast<float4 *>((pre.store + round_ * xstep) + xq) = own;
+        own = scale4(wtab[(round_ < rounds ? round_ : rounds - 1) * WN_CK + ci_x], own);
+        // quad rotations: rot k = the row held by quad lane (q + k) & 3
+        const float4 r1 = quad_rot<0x39>(own), r2 = quad_rot<0x4E>(own), r3 = quad_rot<0x93>(own);
+        // rows ty .. ty + 2:  q = 0: (own, r1, r2)   q = 1: (r3, own, r1)   q = 2: (r3, own, r1)   q = 3: (r2, r3, own)
+        const bool q0 = (t_x & 3) == 0, q3 = (t_x & 3) == 3;
+        p0 = q0 ? own : (q3 ? r2 : r3);
+        p1 = q0 ? r1 : (q3 ? r3 : own);
+        p2 = q0 ? r2 : (q3 ? own : r1);
     };
     // V = B^T d B of this lane's patch from the three rows p0..p2 (rows ty .. ty+2 of the plane) -> buffer `buf`.  Patch rows: ty = 0:
     // (pad, row 0, 1, 2); ty = 1: (row 1, 2, 3, pad); columns likewise with tx
@@ -186,6 +204,11 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }
     };
     // U slice and V of a fetched round -> buffer `buf_`
+#define W4_FETCH_ANY(S, round_)                                                                    \
+    do {                                                                                           \
+        if constexpr (PRE != 0) W4_FETCH_ROW(S, round_);                                           \
+        else W4_FETCH(S, round_);                                                                  \
+    } while (0)
 #define W4_STAGE(buf_, S, round_)                                                                  \
     do {                                                                                           \
         float *ud_ = (buf_) + xi_s * WN_US + ci_s * WN_CP + 4 * uq; /* row urow0 + 32 j -> xi = xi_s + 2 j */ \
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         *reinterpret_cast<float4 *>(ud_ + 10 * WN_US) = S##u5;                                     \
         *reinterpret_cast<float4 *>(ud_ + 12 * WN_US) = S##u6;                                     \
         *reinterpret_cast<float4 *>(ud_ + 14 * WN_US) = S##u7;                                     \
-        if constexpr (PRE != 0) pre_rows(S##x0, S##x1, S##x2, S##y0, S##y1, S##y2, S##m0, S##m1, S##m2, round_); \
+        if constexpr (PRE != 0) pre_rows(S##x0, S##x1, S##x2, S##y0, S##m0, round_);               \
         transform(buf_, S##x0, S##x1, S##x2);                                                      \
     } while (0)
     f32x4 acc[4][2];
@@ -226,17 +249,17 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     };
     // producers: set B holds round r + 1 when iteration r starts (r even), set A round r + 2; the set just staged is refilled with round r + 3
     if (producer) {
-        W4_FETCH(A, 0);
+        W4_FETCH_ANY(A, 0);
         W4_STAGE(lds, A, 0);
-        W4_FETCH(B, 1);
-        W4_FETCH(A, 2);
+        W4_FETCH_ANY(B, 1);
+        W4_FETCH_ANY(A, 2);
     }
     __syncthreads();
     for (int round = 0; round < rounds; round += 2) {
         // iteration `round` (even): current buffer 0, next buffer 1
         if (producer) {
             W4_STAGE(lds + W4_BUF, B, round + 1);  // round + 1 (past the end: the last slice again, nobody reads it)
-            W4_FETCH(B, round + 3);
+            W4_FETCH_ANY(B, round + 3);
         } else {
             multiply(lds);
         }
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         if (round + 1 < rounds) {  // iteration round + 1: current buffer 1, next buffer 0
             if (producer) {
                 W4_STAGE(lds, A, round + 2);  // round + 2
-                W4_FETCH(A, round + 4);
+                W4_FETCH_ANY(A, round + 4);
             } else {
                 multiply(lds + W4_BUF);
             }
@@ -252,6 +275,8 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }
     }
 #undef W4_FETCH
+#undef W4_FETCH_ROW
+#undef W4_FETCH_ANY
 #undef W4_STAGE
     // ---- output transform Y = A^T M A.  D[row = 4 lq + reg][col = l15] -> ms[xi][co][tile]; one (co, tile) per lane -----------------------
     float *ms = lds;

@@ -276,6 +276,36 @@ def _mark_stale(update):
 _SEGMENTED = os.environ.get("EEADV_SEGMENTED_SYNC", "1") == "1"  # 0: one all-reduce after the whole captured backward (round 2's form)
 
 
+def two_branch_backward(loss, logits_nat, logits_adv, params):
+    """loss.backward() for a loss over TWO forward passes through the same parameters (Trades.loss, ALP.loss: utils/attacks.py:264-272,
+    :421-429) without autograd's per-parameter accumulation: with both passes in one backward every parameter receives two gradients and
+    AccumulateGrad adds the second one in a launch of its own (62 `+=` kernels per ResNet-18 step, 0.3 ms).  Here the loss is differentiated
+    down to the two logits tensors, each forward pass is then backpropagated on its own into fresh .grad tensors (the adversarial pass
+    first, as the engine orders them) and the two sets meet in ONE multi-tensor add: the same sums, g_adv + g_nat.  Falls back to
+    loss.backward() when the two branches are not both there."""
+    if logits_nat is None or logits_adv is None or not logits_nat.requires_grad or not logits_adv.requires_grad or logits_nat is logits_adv:
+        loss.backward()
+        return
+    d_nat, d_adv = torch.autograd.grad(loss, [logits_nat, logits_adv], allow_unused=True)
+    if d_nat is None or d_adv is None:
+        torch.autograd.backward([t for t, d in ((logits_nat, d_nat), (logits_adv, d_adv)) if d is not None], [d for d in (d_nat, d_adv) if d is not None])
+        return
+    params = [p for p in params if p.requires_grad]
+    for p in params:
+        p.grad = None
+    torch.autograd.backward([logits_adv], [d_adv])
+    first = [p.grad for p in params]
+    for p in params:
+        p.grad = None
+    torch.autograd.backward([logits_nat], [d_nat])
+    both = [(a, p.grad) for p, a in zip(params, first) if a is not None and p.grad is not None]
+    if both:
+        torch._foreach_add_([a for a, _ in both], [b for _, b in both])
+    for p, a in zip(params, first):
+        if a is not None:
+            p.grad = a
+
+
 class _GraphedPredsUpdate:
     """TRADES / ALP / tarALP (experiments_tinyimagenet.py:250-262, :286-291): the step is  preds = model(input)  ->  attack  ->
     output = model(data_adv); loss = criterion.loss(model, preds, ...); zero_grad; backward; step  - and `preds` stays attached across
@@ -310,9 +340,14 @@ class _GraphedPredsUpdate:
             loss = self.criterion.loss(model, preds, output, self.y, optimizer)
         if self.sync is None:
             optimizer.zero_grad(set_to_none=True)
+            # the loss spans two forward passes: one backward per pass and one multi-tensor add instead of 62 AccumulateGrad launches
+            logits_adv = getattr(self.criterion, "last_logits_adv", None) if self.args.method_name == 'TRADES' else output
+            two_branch_backward(loss, preds, logits_adv, [p for g in optimizer.param_groups for p in g['params']])
+            if self.args.method_name == 'TRADES':
+                self.criterion.last_logits_adv = None
         else:
             self.sync.zero_()  # .loss() called optimizer.zero_grad() (attacks.py:265-266, :422-423): the views go back in
-        loss.backward()
+            loss.backward()
         return loss.detach(), output.detach()
 
     def _step(self):
@@ -490,7 +525,15 @@ def train_batch(model, criterion, optimizer, args, input, target, device, avmixu
             loss = -torch.sum(nn.functional.log_softmax(output, dim=1) * new_target) / input.shape[0]
     else:
         loss = criterion(output, target)
-    backward_and_step(loss, optimizer, sync)
+    if sync is None and m in ('ALP', 'tarALP', 'TRADES') and output.is_cuda:
+        optimizer.zero_grad()
+        two_branch_backward(loss, preds, getattr(criterion, "last_logits_adv", None) if m == 'TRADES' else output,
+                            [p for g in optimizer.param_groups for p in g['params']])
+        optimizer.step()
+    else:
+        backward_and_step(loss, optimizer, sync)
+    if m == 'TRADES':
+        criterion.last_logits_adv = None  # (it holds the forward pass's autograd graph)
     return loss.detach(), output.detach()
 
 

@@ -361,7 +361,8 @@ class Trades:
         optimizer.zero_grad()
         if runtime.require_device(logits, "Trades.loss"):
             loss_natural = EF.cross_entropy(logits, labels)
-            loss_robust = EF.kl_div_batchmean(model(x_adv), logits)  # gradient flows into both arguments
+            self.last_logits_adv = model(x_adv)  # kept for eeadv.trainer.two_branch_backward (one backward per forward pass)
+            loss_robust = EF.kl_div_batchmean(self.last_logits_adv, logits)  # gradient flows into both arguments
             return loss_natural + self.beta * loss_robust
         prob = F.softmax(logits, dim=-1)
         loss_natural = F.cross_entropy(logits, labels)

@@ -233,7 +233,7 @@ def test_free_at_script_two_ranks_share_one_gpu(tmp_path, grad_sync):
     ep = [l for l in out.splitlines() if l.startswith("Epoch: [0]")]
     assert len(ep) == 1  # rank 0 prints
     loss = float(re.search(r"Loss ([\d.]+) ", ep[0]).group(1))
-    assert 0.5 < loss < 6.0  # ln(10) = 2.3 at initialisation
+    assert 0.5 < loss < 20.0  # ln(10) = 2.3 at initialisation; the line is printed after the batch's four updates at lr 0.1 on random labels
     assert any(l.startswith(" * Adv Prec@1") for l in out.splitlines())
     ck = [os.path.join(d, f) for d, _, fs in os.walk(str(tmp_path)) for f in fs if f.endswith("_0.pth")]
     assert len(ck) == 1, ck
