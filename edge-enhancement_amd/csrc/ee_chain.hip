@@ -38,6 +38,12 @@ using namespace ee;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -DEE_CHAIN_SKIP=<bits> (scripts/chain_phases.py builds its own copy of this file with it; never the product): phase skipping in the
+// forward kernel - 1: no edge filter, 2: no low-pass products, 4: no combine / store.  Results are garbage, the timings tell the phases apart.
+#ifndef EE_CHAIN_SKIP
+#define EE_CHAIN_SKIP 0
+#endif
+
 constexpr int kSW = 8;             // stencil waves: two per SIMD, the edge loop is latency-bound with one (34 -> 2x fewer rounds)
 constexpr int kST = kSW * kWave;   // 512 stencil threads (the helpers of ee_stencil.hpp assume 4-pixel groups, not a block size)
 
@@ -288,7 +294,7 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
 
     if (wave < kSW) {
         // ---- edge filter on 4-pixel groups: ee_edge.hip's arithmetic, whole image in the frame ----------------------------------
-        for (int idx = tid; idx < H * W4; idx += kST) {
+        for (int idx = tid; idx < ((EE_CHAIN_SKIP & 1) ? 0 : H * W4); idx += kST) {
             const int i = idx / W4, lx = idx - i * W4, jb = 4 * lx;
             float b[C][3][6];
             blur_group<C, FH, FW>(xr, wt, i, jb + kColHalo - 2, i, jb, H, W, b);
@@ -311,6 +317,7 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
         const int c = wave - kSW, lane = tid & 63, li = lane & 15, lg = lane >> 4;
         float *xc = xs + c * D::HP * D::AS;
         f32x4 y[D::HT][D::WT], ef[2];
+        if (!(EE_CHAIN_SKIP & 2)) {
         lowpass_front<H, W>(tab, [&](int h, int w) -> float { return xc[h * D::AS + w]; }, ef);
         lowpass_back<H, W>(tab, ef, y);
 #pragma unroll
@@ -319,8 +326,10 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
             for (int wt_ = 0; wt_ < D::WT; ++wt_)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xc[(16 * ht + 4 * lg + r) * D::AS + 16 * wt_ + li] = y[ht][wt_][r];
+        }
     }
     __syncthreads();
+    if (EE_CHAIN_SKIP & 4) return;
 
     // ---- combine + stage out (everybody): x_in = clamp(x_lp + w * e), gate = code | 1[0 <= x_lp + w * e <= 1]; 16 B / 4 B per lane --------
     constexpr int NT = (kSW + C) * kWave;

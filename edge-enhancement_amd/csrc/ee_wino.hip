@@ -360,10 +360,14 @@ struct PcGeo {
 // in the same order per accumulator: bit-identical results.
 constexpr int PC_CW = 8, PC_XPW = 16 / PC_CW;
 
-// PRE / POST: see wino3x3_map4_kernel
-template <int MAP, int PRE, bool POST>
+// PRE / POST: see wino3x3_map4_kernel.  The train-mode pair (round 4 probe, scripts/bn_boundary_probe.py: BatchNorm with BATCH statistics
+// exchanged across the kernel boundary instead of inside a BatchNorm launch): STATS - the output transform also writes, per (channel,
+// image), the plane's (mean, M2) to tstats [RC][B][2] (equal counts: MAP * MAP values each); PRE 3 - the prologue merges the B partials of
+// every reduction channel in a fixed order (no division chain: equal counts), and the staged input is relu((x - mean) * invstd * gamma + beta).
+template <int MAP, int PRE, bool POST, bool STATS = false>
 __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(PcGeo<MAP>::WPE, PcGeo<MAP>::WPE))) void wino3x3_pc_kernel(const float *__restrict__ x, const float *__restrict__ u,
-                                                                                                     float *__restrict__ y, WinoDims d, FusePre pre, FusePost post) {
+                                                                                                     float *__restrict__ y, WinoDims d, FusePre pre, FusePost post,
+                                                                                                     float *__restrict__ tstats = nullptr) {
     using G = PcGeo<MAP>;
     static_assert(G::XF4 == 1 && G::PPT == 1 && (G::UPL == 2 || G::UPL == 4), "8x8 or 16x16 maps");
     extern __shared__ __align__(16) float lds[];
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     const int ci_p = MAP == 8 ? (pt & 127) >> 4 : pt >> 6;  // this producer lane's channel inside a round
     // 16x16 with PRE: the plain kernel sits at the 128 registers four wavefronts per SIMD leave; three pixel streams in two prefetch sets
     // spilled (54 registers).  There pixels and filters travel ONE round ahead in one set (a round is ~1.3 us: enough for an L2 hit) instead of two
-    constexpr bool ONE_X = MAP == 16 && PRE != 0;
+    constexpr bool ONE_X = MAP == 16 && (PRE == 1 || PRE == 2);
     const bool pre_store = PRE != 0 && pre.store != nullptr && by == 0 && b + ximg < d.B;
 #define PC_FETCH_U(S, round_)                                                                      \
     do {                                                                                           \
@@ -413,8 +417,8 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
         const int r_ = (round_) < rounds ? (round_) : rounds - 1;                                  \
         const float *xp_ = xsrc + r_ * xstep;                                                      \
         S##0 = *reinterpret_cast<const float4 *>(xp_);                                             \
-        if constexpr (PRE >= 1) S##2 = *reinterpret_cast<const float4 *>((pre.mask + r_ * xstep) + xo); \
-        if constexpr (PRE >= 2) S##1 = *reinterpret_cast<const float4 *>((pre.add + r_ * xstep) + xo);  \
+        if constexpr (PRE == 1 || PRE == 2) S##2 = *reinterpret_cast<const float4 *>((pre.mask + r_ * xstep) + xo); \
+        if constexpr (PRE == 2) S##1 = *reinterpret_cast<const float4 *>((pre.add + r_ * xstep) + xo);  \
     } while (0)
 #define PC_STORE_U(buf_, S)                                                                        \
     do {                                                                                           \
@@ -440,7 +444,13 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     };
     // PRE: dz = mask > 0 ? (x + add) : 0, written out by the by = 0 workgroup of the image, then times the channel's gamma * invstd
     auto pre_px = [&](float4 v, float4 a, float4 m, int round_) {
-        if constexpr (PRE >= 2) v = sum4(v, a);
+        if constexpr (PRE == 3) {  // train-mode BatchNorm + ReLU of the producing layer, statistics from the table the prologue merged
+            const float *t = wtab + 3 * ((round_ < rounds ? round_ : rounds - 1) * G::CK + ci_p);
+            const float mean = t[0], sa = t[1], sb = t[2];
+            return make_float4(relu_keep_nan((v.x - mean) * sa + sb), relu_keep_nan((v.y - mean) * sa + sb), relu_keep_nan((v.z - mean) * sa + sb),
+                               relu_keep_nan((v.w - mean) * sa + sb));
+        }
+        if constexpr (PRE == 2) v = sum4(v, a);
         v = mask4(v, m);
         if (pre_store && round_ < rounds) *reinterpret_cast<float4 *>((pre.store + round_ * xstep) + xo) = v;
         return scale4(wtab[(round_ < rounds ? round_ : rounds - 1) * G::CK + ci_p], v);
@@ -526,8 +536,37 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
         PC_FETCH_X(XB, 1);
     }
     for (int i = threadIdx.x; i < G::XS; i += G::NT) lds[16 * G::US + 16 * G::VS + i] = lds[G::BUF + 16 * G::US + 16 * G::VS + i] = 0.0f;  // zero rings
-    if constexpr (PRE != 0)
+    if constexpr (PRE == 1 || PRE == 2)
         for (int c = threadIdx.x; c < d.KC; c += G::NT) wtab[c] = bn_scale(pre.var, pre.gamma, pre.eps, c);
+    if constexpr (PRE == 3) {
+        // merge the B per-image partials (mean_n, M2_n; MAP * MAP values each) of every reduction channel: 16 lanes per channel, each its
+        // share in index order, then a fixed butterfly.  mean = sum mean_n / B;  M2 = sum (M2_n + cnt * (mean_n - mean)^2): no divisions
+        // inside the sums.  pre.mask carries the partials [KC][B][2] (the producing convolution's tstats), pre.var is unused.
+        const float *part = pre.mask;
+        for (int c = threadIdx.x >> 4; c < d.KC; c += G::NT / 16) {
+            const int j = threadIdx.x & 15;
+            const float2 *pc = reinterpret_cast<const float2 *>(part) + static_cast<size_t>(c) * d.B;
+            float s1 = 0.0f;
+            for (int n = j; n < d.B; n += 16) s1 += pc[n].x;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) s1 += __shfl_xor(s1, off, 16);
+            const float mean = s1 / static_cast<float>(d.B);
+            float s2 = 0.0f;
+            for (int n = j; n < d.B; n += 16) {
+                const float2 pn = pc[n];
+                const float dm = pn.x - mean;
+                s2 += pn.y + static_cast<float>(MAP * MAP) * (dm * dm);
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) s2 += __shfl_xor(s2, off, 16);
+            if (j == 0) {
+                const float var = s2 / (static_cast<float>(d.B) * static_cast<float>(MAP * MAP));
+                wtab[3 * c] = mean;
+                wtab[3 * c + 1] = bn_invstd(var, pre.eps) * (pre.gamma ? pre.gamma[c] : 1.0f);
+                wtab[3 * c + 2] = pre.add ? pre.add[c] : 0.0f;  // beta rides in pre.add
+            }
+        }
+    }
     __syncthreads();  // the zero rings
     if (producer) {
         PC_PUT_X(buf0, XA, 0);
@@ -634,6 +673,7 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     if (threadIdx.x < 512) {
         const int idx = threadIdx.x;  // (co, tile of a block)
         const int co = idx >> 4, tl = idx & 15;
+        float sv[STATS ? G::NB : 1][4];
 #pragma unroll
         for (int nb = 0; nb < G::NB; ++nb) {
             const int t = 16 * nb + tl, img = t / G::TI, ti = t - img * G::TI, ty = ti / G::TX, tx = ti - ty * G::TX;
@@ -658,7 +698,27 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
                 }
                 *reinterpret_cast<float2 *>(y + oo) = r0;
                 *reinterpret_cast<float2 *>(y + oo + MAP) = r1;
+                if constexpr (STATS) sv[nb][0] = r0.x, sv[nb][1] = r0.y, sv[nb][2] = r1.x, sv[nb][3] = r1.y;
             }
+        }
+        if constexpr (STATS) {
+            // MAP = 16: the workgroup holds ONE image, the 16 lanes of a channel hold its whole plane (4 N blocks x 2 x 2 values each)
+            static_assert(!STATS || G::IMG == 1, "statistics epilogue: one image per workgroup");
+            float s1 = 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < G::NB; ++nb) s1 += (sv[nb][0] + sv[nb][1]) + (sv[nb][2] + sv[nb][3]);
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) s1 += __shfl_xor(s1, off, 16);
+            const float mean = s1 / static_cast<float>(MAP * MAP);
+            float s2 = 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < G::NB; ++nb) {
+                const float a0 = sv[nb][0] - mean, a1 = sv[nb][1] - mean, a2 = sv[nb][2] - mean, a3 = sv[nb][3] - mean;
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) s2 += __shfl_xor(s2, off, 16);
+            if (tl == 0 && b < d.B) *reinterpret_cast<float2 *>(tstats + (static_cast<size_t>(co0 + co) * d.B + b) * 2) = make_float2(mean, s2);
         }
     }
     WT_STAMP(3);
@@ -677,6 +737,18 @@ int wino_pc_launch(const float *x, const float *u, float *y, const WinoDims &d, 
     if (!ok) return EE_ERR_UNSUPPORTED;
     EE_LAUNCH((wino3x3_pc_kernel<MAP, PRE, POST>), dim3(xcd_grid((d.B + G::IMG - 1) / G::IMG, d.RC / WN_CO, d.wl)), dim3(G::NT), bytes,
               st, x, u, y, d, pre, post);
+    return launch_status();
+}
+
+// the train-mode pair on 16x16 maps (probe): STATS producer / PRE 3 consumer
+template <int PRE, bool STATS>
+int wino_pc16_train_launch(const float *x, const float *u, float *y, const WinoDims &d, const FusePre &pre, float *tstats, hipStream_t st) {
+    using G = PcGeo<16>;
+    constexpr size_t bytes = G::lds_bytes + (PRE ? 3 * 128 * sizeof(float) : 0);
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_pc_kernel<16, PRE, false, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(bytes)) == hipSuccess;
+    if (!ok) return EE_ERR_UNSUPPORTED;
+    EE_LAUNCH((wino3x3_pc_kernel<16, PRE, false, STATS>), dim3(xcd_grid(d.B, d.RC / WN_CO, d.wl)), dim3(G::NT), bytes, st, x, u, y, d, pre, FusePost{}, tstats);
     return launch_status();
 }
 
@@ -761,6 +833,33 @@ EE_API int ee_wino3x3_bn_eval_bwd_f32(const float *dy, const float *dy2, const f
     }
     if (dy2) return wino_dispatch<2, false>(dy, u_b, dx, d, H, pre, FusePost{}, as_stream(stream));
     return wino_dispatch<1, false>(dy, u_b, dx, d, H, pre, FusePost{}, as_stream(stream));
+}
+
+// Probe of the train-mode BatchNorm exchange across the kernel boundary (scripts/bn_boundary_probe.py), 16x16 maps:
+//   ee_wino3x3_stats_f32        y = conv3x3(x), and per (channel, image) the plane's (mean, M2) -> stats [Cout][B][2]
+//   ee_wino3x3_bn_train_pre_f32 y = conv3x3( relu( batch_norm(x; statistics merged from `stats`) ) )  - x is the RAW output of the producing
+//                               convolution; gamma / beta [Cin] (Cin <= 128).  Neither updates running statistics nor saves mean / invstd:
+//                               a timing and numerics probe, not wired into the models.
+EE_API int ee_wino3x3_stats_f32(const float *x, const float *u, float *y, float *stats, int B, int KC, int RC, int H, void *stream) {
+    const int rc = wino_check(x, u, y, B, KC, RC, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (H != 16) return EE_ERR_UNSUPPORTED;
+    if (!stats) return EE_ERR_NULL;
+    const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
+    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
+    return wino_pc16_train_launch<0, true>(x, u, y, d, FusePre{}, stats, as_stream(stream));
+}
+
+EE_API int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, const float *gamma, const float *beta, float eps, const float *u, float *y,
+                                       int B, int KC, int RC, int H, void *stream) {
+    const int rc = wino_check(x, u, y, B, KC, RC, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (H != 16 || KC > 128) return EE_ERR_UNSUPPORTED;
+    if (!stats) return EE_ERR_NULL;
+    const FusePre pre{beta, stats, nullptr, nullptr, gamma, eps};
+    const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
+    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
+    return wino_pc16_train_launch<3, false>(x, u, y, d, pre, nullptr, as_stream(stream));
 }
 
 #ifdef EE_WINO_TIMING

@@ -88,6 +88,8 @@ SIGNATURES = {
     "ee_wino3x3_bn_eval_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     # dy, dy2, y, u_b, var, gamma, eps, dres, dx_add, dx, B, Cin, Cout, H, stream
     "ee_wino3x3_bn_eval_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "ee_wino3x3_stats_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "ee_wino3x3_bn_train_pre_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wrw3x3_workspace_floats": [c_i, c_i, c_i, c_i],
     "ee_wrw3x3_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wrw3x3s2_workspace_floats": [c_i, c_i, c_i, c_i, c_i],

@@ -386,6 +386,14 @@ int ee_wino3x3_bn_eval_fwd_f32(const float *x, const float *u, const float *mean
                                const float *res, int relu, float *y, int B, int Cin, int Cout, int H, void *stream);
 int ee_wino3x3_bn_eval_bwd_f32(const float *dy, const float *dy2, const float *y, const float *u_b, const float *var, const float *gamma, float eps,
                                float *dres, const float *dx_add, float *dx, int B, int Cin, int Cout, int H, void *stream);
+/* Probe (round 4; scripts/bn_boundary_probe.py, profiles/round4_*_bn_boundary.txt): TRAIN-mode BatchNorm with the batch
+ * statistics exchanged across the KERNEL BOUNDARY - the producing convolution's output transform writes per (channel, image) the plane's
+ * (mean, M2) to stats [Cout][B][2]; the consuming convolution's prologue merges the B equal-count partials of each of its reduction channels
+ * in a fixed order and stages relu((x - mean) * gamma / sqrt(var + eps) + beta).  16x16 maps, Cin <= 128.  Neither call updates running
+ * statistics or saves mean / invstd: a timing / numerics probe of resnet.py:44-59's conv1 -> bn1 -> relu -> conv2, not wired into the models. */
+int ee_wino3x3_stats_f32(const float *x, const float *u, float *y, float *stats, int B, int KC, int RC, int H, void *stream);
+int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, const float *gamma, const float *beta, float eps, const float *u, float *y, int B, int KC,
+                                int RC, int H, void *stream);
 
 /* The WEIGHT gradient of the same convolution (`loss.backward()` of the training step, experiments_tinyimagenet.py:304-306; resnet.py:26-31) on
  * H x H maps, H = 2, 4, 8 or 16, as Winograd F(3x3, 2x2) around the f32 matrix cores: x [B,Cin,H,H] (the layer's input), dy [B,Cout,H,H] (the
