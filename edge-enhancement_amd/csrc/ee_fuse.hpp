@@ -57,6 +57,84 @@ __device__ __forceinline__ float4 mask4(float4 v, float4 m) {
 __device__ __forceinline__ float4 sum4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 scale4(float w, float4 v) { return make_float4(w * v.x, w * v.y, w * v.z, w * v.w); }
 
+// ---- TRAIN-mode BatchNorm across the kernel boundary (round 4) ------------------------------------------------------------------------
+// The convolution in front of a mid-block BatchNorm (resnet.py:44-49: conv1 -> bn1 -> relu -> conv2) writes, next to its raw output, the
+// moments of what each workgroup holds: stats_out [channels][S][2] = (mean, M2) of `cnt` values each (equal counts).  The convolution
+// behind it merges the S partials of every reduction channel in its prologue - each of 16 lanes its share in index order, then a fixed
+// butterfly: mean = sum mean_s / S, M2 = sum (M2_s + cnt * (mean_s - mean)^2), no division inside the sums, the same bits in every
+// workgroup and every run - and stages relu((x - mean) * invstd * gamma + beta).  Workgroup 0 also writes save_mean / save_invstd (the
+// backward pass reads them) and moves the running statistics exactly as ee_bn.hip's forward does.
+struct TrainBn {
+    float *stats_out;            // producer: [result channels][S][2]; null: no statistics epilogue
+    const float *part;           // consumer: the producer's stats_out, [reduction channels][S][2]
+    int S;                       // partials per channel
+    float cnt;                   // values per partial
+    const float *gamma, *beta;   // [reduction channels]; null: 1 / 0
+    float eps, momentum;
+    float *running_mean, *running_var, *save_mean, *save_invstd;  // written by workgroup 0 (running_*: may be null)
+};
+
+// table [3 c + {0, 1, 2}] = (mean, invstd * gamma, beta) of channel c, for c < KC; call with all NT threads of the workgroup, then barrier
+template <int NT>
+__device__ __forceinline__ void train_bn_merge(const TrainBn &tb, int KC, float *table, bool writer) {
+    const float n = static_cast<float>(tb.S) * tb.cnt;
+    for (int c = threadIdx.x >> 4; c < KC; c += NT / 16) {
+        const int j = threadIdx.x & 15;
+        const float2 *pc = reinterpret_cast<const float2 *>(tb.part) + static_cast<size_t>(c) * tb.S;
+        float s1 = 0.0f;
+        for (int i = j; i < tb.S; i += 16) s1 += pc[i].x;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) s1 += __shfl_xor(s1, off, 16);
+        const float mean = s1 / static_cast<float>(tb.S);
+        float s2 = 0.0f;
+        for (int i = j; i < tb.S; i += 16) {
+            const float2 pn = pc[i];
+            const float dm = pn.x - mean;
+            s2 += pn.y + tb.cnt * (dm * dm);
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) s2 += __shfl_xor(s2, off, 16);
+        if (j == 0) {
+            const float var = s2 / n, invstd = bn_invstd(var, tb.eps);
+            table[3 * c] = mean;
+            table[3 * c + 1] = invstd * (tb.gamma ? tb.gamma[c] : 1.0f);
+            table[3 * c + 2] = tb.beta ? tb.beta[c] : 0.0f;
+            if (writer) {
+                tb.save_mean[c] = mean;
+                tb.save_invstd[c] = invstd;
+                if (tb.running_mean) {  // ee_bn.hip: bn_fwd_cached_kernel
+                    const float unbiased = (n > 1.0f) ? var * (n / (n - 1.0f)) : var;
+                    tb.running_mean[c] = (1.0f - tb.momentum) * tb.running_mean[c] + tb.momentum * mean;
+                    tb.running_var[c] = (1.0f - tb.momentum) * tb.running_var[c] + tb.momentum * unbiased;
+                }
+            }
+        }
+    }
+}
+__device__ __forceinline__ float train_bn_apply(float v, const float *t) { return relu_keep_nan((v - t[0]) * t[1] + t[2]); }
+__device__ __forceinline__ float4 train_bn_apply4(float4 v, const float *t) {
+    return make_float4(train_bn_apply(v.x, t), train_bn_apply(v.y, t), train_bn_apply(v.z, t), train_bn_apply(v.w, t));
+}
+// (mean, M2) of a group of LANES consecutive lanes' values, NV per lane; every lane of the group returns the pair
+template <int LANES, int NV>
+__device__ __forceinline__ float2 group_moments(const float (&v)[NV]) {
+    float s1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s1 += v[i];
+#pragma unroll
+    for (int off = 1; off < LANES; off <<= 1) s1 += __shfl_xor(s1, off, LANES);
+    const float mean = s1 / static_cast<float>(LANES * NV);
+    float s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i] - mean;
+        s2 += a * a;
+    }
+#pragma unroll
+    for (int off = 1; off < LANES; off <<= 1) s2 += __shfl_xor(s2, off, LANES);
+    return make_float2(mean, s2);
+}
+
 static inline int check_post(const FusePost &p) {
     if (p.mean && !p.var) return EE_ERR_NULL;
     if (p.res && !aligned16(p.res)) return EE_ERR_ALIGN;

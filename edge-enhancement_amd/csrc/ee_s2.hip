@@ -111,9 +111,11 @@ constexpr int S2_XS = 9 * 4 * 2 * 64;  // forward: a round's inputs [tap][quad][
 // DS: the block's shortcut Conv2d(1x1, stride 2) of the SAME input (resnet.py:137-142) rides along as a tenth tap - its B operand is the centre
 // tap's plane - into accumulators of its own -> y1
 // POST (eval-mode BatchNorm folded in, ee_fuse.hpp): y = relu(bn(conv3x3s2(x))) by `post`, y1 = bn_ds(conv1x1s2(x)) by `post1`
-template <int H, int MT, bool DS, bool POST>
+// STATS (train-mode BatchNorm across the kernel boundary, ee_fuse.hpp: TrainBn): next to the raw y, per result channel the (mean, M2) of the
+// workgroup's pixels of each image -> stats_out [RC][S][2]: H = 16: S = 2 B half images of 32 values; H = 8: S = B images of 16 values
+template <int H, int MT, bool DS, bool POST, bool STATS = false>
 __global__ __launch_bounds__(S2_NT, 4) void conv3s2_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w9, float *__restrict__ y,
-                                                                 float *__restrict__ y1, S2Dims d, FusePost post, FusePost post1) {
+                                                                 float *__restrict__ y1, S2Dims d, FusePost post, FusePost post1, float *__restrict__ stats_out = nullptr) {
     using G = S2Geo<H>;
     constexpr int OH = G::OH, PX = G::PX, IMG = G::IMG, TAPS = DS ? 10 : 9;
     constexpr int WFM = TAPS * 4 * MT * 64, BUF = WFM + S2_XS, RB = 16 * MT;
@@ -299,6 +301,16 @@ __global__ __launch_bounds__(S2_NT, 4) void conv3s2_fwd_mfma_kernel(const float 
                 if (pp.relu) s.x = relu_keep_nan(s.x), s.y = relu_keep_nan(s.y), s.z = relu_keep_nan(s.z), s.w = relu_keep_nan(s.w);
             }
             if (b0 + img < d.B) *reinterpret_cast<float4 *>((set == 0 ? y : y1) + dst) = s;
+            if constexpr (STATS) {
+                static_assert(!STATS || H == 16 || H == 8, "statistics epilogue: 8x8 or 4x4 results");
+                if (set == 0) {
+                    constexpr int LANES = H == 16 ? 8 : 4;  // the lanes holding one image's pixels of this workgroup
+                    const float vals[4] = {s.x, s.y, s.z, s.w};
+                    const float2 m = group_moments<LANES, 4>(vals);
+                    const int part = H == 16 ? 2 * b0 + hh : b0 + img, S = H == 16 ? 2 * d.B : d.B;
+                    if ((nq & (LANES - 1)) == 0 && b0 + img < d.B) *reinterpret_cast<float2 *>(stats_out + (static_cast<size_t>(co0 + co) * S + part) * 2) = m;
+                }
+            }
         }
     }
 }
@@ -545,6 +557,18 @@ int s2_launch(bool bwd, const float *in, const float *in1, const float *w9, floa
     return launch_status();
 }
 
+// the pair's forward with the statistics epilogue on y3 (MT as the plain forward)
+template <int H, int MT>
+int s2_launch_stats(const float *x, const float *w10, float *y3, float *y1, float *stats, const S2Dims &d, hipStream_t st) {
+    const dim3 grid(xcd_grid(H == 16 ? 2 * d.B : (d.B + S2Geo<H>::IMG - 1) / S2Geo<H>::IMG, d.RC / (16 * MT), d.wl));
+    constexpr size_t bytes = 2 * (10 * 4 * MT * 64 + S2_XS) * sizeof(float);
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3s2_fwd_mfma_kernel<H, MT, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(bytes)) == hipSuccess;
+    if (!ok) return EE_ERR_UNSUPPORTED;
+    EE_LAUNCH((conv3s2_fwd_mfma_kernel<H, MT, true, false, true>), grid, dim3(S2_NT), bytes, st, x, w10, y3, y1, d, FusePost{}, FusePost{}, stats);
+    return launch_status();
+}
+
 // f0 / f1: null (the plain convolutions) or the two FusePost (forward) / FusePre (backward-data) of the eval-mode BatchNorms folded in
 template <bool DS, bool FUSED>
 int s2_dispatch_f(bool bwd, const float *in, const float *in1, const float *w9, float *out, float *out1, const S2Dims &d, int H, hipStream_t st, const void *f0, const void *f1) {
@@ -648,4 +672,19 @@ EE_API int ee_conv3x3s2_pair_bn_eval_bwd_f32(const float *dy3, const float *y3, 
     const S2Dims d{B, Cout, Cin, xcd_weights_local(2.0 * B * Cout * H * H, 40.0 * Cin * Cout, Cin / 32) ? 1 : 0};
     ProfScope prof(EE_K_CONV3S2_BWD, as_stream(stream), 2.0 * 10.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
     return s2_dispatch_f<true, true>(true, dy3, dy1, w10, dx, nullptr, d, H, as_stream(stream), &p3, &p1);
+}
+
+// The pair's forward with the statistics of y3 for the TRAIN-mode BatchNorm behind it (ee_wino3x3_bn_train_pre_f32 consumes them): next to the raw
+// y3 / y1, stats [Cout][S][2] = (mean, M2) per result channel and partial - H = 16: S = 2 B (half images, 32 values each); H = 8: S = B (16 values).
+EE_API int ee_conv3x3s2_pair_stats_fwd_f32(const float *x, const float *w10, float *y3, float *y1, float *stats, int B, int Cin, int Cout, int H, void *stream) {
+    const int rc = s2_check(x, w10, y3, B, Cin, Cout, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (H != 16 && H != 8) return EE_ERR_UNSUPPORTED;
+    if (!y1 || !stats) return EE_ERR_NULL;
+    if (!aligned16(y1) || (reinterpret_cast<uintptr_t>(stats) & 7u)) return EE_ERR_ALIGN;
+    const S2Dims d{B, Cin, Cout, xcd_weights_local(4.0 * B * Cin * H * H, 40.0 * Cin * Cout, Cout / 32) ? 1 : 0};
+    ProfScope prof(EE_K_CONV3S2_FWD, as_stream(stream), 2.0 * 10.0 * Cin * Cout * static_cast<double>(B) * (H / 2) * (H / 2));
+    const int mt = s2_mt(false, H);
+    if (H == 16) return mt == 2 ? s2_launch_stats<16, 2>(x, w10, y3, y1, stats, d, as_stream(stream)) : s2_launch_stats<16, 1>(x, w10, y3, y1, stats, d, as_stream(stream));
+    return mt == 2 ? s2_launch_stats<8, 2>(x, w10, y3, y1, stats, d, as_stream(stream)) : s2_launch_stats<8, 1>(x, w10, y3, y1, stats, d, as_stream(stream));
 }

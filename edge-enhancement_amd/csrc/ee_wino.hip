@@ -79,9 +79,10 @@ constexpr int W4_NT = 512;
 // (BatchNorm + ReLU backward with running statistics), PRE 2: with a second input piece added first; both write the masked sum to pre.store
 // (one workgroup per image) when it is given.  POST: the output transform applies (c - mean) * invstd * gamma + beta, the residual, the ReLU.
 // PRE = 0, POST = false is the plain convolution, instruction for instruction what it was.
-template <int PRE, bool POST>
+// PRE 3 / STATS: the train-mode pair (see wino3x3_pc_kernel; four images per workgroup: four lanes hold a 4x4 plane).
+template <int PRE, bool POST, bool STATS = false>
 __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino3x3_map4_kernel(const float *__restrict__ x, const float *__restrict__ u, float *__restrict__ y, WinoDims d,
-                                                                                                        FusePre pre, FusePost post) {
+                                                                                                        FusePre pre, FusePost post, TrainBn tb = TrainBn{}) {
     extern __shared__ __align__(16) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave >= 4;
@@ -104,12 +105,16 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const size_t ustep = static_cast<size_t>(WN_CK) * d.RC, xstep = static_cast<size_t>(WN_CK) * 16;
     const int rounds = d.KC / WN_CK;
     float *wtab = lds + 2 * W4_BUF;  // PRE: gamma * invstd of every reduction channel
-    if constexpr (PRE != 0) {
+    if constexpr (PRE == 1 || PRE == 2) {
         for (int c = threadIdx.x; c < d.KC; c += W4_NT) wtab[c] = bn_scale(pre.var, pre.gamma, pre.eps, c);
         __syncthreads();
     }
+    if constexpr (PRE == 3) {
+        train_bn_merge<W4_NT>(tb, d.KC, wtab, blockIdx.x == 0);
+        __syncthreads();
+    }
     const unsigned xq = static_cast<unsigned>(xb * d.KC + ci_x) * 16u + 4u * (t_x & 3);  // PRE: row q = t_x & 3 of the lane's plane
-    const bool pre_store = PRE != 0 && pre.store != nullptr && by == 0 && b + (t_x >> 2) < d.B;
+    const bool pre_store = (PRE == 1 || PRE == 2) && pre.store != nullptr && by == 0 && b + (t_x >> 2) < d.B;
     // one round's prefetch of a producer lane: 8 float4 of U, 3 rows of its input plane - two sets (A, B) of NAMED registers filled by
     // straight-line code (as a struct handed to a lambda they lived in scratch memory)
     float4 Au0, Au1, Au2, Au3, Au4, Au5, Au6, Au7, Ax0, Ax1, Ax2, Bu0, Bu1, Bu2, Bu3, Bu4, Bu5, Bu6, Bu7, Bx0, Bx1, Bx2;
@@ -148,17 +153,21 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         S##u6 = *reinterpret_cast<const float4 *>(up_ + 6 * uxi2);                                 \
         S##u7 = *reinterpret_cast<const float4 *>(up_ + 7 * uxi2);                                 \
         S##x0 = *reinterpret_cast<const float4 *>((x + r_ * xstep) + xq);                          \
-        S##m0 = *reinterpret_cast<const float4 *>((pre.mask + r_ * xstep) + xq);                   \
-        if constexpr (PRE >= 2) S##y0 = *reinterpret_cast<const float4 *>((pre.add + r_ * xstep) + xq); \
+        if constexpr (PRE != 3) S##m0 = *reinterpret_cast<const float4 *>((pre.mask + r_ * xstep) + xq); \
+        if constexpr (PRE == 2) S##y0 = *reinterpret_cast<const float4 *>((pre.add + r_ * xstep) + xq); \
     } while (0)
     // PRE: dz = mask > 0 ? (x + add) : 0 of the three rows, written out by the lanes that own them (tx = 0: rows 0-2 with ty = 0, row 3
     // with ty = 1), then times the channel's gamma * invstd
     auto pre_rows = [&](float4 &p0, float4 &p1, float4 &p2, float4 y0, float4 m0, int round_) {
         float4 own = p0;  // row q of the plane
-        if constexpr (PRE >= 2) own = sum4(own, y0);
-        own = mask4(own, m0);
-        if (pre_store && round_ < rounds) *reinterpret_cast<float4 *>((pre.store + round_ * xstep) + xq) = own;
-        own = scale4(wtab[(round_ < rounds ? round_ : rounds - 1) * WN_CK + ci_x], own);
+        if constexpr (PRE == 3) {
+            own = train_bn_apply4(own, wtab + 3 * ((round_ < rounds ? round_ : rounds - 1) * WN_CK + ci_x));
+        } else {
+            if constexpr (PRE == 2) own = sum4(own, y0);
+            own = mask4(own, m0);
+            if (pre_store && round_ < rounds) *reinterpret_cast<float4 *>((pre.store + round_ * xstep) + xq) = own;
+            own = scale4(wtab[(round_ < rounds ? round_ : rounds - 1) * WN_CK + ci_x], own);
+        }
         // quad rotations: rot k = the row held by quad lane (q + k) & 3
         const float4 r1 = quad_rot<0x39>(own), r2 = quad_rot<0x4E>(own), r3 = quad_rot<0x93>(own);
         // rows ty .. ty + 2:  q = 0: (own, r1, r2)   q = 1: (r3, own, r1)   q = 2: (r3, own, r1)   q = 3: (r2, r3, own)
@@ -320,6 +329,11 @@ __global__ __launch_bounds__(W4_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             *reinterpret_cast<float2 *>(y + oo) = r0;
             *reinterpret_cast<float2 *>(y + oo + 4) = r1;
         }
+        if constexpr (STATS) {  // the four lanes (tiles) of an image hold its 4x4 plane of channel co
+            const float vals[4] = {(t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3], (t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]};
+            const float2 m = group_moments<4, 4>(vals);
+            if ((tl & 3) == 0 && b + img < d.B) *reinterpret_cast<float2 *>(tb.stats_out + (static_cast<size_t>(co0 + co) * d.B + b + img) * 2) = m;
+        }
     }
 }
 
@@ -360,14 +374,14 @@ struct PcGeo {
 // in the same order per accumulator: bit-identical results.
 constexpr int PC_CW = 8, PC_XPW = 16 / PC_CW;
 
-// PRE / POST: see wino3x3_map4_kernel.  The train-mode pair (round 4 probe, scripts/bn_boundary_probe.py: BatchNorm with BATCH statistics
-// exchanged across the kernel boundary instead of inside a BatchNorm launch): STATS - the output transform also writes, per (channel,
-// image), the plane's (mean, M2) to tstats [RC][B][2] (equal counts: MAP * MAP values each); PRE 3 - the prologue merges the B partials of
-// every reduction channel in a fixed order (no division chain: equal counts), and the staged input is relu((x - mean) * invstd * gamma + beta).
+// PRE / POST: see wino3x3_map4_kernel.  The train-mode pair (round 4; ee_fuse.hpp: TrainBn - BatchNorm with BATCH statistics exchanged
+// across the kernel boundary instead of inside a BatchNorm launch): STATS - the output transform also writes, per (channel, image), the
+// plane's (mean, M2) to tb.stats_out [RC][B][2]; PRE 3 - the prologue merges the partials of every reduction channel in a fixed order and
+// the staged input is relu((x - mean) * invstd * gamma + beta).
 template <int MAP, int PRE, bool POST, bool STATS = false>
 __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(PcGeo<MAP>::WPE, PcGeo<MAP>::WPE))) void wino3x3_pc_kernel(const float *__restrict__ x, const float *__restrict__ u,
                                                                                                      float *__restrict__ y, WinoDims d, FusePre pre, FusePost post,
-                                                                                                     float *__restrict__ tstats = nullptr) {
+                                                                                                     TrainBn tb = TrainBn{}) {
     using G = PcGeo<MAP>;
     static_assert(G::XF4 == 1 && G::PPT == 1 && (G::UPL == 2 || G::UPL == 4), "8x8 or 16x16 maps");
     extern __shared__ __align__(16) float lds[];
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     // 16x16 with PRE: the plain kernel sits at the 128 registers four wavefronts per SIMD leave; three pixel streams in two prefetch sets
     // spilled (54 registers).  There pixels and filters travel ONE round ahead in one set (a round is ~1.3 us: enough for an L2 hit) instead of two
     constexpr bool ONE_X = MAP == 16 && (PRE == 1 || PRE == 2);
-    const bool pre_store = PRE != 0 && pre.store != nullptr && by == 0 && b + ximg < d.B;
+    const bool pre_store = (PRE == 1 || PRE == 2) && pre.store != nullptr && by == 0 && b + ximg < d.B;
 #define PC_FETCH_U(S, round_)                                                                      \
     do {                                                                                           \
         const int r_ = (round_) < rounds ? (round_) : rounds - 1; /* always issued */              \
@@ -444,12 +458,8 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     };
     // PRE: dz = mask > 0 ? (x + add) : 0, written out by the by = 0 workgroup of the image, then times the channel's gamma * invstd
     auto pre_px = [&](float4 v, float4 a, float4 m, int round_) {
-        if constexpr (PRE == 3) {  // train-mode BatchNorm + ReLU of the producing layer, statistics from the table the prologue merged
-            const float *t = wtab + 3 * ((round_ < rounds ? round_ : rounds - 1) * G::CK + ci_p);
-            const float mean = t[0], sa = t[1], sb = t[2];
-            return make_float4(relu_keep_nan((v.x - mean) * sa + sb), relu_keep_nan((v.y - mean) * sa + sb), relu_keep_nan((v.z - mean) * sa + sb),
-                               relu_keep_nan((v.w - mean) * sa + sb));
-        }
+        if constexpr (PRE == 3)  // train-mode BatchNorm + ReLU of the producing layer, statistics from the table the prologue merged
+            return train_bn_apply4(v, wtab + 3 * ((round_ < rounds ? round_ : rounds - 1) * G::CK + ci_p));
         if constexpr (PRE == 2) v = sum4(v, a);
         v = mask4(v, m);
         if (pre_store && round_ < rounds) *reinterpret_cast<float4 *>((pre.store + round_ * xstep) + xo) = v;
@@ -538,35 +548,7 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     for (int i = threadIdx.x; i < G::XS; i += G::NT) lds[16 * G::US + 16 * G::VS + i] = lds[G::BUF + 16 * G::US + 16 * G::VS + i] = 0.0f;  // zero rings
     if constexpr (PRE == 1 || PRE == 2)
         for (int c = threadIdx.x; c < d.KC; c += G::NT) wtab[c] = bn_scale(pre.var, pre.gamma, pre.eps, c);
-    if constexpr (PRE == 3) {
-        // merge the B per-image partials (mean_n, M2_n; MAP * MAP values each) of every reduction channel: 16 lanes per channel, each its
-        // share in index order, then a fixed butterfly.  mean = sum mean_n / B;  M2 = sum (M2_n + cnt * (mean_n - mean)^2): no divisions
-        // inside the sums.  pre.mask carries the partials [KC][B][2] (the producing convolution's tstats), pre.var is unused.
-        const float *part = pre.mask;
-        for (int c = threadIdx.x >> 4; c < d.KC; c += G::NT / 16) {
-            const int j = threadIdx.x & 15;
-            const float2 *pc = reinterpret_cast<const float2 *>(part) + static_cast<size_t>(c) * d.B;
-            float s1 = 0.0f;
-            for (int n = j; n < d.B; n += 16) s1 += pc[n].x;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) s1 += __shfl_xor(s1, off, 16);
-            const float mean = s1 / static_cast<float>(d.B);
-            float s2 = 0.0f;
-            for (int n = j; n < d.B; n += 16) {
-                const float2 pn = pc[n];
-                const float dm = pn.x - mean;
-                s2 += pn.y + static_cast<float>(MAP * MAP) * (dm * dm);
-            }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) s2 += __shfl_xor(s2, off, 16);
-            if (j == 0) {
-                const float var = s2 / (static_cast<float>(d.B) * static_cast<float>(MAP * MAP));
-                wtab[3 * c] = mean;
-                wtab[3 * c + 1] = bn_invstd(var, pre.eps) * (pre.gamma ? pre.gamma[c] : 1.0f);
-                wtab[3 * c + 2] = pre.add ? pre.add[c] : 0.0f;  // beta rides in pre.add
-            }
-        }
-    }
+    if constexpr (PRE == 3) train_bn_merge<G::NT>(tb, d.KC, wtab, blockIdx.x == 0);
     __syncthreads();  // the zero rings
     if (producer) {
         PC_PUT_X(buf0, XA, 0);
@@ -688,9 +670,9 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
                 t0[j] = (mm[0][j] + mm[1][j]) + mm[2][j];
                 t1[j] = (mm[1][j] - mm[2][j]) - mm[3][j];
             }
+            float2 r0 = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]), r1 = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
             if (b + img < d.B) {
                 const size_t oo = ((static_cast<size_t>(b + img) * d.RC + co0 + co) * MAP + 2 * ty) * MAP + 2 * tx;
-                float2 r0 = make_float2((t0[0] + t0[1]) + t0[2], (t0[1] - t0[2]) - t0[3]), r1 = make_float2((t1[0] + t1[1]) + t1[2], (t1[1] - t1[2]) - t1[3]);
                 if constexpr (POST) {
                     if (post.mean) r0.x = post_apply(r0.x, pk), r0.y = post_apply(r0.y, pk), r1.x = post_apply(r1.x, pk), r1.y = post_apply(r1.y, pk);
                     if (post.res) r0.x += q0[nb].x, r0.y += q0[nb].y, r1.x += q1[nb].x, r1.y += q1[nb].y;
@@ -698,68 +680,67 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
                 }
                 *reinterpret_cast<float2 *>(y + oo) = r0;
                 *reinterpret_cast<float2 *>(y + oo + MAP) = r1;
-                if constexpr (STATS) sv[nb][0] = r0.x, sv[nb][1] = r0.y, sv[nb][2] = r1.x, sv[nb][3] = r1.y;
             }
+            if constexpr (STATS) sv[nb][0] = r0.x, sv[nb][1] = r0.y, sv[nb][2] = r1.x, sv[nb][3] = r1.y;  // (past the batch: never written out)
         }
         if constexpr (STATS) {
-            // MAP = 16: the workgroup holds ONE image, the 16 lanes of a channel hold its whole plane (4 N blocks x 2 x 2 values each)
-            static_assert(!STATS || G::IMG == 1, "statistics epilogue: one image per workgroup");
-            float s1 = 0.0f;
+            // the 16 lanes of a channel hold whole planes: N blocks [i * NBI, (i + 1) * NBI) are image i of the workgroup (MAP 16: one image
+            // in four blocks; MAP 8: two images, one block each)
+            constexpr int NBI = G::NB / G::IMG;
 #pragma unroll
-            for (int nb = 0; nb < G::NB; ++nb) s1 += (sv[nb][0] + sv[nb][1]) + (sv[nb][2] + sv[nb][3]);
+            for (int i = 0; i < G::IMG; ++i) {
+                float vals[NBI * 4];
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) s1 += __shfl_xor(s1, off, 16);
-            const float mean = s1 / static_cast<float>(MAP * MAP);
-            float s2 = 0.0f;
+                for (int k = 0; k < NBI; ++k)
 #pragma unroll
-            for (int nb = 0; nb < G::NB; ++nb) {
-                const float a0 = sv[nb][0] - mean, a1 = sv[nb][1] - mean, a2 = sv[nb][2] - mean, a3 = sv[nb][3] - mean;
-                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                    for (int e = 0; e < 4; ++e) vals[4 * k + e] = sv[i * NBI + k][e];
+                const float2 m = group_moments<16, NBI * 4>(vals);
+                if (tl == 0 && b + i < d.B) *reinterpret_cast<float2 *>(tb.stats_out + (static_cast<size_t>(co0 + co) * d.B + b + i) * 2) = m;
             }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) s2 += __shfl_xor(s2, off, 16);
-            if (tl == 0 && b < d.B) *reinterpret_cast<float2 *>(tstats + (static_cast<size_t>(co0 + co) * d.B + b) * 2) = make_float2(mean, s2);
         }
     }
     WT_STAMP(3);
     WT_DUMP;
 }
 
-constexpr int WN_MAX_KC = 512;  // PRE: the channel-scale table behind the two round buffers (2 KB; the 16x16 kernel has 5 KB to spare)
+constexpr int WN_MAX_KC = 512;  // PRE 1 / 2: the channel-scale table behind the two round buffers (2 KB; the 16x16 kernel has 5 KB to spare)
+constexpr int WN_MAX_KC_TRAIN = 256;  // PRE 3: (mean, scale, shift) per reduction channel, 3 KB
 
-template <int MAP, int PRE, bool POST>
-int wino_pc_launch(const float *x, const float *u, float *y, const WinoDims &d, const FusePre &pre, const FusePost &post, hipStream_t st) {
+template <int PRE>
+constexpr size_t wino_table_bytes() {
+    return PRE == 3 ? 3 * WN_MAX_KC_TRAIN * sizeof(float) : (PRE ? WN_MAX_KC * sizeof(float) : 0);
+}
+
+template <int MAP, int PRE, bool POST, bool STATS = false>
+int wino_pc_launch(const float *x, const float *u, float *y, const WinoDims &d, const FusePre &pre, const FusePost &post, hipStream_t st,
+                   const TrainBn &tb = TrainBn{}) {
     using G = PcGeo<MAP>;
-    constexpr size_t bytes = G::lds_bytes + (PRE ? WN_MAX_KC * sizeof(float) : 0);
+    constexpr size_t bytes = G::lds_bytes + wino_table_bytes<PRE>();
     static_assert(bytes <= 160 * 1024, "fits the LDS of a CU");
-    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_pc_kernel<MAP, PRE, POST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_pc_kernel<MAP, PRE, POST, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(bytes)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH((wino3x3_pc_kernel<MAP, PRE, POST>), dim3(xcd_grid((d.B + G::IMG - 1) / G::IMG, d.RC / WN_CO, d.wl)), dim3(G::NT), bytes,
-              st, x, u, y, d, pre, post);
+    EE_LAUNCH((wino3x3_pc_kernel<MAP, PRE, POST, STATS>), dim3(xcd_grid((d.B + G::IMG - 1) / G::IMG, d.RC / WN_CO, d.wl)), dim3(G::NT), bytes,
+              st, x, u, y, d, pre, post, tb);
     return launch_status();
 }
 
-// the train-mode pair on 16x16 maps (probe): STATS producer / PRE 3 consumer
-template <int PRE, bool STATS>
-int wino_pc16_train_launch(const float *x, const float *u, float *y, const WinoDims &d, const FusePre &pre, float *tstats, hipStream_t st) {
-    using G = PcGeo<16>;
-    constexpr size_t bytes = G::lds_bytes + (PRE ? 3 * 128 * sizeof(float) : 0);
-    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_pc_kernel<16, PRE, false, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+template <int PRE, bool POST, bool STATS = false>
+int wino_map4_launch(const float *x, const float *u, float *y, const WinoDims &d, const FusePre &pre, const FusePost &post, hipStream_t st,
+                     const TrainBn &tb = TrainBn{}) {
+    constexpr size_t bytes = W4_LDS + wino_table_bytes<PRE>();
+    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_map4_kernel<PRE, POST, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(bytes)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH((wino3x3_pc_kernel<16, PRE, false, STATS>), dim3(xcd_grid(d.B, d.RC / WN_CO, d.wl)), dim3(G::NT), bytes, st, x, u, y, d, pre, FusePost{}, tstats);
+    EE_LAUNCH((wino3x3_map4_kernel<PRE, POST, STATS>), dim3(xcd_grid((d.B + 3) / 4, d.RC / WN_CO, d.wl)), dim3(W4_NT), bytes, st, x, u, y, d, pre, post, tb);
     return launch_status();
 }
 
-template <int PRE, bool POST>
-int wino_map4_launch(const float *x, const float *u, float *y, const WinoDims &d, const FusePre &pre, const FusePost &post, hipStream_t st) {
-    constexpr size_t bytes = W4_LDS + (PRE ? WN_MAX_KC * sizeof(float) : 0);
-    static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_map4_kernel<PRE, POST>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(bytes)) == hipSuccess;
-    if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH((wino3x3_map4_kernel<PRE, POST>), dim3(xcd_grid((d.B + 3) / 4, d.RC / WN_CO, d.wl)), dim3(W4_NT), bytes, st, x, u, y, d, pre, post);
-    return launch_status();
+template <int PRE, bool POST, bool STATS = false>
+int wino_dispatch_t(const float *x, const float *u, float *y, const WinoDims &d, int H, const FusePre &pre, const FusePost &post, hipStream_t st, const TrainBn &tb) {
+    if (H == 4) return wino_map4_launch<PRE, POST, STATS>(x, u, y, d, pre, post, st, tb);
+    if (H == 8) return wino_pc_launch<8, PRE, POST, STATS>(x, u, y, d, pre, post, st, tb);
+    return wino_pc_launch<16, PRE, POST, STATS>(x, u, y, d, pre, post, st, tb);
 }
 
 template <int PRE, bool POST>
@@ -835,31 +816,35 @@ EE_API int ee_wino3x3_bn_eval_bwd_f32(const float *dy, const float *dy2, const f
     return wino_dispatch<1, false>(dy, u_b, dx, d, H, pre, FusePost{}, as_stream(stream));
 }
 
-// Probe of the train-mode BatchNorm exchange across the kernel boundary (scripts/bn_boundary_probe.py), 16x16 maps:
+// TRAIN-mode BatchNorm across the kernel boundary (round 4; ee_fuse.hpp: TrainBn; resnet.py:44-49: conv1 -> bn1 -> relu -> conv2):
 //   ee_wino3x3_stats_f32        y = conv3x3(x), and per (channel, image) the plane's (mean, M2) -> stats [Cout][B][2]
-//   ee_wino3x3_bn_train_pre_f32 y = conv3x3( relu( batch_norm(x; statistics merged from `stats`) ) )  - x is the RAW output of the producing
-//                               convolution; gamma / beta [Cin] (Cin <= 128).  Neither updates running statistics nor saves mean / invstd:
-//                               a timing and numerics probe, not wired into the models.
+//   ee_wino3x3_bn_train_pre_f32 y = conv3x3( relu( batch_norm(x) ) ): x = the RAW output of the producing convolution, its batch statistics
+//                               merged from `stats` [Cin][S][2] (S partials of cnt values each); save_mean / save_invstd [Cin] are written
+//                               and running_mean / running_var (may be NULL) moved with `momentum` as ee_bn_act_fwd_f32(training = 1) does.
 EE_API int ee_wino3x3_stats_f32(const float *x, const float *u, float *y, float *stats, int B, int KC, int RC, int H, void *stream) {
     const int rc = wino_check(x, u, y, B, KC, RC, H);
     if (rc != EE_OK || B == 0) return rc;
-    if (H != 16) return EE_ERR_UNSUPPORTED;
     if (!stats) return EE_ERR_NULL;
     const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
     ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
-    return wino_pc16_train_launch<0, true>(x, u, y, d, FusePre{}, stats, as_stream(stream));
+    TrainBn tb{};
+    tb.stats_out = stats;
+    return wino_dispatch_t<0, false, true>(x, u, y, d, H, FusePre{}, FusePost{}, as_stream(stream), tb);
 }
 
-EE_API int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, const float *gamma, const float *beta, float eps, const float *u, float *y,
-                                       int B, int KC, int RC, int H, void *stream) {
+EE_API int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, int S, int cnt, const float *gamma, const float *beta, float eps, float momentum,
+                                       float *running_mean, float *running_var, float *save_mean, float *save_invstd, const float *u, float *y, int B,
+                                       int KC, int RC, int H, void *stream) {
     const int rc = wino_check(x, u, y, B, KC, RC, H);
     if (rc != EE_OK || B == 0) return rc;
-    if (H != 16 || KC > 128) return EE_ERR_UNSUPPORTED;
-    if (!stats) return EE_ERR_NULL;
-    const FusePre pre{beta, stats, nullptr, nullptr, gamma, eps};
+    if (KC > WN_MAX_KC_TRAIN) return EE_ERR_UNSUPPORTED;
+    if (!stats || !save_mean || !save_invstd) return EE_ERR_NULL;
+    if (S < 1 || cnt < 1 || (running_mean == nullptr) != (running_var == nullptr)) return EE_ERR_SHAPE;
+    if (reinterpret_cast<uintptr_t>(stats) & 7u) return EE_ERR_ALIGN;
+    const TrainBn tb{nullptr, stats, S, static_cast<float>(cnt), gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd};
     const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
     ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
-    return wino_pc16_train_launch<3, false>(x, u, y, d, pre, nullptr, as_stream(stream));
+    return wino_dispatch_t<3, false, false>(x, u, y, d, H, FusePre{}, FusePost{}, as_stream(stream), tb);
 }
 
 #ifdef EE_WINO_TIMING

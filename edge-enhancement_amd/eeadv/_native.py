@@ -89,7 +89,8 @@ SIGNATURES = {
     # dy, dy2, y, u_b, var, gamma, eps, dres, dx_add, dx, B, Cin, Cout, H, stream
     "ee_wino3x3_bn_eval_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wino3x3_stats_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "ee_wino3x3_bn_train_pre_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    # x, stats, S, cnt, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, u, y, B, KC, RC, H, stream
+    "ee_wino3x3_bn_train_pre_f32": [c_p, c_p, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wrw3x3_workspace_floats": [c_i, c_i, c_i, c_i],
     "ee_wrw3x3_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wrw3x3s2_workspace_floats": [c_i, c_i, c_i, c_i, c_i],
@@ -105,6 +106,7 @@ SIGNATURES = {
     "ee_conv3x3s2_pair_bwd_data_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     # x, w10, mean3, var3, gamma3, beta3, eps3, mean1, var1, gamma1, beta1, eps1, y3, y1, B, Cin, Cout, H, stream
     "ee_conv3x3s2_pair_bn_eval_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "ee_conv3x3s2_pair_stats_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     # dy3, y3, dy1, w10, var3, gamma3, eps3, var1, gamma1, eps1, dx, B, Cin, Cout, H, stream
     "ee_conv3x3s2_pair_bn_eval_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_net2_conv_wrw_workspace_floats": [c_i],

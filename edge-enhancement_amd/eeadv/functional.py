@@ -42,6 +42,10 @@ class attack_forward:
         _ATTACK_FORWARD = self._prev
 
 
+def attack_forward_active():
+    return _ATTACK_FORWARD
+
+
 def input_only_forward():
     """True where a forward pass will never be asked for parameter gradients: inside the attack loop, or with autograd off"""
     return _ATTACK_FORWARD or not torch.is_grad_enabled()
@@ -644,6 +648,60 @@ class EvalDownBlockFn(torch.autograd.Function):
         d1, dsc = ops.wino3x3_bn_eval_bwd(dy, dy2, out2, wino_sets(w2)[1], (rv2, g2, ctx.eps[2]), True)
         dx = ops.conv3x3s2_pair_bn_eval_bwd(d1, out1, dsc, _dense_weight(w3, "s2p_b", wd), w3.shape[1], (rv1, g1, ctx.eps[0]), (rvd, gd, ctx.eps[1]))
         return (dx,) + none[1:]
+
+
+class TrainConvBnConvFn(torch.autograd.Function):
+    """conv2(relu(bn1(conv1(x)))) of a BasicBlock (resnet.py:44-49) in TRAIN mode inside the attack loop, TWO launches forward: conv1's output
+    transform also writes per-image moments, conv2's prologue merges them (the batch statistics: a grid-wide exchange through the kernel
+    boundary instead of a BatchNorm launch), normalises and applies the ReLU while it stages its input (ee_wino3x3_stats_f32 /
+    ee_wino3x3_bn_train_pre_f32).  The statistics are summed in another order than ee_bn.hip's: rounding-level difference, bit-reproducible.
+    Backward (input gradient only; the parameters get None): conv2^T, the BatchNorm / ReLU backward kernel on the saved statistics, conv1^T."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, gamma, beta, running_mean, running_var, momentum, eps):
+        c1, stats = ops.wino3x3_stats(x, wino_sets(w1)[0])
+        c2, sm, si = ops.wino3x3_bn_train_pre(c1, stats, x.shape[2] * x.shape[3], gamma, beta, eps, momentum, running_mean, running_var, wino_sets(w2)[0])
+        ctx.save_for_backward(c1, w1, w2, gamma, beta, sm, si)
+        ctx.eps = eps
+        return c2
+
+    @staticmethod
+    def backward(ctx, dc2):
+        c1, w1, w2, gamma, beta, sm, si = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 9
+        d_a1 = ops.wino3x3(dc2.contiguous(), wino_sets(w2)[1])
+        d_c1 = ops.bn_act_bwd(d_a1, None, c1, gamma, sm, si, None, None, ctx.eps, True, True, True, False, False, None, beta)[0]
+        return (ops.wino3x3(d_c1, wino_sets(w1)[1]),) + (None,) * 8
+
+
+class TrainPairBnConvFn(torch.autograd.Function):
+    """(conv2(relu(bn1(conv1(x)))), downsample[0](x)) of a down-sampling BasicBlock in TRAIN mode inside the attack loop: the stride-2 pair
+    kernel with the moments of its 3x3 output, then conv2 with the merge / normalisation / ReLU in its prologue - see TrainConvBnConvFn."""
+
+    @staticmethod
+    def forward(ctx, x, w3, wd, w2, gamma, beta, running_mean, running_var, momentum, eps):
+        w10 = _dense_weight(w3, "s2p_f", wd)
+        _dense_weight(w3, "s2p_b", wd)  # created outside any capture; the backward only reads it
+        y3, y1, stats, cnt = ops.conv3x3s2_pair_stats_fwd(x, w10, w3.shape[0])
+        c2, sm, si = ops.wino3x3_bn_train_pre(y3, stats, cnt, gamma, beta, eps, momentum, running_mean, running_var, wino_sets(w2)[0])
+        ctx.save_for_backward(y3, w3, wd, w2, gamma, beta, sm, si)
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        return c2, y1
+
+    @staticmethod
+    def backward(ctx, dc2, dy1):
+        y3, w3, wd, w2, gamma, beta, sm, si = ctx.saved_tensors
+        if not ctx.needs_input_grad[0] or (dc2 is None and dy1 is None):
+            return (None,) * 10
+        if dc2 is None:
+            d_y3 = torch.zeros_like(y3)
+        else:
+            d_a1 = ops.wino3x3(dc2.contiguous(), wino_sets(w2)[1])
+            d_y3 = ops.bn_act_bwd(d_a1, None, y3, gamma, sm, si, None, None, ctx.eps, True, True, True, False, False, None, beta)[0]
+        dy1 = torch.zeros_like(y3) if dy1 is None else dy1.contiguous()
+        return (ops.conv3x3s2_pair_bwd_data(d_y3, dy1, _dense_weight(w3, "s2p_b", wd), w3.shape[1]),) + (None,) * 9
 
 
 class Conv3x3S2SmallFn(torch.autograd.Function):

@@ -23,7 +23,7 @@ from utils.core import (Add_Square, CannyFilter, CannyFilter_BPDA, CannyFilter_s
 
 from . import hfs as _hfs, ops, runtime, syncbn as _syncbn
 from . import functional as _fn
-from .functional import EvalBasicBlockFn, EvalDownBlockFn, Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1Fn, Conv1x1S2Fn, Conv3x3Map2Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
+from .functional import EvalBasicBlockFn, EvalDownBlockFn, TrainConvBnConvFn, TrainPairBnConvFn, Net2ConvFn, BnActFn, BnDualFn, BnReluPoolFn, Conv1x1Fn, Conv1x1S2Fn, Conv3x3Map2Fn, Conv3x3S2PairFn, Conv3x3S2SmallFn, Conv3x3WinoFn, MaxPool3s2Fn, PoolLinearFn, StemConvFn
 
 _CANNY = {"CannyFilter": CannyFilter, "CannyFilter_step125_1": CannyFilter_step125_1, "CannyFilter_BPDA": CannyFilter_BPDA}
 
@@ -505,6 +505,43 @@ def eval_block(block, xm, xs, fork):
                                  fork and _FORK)
 
 
+# Widths of conv2's map (the consumer) that take the boundary path.  The consumer's prologue merges S partials for EVERY reduction channel in EVERY workgroup:
+# on 16x16 maps that is 6.4 K pairs against 1.6 M activations (layer1: the BatchNorm launch costs 10.3 us, the exchange 5.2 us,
+# profiles/round4_a_bn_boundary_probe.txt); on the 8x8 / 4x4 maps of layers 2-3 it is 12.8 K / 25.6 K pairs per workgroup - more traffic than the
+# 5 us BatchNorm launch it would replace (all six blocks on the path: tiny_ee_at 8452 -> 8069 img/s).  EEADV_TRAINFUSE_MAPS=16,8,4 overrides (A/B).
+_TRAINFUSE_MAPS = frozenset(int(t) for t in os.environ.get("EEADV_TRAINFUSE_MAPS", "16").split(",") if t)
+
+
+def train_mid_bn(block, xm):
+    """conv2(relu(bn1(conv1(x)))) of a BasicBlock in TRAIN mode where only the input gradient can be asked for (the attack loop of the
+    training drivers runs in train mode): bn1's batch statistics cross the kernel boundary between the two convolutions instead of a
+    BatchNorm launch (functional.TrainConvBnConvFn / TrainPairBnConvFn; EEADV_STOCK_GLUE=trainfuse switches it off).  Returns conv2's raw
+    output (and the shortcut convolution's for a down-sampling block), or None where it does not apply."""
+    bn = block.bn1
+    if ("trainfuse" in _STOCK or "bn" in _STOCK or "conv3" in _STOCK or "wino" in _STOCK or not block.training or not _fn.attack_forward_active()
+            or not _dense_f32(xm) or xm.dim() != 4 or xm.shape[2] != xm.shape[3] or type(bn) is not BatchNorm2d or not bn.training or not bn.affine
+            or not bn.track_running_stats or bn.weight.dtype != torch.float32 or not _plain_conv3(block.conv2, 1) or block.conv2.in_channels > 256):
+        return None
+    ds, hw = block.downsample, xm.shape[2]
+    mom = 0.0 if bn.momentum is None else bn.momentum
+    if (hw if ds is None else hw // 2) not in _TRAINFUSE_MAPS:  # the CONSUMER's map: conv2 runs behind the block's stride
+        return None
+    if ds is None:
+        if hw not in (4, 8, 16) or not _plain_conv3(block.conv1, 1):
+            return None
+        _route(block.conv1, "ee_wino+stats"), _route(block.conv2, "ee_wino+bn(train)")
+        return TrainConvBnConvFn.apply(xm, block.conv1.weight, block.conv2.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps), None
+    if ("s2pair" in _STOCK or "s2small" in _STOCK or hw not in (8, 16) or not _plain_conv3(block.conv1, 2) or not isinstance(ds, nn.Sequential) or len(ds) != 2
+            or type(ds[0]) is not nn.Conv2d):
+        return None
+    c1 = ds[0]
+    if (c1.kernel_size != (1, 1) or c1.stride != (2, 2) or c1.padding != (0, 0) or c1.groups != 1 or c1.bias is not None or c1.in_channels != block.conv1.in_channels
+            or c1.out_channels != block.conv1.out_channels or not c1.weight.is_contiguous()):
+        return None
+    _route(block.conv1, "ee_s2.pair+stats"), _route(c1, "ee_s2.pair+stats"), _route(block.conv2, "ee_wino+bn(train)")
+    return TrainPairBnConvFn.apply(xm, block.conv1.weight, c1.weight, block.conv2.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -525,6 +562,10 @@ class BasicBlock(nn.Module):
             out = eval_block(self, xm, xs, fork)
             if out is not None:
                 return out
+        if self.training:
+            mid = train_mid_bn(self, xm)
+            if mid is not None:
+                return block_tail(self, self.bn2, mid[0], xs, fork, sc=mid[1])
         both = s2_pair(self, xm) if self.downsample is not None else None
         if both is not None:  # conv1 and the shortcut's convolution in one launch; the identity piece xs gets no gradient of its own
             return block_tail(self, self.bn2, conv3(self.conv2, bn_act(self.bn1, both[0])), xs, fork, sc=both[1])

@@ -853,6 +853,46 @@ def conv3x3s2_pair_bn_eval_bwd(dy3, y3, dy1, w10, cin, bn3, bn1):
     return dx
 
 
+def wino3x3_stats(x, u):
+    """conv3x3(x) and, per (result channel, image), the plane's (mean, M2): (y, stats [RC, B, 2]) - the producer half of a train-mode
+    BatchNorm exchanged across the kernel boundary (ee_wino3x3_stats_f32)"""
+    B, KC, H = x.shape[0], x.shape[1], x.shape[2]
+    RC = u.shape[2]
+    y = torch.empty((B, RC, H, H), dtype=torch.float32, device=x.device)
+    stats = torch.empty((RC, B, 2), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_wino3x3_stats_f32(_chk(x, torch.float32, "x", (B, KC, H, H)), _chk(u, torch.float32, "u", (16, KC, RC)), y.data_ptr(), stats.data_ptr(),
+                                       B, KC, RC, H, _stream()), "ee_wino3x3_stats_f32")
+    return y, stats
+
+
+def wino3x3_bn_train_pre(x, stats, cnt, gamma, beta, eps, momentum, running_mean, running_var, u):
+    """conv3x3(relu(batch_norm(x))) in TRAIN mode, the batch statistics merged from `stats` [KC, S, 2] (S partials of `cnt` values each):
+    (y, save_mean, save_invstd); running_mean / running_var (or None) move by `momentum` (ee_wino3x3_bn_train_pre_f32)"""
+    B, KC, H = x.shape[0], x.shape[1], x.shape[2]
+    RC = u.shape[2]
+    S = stats.shape[1]
+    y = torch.empty((B, RC, H, H), dtype=torch.float32, device=x.device)
+    sm = torch.empty(KC, dtype=torch.float32, device=x.device)
+    si = torch.empty(KC, dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_wino3x3_bn_train_pre_f32(_chk(x, torch.float32, "x", (B, KC, H, H)), _chk(stats, torch.float32, "stats", (KC, S, 2)), S, int(cnt),
+                                              _optf(gamma, "gamma", (KC,)), _optf(beta, "beta", (KC,)), float(eps), float(momentum),
+                                              _optf(running_mean, "running_mean", (KC,)), _optf(running_var, "running_var", (KC,)), sm.data_ptr(), si.data_ptr(),
+                                              _chk(u, torch.float32, "u", (16, KC, RC)), y.data_ptr(), B, KC, RC, H, _stream()), "ee_wino3x3_bn_train_pre_f32")
+    return y, sm, si
+
+
+def conv3x3s2_pair_stats_fwd(x, w10, cout):
+    """conv3x3s2_pair_fwd plus the statistics of y3 for the train-mode BatchNorm behind it: (y3, y1, stats [Cout, S, 2], cnt)"""
+    B, Cin, H = x.shape[0], x.shape[1], x.shape[2]
+    y3 = torch.empty((B, cout, H // 2, H // 2), dtype=torch.float32, device=x.device)
+    y1 = torch.empty_like(y3)
+    S, cnt = (2 * B, 32) if H == 16 else (B, 16)
+    stats = torch.empty((cout, S, 2), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_conv3x3s2_pair_stats_fwd_f32(_chk(x, torch.float32, "x", (B, Cin, H, H)), _chk(w10, torch.float32, "w10", (cout // 32, Cin // 16, 10, 4, 2, 16, 4)),
+                                                  y3.data_ptr(), y1.data_ptr(), stats.data_ptr(), B, Cin, cout, H, _stream()), "ee_conv3x3s2_pair_stats_fwd_f32")
+    return y3, y1, stats, cnt
+
+
 def wrw3x3_supported(x, dy):
     """ee_wrw.hip: weight gradient of a 3x3 / stride 1 / padding 1 convolution on 2x2, 4x4, 8x8 or 16x16 maps"""
     return (x.dim() == 4 and dy.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (2, 4, 8, 16) and x.shape[2:] == dy.shape[2:]

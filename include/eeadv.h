@@ -386,13 +386,18 @@ int ee_wino3x3_bn_eval_fwd_f32(const float *x, const float *u, const float *mean
                                const float *res, int relu, float *y, int B, int Cin, int Cout, int H, void *stream);
 int ee_wino3x3_bn_eval_bwd_f32(const float *dy, const float *dy2, const float *y, const float *u_b, const float *var, const float *gamma, float eps,
                                float *dres, const float *dx_add, float *dx, int B, int Cin, int Cout, int H, void *stream);
-/* Probe (round 4; scripts/bn_boundary_probe.py, profiles/round4_*_bn_boundary.txt): TRAIN-mode BatchNorm with the batch
- * statistics exchanged across the KERNEL BOUNDARY - the producing convolution's output transform writes per (channel, image) the plane's
- * (mean, M2) to stats [Cout][B][2]; the consuming convolution's prologue merges the B equal-count partials of each of its reduction channels
- * in a fixed order and stages relu((x - mean) * gamma / sqrt(var + eps) + beta).  16x16 maps, Cin <= 128.  Neither call updates running
- * statistics or saves mean / invstd: a timing / numerics probe of resnet.py:44-59's conv1 -> bn1 -> relu -> conv2, not wired into the models. */
+/* TRAIN-mode BatchNorm with the batch statistics exchanged across the KERNEL BOUNDARY (round 4; resnet.py:44-49: conv1 -> bn1 -> relu ->
+ * conv2 inside the attack loop of the training drivers, which runs in train mode - experiments_tinyimagenet.py:234-282).  The producing
+ * convolution's output transform writes, next to its raw output, per (channel, image) the plane's (mean, M2) to stats [Cout][B][2]; the
+ * consuming convolution's prologue merges the S equal-count partials of each of its reduction channels in a fixed order (bit-reproducible)
+ * and stages relu((x - mean) * gamma / sqrt(var + eps) + beta); its first workgroup writes save_mean / save_invstd [Cin] (what
+ * ee_bn_act_bwd2_f32(training = 1) reads) and moves running_mean / running_var (may both be NULL) by `momentum` with the unbiased variance,
+ * as ee_bn_act_fwd_f32(training = 1) does.  One BatchNorm launch less per residual block and forward pass (10.3 -> 5.2 us,
+ * profiles/round4_a_bn_boundary_probe.txt); the statistics are summed in another order than ee_bn_act_fwd_f32's: rounding-level difference.
+ * H = 4, 8 or 16; Cin <= 256 for the consumer.  S partials of cnt values each (ee_wino3x3_stats_f32: S = B, cnt = H * H). */
 int ee_wino3x3_stats_f32(const float *x, const float *u, float *y, float *stats, int B, int KC, int RC, int H, void *stream);
-int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, const float *gamma, const float *beta, float eps, const float *u, float *y, int B, int KC,
+int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, int S, int cnt, const float *gamma, const float *beta, float eps, float momentum,
+                                float *running_mean, float *running_var, float *save_mean, float *save_invstd, const float *u, float *y, int B, int KC,
                                 int RC, int H, void *stream);
 
 /* The WEIGHT gradient of the same convolution (`loss.backward()` of the training step, experiments_tinyimagenet.py:304-306; resnet.py:26-31) on
@@ -445,6 +450,9 @@ int ee_conv3x3s2_pair_bn_eval_fwd_f32(const float *x, const float *w10, const fl
 int ee_conv3x3s2_pair_bn_eval_bwd_f32(const float *dy3, const float *y3, const float *dy1, const float *w10, const float *var3, const float *gamma3,
                                       float eps3, const float *var1, const float *gamma1, float eps1, float *dx, int B, int Cin, int Cout, int H,
                                       void *stream);
+/* ... and, for TRAIN mode, with the statistics of y3 for the BatchNorm behind it (see ee_wino3x3_bn_train_pre_f32): stats [Cout][S][2] = (mean, M2)
+ * per result channel and partial - H = 16: S = 2 B half images of 32 values; H = 8: S = B images of 16 values (H = 4: EE_ERR_UNSUPPORTED). */
+int ee_conv3x3s2_pair_stats_fwd_f32(const float *x, const float *w10, float *y3, float *y1, float *stats, int B, int Cin, int Cout, int H, void *stream);
 
 /* The filters of the convolution kernels above in the order those kernels read them, from the Conv2d weight [Cout,Cin,3,3] (one launch;
  * the host rebuilds them once per optimiser step, inside the captured update graph):
