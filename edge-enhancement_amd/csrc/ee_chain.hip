@@ -352,293 +352,12 @@ __global__ __launch_bounds__((kSW + C) * kWave) void chain_fwd_kernel(FwdParams 
     }
 }
 
-// ---- the forward in row bands (round 4): one workgroup per (image, band of 16 rows) ------------------------------------------------------
-// chain_fwd_kernel puts ONE workgroup on an image: 100 workgroups on 256 CUs at the reference batch, 150 KB of LDS each, and phase
-// skipping (scripts/chain_phases.py, profiles/round4_a_chain_fwd_phases.txt) prices its 23 us as 9.4 us of launch / loads / staging,
-// 8.4 us of edge filter (VALU: 1024 four-pixel groups on eight wavefronts), 3.7 us of low-pass products hidden behind it, 2.8 us of
-// combine / store.  The edge filter is local (a 2-row halo); the low-pass output of a band needs every row of the plane as INPUT but only
-// the band's rows of the last two products.  So a band workgroup stages the whole image into the A planes (Add_Square applied), keeps the
-// raw frame of its own 20 rows for the edge filter, runs products 1-2 in full and 3-4 for its own row tile (120 of the 192 MFMAs), and
-// combines / stores its 16 rows: 4 stencil + C matrix wavefronts, 78 KB of LDS - two workgroups per CU, 400 of them at batch 100.  The
-// constant fragments of products 2-4 travel through registers (prefetched from L2 while the image is staged), those of product 1 through
-// LDS.  Every value is computed by the same instruction sequence as in chain_fwd_kernel: bit-identical outputs.  The draws are made by
-// every band workgroup from the same counters; all B * bands workgroups take a ticket.
-constexpr int kSWB = 4, kSTB = kSWB * kWave;
-
-template <int C, int H, int W, bool SQUARE>
-__global__ __launch_bounds__((kSWB + C) * kWave, 4) void chain_fwd_band_kernel(FwdParams p, Weights wt) {
-    using D = Dims<H, W>;
-    constexpr int NBANDS = D::HT, BR = 16, FHB = BR + 4, FW = W + 2 * kColHalo, F4 = FW / 4, PLB = FHB * FW, W4 = W / 4;
-    constexpr int NT = (kSWB + C) * kWave;
-    static_assert(W % 4 == 0 && H <= 64 && W <= 64 && C <= 3, "shape class of the reference configs");
-    extern __shared__ __align__(16) float lds[];
-    float *xr = lds;                       // [C][FHB][FW] clamped frame of x, image rows r0 - 2 .. r0 + 17: the edge filter's input
-    float *xs = xr + C * PLB;              // [C][HP][AS] add_square(x), every row: the MFMA A operand; the band's rows later hold the low-pass result
-    float *t1s = xs + C * D::HP * D::AS;   // product 1's constant fragments [N1][64]
-    float *stripe = t1s + D::N1 * 64;      // [C][W] stripe signs of this image (+ 4 floats of square draws)
-    uint8_t *emap = reinterpret_cast<uint8_t *>(stripe + C * W + 4);  // [BR][W] edge map of the band
-    uint8_t *gst = emap + BR * W;                                   // [C][BR][W] derivative codes of the band
-    // eight consecutive workgroup numbers go to the eight XCDs: the bands of an image sit eight apart, on the same XCD's L2
-    const int id = blockIdx.x, n = (id / (8 * NBANDS)) * 8 + (id & 7), band = (id >> 3) % NBANDS;
-    if (n >= p.B) return;
-    const int tid = threadIdx.x, wave = tid >> 6, r0 = band * BR, rows = H - r0 < BR ? H - r0 : BR;
-    const float *xn = p.x + static_cast<size_t>(n) * C * H * W;
-
-    // ---- global loads, all up front on clamped addresses: (a) the band's frame (stencil waves), (b) every row of the image for the A
-    // planes (everybody), the constant fragments (matrix waves: product 1's to LDS, 2-4's stay in registers) ---------------------------------
-    constexpr int TOT_A = C * FHB * F4, PER_A = (TOT_A + kSTB - 1) / kSTB;
-    constexpr int TOT_B = C * H * W4, PER_B = (TOT_B + NT - 1) / NT;
-    float4 va[PER_A], vb[PER_B];
-    int gja[PER_A];
-    if (wave < kSWB) {
-#pragma unroll
-        for (int q = 0; q < PER_A; ++q) {
-            const int idx0 = tid + q * kSTB, idx = idx0 < TOT_A ? idx0 : TOT_A - 1;
-            const int c = idx / (FHB * F4), rem = idx - c * (FHB * F4), r = rem / F4, f = rem - r * F4;
-            gja[q] = 4 * f - kColHalo;
-            va[q] = *reinterpret_cast<const float4 *>(xn + (static_cast<size_t>(c) * H + clampi(r0 - 2 + r, 0, H - 1)) * W + clamp_col4(gja[q], W));
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < PER_B; ++q) {
-        const int idx0 = tid + q * NT, idx = idx0 < TOT_B ? idx0 : TOT_B - 1;
-        vb[q] = reinterpret_cast<const float4 *>(xn)[idx];
-    }
-    const int lane = tid & 63;
-    if (wave >= kSWB) {
-        constexpr int MT = C * kWave;
-        for (int i = tid - kSTB; i < D::N1 * 64; i += MT) t1s[i] = p.tables[i];
-    }
-
-    // ---- draws by wave 0 (as chain_fwd_kernel: the same element <-> Philox mapping; every band workgroup of an image makes the same draws) ----
-    float *sqp = stripe + C * W;
-    const bool rng_mode = SQUARE && !p.stripe_in;
-    unsigned long long rng_base = 0ull, ticket = 0ull;
-    if (SQUARE && wave == 0) {
-        if (p.stripe_in) {
-            for (int i = tid; i < C * W; i += kWave) stripe[i] = p.stripe_in[static_cast<size_t>(n) * C * W + i];
-            if (tid == 0) sqp[0] = __int_as_float(static_cast<int>(p.sq_pos_in[0]));
-            if (tid < C) sqp[1 + tid] = p.two_eps * p.sq_sign_in[tid];
-        } else {
-            const unsigned long long seed = p.state[0], base = p.state[1];
-            const Philox rng(seed);
-            const long long n_stripe = static_cast<long long>(p.B) * C * W;
-            if (tid < C * W4) {
-                const uint4 r = rng(base + static_cast<unsigned long long>(n) * (C * W4) + tid);
-                *reinterpret_cast<float4 *>(stripe + 4 * tid) =
-                    make_float4(sgn(2.0f * u01(r.x) - 1.0f), sgn(2.0f * u01(r.y) - 1.0f), sgn(2.0f * u01(r.z) - 1.0f), sgn(2.0f * u01(r.w) - 1.0f));
-            } else if (tid < C * W4 + 1 + C) {
-                const int k = tid - C * W4;
-                const long long e = n_stripe + k;
-                const uint4 r = rng(base + static_cast<unsigned long long>(e >> 2));
-                const unsigned rr[4] = {r.x, r.y, r.z, r.w};
-                const float u = u01(rr[e & 3]);
-                if (k == 0) {
-                    const float span = static_cast<float>(H) - static_cast<float>(p.sq_size);
-                    sqp[0] = __int_as_float(static_cast<int>(static_cast<long long>(0.0f + (span - 0.0f) * u)));
-                } else {
-                    sqp[k] = p.two_eps * sgn(2.0f * u - 1.0f);
-                }
-            }
-            rng_base = base;
-        }
-    }
-    int vh = 0;
-    float sq_delta[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) sq_delta[c] = 0.0f;
-    if (SQUARE) {
-        __syncthreads();  // the draws are in LDS
-        vh = __float_as_int(sqp[0]);
-#pragma unroll
-        for (int c = 0; c < C; ++c) sq_delta[c] = sqp[1 + c];
-        if (rng_mode && tid == 0) ticket = atomicAdd(p.state + 2, 1ull);  // B * NBANDS tickets in all; read at the end (see chain_fwd_kernel)
-    }
-
-    // ---- stage in: (a) frame -> LDS, the derivative codes of the band's interior; (b) Add_Square of every row -> A planes -----------------------
-    SquareArgs sa{};
-    sa.nq = 1; sa.C = C; sa.H = H; sa.W = W; sa.eps = p.eps; sa.two_eps = p.two_eps;
-    // values only (the A planes: every row of the image, in every band workgroup - no derivative chain)
-    auto square4_value = [&](float4 v, int c, int h, int w0, float (&o)[4]) {
-        const float xv[4] = {v.x, v.y, v.z, v.w};
-        if (SQUARE) {
-            SquarePlane pl{};
-            pl.vh[0] = vh; pl.s[0] = p.sq_size;
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc)
-                if (cc == c) pl.delta[0] = sq_delta[cc];
-            const float4 st = *reinterpret_cast<const float4 *>(stripe + c * W + w0);
-            const float sv[4] = {st.x, st.y, st.z, st.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float d;
-                o[k] = square_elem<false>(sa, pl, xv[k], sv[k], c, h, w0 + k, d);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = xv[k];
-        }
-    };
-    auto square4 = [&](float4 v, int c, int h, int w0, float (&o)[4], unsigned (&code)[4]) {
-        const float xv[4] = {v.x, v.y, v.z, v.w};
-        if (SQUARE) {
-            SquarePlane pl{};
-            pl.vh[0] = vh; pl.s[0] = p.sq_size;
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc)
-                if (cc == c) pl.delta[0] = sq_delta[cc];
-            const float4 st = *reinterpret_cast<const float4 *>(stripe + c * W + w0);
-            const float sv[4] = {st.x, st.y, st.z, st.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float d;
-                o[k] = square_elem<true>(sa, pl, xv[k], sv[k], c, h, w0 + k, d);
-                code[k] = dsq_code(d) << 1;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = xv[k], code[k] = 3u << 1;
-        }
-    };
-    if (wave < kSWB) {
-#pragma unroll
-        for (int q = 0; q < PER_A; ++q) {
-            const int idx = tid + q * kSTB;
-            if (idx < TOT_A) {
-                *reinterpret_cast<float4 *>(xr + idx * 4) = replicate4(va[q], gja[q], W);
-                const int c = idx / (FHB * F4), rem = idx - c * (FHB * F4), r = rem / F4, f = rem - r * F4;
-                const int hb = r - 2, w0 = 4 * f - kColHalo;  // row inside the band
-                if (hb >= 0 && hb < rows && w0 >= 0 && w0 < W) {
-                    float o[4];
-                    unsigned code[4];
-                    square4(va[q], c, r0 + hb, w0, o, code);
-                    *reinterpret_cast<uchar4 *>(gst + (c * BR + hb) * W + w0) = make_uchar4(code[0], code[1], code[2], code[3]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < PER_B; ++q) {
-        const int idx = tid + q * NT;
-        if (idx < TOT_B) {
-            const int c = idx / (H * W4), rem = idx - c * (H * W4), h = rem / W4, w0 = 4 * (rem - h * W4);
-            float o[4];
-            square4_value(vb[q], c, h, w0, o);
-            *reinterpret_cast<float4 *>(xs + (c * D::HP + h) * D::AS + w0) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-    if (D::HP != H || D::WP != W) {  // padding rows / columns of the A planes (28 -> 32): zeros (their table entries are zero too)
-        for (int idx = tid; idx < C * D::HP * D::AS; idx += NT) {
-            const int rem = idx % (D::HP * D::AS);
-            const int h = rem / D::AS, w = rem - h * D::AS;
-            if (h >= H || w >= W) xs[idx] = 0.0f;
-        }
-    }
-    __syncthreads();
-
-    if (wave < kSWB) {
-        // ---- edge filter of the band's rows: ee_edge.hip's arithmetic on the band frame (frame row of image row i - 2 = i - r0) ----------------
-        for (int idx = tid; idx < rows * W4; idx += kSTB) {
-            const int ib = idx / W4, lx = idx - ib * W4, jb = 4 * lx, i = r0 + ib;
-            float b[C][3][6];
-            blur_group<C, FHB, FW>(xr, wt, ib, jb + kColHalo - 2, i, jb, H, W, b);
-            float e[4], gxs[4], gys[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float ax, ay, s2, mag, mag_a;
-                sobel_px<C>(b, wt, k, ax, ay);
-                edge_from_sums<C>(ax, ay, p.alpha, p.high, gxs[k], gys[k], s2, mag, mag_a, e[k]);
-            }
-            *reinterpret_cast<uchar4 *>(emap + ib * W + jb) = make_uchar4(e[0] != 0.0f, e[1] != 0.0f, e[2] != 0.0f, e[3] != 0.0f);
-            const size_t pix = (static_cast<size_t>(n) * H + i) * W + jb;
-            *reinterpret_cast<float4 *>(p.gx + pix) = make_float4(gxs[0], gxs[1], gxs[2], gxs[3]);
-            *reinterpret_cast<float4 *>(p.gy + pix) = make_float4(gys[0], gys[1], gys[2], gys[3]);
-            if (p.edge) *reinterpret_cast<float4 *>(p.edge + pix) = make_float4(e[0], e[1], e[2], e[3]);
-        }
-    } else {
-        // ---- low-pass of add_square(x), plane c: products 1-2 over the whole plane, 3-4 for the band's row tile only --------------------------
-        const int c = wave - kSWB, li = lane & 15, lg = lane >> 4;
-        float *xc = xs + c * D::HP * D::AS;
-        // the constant fragments of products 2-4 (56 floats per lane, L2-resident): issued now, they arrive while product 1 runs from LDS
-        // (held across the staging above they spilled 60 registers of the 128 that two workgroups per CU leave)
-        float t2r[D::N2], t3r[8], t4r[D::N4];
-        {
-            const float *tg = p.tables + lane;
-#pragma unroll
-            for (int i = 0; i < D::N2; ++i) t2r[i] = tg[(D::N1 + i) * 64];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t3r[i] = tg[(D::N1 + D::N2 + band * 8 + i) * 64];
-#pragma unroll
-            for (int i = 0; i < D::N4; ++i) t4r[i] = tg[(D::N1 + D::N2 + D::N3 + i) * 64];
-        }
-        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-        f32x4 pq[D::HT];
-#pragma unroll
-        for (int mt = 0; mt < D::HT; ++mt) pq[mt] = zero;
-        const float *t1 = t1s + lane;
-#pragma unroll 4
-        for (int s_ = 0; s_ < D::N1; ++s_) {  // P | Q = X T1 (lowpass_front's loop)
-            const float bb = t1[s_ * 64];
-#pragma unroll
-            for (int mt = 0; mt < D::HT; ++mt) pq[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[(16 * mt + li) * D::AS + 4 * s_ + lg], bb, pq[mt], 0, 0, 0);
-        }
-        f32x4 rc[2] = {zero, zero};
-#pragma unroll
-        for (int t = 0; t < D::HT; ++t)  // R = CS^T [P | Q]
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) rc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(t2r[(mt * D::HT + t) * 4 + r], pq[t][r], rc[mt], 0, 0, 0);
-        f32x4 ef[2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float pc = __shfl_xor(rc[0][r], 8), ps = __shfl_xor(rc[1][r], 8);
-            ef[0][r] = (li < 8) ? rc[0][r] - ps : rc[0][r] + ps;
-            ef[1][r] = (li < 8) ? rc[1][r] + pc : rc[1][r] - pc;
-        }
-        f32x4 uv = zero;  // UV^T of row tile `band` (lowpass_back's first product, ht = band)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) uv = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[t][r], t3r[t * 4 + r], uv, 0, 0, 0);
-        f32x4 y[D::WT];
-#pragma unroll
-        for (int wt_ = 0; wt_ < D::WT; ++wt_) y[wt_] = zero;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int wt_ = 0; wt_ < D::WT; ++wt_) y[wt_] = __builtin_amdgcn_mfma_f32_16x16x4f32(uv[r], t4r[wt_ * 4 + r], y[wt_], 0, 0, 0);
-        // every A operand of this plane has been consumed (by this wave only): the band's rows take the result in place
-#pragma unroll
-        for (int wt_ = 0; wt_ < D::WT; ++wt_)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xc[(r0 + 4 * lg + r) * D::AS + 16 * wt_ + li] = y[wt_][r];
-    }
-    __syncthreads();
-
-    // ---- combine + stage out the band's rows (everybody) -------------------------------------------------------------------------------------
-    float *xo = p.x_in + static_cast<size_t>(n) * C * H * W;
-    uint8_t *go = p.gate + static_cast<size_t>(n) * C * H * W;
-    for (int idx = tid; idx < C * rows * W4; idx += NT) {
-        const int c = idx / (rows * W4), rem = idx - c * (rows * W4);
-        const int hb = rem / W4, w0 = 4 * (rem - hb * W4), h = r0 + hb;
-        const float4 lp = *reinterpret_cast<const float4 *>(xs + (c * D::HP + h) * D::AS + w0);
-        const uchar4 e4 = *reinterpret_cast<const uchar4 *>(emap + hb * W + w0);
-        const uchar4 cd = *reinterpret_cast<const uchar4 *>(gst + (c * BR + hb) * W + w0);
-        const float s0 = lp.x + p.w * (e4.x ? 1.0f : 0.0f), s1 = lp.y + p.w * (e4.y ? 1.0f : 0.0f);
-        const float s2 = lp.z + p.w * (e4.z ? 1.0f : 0.0f), s3 = lp.w + p.w * (e4.w ? 1.0f : 0.0f);
-        *reinterpret_cast<float4 *>(xo + (static_cast<size_t>(c) * H + h) * W + w0) =
-            make_float4(tclamp(s0, 0.0f, 1.0f), tclamp(s1, 0.0f, 1.0f), tclamp(s2, 0.0f, 1.0f), tclamp(s3, 0.0f, 1.0f));
-        *reinterpret_cast<uchar4 *>(go + (static_cast<size_t>(c) * H + h) * W + w0) =
-            make_uchar4(cd.x | (s0 >= 0.0f && s0 <= 1.0f), cd.y | (s1 >= 0.0f && s1 <= 1.0f), cd.z | (s2 >= 0.0f && s2 <= 1.0f),
-                        cd.w | (s3 >= 0.0f && s3 <= 1.0f));
-    }
-    if (rng_mode && tid == 0 && ticket + 1ull == static_cast<unsigned long long>(p.B) * NBANDS) {
-        const long long total = static_cast<long long>(p.B) * C * W + 1 + C;
-        p.state[1] = rng_base + static_cast<unsigned long long>((total + 3) >> 2);
-        p.state[2] = 0ull;
-    }
-}
+// Round 4 priced this kernel (scripts/chain_phases.py, profiles/round4_a_chain_fwd_phases.txt) and a row-band variant of it (one workgroup
+// per image and 16 rows, two per CU, 400 at batch 100; commit 614de05, profiles/round4_c_chain_fwd_bands.txt): of the 23 us at 100 x 3 x 64 x 64,
+// 9.4 are launch / loads / draws / Add_Square / staging, 8.4 the edge filter (VALU-bound: ~770 K lane-operations per image = 5 us of a CU's
+// vector pipes at full rate), 3.7 the low-pass products (hidden behind it), 2.8 combine / store.  Bands spread the edge filter over more CUs
+// but every band workgroup needs add_square(x) of EVERY row as low-pass input: 23.1 us against 22.6 with Add_Square (14.5 against 16.2
+// without), 210 against 140 us at batch 1600.  Removed; what stayed is the draw-state ticket issued behind the barrier (-0.5 us).
 
 struct BwdParams {
     const float *g_in;
@@ -884,39 +603,8 @@ int opt_in_lds(K kernel, size_t bytes) {
     return EE_OK;
 }
 
-template <int H, int W>
-size_t fwd_band_lds_bytes(int C) {
-    using D = Dims<H, W>;
-    return sizeof(float) * (static_cast<size_t>(C) * 20 * (W + 2 * kColHalo) + static_cast<size_t>(C) * D::HP * D::AS + D::N1 * 64 + C * W + 4) +
-           static_cast<size_t>(16) * W + static_cast<size_t>(C) * 16 * W;
-}
-
-// EEADV_CHAIN_BANDS=0: the one-workgroup-per-image forward (A/B, and the reference the band kernel is tested against); read per call
-inline bool chain_bands_on() {
-    const char *e = getenv("EEADV_CHAIN_BANDS");
-    return !(e && e[0] == '0');
-}
-
-template <int C, int H, int W>
-int launch_fwd_band(const FwdParams &p, const Weights &wt, bool square, hipStream_t s) {
-    using D = Dims<H, W>;
-    const size_t bytes = fwd_band_lds_bytes<H, W>(C);
-    const dim3 grid(static_cast<unsigned>((p.B + 7) / 8 * 8 * D::HT)), block((kSWB + C) * kWave);
-    if (square) {
-        static int ok = opt_in_lds(chain_fwd_band_kernel<C, H, W, true>, fwd_band_lds_bytes<H, W>(C));
-        if (ok != EE_OK) return ok;
-        EE_LAUNCH((chain_fwd_band_kernel<C, H, W, true>), grid, block, bytes, s, p, wt);
-    } else {
-        static int ok = opt_in_lds(chain_fwd_band_kernel<C, H, W, false>, fwd_band_lds_bytes<H, W>(C));
-        if (ok != EE_OK) return ok;
-        EE_LAUNCH((chain_fwd_band_kernel<C, H, W, false>), grid, block, bytes, s, p, wt);
-    }
-    return launch_status();
-}
-
 template <int C, int H, int W>
 int launch_fwd(const FwdParams &p, const Weights &wt, bool square, hipStream_t s) {
-    if (Dims<H, W>::HT >= 2 && chain_bands_on()) return launch_fwd_band<C, H, W>(p, wt, square, s);
     const size_t bytes = fwd_lds_bytes<H, W>(C);
     const dim3 grid(static_cast<unsigned>(p.B)), block((kSW + C) * kWave);
     if (square) {

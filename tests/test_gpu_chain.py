@@ -89,38 +89,6 @@ def test_chain_forward_vs_separate_kernels(ops, C, n, r, B):
     assert np.array_equal(np.where(code == 0, 0.0, (code + 1) * 0.25).astype(np.float32), mask)
 
 
-@pytest.mark.parametrize("C,n,r", SHAPES)
-@pytest.mark.parametrize("B", [1, 7, 9, 100])
-@pytest.mark.parametrize("square", [True, False])
-def test_chain_forward_row_bands_equal_one_workgroup_per_image(ops, C, n, r, B, square, monkeypatch):
-    """round 4: ee_chain_fwd_f32 as one workgroup per (image, band of 16 rows) - the default - against the one-workgroup-per-image kernel
-    (EEADV_CHAIN_BANDS=0, read by the library per call): every output bit for bit, with injected draws, with the device-side draws (the
-    same Philox counters in every band workgroup, B * bands tickets: the state advances identically), and without Add_Square."""
-    x, op = _setup(C, n, r, B, 11)
-    eps = 16 / 255 if C == 3 else 0.3
-    alpha, high, w = (0.0, 76 / 255, 1.0) if C == 3 else (0.3, 51 / 255, 1.0)
-    s = max(int(round((0.8 * n * n) ** 0.5)), 1)
-    wts = ops.EdgeWeights(1.0)
-
-    def run(bands, state, draws):
-        monkeypatch.setenv("EEADV_CHAIN_BANDS", "1" if bands else "0")
-        if square:
-            return ops.chain_fwd(x, op.chain, wts, alpha, high, w, True, eps, s, state, draws, want_edge=True)
-        return ops.chain_fwd(x, op.chain, wts, alpha, high, w, want_edge=True)
-    d = _draws(ops, B, C, n, s) if square else None
-    one, band = run(False, None, d), run(True, None, d)
-    for a, b, what in zip(band, one, ("x_in", "gate", "gx", "gy", "edge")):
-        assert torch.equal(a, b), what
-    if square:  # device-side draws: two consecutive launches each, the state after them
-        st_one = torch.tensor([123, 8, 0, 0], dtype=torch.int64, device=DEV)
-        st_band = st_one.clone()
-        for _ in range(2):
-            one, band = run(False, st_one, None), run(True, st_band, None)
-            for a, b, what in zip(band, one, ("x_in", "gate", "gx", "gy", "edge")):
-                assert torch.equal(a, b), what
-        assert st_band.tolist() == st_one.tolist() and st_band[2].item() == 0
-
-
 @pytest.mark.parametrize("C,n,r", [(3, 64, 8), (1, 28, 4)])
 def test_chain_forward_draws_on_the_device(ops, C, n, r):
     """Philox mode: same element <-> counter mapping as ee_square_draw_f32, the last workgroup advances the state, the ticket
