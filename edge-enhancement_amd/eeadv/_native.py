@@ -91,6 +91,11 @@ SIGNATURES = {
     "ee_wino3x3_stats_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     # x, stats, S, cnt, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, u, y, B, KC, RC, H, stream
     "ee_wino3x3_bn_train_pre_f32": [c_p, c_p, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "ee_dense2x2_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    # x, w2, mean, var, gamma, beta, eps, res, relu, y, B, Cin, Cout, stream
+    "ee_dense2x2_bn_eval_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_i, c_i, c_i, c_p],
+    # dy, dy2, y, w2t, var, gamma, eps, dres, dx_add, dx, B, Cin, Cout, stream
+    "ee_dense2x2_bn_eval_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_wrw3x3_workspace_floats": [c_i, c_i, c_i, c_i],
     "ee_wrw3x3_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wrw3x3s2_workspace_floats": [c_i, c_i, c_i, c_i, c_i],

@@ -395,6 +395,8 @@ def _rearranged(weight, kind="s1", extra=None):
         if kind in ("s2m_f", "s2p_f"):  # result = co = 32 cb + 16 h + m, reduction = ci = 16 rd + 4 q + k
             return w.view(co // 32, 2, 16, ci // 16, 4, 4, taps).permute(0, 3, 6, 4, 1, 2, 5)
         return w.view(co // 16, 4, 4, ci // 32, 2, 16, taps).permute(3, 0, 6, 1, 4, 5, 2)  # result = ci, reduction = co
+    if kind == "s1t":  # the dense 2x2 matrix transposed: what ee_dense.hip's backward-data product reads ([4 Cout, 4 Cin])
+        return _rearranged(weight, "s1").t().contiguous()
     idx = _DENSE_IDX.get((weight.device, kind))
     if idx is None:
         n_in, stride = (2, 1) if kind == "s1" else (4, 2)
@@ -593,6 +595,35 @@ def _bn_fwd_consts(g, b, rm, rv, eps):
     return (rm, rv, g, b, eps)
 
 
+def _eval_conv_fwd(x, w, bn, res):
+    """relu(bn(conv3x3(x)) [+ res]) with bn in eval mode, one launch: Winograd on 4 / 8 / 16-wide maps, the dense product on 2x2 maps"""
+    if x.shape[2] == 2:
+        if _DENSE_FOLD_BWD:
+            _dense_weight(w, "s1t")  # created outside any capture; the backward only reads it
+        return ops.dense2x2_bn_eval_fwd(x, _dense_weight(w, "s1"), bn, res, True)
+    return ops.wino3x3_bn_eval_fwd(x, wino_sets(w)[0], bn, res, True)
+
+
+# 2x2 maps, backward: ee_dense2x2_bn_eval_bwd_f32 is built and tested, but folding the BatchNorm / ReLU backward into the product's A staging makes
+# each of its 64 column-tile workgroups read the gradient AND the mask (196 MB through L2 per launch instead of 128): 26.4 us against 21.4 for the
+# BatchNorm launch + Tensile's product (profiles/round4_d_dense_probe.txt).  The forward fold wins (17.2 against 20.0 us) and is what runs.
+_DENSE_FOLD_BWD = os.environ.get("EEADV_DENSE_FOLD_BWD", "0") == "1"
+
+
+def _eval_conv_bwd(dy, dy2, y, w, bn, want_dres, dx_add=None):
+    """bn = (running_var, gamma, eps, running_mean): the backward of _eval_conv_fwd with respect to x -> (dx [+ dx_add], dz or None)"""
+    if dy.shape[2] == 2:
+        if _DENSE_FOLD_BWD:
+            return ops.dense2x2_bn_eval_bwd(dy, dy2, y, _dense_weight(w, "s1t"), bn[:3], want_dres, dx_add)
+        # the BatchNorm / ReLU backward launch (x only enters as xhat * 0: y stands in for it), then Tensile's product with dx_add as its C operand
+        dzs, dz, _, _ = ops.bn_act_bwd(dy, y, y, bn[1], None, None, bn[3], bn[0], bn[2], False, True, True, want_dres, False, dy2)
+        B = dy.shape[0]
+        w2 = _dense_weight(w, "s1")
+        dx = torch.mm(dzs.reshape(B, -1), w2.t()) if dx_add is None else torch.addmm(dx_add.reshape(B, -1), dzs.reshape(B, -1), w2.t())
+        return dx.view(B, w.shape[1], 2, 2), dz
+    return ops.wino3x3_bn_eval_bwd(dy, dy2, y, wino_sets(w)[1], bn[:3], want_dres, dx_add)
+
+
 class EvalBasicBlockFn(torch.autograd.Function):
     """relu(bn2(conv2(relu(bn1(conv1(x))))) + x): a BasicBlock without shortcut convolution (resnet.py:44-59) under model.eval(), TWO launches
     each way - the Winograd kernels with the running-statistics BatchNorm, the residual and the ReLU in their output transform (forward)
@@ -603,22 +634,22 @@ class EvalBasicBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xa, xb, w1, w2, g1, b1, rm1, rv1, eps1, g2, b2, rm2, rv2, eps2, fork):
-        out1 = ops.wino3x3_bn_eval_fwd(xa, wino_sets(w1)[0], _bn_fwd_consts(g1, b1, rm1, rv1, eps1), None, True)
-        out2 = ops.wino3x3_bn_eval_fwd(out1, wino_sets(w2)[0], _bn_fwd_consts(g2, b2, rm2, rv2, eps2), xa, True)
-        ctx.save_for_backward(out1, out2, w1, w2, g1, rv1, g2, rv2)
+        out1 = _eval_conv_fwd(xa, w1, _bn_fwd_consts(g1, b1, rm1, rv1, eps1), None)
+        out2 = _eval_conv_fwd(out1, w2, _bn_fwd_consts(g2, b2, rm2, rv2, eps2), xa)
+        ctx.save_for_backward(out1, out2, w1, w2, g1, rv1, g2, rv2, rm1, rm2)
         ctx.eps = (eps1, eps2)
         ctx.set_materialize_grads(False)
         return (out2, out2.view_as(out2)) if fork else out2
 
     @staticmethod
     def backward(ctx, *grads):
-        out1, out2, w1, w2, g1, rv1, g2, rv2 = ctx.saved_tensors
+        out1, out2, w1, w2, g1, rv1, g2, rv2, rm1, rm2 = ctx.saved_tensors
         none = (None,) * 15
         dy, dy2 = _two_pieces(grads)
         if dy is None or not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             return none
-        d1, dres = ops.wino3x3_bn_eval_bwd(dy, dy2, out2, wino_sets(w2)[1], (rv2, g2, ctx.eps[1]), True)
-        dx, _ = ops.wino3x3_bn_eval_bwd(d1, None, out1, wino_sets(w1)[1], (rv1, g1, ctx.eps[0]), False, dx_add=dres)
+        d1, dres = _eval_conv_bwd(dy, dy2, out2, w2, (rv2, g2, ctx.eps[1], rm2), True)
+        dx, _ = _eval_conv_bwd(d1, None, out1, w1, (rv1, g1, ctx.eps[0], rm1), False, dx_add=dres)
         return (dx,) + none[1:]
 
 
@@ -632,20 +663,20 @@ class EvalDownBlockFn(torch.autograd.Function):
         w10 = _dense_weight(w3, "s2p_f", wd)
         _dense_weight(w3, "s2p_b", wd)  # created outside any capture; the backward only reads it
         out1, sc = ops.conv3x3s2_pair_bn_eval_fwd(xa, w10, w3.shape[0], _bn_fwd_consts(g1, b1, rm1, rv1, eps1), _bn_fwd_consts(gd, bd, rmd, rvd, epsd))
-        out2 = ops.wino3x3_bn_eval_fwd(out1, wino_sets(w2)[0], _bn_fwd_consts(g2, b2, rm2, rv2, eps2), sc, True)
-        ctx.save_for_backward(out1, out2, w3, wd, w2, g1, rv1, gd, rvd, g2, rv2)
+        out2 = _eval_conv_fwd(out1, w2, _bn_fwd_consts(g2, b2, rm2, rv2, eps2), sc)
+        ctx.save_for_backward(out1, out2, w3, wd, w2, g1, rv1, gd, rvd, g2, rv2, rm2)
         ctx.eps = (eps1, epsd, eps2)
         ctx.set_materialize_grads(False)
         return (out2, out2.view_as(out2)) if fork else out2
 
     @staticmethod
     def backward(ctx, *grads):
-        out1, out2, w3, wd, w2, g1, rv1, gd, rvd, g2, rv2 = ctx.saved_tensors
+        out1, out2, w3, wd, w2, g1, rv1, gd, rvd, g2, rv2, rm2 = ctx.saved_tensors
         none = (None,) * 21
         dy, dy2 = _two_pieces(grads)
         if dy is None or not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             return none
-        d1, dsc = ops.wino3x3_bn_eval_bwd(dy, dy2, out2, wino_sets(w2)[1], (rv2, g2, ctx.eps[2]), True)
+        d1, dsc = _eval_conv_bwd(dy, dy2, out2, w2, (rv2, g2, ctx.eps[2], rm2), True)
         dx = ops.conv3x3s2_pair_bn_eval_bwd(d1, out1, dsc, _dense_weight(w3, "s2p_b", wd), w3.shape[1], (rv1, g1, ctx.eps[0]), (rvd, gd, ctx.eps[1]))
         return (dx,) + none[1:]
 

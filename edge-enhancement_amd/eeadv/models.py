@@ -488,19 +488,21 @@ def eval_block(block, xm, xs, fork):
             or not _plain_conv3(block.conv2, 1) or block.conv2.out_channels > 512):
         return None
     ds, hw = block.downsample, xm.shape[2]
+    dense_ok = "dense" not in _STOCK and "densefuse" not in _STOCK and ops.dense2x2_supported(block.conv2.in_channels, block.conv2.out_channels)
     if ds is None:
-        if hw not in (4, 8, 16) or not _plain_conv3(block.conv1, 1) or block.conv1.in_channels != block.conv2.out_channels:
+        if (hw not in (4, 8, 16) and not (hw == 2 and dense_ok)) or not _plain_conv3(block.conv1, 1) or block.conv1.in_channels != block.conv2.out_channels:
             return None
-        _route(block.conv1, "ee_wino+bn"), _route(block.conv2, "ee_wino+bn")
+        how = "ee_dense+bn" if hw == 2 else "ee_wino+bn"
+        _route(block.conv1, how), _route(block.conv2, how)
         return EvalBasicBlockFn.apply(xm, xs, block.conv1.weight, block.conv2.weight, *_bn_args(block.bn1), *_bn_args(block.bn2), fork and _FORK)
-    if ("s2pair" in _STOCK or "s2small" in _STOCK or hw not in (8, 16) or not _plain_conv3(block.conv1, 2) or not isinstance(ds, nn.Sequential) or len(ds) != 2
+    if ("s2pair" in _STOCK or "s2small" in _STOCK or (hw not in (8, 16) and not (hw == 4 and dense_ok)) or not _plain_conv3(block.conv1, 2) or not isinstance(ds, nn.Sequential) or len(ds) != 2
             or type(ds[0]) is not nn.Conv2d or not _plain_bn(ds[1])):
         return None
     c1 = ds[0]
     if (c1.kernel_size != (1, 1) or c1.stride != (2, 2) or c1.padding != (0, 0) or c1.groups != 1 or c1.bias is not None or c1.in_channels != block.conv1.in_channels
             or c1.out_channels != block.conv1.out_channels or not c1.weight.is_contiguous()):
         return None
-    _route(block.conv1, "ee_s2.pair+bn"), _route(c1, "ee_s2.pair+bn"), _route(block.conv2, "ee_wino+bn")
+    _route(block.conv1, "ee_s2.pair+bn"), _route(c1, "ee_s2.pair+bn"), _route(block.conv2, "ee_dense+bn" if hw == 4 else "ee_wino+bn")
     return EvalDownBlockFn.apply(xm, xs, block.conv1.weight, c1.weight, block.conv2.weight, *_bn_args(block.bn1), *_bn_args(ds[1]), *_bn_args(block.bn2),
                                  fork and _FORK)
 

@@ -893,6 +893,48 @@ def conv3x3s2_pair_stats_fwd(x, w10, cout):
     return y3, y1, stats, cnt
 
 
+def dense2x2_supported(cin, cout):
+    return cin % 128 == 0 and cout % 8 == 0
+
+
+def dense2x2(x, w2):
+    """conv3x3 on a 2x2 map as one dense product (ee_dense.hip): x [B, Cin, 2, 2], w2 [4 Cin, 4 Cout] -> [B, Cout, 2, 2]"""
+    B, Cin = x.shape[0], x.shape[1]
+    Cout = w2.shape[1] // 4
+    y = torch.empty((B, Cout, 2, 2), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_dense2x2_f32(_chk(x, torch.float32, "x", (B, Cin, 2, 2)), _chk(w2, torch.float32, "w2", (4 * Cin, 4 * Cout)), y.data_ptr(), B, Cin, Cout,
+                                  _stream()), "ee_dense2x2_f32")
+    return y
+
+
+def dense2x2_bn_eval_fwd(x, w2, bn, res, relu):
+    """[relu]( bn(conv3x3(x)) [+ res] ) on a 2x2 map with bn in eval mode, ONE launch: bn = (mean, var, gamma, beta, eps)"""
+    B, Cin = x.shape[0], x.shape[1]
+    Cout = w2.shape[1] // 4
+    mean, var, gamma, beta, eps = bn
+    y = torch.empty((B, Cout, 2, 2), dtype=torch.float32, device=x.device)
+    N.check(N.lib.ee_dense2x2_bn_eval_fwd_f32(_chk(x, torch.float32, "x", (B, Cin, 2, 2)), _chk(w2, torch.float32, "w2", (4 * Cin, 4 * Cout)),
+                                              _chk(mean, torch.float32, "running_mean", (Cout,)), _chk(var, torch.float32, "running_var", (Cout,)),
+                                              _optf(gamma, "gamma", (Cout,)), _optf(beta, "beta", (Cout,)), float(eps), _optf(res, "res", (B, Cout, 2, 2)),
+                                              1 if relu else 0, y.data_ptr(), B, Cin, Cout, _stream()), "ee_dense2x2_bn_eval_fwd_f32")
+    return y
+
+
+def dense2x2_bn_eval_bwd(dy, dy2, y, w2t, bn, want_dres, dx_add=None):
+    """dz = (y > 0) * (dy [+ dy2]); dx = (gamma / sqrt(var + eps) * dz) . w2t [+ dx_add] -> (dx, dz or None); w2t [4 Cout, 4 Cin]; bn = (var, gamma, eps)"""
+    B, Cout = dy.shape[0], dy.shape[1]
+    Cin = w2t.shape[1] // 4
+    var, gamma, eps = bn
+    dx = torch.empty((B, Cin, 2, 2), dtype=torch.float32, device=dy.device)
+    dres = torch.empty_like(dy) if want_dres else None
+    N.check(N.lib.ee_dense2x2_bn_eval_bwd_f32(_chk(dy, torch.float32, "dy", (B, Cout, 2, 2)), _optf(dy2, "dy2", (B, Cout, 2, 2)),
+                                              _chk(y, torch.float32, "y", (B, Cout, 2, 2)), _chk(w2t, torch.float32, "w2t", (4 * Cout, 4 * Cin)),
+                                              _chk(var, torch.float32, "running_var", (Cout,)), _optf(gamma, "gamma", (Cout,)), float(eps),
+                                              None if dres is None else dres.data_ptr(), _optf(dx_add, "dx_add", (B, Cin, 2, 2)), dx.data_ptr(),
+                                              B, Cin, Cout, _stream()), "ee_dense2x2_bn_eval_bwd_f32")
+    return dx, dres
+
+
 def wrw3x3_supported(x, dy):
     """ee_wrw.hip: weight gradient of a 3x3 / stride 1 / padding 1 convolution on 2x2, 4x4, 8x8 or 16x16 maps"""
     return (x.dim() == 4 and dy.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] in (2, 4, 8, 16) and x.shape[2:] == dy.shape[2:]

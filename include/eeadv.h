@@ -400,6 +400,17 @@ int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, int S, int c
                                 float *running_mean, float *running_var, float *save_mean, float *save_invstd, const float *u, float *y, int B, int KC,
                                 int RC, int H, void *stream);
 
+/* Conv2d(3x3, stride 1, padding 1, bias=False) on a 2x2 map (ResNet-18's layer4 at 64x64 inputs, resnet.py:26-31) as ONE dense product on the
+ * f32 matrix cores: every input pixel reaches every output pixel, y[n][(co,p)] = sum x[n][(ci,q)] * w2[(ci,q)][(co,p)], w2 [4 Cin][4 Cout] =
+ * EE_WPREP_DENSE_S1 (the backward-data product takes its transpose and Cin / Cout exchanged).  x [B,Cin,2,2] -> y [B,Cout,2,2]; Cin a multiple
+ * of 128, Cout of 8.  The *_bn_eval_* forms fold the eval-mode BatchNorm, the residual and the ReLU of the block in exactly as
+ * ee_wino3x3_bn_eval_fwd_f32 / _bwd_f32 do (same arguments; w2t [4 Cout][4 Cin] = w2 transposed; Cout <= 512 for the backward). */
+int ee_dense2x2_f32(const float *x, const float *w2, float *y, int B, int Cin, int Cout, void *stream);
+int ee_dense2x2_bn_eval_fwd_f32(const float *x, const float *w2, const float *mean, const float *var, const float *gamma, const float *beta, float eps,
+                                const float *res, int relu, float *y, int B, int Cin, int Cout, void *stream);
+int ee_dense2x2_bn_eval_bwd_f32(const float *dy, const float *dy2, const float *y, const float *w2t, const float *var, const float *gamma, float eps,
+                                float *dres, const float *dx_add, float *dx, int B, int Cin, int Cout, void *stream);
+
 /* The WEIGHT gradient of the same convolution (`loss.backward()` of the training step, experiments_tinyimagenet.py:304-306; resnet.py:26-31) on
  * H x H maps, H = 2, 4, 8 or 16, as Winograd F(3x3, 2x2) around the f32 matrix cores: x [B,Cin,H,H] (the layer's input), dy [B,Cout,H,H] (the
  * gradient of its output) -> dw [Cout,Cin,3,3] (overwritten).  The sum over images and tiles is split over ~256 workgroups whose partial results

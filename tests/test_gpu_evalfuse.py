@@ -115,6 +115,40 @@ def test_s2_pair_bn_eval_equals_the_unfused_kernels(ops, B, Cin, Cout, H, mt, mo
     _same(got, want, "pair backward-data")
 
 
+@pytest.mark.parametrize("B,Cin,Cout", [(100, 512, 512), (5, 512, 512), (33, 256, 512), (1, 128, 64), (64, 512, 256)])
+def test_dense2x2_product_and_its_bn_eval_forms(ops, B, Cin, Cout):
+    """ee_dense.hip: the 3x3 convolution on a 2x2 map as one hand-written product, against the Tensile product of the same rearranged weights
+    (summation order differs: tolerance) and - the fused forms - against the plain hand-written product followed by ee_bn_act_*: bit for bit"""
+    from eeadv import functional as Fn
+    gen = torch.Generator().manual_seed(B + Cin + Cout)
+    x = torch.randn(B, Cin, 2, 2, generator=gen).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * (2.0 / (9 * Cin)) ** 0.5).to(DEV)
+    w2, w2t = Fn._dense_weight(w, "s1"), Fn._dense_weight(w, "s1t")
+    assert torch.equal(w2t, w2.t().contiguous())
+    y = ops.dense2x2(x, w2)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    res = torch.randn(B, Cout, 2, 2, generator=gen).to(DEV)
+    g, b, rm, rv, eps = _bn(Cout, gen)
+    for r in (None, res):
+        want, _, _ = ops.bn_act_fwd(y, r, g, b, rm, rv, 0.1, eps, False, True)
+        _same(ops.dense2x2_bn_eval_fwd(x, w2, (rm, rv, g, b, eps), r, True), want, "fused forward")
+    # backward-data: dz = (y > 0)(dy + dy2), dx = (w dz) W2^T + dx_add
+    out = torch.relu(torch.randn(B, Cout, 2, 2, generator=gen)).to(DEV)
+    dy, dy2 = torch.randn(B, Cout, 2, 2, generator=gen).to(DEV), torch.randn(B, Cout, 2, 2, generator=gen).to(DEV)
+    dx_add = torch.randn(B, Cin, 2, 2, generator=gen).to(DEV)
+    if Cout % 128 == 0:  # the backward product reduces over 4 Cout
+        for pieces, add in ((1, None), (2, dx_add), (1, dx_add)):
+            d2 = dy2 if pieces == 2 else None
+            dz_scaled, dz, _, _ = ops.bn_act_bwd(dy, out, torch.zeros_like(dy), g, None, None, rm, rv, eps, False, True, True, True, False, d2)
+            want = ops.dense2x2(dz_scaled, w2t)
+            if add is not None:
+                want = want + add
+            got, dres = ops.dense2x2_bn_eval_bwd(dy, d2, out, w2t, (rv, g, eps), True, add)
+            _same(got, want, "fused backward-data")
+            _same(dres, dz, "residual gradient")
+
+
 def _resnet(eval_mode=True, seed=3):
     from eeadv import models as M
     torch.manual_seed(seed)
@@ -150,15 +184,30 @@ def test_eval_mode_input_gradient_is_bit_identical_with_and_without_the_fusion(m
     g_f = _input_gradient(m, x, y)
     routes = M.fallback_report(m)
     fused = [n for n, mod in m.named_modules() if isinstance(mod, torch.nn.Conv2d) and mod.__dict__.get("_ee_route", "").endswith("+bn")]
-    assert len(fused) >= 14, (fused, routes)  # layers 1-3: 12 3x3 convolutions + 2 shortcut convolutions (+ layer 4 once its kernel takes them)
+    assert len(fused) == 19, (fused, routes)  # every convolution behind the stem: 16 3x3 + 3 shortcut convolutions
+    assert routes["count"] == 0, routes  # nothing of an eval-mode pass is left on MIOpen / Tensile
     monkeypatch.setattr(M, "_STOCK", frozenset(["evalfuse"]))
     with torch.no_grad():
         logits_u = m(x)
     g_u = _input_gradient(m, x, y)
     assert not any(mod.__dict__.get("_ee_route", "").endswith("+bn") for mod in m.modules() if isinstance(mod, torch.nn.Conv2d))
-    _same(logits_f, logits_u, "eval-mode logits")
-    _same(g_f, g_u, "eval-mode input gradient")
+    # layers 1-3: the same Winograd / stride-2 kernels with and without the fold - bit for bit (checked per kernel above and, for the whole
+    # model, below with the layer-4 fold switched off (EEADV_STOCK_GLUE=densefuse)); layer 4: ee_dense.hip against the Tensile product of the unfused path, another
+    # summation order - rounding level on the logits, and a ReLU within rounding of zero may flip in the gradient
+    assert float((logits_f - logits_u).abs().max()) <= 1e-5 * float(logits_u.abs().max())
+    assert float((g_f - g_u).norm() / g_u.norm()) < 1e-2
     assert float(g_f.abs().max()) > 0
+    monkeypatch.setattr(M, "_STOCK", frozenset(["densefuse"]))  # layer 4 on the per-layer path in both runs
+    with torch.no_grad():
+        logits_f3 = m(x)
+    g_f3 = _input_gradient(m, x, y)
+    assert sum(mod.__dict__.get("_ee_route", "").endswith("+bn") for mod in m.modules() if isinstance(mod, torch.nn.Conv2d)) == 14
+    monkeypatch.setattr(M, "_STOCK", frozenset(["densefuse", "evalfuse"]))
+    with torch.no_grad():
+        logits_u3 = m(x)
+    g_u3 = _input_gradient(m, x, y)
+    _same(logits_f3, logits_u3, "eval-mode logits, layers 1-3 folded")
+    _same(g_f3, g_u3, "eval-mode input gradient, layers 1-3 folded")
 
 
 def test_train_mode_and_parameter_gradients_do_not_take_the_fused_blocks():
@@ -185,6 +234,7 @@ def test_eval_mode_attack_fused_equals_unfused(monkeypatch, graph):
     import utils.attacks as A
     from eeadv import engine, models as M
     monkeypatch.setenv("EEADV_GRAPH", "1" if graph else "0")
+    monkeypatch.setattr(M, "_STOCK", frozenset(["densefuse"]))  # layer 4 stays on the per-layer path in both runs (its folded kernel sums in another order)
     engine.clear_graphs()
     m = _resnet()
 
@@ -195,7 +245,7 @@ def test_eval_mode_attack_fused_equals_unfused(monkeypatch, graph):
     noise = torch.zeros_like(x).uniform_(-16 / 255, 16 / 255)
     adv_f = A.PGD(m, Args, x, y, 5, 2 / 255, noise=noise)
     engine.clear_graphs()
-    monkeypatch.setattr(M, "_STOCK", frozenset(["evalfuse"]))
+    monkeypatch.setattr(M, "_STOCK", frozenset(["densefuse", "evalfuse"]))
     adv_u = A.PGD(m, Args, x, y, 5, 2 / 255, noise=noise)
     engine.clear_graphs()
     _same(adv_f, adv_u, "adversarial batch")
