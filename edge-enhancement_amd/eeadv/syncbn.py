@@ -16,6 +16,8 @@ State-dict keys, constructor arguments and the eval-mode behaviour (running stat
 With one rank (or no process group) the exchange is the identity and the result is that of BatchNorm2d on the same batch.
 CPU tensors (the gloo tests, `runtime.allow_cpu_plumbing`) go through a torch restatement of the same formulas.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -28,10 +30,16 @@ def _group_size(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _forced():
+    """EEADV_FORCE_COLLECTIVES=1 with a process group of ONE rank: the collectives are issued anyway (the rehearsal of the N > 1 path on a
+    one-GPU box: scripts/freeat_graph_collectives.py captures them into the repeat's graph over RCCL)"""
+    return os.environ.get("EEADV_FORCE_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def _all_gather(t, group):
     """[...] -> [W, ...] in rank order"""
     W = _group_size(group)
-    if W == 1:
+    if W == 1 and not _forced():
         return t.unsqueeze(0)
     if t.is_cuda and dist.get_backend(group) == "gloo":  # two ranks time-sharing one GPU in the tests: stage through the host
         host = [torch.empty(t.shape, dtype=t.dtype) for _ in range(W)]
@@ -43,7 +51,7 @@ def _all_gather(t, group):
 
 
 def _all_reduce_sum(t, group):
-    if _group_size(group) == 1:
+    if _group_size(group) == 1 and not _forced():
         return t
     if t.is_cuda and dist.get_backend(group) == "gloo":
         h = t.cpu()

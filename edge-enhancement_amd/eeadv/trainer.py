@@ -596,6 +596,12 @@ def awp_train_batch(model, awp_adversary, criterion, optimizer, args, input, tar
     return robust_loss.detach(), robust_output.detach()
 
 
+def graph_collectives_enabled():
+    """EEADV_GRAPH_COLLECTIVES=1 and a process group on RCCL ("nccl"): collectives may sit inside a captured graph"""
+    import torch.distributed as dist
+    return (os.environ.get("EEADV_GRAPH_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl")
+
+
 class FreeAtStep:
     """One batch through the `n_repeats` repeats of free adversarial training (AT_free_imagenet_ddp.py:286-309) - the "step" of
     BASELINE config 5.  With HIP graphs enabled and no collective inside the repeat (one rank: plain BatchNorm, no gradient exchange)
@@ -612,9 +618,13 @@ class FreeAtStep:
     def _graphable(self, x):
         from eeadv import engine
         m = self.model
-        return (engine.graphs_enabled() and x.is_cuda and self.sync is None and isinstance(self.optimizer, torch.optim.SGD) and m.training
-                and not isinstance(m, (nn.parallel.DistributedDataParallel, nn.DataParallel))
-                and not any(isinstance(k, nn.SyncBatchNorm) for k in m.modules()))
+        if not (engine.graphs_enabled() and x.is_cuda and isinstance(self.optimizer, torch.optim.SGD) and m.training
+                and not isinstance(m, (nn.parallel.DistributedDataParallel, nn.DataParallel))):
+            return False
+        collectives = self.sync is not None or any(isinstance(k, nn.SyncBatchNorm) for k in m.modules())
+        # round 4: the repeat WITH its collectives (SyncBatchNorm's two per layer, the gradient pieces' all-reduce) as one captured graph - opt-in
+        # (EEADV_GRAPH_COLLECTIVES=1, RCCL only) until it has run on a multi-GPU node; scripts/freeat_graph_collectives.py rehearses it on one rank
+        return not collectives or graph_collectives_enabled()
 
     def _repeat(self, x, y):
         return free_at_repeat(self.model, self.criterion, self.optimizer, x, y, self.noise, self.fgsm_step, self.clip_eps, sync=self.sync)

@@ -102,3 +102,20 @@ def test_filter_caches_follow_an_eager_fused_sgd_step():
     fresh = fwd()
     assert float((after - before).abs().max()) > 1e-3  # the step moved the logits ...
     assert torch.equal(after, fresh)                   # ... and the cached filter copies moved with it
+
+
+@pytest.mark.gpu
+def test_free_at_repeat_with_its_collectives_in_one_graph():
+    """config 5's multi-rank repeat (SyncBatchNorm's exchanges + the gradient pieces' all-reduce) captured into ONE HIP graph
+    (EEADV_GRAPH_COLLECTIVES=1), rehearsed with one rank over RCCL and every collective forced on: on the 64 x 64 ResNet-18 - whose whole step
+    is bit-reproducible - the graphed repeats reproduce the eager ones BIT FOR BIT (parameters, running statistics, noise), and the host needs
+    less time per repeat than the device (scripts/freeat_graph_collectives.py asserts both)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(29700 + os.getpid() % 200), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "freeat_graph_collectives.py"), "18", "16", "64", "tiny"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "eager vs graphed: max |parameter difference| 0.000e+00" in r.stdout, r.stdout[-1500:]
