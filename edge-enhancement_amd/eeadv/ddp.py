@@ -226,9 +226,21 @@ class FlatGradSync:
         todo = self.pieces if piece is None else [self.pieces[piece]]
         self._works += [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in todo]
 
+    def _check_detached(self):
+        """a parameter the FIRST backward did not reach lost its view for good; if a later backward reaches it after all (a branch
+        switch, an unfrozen layer) autograd gives it a private .grad that no all-reduce sees - the replicas would drift apart silently."""
+        if all(self._live):
+            return
+        for p, live in zip(self.params, self._live):
+            if not live and p.grad is not None:
+                raise RuntimeError("ddp.FlatGradSync: a parameter that received no gradient in the first backward pass has one now; its gradient lies "
+                                   "outside the exchanged buffer.  Build a new FlatGradSync after changing which parameters train (or use EEADV_GRAD_SYNC=ddp "
+                                   "with find_unused_parameters)")
+
     def finish(self):
         """The current stream waits (on the device) for every piece issued since the last finish()."""
         self._settle()  # the first whole backward has been through autograd by now
+        self._check_detached()
         works, self._works = self._works, []
         for w in works:
             w.wait()

@@ -110,6 +110,8 @@ class SyncBnActFn(torch.autograd.Function):
         # (DistributedSampler pads, experiments_imagenet.py:154-161); ranks with different shapes exchange their counts once per call
         W = _group_size(group)
         local_n = x.numel() // x.shape[1]
+        if _EQUAL_SHARDS and W > 1:
+            _check_equal_counts(all_m, x, group)
         ctx.n_global = float(local_n * W) if _EQUAL_SHARDS else float(all_m[:, 0, 2].sum().item())
         ctx.save_for_backward(x, y if relu else None, gamma, beta, sm, si)
         ctx.cfg = (relu, residual is not None, group)
@@ -144,6 +146,23 @@ class SyncBnActFn(torch.autograd.Function):
         return dx, (dz if has_res and need[1] else None), (local[:, 1] if want_params and need[2] else None), (local[:, 0] if want_params and need[3] else None), None, None, None, None, None, None
 
 
+_COUNTS_CHECKED = set()
+
+
+def _check_equal_counts(all_m, x, group):
+    """the backward takes n_global = local count * W.  The forward merge already holds every rank's count on the device
+    (all_m[:, 0, 2]): compared ONCE per (tensor shape, group) - one host read, never inside a graph capture - and a difference is an error
+    instead of a silently mis-scaled input gradient (set eeadv.syncbn._EQUAL_SHARDS = False for samplers that do not pad)."""
+    key = (tuple(x.shape), id(group))
+    if key in _COUNTS_CHECKED or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return
+    _COUNTS_CHECKED.add(key)
+    counts = all_m[:, 0, 2]
+    if not bool((counts == counts[0]).all().item()):
+        raise RuntimeError("eeadv.syncbn: the ranks hold different per-rank batch sizes %s; set eeadv.syncbn._EQUAL_SHARDS = False (the global count "
+                           "is then read from the exchanged moments every step)" % counts.tolist())
+
+
 _EQUAL_SHARDS = True  # every rank's batch has the same shape (what the reference's DistributedSampler guarantees); False: exchange the counts
 
 
@@ -166,8 +185,9 @@ def sync_bn_act(bn, x, residual=None, relu=False):
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         return SyncBnActFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, bn.process_group)
-    out = nn.SyncBatchNorm.forward(bn, x) if (bn.training and _group_size(bn.process_group) > 1 and x.is_cuda) else F.batch_norm(
-        x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, 0.0 if bn.momentum is None else bn.momentum, bn.eps)
+    # everything the kernels do not take: torch's own SyncBatchNorm forward (one rank, eval mode, momentum = None with its cumulative average,
+    # track_running_stats = False, num_batches_tracked - ADVICE r3); it refuses host tensors when ranks would have to exchange statistics
+    out = nn.SyncBatchNorm.forward(bn, x)
     if residual is not None:
         out = out + residual
     return F.relu(out) if relu else out
