@@ -14,6 +14,7 @@
 #include "ee_common.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -184,6 +185,112 @@ __global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_kernel(const float *__re
     }
 }
 
+// ---- conv2 on the matrix cores (round 4) -------------------------------------------------------------------------------------
+// The scalar kernel above runs 64 x 800 fused multiply-adds per output pixel on the vector pipes (15.8 us per launch, bound by their issue rate).
+// As a product per image: D[co][pixel] = sum_k W[co][k] * P[k][pixel], K = 32 channels x 25 taps = 800, 64 x 64 results.  A workgroup owns one
+// image x 16 output channels (grid (B, 4): 200 workgroups at batch 50); its four wavefronts take 16 pixels each (two rows of the 8 x 8 result)
+// and walk K in steps of four input channels at one tap: 200 v_mfma_f32_16x16x4_f32 per wavefront.  Operands straight from LDS: the image's
+// a1 planes as they lie ([32][144]: the im2col operand is one ds_read_b32 at lane offset ci * 144 + oy * 12 + ox plus a compile-time tap
+// offset), the 16 filter rows as they lie in memory ([co][800], row pitch 836: bank = (4 co + 25 lq) % 64 over the 16 x 4 lanes of an operand
+// read - conflict-free).  Epilogue as the scalar kernel's: bias, dropout scale, 2 x 2 pool in ATen's scan order (the window's four pixels sit
+// in lanes l, l + 1, l + 8, l + 9 of the accumulator tile), ReLU that keeps NaN, the argmax code.  The products are summed in another order
+// than the scalar chain's: rounding-level difference (tests: 1e-5 against ATen), the same NaN footprint (a column of D depends on its own
+// pixel's window only).
+constexpr int N2_WPITCH = 836;  // 800 + 36
+
+template <bool RNG>
+__global__ __launch_bounds__(N2_NT) void net2_conv2_fwd_mfma_kernel(const float *__restrict__ a1, const float *__restrict__ w, const float *__restrict__ bias,
+                                                                    const float *__restrict__ drop, float keep, float *__restrict__ a2,
+                                                                    uint8_t *__restrict__ code2, unsigned long long *state, float *__restrict__ drop_out, int B) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __align__(16) float lds[];
+    float *as = lds;                      // [32][144]
+    float *ws = lds + N2_C1 * 144;        // [16][836]
+    const int b = blockIdx.x, c0 = blockIdx.y * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    unsigned long long seed = 0ull, base = 0ull;
+    if (RNG) seed = state[0], base = state[1];
+    // every global load first, on clamped indices (a load -> store loop with a run-time trip count is one memory round trip PER ITERATION:
+    // 12 of them for the filters), the LDS stores afterwards
+    const float4 *src = reinterpret_cast<const float4 *>(a1 + static_cast<size_t>(b) * N2_C1 * 144);
+    const float4 *wsrc = reinterpret_cast<const float4 *>(w + static_cast<size_t>(c0) * 800);  // 16 rows of 800 floats, contiguous
+    constexpr int NA = (N2_C1 * 144 / 4 + N2_NT - 1) / N2_NT, NW = (16 * 200 + N2_NT - 1) / N2_NT;  // 5, 13
+    float4 va[NA], vw[NW];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int i = threadIdx.x + j * N2_NT;
+        va[j] = src[i < N2_C1 * 144 / 4 ? i : N2_C1 * 144 / 4 - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int i = threadIdx.x + j * N2_NT;
+        vw[j] = wsrc[i < 16 * 200 ? i : 16 * 200 - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int i = threadIdx.x + j * N2_NT;
+        if (i < N2_C1 * 144 / 4) reinterpret_cast<float4 *>(as)[i] = va[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int i = threadIdx.x + j * N2_NT;
+        if (i < 16 * 200) {
+            const int r = i / 200, f = i - r * 200;
+            *reinterpret_cast<float4 *>(ws + r * N2_WPITCH + 4 * f) = vw[j];
+        }
+    }
+    __syncthreads();  // (waits for every outstanding load of the workgroup, the state's included)
+    unsigned long long ticket = 0ull;
+    if (RNG && threadIdx.x == 0) ticket = atomicAdd(state + 2, 1ull);  // read at the end: the round trip hides behind the products (see ee_chain.hip)
+    // pixel of this lane: rows 2 wave, 2 wave + 1 of the 8 x 8 result, column l15 & 7
+    const float *bp = as + lq * 144 + (2 * wave + (l15 >> 3)) * N2_H1 + (l15 & 7);
+    const float *ap = ws + l15 * N2_WPITCH + lq * 25;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)  // input channels 4 s + lq
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(4 * s) * 25 + ky * 5 + kx], bp[(4 * s) * 144 + ky * N2_H1 + kx], acc, 0, 0, 0);
+    // D[row = 4 lq + r = output channel][column = l15 = pixel]: bias, dropout scale, then the 2 x 2 pool across lanes l, l + 1, l + 8, l + 9
+    float mask4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    const bool dropping = RNG || drop != nullptr;
+    if (RNG) {
+        const long long e = static_cast<long long>(b) * N2_C2 + c0 + 4 * lq;  // elements e .. e + 3: one counter
+        const uint4 r = Philox(seed)(base + static_cast<unsigned long long>(e >> 2), 7u);
+        const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mask4[k] = u01(rr[k]) < keep ? 1.0f : 0.0f;
+        if (wave == 0 && l15 == 0) *reinterpret_cast<float4 *>(drop_out + e) = make_float4(mask4[0], mask4[1], mask4[2], mask4[3]);
+    } else if (drop) {
+        const float4 m = *reinterpret_cast<const float4 *>(drop + static_cast<size_t>(b) * N2_C2 + c0 + 4 * lq);
+        mask4[0] = m.x, mask4[1] = m.y, mask4[2] = m.z, mask4[3] = m.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = c0 + 4 * lq + r;
+        const float s = acc[r] + (bias ? bias[co] : 0.0f);
+        const float v0 = dropping ? s * (mask4[r] / keep) : s;
+        float v[4];
+        v[0] = v0;
+        v[1] = __shfl_down(v0, 1, 16);
+        v[2] = __shfl_down(v0, 8, 16);
+        v[3] = __shfl_down(v0, 9, 16);
+        if (l15 < 8 && !(l15 & 1)) {
+            int code;
+            const float best = pool4(v, code);
+            const size_t dst = (static_cast<size_t>(b) * N2_C2 + co) * (N2_H2 * N2_H2) + wave * N2_H2 + (l15 >> 1);
+            a2[dst] = relu_keep_nan(best);
+            code2[dst] = static_cast<uint8_t>(code);
+        }
+    }
+    if (RNG && threadIdx.x == 0 && ticket + 1ull == static_cast<unsigned long long>(B) * 4ull) {  // the last ticket of the grid advances the offset
+        state[1] = base + static_cast<unsigned long long>((static_cast<long long>(B) * N2_C2 + 3) >> 2);
+        state[2] = 0ull;
+    }
+}
+
 // ---- backward of the second half: d a2 -> d a1.  G[co][8][8] = the un-pooled gradient (threshold rule, argmax position, dropout scale),
 // then the transposed convolution d a1[ci][y][x] = sum_co sum_{ky,kx} G[co][y - ky][x - kx] * w[co][ci][ky][kx].
 // grid (B, 8): 4 input channels per workgroup; a thread owns one row y of one channel for an eighth of the output channels in flight
@@ -269,6 +376,117 @@ __global__ __launch_bounds__(N2_BT) void net2_conv2_bwd_kernel(const float *__re
             for (int g = 0; g < N2_BG - 1; ++g) sacc += part[(g * 48 + rem) * N2_H1 + xx];
             dst[xx] = sacc;
         }
+    }
+}
+
+// ---- conv2's backward-data on the matrix cores (round 4) ------------------------------------------------------------------------------------------
+// The un-pooled gradient G[co][8][8] has ONE non-zero per 2 x 2 window (the argmax the forward recorded): the scalar kernel above multiplies the
+// zeros too (64 x 25 fused multiply-adds per output element, 22 us).  Group the non-zeros by their position inside the window, d = (dy, dx):
+//     P_d[w][ci][tap] = sum_co  W[co][ci][tap] * G_d[co][w],      G_d[co][w] = g[co][w] if the window's argmax sits at d, else 0
+// is a product on the matrix cores - M = (ci, tap), K = 64 output channels, N = 4 classes x 16 windows = 64 columns - and
+//     d a1[ci][y][x] = sum over (ky, kx) of  P_d[w][ci][ky][kx]   with  (2 wy + dy, 2 wx + dx) = (y - ky, x - kx)
+// is a gather of at most 25 of its entries per output element, in a fixed order (bit-reproducible).  A workgroup owns one image x 8 input
+// channels (grid (B, 4)): M = 200 rows in 13 tiles, each wavefront one column tile: 13 x 16 = 208 MFMAs per wavefront against 1600 scalar
+// fused multiply-adds per output element before.  Filters as they lie in memory ([co][8 ci x 25 taps], row pitch 208: conflict-free A reads),
+// G_d as [co][80]; P overlays the filters once they have been consumed.  NaN / inf footprint: a column of the product depends on its own window
+// only, and the zeros of the other classes meet finite filters - what the scalar kernel's zeros do.
+// -DEE_NET2_SKIP=<bits> (scripts/net2_phases.py builds its own copy; never the product): 1: no products, 2: no gather (zeros stored), 4: no P store
+#ifndef EE_NET2_SKIP
+#define EE_NET2_SKIP 0
+#endif
+constexpr int N2_BWP = 208, N2_BGP = 80, N2_BPP = 201;  // P's column pitch: odd, so that the gather's 64 lanes (64 different columns) hit 64 banks
+
+__global__ __launch_bounds__(N2_NT) void net2_conv2_bwd_mfma_kernel(const float *__restrict__ da2, const float *__restrict__ a2, const uint8_t *__restrict__ code2,
+                                                                    const float *__restrict__ drop, float keep, const float *__restrict__ w,
+                                                                    float *__restrict__ da1) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __align__(16) float lds[];
+    float *ws = lds;                       // [64 co][208]: w[co][ci0 .. ci0 + 7][25]; later P [64 columns][208]
+    float *gs = lds + N2_C2 * N2_BWP;      // [64 co][80]: column n = 16 d + window
+    const int b = blockIdx.x, ci0 = blockIdx.y * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    // every global load first (see the forward kernel): 64 filter rows of 200 contiguous floats = 3200 float4, 13 per lane; the gradient,
+    // activation, code and dropout draw of the image's 1024 pooled elements, 4 per lane
+    constexpr int NW = (N2_C2 * 50 + N2_NT - 1) / N2_NT, NG = N2_C2 * 16 / N2_NT;  // 13, 4
+    float4 vw[NW];
+    float gv[NG], av[NG], dv[NG];
+    int cv[NG];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int i0 = threadIdx.x + j * N2_NT, i = i0 < N2_C2 * 50 ? i0 : N2_C2 * 50 - 1;
+        const int co = i / 50, f = i - co * 50;
+        vw[j] = *reinterpret_cast<const float4 *>(w + (static_cast<size_t>(co) * N2_C1 + ci0) * 25 + 4 * f);
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int i = threadIdx.x + j * N2_NT;
+        const size_t src = static_cast<size_t>(b) * N2_C2 * 16 + i;
+        gv[j] = da2[src];
+        av[j] = a2[src];
+        cv[j] = code2[src];
+        dv[j] = drop ? drop[static_cast<size_t>(b) * N2_C2 + (i >> 4)] : 1.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int i = threadIdx.x + j * N2_NT;
+        if (i < N2_C2 * 50) {
+            const int co = i / 50, f = i - co * 50;
+            *reinterpret_cast<float4 *>(ws + co * N2_BWP + 4 * f) = vw[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int i = threadIdx.x + j * N2_NT, co = i >> 4, p = i & 15;
+        float g = gv[j];
+        if (av[j] <= 0.0f) g = 0.0f;  // ATen's threshold_backward: the gradient passes unless the output is <= 0
+        if (drop) g *= dv[j] / keep;
+#pragma unroll
+        for (int dcl = 0; dcl < 4; ++dcl) gs[co * N2_BGP + 16 * dcl + p] = dcl == cv[j] ? g : 0.0f;
+    }
+    __syncthreads();
+    f32x4 acc[13];
+#pragma unroll
+    for (int mt = 0; mt < 13; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        const float *ap = ws + lq * N2_BWP + l15, *bp = gs + lq * N2_BGP + 16 * wave + l15;
+#pragma unroll 4
+        for (int s_ = 0; s_ < ((EE_NET2_SKIP & 1) ? 0 : 16); ++s_) {  // output channels 4 s + lq
+            const float bv = bp[4 * s_ * N2_BGP];
+#pragma unroll
+            for (int mt = 0; mt < 13; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s_ * N2_BWP + 16 * mt], bv, acc[mt], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every filter has been consumed: P takes their place
+    float *ps = ws;   // [64 columns][pitch 201: 200 rows used] (at the filters' pitch of 208 the gather below was a 16-way bank conflict)
+#pragma unroll
+    for (int mt = 0; mt < 13; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (!(EE_NET2_SKIP & 4) && 16 * mt + 4 * lq + r < 200) ps[(16 * wave + l15) * N2_BPP + 16 * mt + 4 * lq + r] = acc[mt][r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 8 * N2_H1 * N2_H1; o += N2_NT) {
+        const int cl = o / (N2_H1 * N2_H1), px = o - cl * (N2_H1 * N2_H1), y = px / N2_H1, x = px - y * N2_H1;
+        // column n = 16 (2 (Y & 1) + (X & 1)) + 4 (Y >> 1) + (X >> 1) of P, row cl * 25 + 5 ky + kx: the index splits into a part per ky and a
+        // part per kx; reads are unconditional on clamped positions and SELECTED (a branch per tap made the gather 7.7 us of the kernel's 16)
+        int colp[5], rowp[5];
+        bool cok[5], rok[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int X = x - k, Y = y - k, Xc = clampi(X, 0, 7), Yc = clampi(Y, 0, 7);
+            cok[k] = X >= 0 && X <= 7;
+            rok[k] = Y >= 0 && Y <= 7;
+            colp[k] = (16 * (Xc & 1) + (Xc >> 1)) * N2_BPP + k;
+            rowp[k] = (32 * (Yc & 1) + 4 * (Yc >> 1)) * N2_BPP + cl * 25 + 5 * k;
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < ((EE_NET2_SKIP & 2) ? 0 : 5); ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const float v = ps[rowp[ky] + colp[kx]];
+                if (rok[ky] && cok[kx]) sum += v;
+            }
+        da1[(static_cast<size_t>(b) * N2_C1 + ci0 + cl) * (N2_H1 * N2_H1) + px] = sum;
     }
 }
 
@@ -442,6 +660,13 @@ __global__ __launch_bounds__(N2_NT) void net2_sum_kernel(const float4 *__restric
     out[i] = a;
 }
 
+// EEADV_NET2_SCALAR=1: conv2 forward / backward-data on the scalar kernels of rounds 1-3 (A/B, and the yardstick of the matrix-core kernels'
+// tests); read per call
+inline bool net2_mfma_on() {
+    const char *e = getenv("EEADV_NET2_SCALAR");
+    return !(e && e[0] == '1');
+}
+
 }  // namespace
 
 EE_API int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *drop, float keep,
@@ -455,6 +680,20 @@ EE_API int ee_net2_conv_fwd_f32(const float *x, const float *w1, const float *b1
     if (!aligned16(x) || !aligned16(a1)) return EE_ERR_ALIGN;
     hipStream_t st = as_stream(stream);
     EE_LAUNCH(net2_conv1_fwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, x, w1, b1, a1, code1);
+    if (net2_mfma_on()) {
+        constexpr size_t bytes = (N2_C1 * 144 + 16 * N2_WPITCH) * sizeof(float);  // 72 KB: above the static limit
+        static int ok = (hipFuncSetAttribute(reinterpret_cast<const void *>(net2_conv2_fwd_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess) &&
+                        (hipFuncSetAttribute(reinterpret_cast<const void *>(net2_conv2_fwd_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess);
+        if (!ok) return EE_ERR_UNSUPPORTED;
+        if (!aligned16(w2) || (drop && !aligned16(drop)) || (drop_out && !aligned16(drop_out))) return EE_ERR_ALIGN;
+        if (rng)
+            EE_LAUNCH(net2_conv2_fwd_mfma_kernel<true>, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), bytes, st, a1, w2, b2, drop, keep, a2, code2,
+                      reinterpret_cast<unsigned long long *>(draw_state), drop_out, B);
+        else
+            EE_LAUNCH(net2_conv2_fwd_mfma_kernel<false>, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), bytes, st, a1, w2, b2, drop, keep, a2, code2,
+                      static_cast<unsigned long long *>(nullptr), static_cast<float *>(nullptr), B);
+        return launch_status();
+    }
     if (rng)
         EE_LAUNCH(net2_conv2_fwd_kernel<true>, dim3(static_cast<unsigned>(B), 8), dim3(N2_NT), 0, st, a1, w2, b2, drop, keep, a2, code2,
                   reinterpret_cast<unsigned long long *>(draw_state), drop_out, B);
@@ -471,7 +710,15 @@ EE_API int ee_net2_conv_bwd_f32(const float *da2, const float *a2, const uint8_t
     if (!da2 || !a2 || !code2 || !w2 || !a1 || !code1 || !w1 || !da1) return EE_ERR_NULL;
     if (dx && !aligned16(dx)) return EE_ERR_ALIGN;
     hipStream_t st = as_stream(stream);
-    EE_LAUNCH(net2_conv2_bwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_BT), 0, st, da2, a2, code2, drop, keep, w2, da1);
+    if (net2_mfma_on() && aligned16(w2)) {
+        constexpr size_t bytes = (N2_C2 * N2_BWP + N2_C2 * N2_BGP) * sizeof(float);  // 73.7 KB: above the static limit
+        static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(net2_conv2_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(bytes)) == hipSuccess;
+        if (!ok) return EE_ERR_UNSUPPORTED;
+        EE_LAUNCH(net2_conv2_bwd_mfma_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), bytes, st, da2, a2, code2, drop, keep, w2, da1);
+    } else {
+        EE_LAUNCH(net2_conv2_bwd_kernel, dim3(static_cast<unsigned>(B), 8), dim3(N2_BT), 0, st, da2, a2, code2, drop, keep, w2, da1);
+    }
     if (dx)  // NULL: only da1 is wanted (a training step whose input needs no gradient; ee_net2_conv_wrw_f32 reads da1)
         EE_LAUNCH(net2_conv1_bwd_kernel, dim3(static_cast<unsigned>(B), 4), dim3(N2_NT), 0, st, da1, a1, code1, w1, dx);
     return launch_status();

@@ -107,6 +107,7 @@ SIGNATURES = {
     "ee_conv3x3s2_small_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_small_bwd_data_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv_weight_prep_f32": [c_i, c_p, c_p, c_p, c_i, c_i, c_p],
+    "ee_conv_weight_prep_batch_f32": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "ee_conv3x3s2_pair_fwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_conv3x3s2_pair_bwd_data_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     # x, w10, mean3, var3, gamma3, beta3, eps3, mean1, var1, gamma1, beta1, eps1, y3, y1, B, Cin, Cout, H, stream

@@ -499,10 +499,11 @@ def rebuild_dense_weights(model=None):
     replaying a graph updates the weights without moving their Python-side version counters.  `model`: only ITS weights - a
     captured graph must not bake in copies into the buffers of another live model (tests, A/B scripts), which would write
     freed memory once that model is gone.  One ee_wprep.hip launch per (weight, kind): ~30 back-to-back launches of a few us inside the
-    replayed graph (one mixed launch from a device-resident table was built in round 2, measured no faster there, and removed in
-    round 3).  Returns the cache keys it rebuilt."""
+    replayed graph before round 4; now ONE launch whose descriptors travel in the kernel arguments (ee_conv_weight_prep_batch_f32: the
+    captured update of ResNet-18 ended with 19 launches, 125 us; round 2's mixed launch read its table from device memory and had measured
+    no faster).  Returns the cache keys it rebuilt."""
     own = None if model is None else {id(p) for p in model.parameters()}
-    rebuilt = set()
+    rebuilt, batch = set(), []
     with torch.no_grad():
         for key in list(_DENSE_W):
             ent = _DENSE_W[key]
@@ -510,9 +511,13 @@ def rebuild_dense_weights(model=None):
             if w is None:
                 del _DENSE_W[key]
             elif own is None or key[0] in own:
-                _fill_rearranged(ent[2], w, ent[3], e)
+                if _native_kind(w, ent[3]) and (e is None or (e.is_contiguous() and e.dtype == torch.float32)):
+                    batch.append((_NATIVE_KIND[ent[3]], w.detach(), None if e is None else e.detach(), ent[2]))  # round 4: ONE launch for all of them
+                else:
+                    _fill_rearranged(ent[2], w, ent[3], e)
                 ent[1] = _versions(w, e)
                 rebuilt.add(key)
+        ops.conv_weight_prep_batch(batch)
     return rebuilt
 
 

@@ -1050,6 +1050,20 @@ def conv_weight_prep(kind, weight, extra, out):
     return out
 
 
+def conv_weight_prep_batch(items):
+    """ee_wprep.hip: `items` = [(kind, weight, extra or None, out)] - every rearranged copy in ONE launch per 64 items (ee_conv_weight_prep_batch_f32)"""
+    n = len(items)
+    if not n:
+        return
+    kinds = (ctypes.c_int * n)(*[int(k) for k, _, _, _ in items])
+    cout = (ctypes.c_int * n)(*[w.shape[0] for _, w, _, _ in items])
+    cin = (ctypes.c_int * n)(*[w.shape[1] for _, w, _, _ in items])
+    pw = (ctypes.c_void_p * n)(*[_chk(w, torch.float32, "weight", (w.shape[0], w.shape[1], 3, 3)).value for _, w, _, _ in items])
+    pe = (ctypes.c_void_p * n)(*[None if e is None else _chk(e, torch.float32, "extra", (w.shape[0], w.shape[1], 1, 1)).value for _, w, e, _ in items])
+    po = (ctypes.c_void_p * n)(*[_chk(o, torch.float32, "out").value for _, _, _, o in items])
+    N.check(N.lib.ee_conv_weight_prep_batch_f32(n, kinds, pw, pe, po, cout, cin, _stream()), "ee_conv_weight_prep_batch_f32")
+
+
 def conv3x3s2_pair_fwd(x, w10, cout):
     """conv3x3 / stride 2 / padding 1 AND conv1x1 / stride 2 of the same x in one launch (a down-sampling BasicBlock's conv1 and shortcut):
     x [B,Cin,H,H], w10 = both filter sets rearranged (functional._rearranged kind "s2p_f") -> (y3, y1), each [B,Cout,H/2,H/2]"""

@@ -482,6 +482,11 @@ int ee_conv3x3s2_pair_stats_fwd_f32(const float *x, const float *w10, float *y3,
 #define EE_WPREP_DENSE_MAP2 6
 #define EE_WPREP_WINO_FB 7
 int ee_conv_weight_prep_f32(int kind, const float *w, const float *w1, float *out, int Cout, int Cin, void *stream);
+/* ... n of them in ONE launch per 64 items (the captured update of a training step ends with every rearranged copy of the model: 19 launches of
+ * ~5 us for ResNet-18 before round 4).  kinds / w / w1 / out / cout / cin: HOST arrays of length n, each item exactly as ee_conv_weight_prep_f32
+ * takes it; the same arithmetic, the same bits. */
+int ee_conv_weight_prep_batch_f32(int n, const int *kinds, const float *const *w, const float *const *w1, float *const *out, const int *cout, const int *cin,
+                                  void *stream);
 
 /* Backward-data of the stem Conv2d(3, K, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113): the gradient
  * with respect to the image, i.e. the last step of every PGD iteration's backward pass.

@@ -908,6 +908,38 @@ def test_net2_conv_half_matches_aten(ops, B, with_drop):
     assert torch.equal(torch.isnan(gn).cpu(), torch.isnan(gc))
 
 
+@pytest.mark.parametrize("B,with_drop", [(50, True), (7, False)])
+def test_net2_conv2_on_the_matrix_cores_against_the_scalar_kernels(ops, monkeypatch, B, with_drop):
+    """round 4: conv2 forward (one image x 16 output channels per workgroup, K = 800 on v_mfma_f32_16x16x4_f32) and backward-data (the
+    un-pooled gradient's one non-zero per window, grouped by its position: a 200 x 64 x 64 product per workgroup + a 25-term gather) against the
+    scalar kernels of rounds 1-3 (EEADV_NET2_SCALAR=1, read by the library per call): values within 1e-5 (another summation order), the same
+    pool winners and ReLU zeros on inputs without ties, the same device-side dropout draws and state."""
+    g = torch.Generator(device="cpu").manual_seed(B)
+    x = torch.rand(B, 1, 28, 28, generator=g).to(DEV)
+    w1 = (torch.randn(32, 1, 5, 5, generator=g) * 0.2).to(DEV)
+    b1 = (torch.randn(32, generator=g) * 0.1).to(DEV)
+    w2 = (torch.randn(64, 32, 5, 5, generator=g) * 0.05).to(DEV)
+    b2 = (torch.randn(64, generator=g) * 0.1).to(DEV)
+    da2 = torch.randn(B, 64, 4, 4, generator=g).to(DEV)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EEADV_NET2_SCALAR", mode)
+        state = torch.tensor([5, 12, 0, 0], dtype=torch.int64, device=DEV) if with_drop else None
+        a2, saved, mask = ops.net2_conv_fwd(x, w1, b1, w2, b2, None, 0.5 if with_drop else 1.0, state)
+        da1 = torch.empty_like(saved[0])
+        dx = ops.net2_conv_bwd(da2, a2, saved, w1, w2, mask, 0.5 if with_drop else 1.0, da1_out=da1)
+        res[mode] = (a2, saved[2], mask, da1, dx, None if state is None else state.tolist())
+    (a_s, c_s, m_s, d_s, x_s, st_s), (a_m, c_m, m_m, d_m, x_m, st_m) = res["1"], res["0"]
+    torch.testing.assert_close(a_m, a_s, rtol=1e-5, atol=1e-5)
+    assert torch.equal(a_m == 0, a_s == 0) and float((c_m == c_s).float().mean()) > 0.999
+    if with_drop:
+        assert torch.equal(m_m, m_s) and st_m == st_s and st_m[2] == 0 and st_m[1] == 12 + (B * 64 + 3) // 4
+    same = (c_m == c_s).all(dim=(1, 2, 3))  # images whose pool winners agree: the same function is differentiated
+    torch.testing.assert_close(d_m[same], d_s[same], rtol=1e-4, atol=1e-5 * float(d_s.abs().max()))
+    torch.testing.assert_close(x_m[same], x_s[same], rtol=1e-4, atol=1e-5 * float(x_s.abs().max()))
+    assert int(same.sum()) >= B - 1
+
+
 def test_net2_model_uses_the_fused_half_and_draws_the_stock_dropout_mask(ops):
     """Net_2.body in train mode: Dropout2d's mask is drawn with the calls F.dropout2d makes, so under the same seed the fused path and the
     stock sequence see the same mask (logits within 1e-4) and leave the generator in the same state."""
@@ -1072,7 +1104,8 @@ def test_weight_preparation_kernels_match_their_torch_restatement(ops, monkeypat
     # the in-place rebuild of every cached item of a model (what a captured optimiser step ends with) gives the per-item launches' bits
     m = torch.nn.Module()
     m.a, m.b = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w1.clone())
-    bufs = {k: EF._dense_weight(m.a, k, m.b if k.startswith("s2p") else None) for k in ("wino_f", "wino_b", "s2p_f", "s2p_b", "s2m_f", "s1")}
+    kinds = ("wino_f", "wino_b", "s2p_f", "s2p_b", "s2m_f", "s1") + (("wino_fb",) if co % 32 == 0 and ci % 32 == 0 else ())
+    bufs = {k: EF._dense_weight(m.a, k, m.b if k.startswith("s2p") else None) for k in kinds}  # (round 4: the rebuild below is ONE batched launch)
     with torch.no_grad():
         m.a.mul_(0.5)
         m.b.add_(1.0)
