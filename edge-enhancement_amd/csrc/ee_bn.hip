@@ -35,6 +35,29 @@ __device__ __forceinline__ float block_sum(float v, float *scratch) {
     return t;
 }
 
+// two / three sums through ONE pair of barriers (round 4: the backward kernels reduced their sums one after the other, four or six
+// barriers of up to sixteen wavefronts); each sum is formed exactly as block_sum forms it: the same bits.  scratch: NV * NT / 64 floats.
+template <int NT, int NV>
+__device__ __forceinline__ void block_sums(float (&v)[NV], float *scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] += __shfl_xor(v[k], off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // scratch may still be read from a previous call
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) scratch[k * (NT / 64) + wave] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) t += scratch[k * (NT / 64) + w];
+        v[k] = t;
+    }
+}
+
 struct BnShape {
     int B, C, HW;
 };
@@ -77,7 +100,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_kernel(const float *__restrict__ x,
                                                     const float *__restrict__ beta, float *running_mean, float *running_var, float momentum,
                                                     float eps, int training, float *__restrict__ y, float *__restrict__ save_mean,
                                                     float *__restrict__ save_invstd, BnShape s) {
-    __shared__ float scratch[NT / 64];
+    __shared__ float scratch[3 * (NT / 64)];
     const int c = blockIdx.x;
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
     float mean, invstd;
@@ -152,7 +175,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy
                                                     const float *__restrict__ save_invstd, const float *__restrict__ running_mean,
                                                     const float *__restrict__ running_var, float eps, int training, float *__restrict__ dx,
                                                     float *__restrict__ dres, float *__restrict__ dgamma, float *__restrict__ dbeta, BnShape s) {
-    __shared__ float scratch[NT / 64];
+    __shared__ float scratch[3 * (NT / 64)];
     const int c = blockIdx.x;
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
     const float mean = training ? save_mean[c] : running_mean[c];
@@ -189,8 +212,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_kernel(const float *__restrict__ dy
             sdzx += g * ((v - mean) * invstd);
         }
     });
-    sdz = block_sum<NT>(sdz, scratch);
-    sdzx = block_sum<NT>(sdzx, scratch);
+    {
+        float two[2] = {sdz, sdzx};
+        block_sums<NT, 2>(two, scratch);
+        sdz = two[0], sdzx = two[1];
+    }
     if (threadIdx.x == 0) {
         if (dgamma) dgamma[c] = sdzx;
         if (dbeta) dbeta[c] = sdz;
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restri
                                                            float *running_mean, float *running_var, float momentum, float eps, int training,
                                                            float *__restrict__ y, float *__restrict__ save_mean,
                                                            float *__restrict__ save_invstd, BnShape s) {
-    __shared__ float scratch[NT / 64];
+    __shared__ float scratch[3 * (NT / 64)];
     const int c = blockIdx.x;
     const int per = s.HW / 4, total = s.B * per;
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
@@ -306,7 +332,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
                                                            const float *__restrict__ running_var, float eps, int training,
                                                            float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ dgamma,
                                                            float *__restrict__ dbeta, BnShape s) {
-    __shared__ float scratch[NT / 64];
+    __shared__ float scratch[3 * (NT / 64)];
     const int c = blockIdx.x;
     const int per = s.HW / 4, total = s.B * per;
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
@@ -353,8 +379,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
         gv[j] = g;
         hv[j] = h;
     }
-    sdz = block_sum<NT>(sdz, scratch);
-    sdzx = block_sum<NT>(sdzx, scratch);
+    {
+        float two[2] = {sdz, sdzx};
+        block_sums<NT, 2>(two, scratch);
+        sdz = two[0], sdzx = two[1];
+    }
     if (threadIdx.x == 0) {
         if (dgamma) dgamma[c] = sdzx;
         if (dbeta) dbeta[c] = sdz;
@@ -419,7 +448,7 @@ __device__ __forceinline__ void cached_stats(const float4 (&xv)[MAXV], int total
 template <int NT, int MAXV>
 __global__ __launch_bounds__(NT) void bn_dual_fwd_cached_kernel(const float *__restrict__ xa, const float *__restrict__ xb, BnParams pa, BnParams pb,
                                                                 int training, float *__restrict__ y, BnShape s) {
-    __shared__ float scratch[NT / 64];
+    __shared__ float scratch[3 * (NT / 64)];
     const int c = blockIdx.x;
     const int per = s.HW / 4, total = s.B * per;
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
@@ -462,7 +491,7 @@ __global__ __launch_bounds__(NT) void bn_dual_bwd_cached_kernel(const float *__r
                                                                 int training, float *__restrict__ dxa, float *__restrict__ dxb,
                                                                 float *__restrict__ dgamma_a, float *__restrict__ dbeta_a,
                                                                 float *__restrict__ dgamma_b, float *__restrict__ dbeta_b, BnShape s) {
-    __shared__ float scratch[NT / 64];
+    __shared__ float scratch[3 * (NT / 64)];
     const int c = blockIdx.x;
     const int per = s.HW / 4, total = s.B * per;
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
@@ -509,9 +538,11 @@ __global__ __launch_bounds__(NT) void bn_dual_bwd_cached_kernel(const float *__r
         ha[j] = xa_;
         hb[j] = xb_;
     }
-    sdz = block_sum<NT>(sdz, scratch);
-    sa = block_sum<NT>(sa, scratch);
-    sb = block_sum<NT>(sb, scratch);
+    {
+        float three[3] = {sdz, sa, sb};
+        block_sums<NT, 3>(three, scratch);
+        sdz = three[0], sa = three[1], sb = three[2];
+    }
     if (threadIdx.x == 0) {
         if (dgamma_a) dgamma_a[c] = sa;
         if (dbeta_a) dbeta_a[c] = sdz;
@@ -634,7 +665,7 @@ __device__ __forceinline__ void combine_slices(const float *__restrict__ ws, int
 
 // ws[(c*S + s)*2 + {0,1}] = (sum, M2 about the slice's own mean)
 __global__ __launch_bounds__(SPLIT_NT) void bn_split_stats_kernel(const float *__restrict__ x, float *__restrict__ ws, BnShape s, int S) {
-    __shared__ float scratch[SPLIT_NT / 64];
+    __shared__ float scratch[3 * (SPLIT_NT / 64)];
     const int c = blockIdx.x, sl_i = blockIdx.y;
     const Slice sl = my_slice(s.B * (s.HW / 4), S, sl_i);
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
@@ -733,7 +764,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const fl
                                                                         const float *__restrict__ running_mean,
                                                                         const float *__restrict__ running_var, float eps, int training,
                                                                         float *__restrict__ ws, BnShape s, int S) {
-    __shared__ float scratch[SPLIT_NT / 64];
+    __shared__ float scratch[3 * (SPLIT_NT / 64)];
     const int c = blockIdx.x, sl_i = blockIdx.y;
     const float mean = training ? save_mean[c] : running_mean[c];
     const float invstd = training ? save_invstd[c] : 1.0f / sqrtf(running_var[c] + eps);
@@ -746,8 +777,11 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_split_bwd_partial_kernel(const fl
         sdz += (g.x + g.y) + (g.z + g.w);
         sdzx += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) + (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
     });
-    sdz = block_sum<SPLIT_NT>(sdz, scratch);
-    sdzx = block_sum<SPLIT_NT>(sdzx, scratch);
+    {
+        float two[2] = {sdz, sdzx};
+        block_sums<SPLIT_NT, 2>(two, scratch);
+        sdz = two[0], sdzx = two[1];
+    }
     if (threadIdx.x == 0) {
         ws[(static_cast<size_t>(c) * S + sl_i) * 2 + 0] = sdz;
         ws[(static_cast<size_t>(c) * S + sl_i) * 2 + 1] = sdzx;
@@ -931,7 +965,7 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_pool_bwd_kernel(const float *__re
                                                                float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                                float *__restrict__ ws, PoolShape p) {
     extern __shared__ __align__(16) float lds[];
-    __shared__ float scratch[SPLIT_NT / 64];
+    __shared__ float scratch[3 * (SPLIT_NT / 64)];
     const int c = blockIdx.x, g = blockIdx.y;
     const int HW = p.H * p.W, HWq = HW / 4, OHW = p.OH * p.OW, Wq = p.W / 4;
     float *gp = lds;                                            // pooled gradient of one plane
@@ -1016,8 +1050,11 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_pool_bwd_kernel(const float *__re
         __syncthreads();
     }
     if (!APPLY) {
-        sdz = block_sum<SPLIT_NT>(sdz, scratch);
-        sdzx = block_sum<SPLIT_NT>(sdzx, scratch);
+        {
+            float two[2] = {sdz, sdzx};
+            block_sums<SPLIT_NT, 2>(two, scratch);
+            sdz = two[0], sdzx = two[1];
+        }
         if (threadIdx.x == 0) {
             ws[(static_cast<size_t>(c) * p.G + g) * 2 + 0] = sdz;
             ws[(static_cast<size_t>(c) * p.G + g) * 2 + 1] = sdzx;
