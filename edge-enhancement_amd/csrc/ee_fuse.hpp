@@ -111,6 +111,40 @@ __device__ __forceinline__ void train_bn_merge(const TrainBn &tb, int KC, float 
         }
     }
 }
+// ... and the BACKWARD direction (input gradient only): dx = gamma * invstd * ((dz - mean(dz)) - xhat * mean(dz * xhat)), dz = (bn(x) > 0) * dy.
+// The convolution that PRODUCES dy (the backward-data of the layer behind the BatchNorm) writes, next to dy, per (channel, image) the sums
+// (sum dz, sum dz * xhat) of the plane it holds - it reads x (the raw output of the layer in front) and the saved statistics for the mask and
+// xhat; the convolution that CONSUMES dx merges the S partials per reduction channel (16 lanes, index order, fixed butterfly) and applies the
+// expression while it stages dy and x.  table [7 c + ..] = (mean, invstd, invstd * gamma, beta, gamma * invstd, m1, m2)
+template <int NT>
+__device__ __forceinline__ void train_bn_bwd_merge(const TrainBn &tb, int KC, float *table) {
+    const float n = static_cast<float>(tb.S) * tb.cnt;
+    for (int c = threadIdx.x >> 4; c < KC; c += NT / 16) {
+        const int j = threadIdx.x & 15;
+        const float2 *pc = reinterpret_cast<const float2 *>(tb.part) + static_cast<size_t>(c) * tb.S;
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int i = j; i < tb.S; i += 16) {
+            const float2 pn = pc[i];
+            s1 += pn.x, s2 += pn.y;
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) s1 += __shfl_xor(s1, off, 16), s2 += __shfl_xor(s2, off, 16);
+        if (j == 0) {
+            const float invstd = tb.save_invstd[c], g = tb.gamma ? tb.gamma[c] : 1.0f;
+            float *t = table + 7 * c;
+            t[0] = tb.save_mean[c], t[1] = invstd, t[2] = invstd * g, t[3] = tb.beta ? tb.beta[c] : 0.0f, t[4] = g * invstd, t[5] = s1 / n, t[6] = s2 / n;
+        }
+    }
+}
+// ee_bn.hip: bn_bwd_cached_kernel with the mask recomputed from x (MaskArgs.on) - the same expressions
+__device__ __forceinline__ float train_bn_bwd_apply(float d, float x, const float *t) {
+    const float dz = ((x - t[0]) * t[2] + t[3]) > 0.0f ? d : 0.0f;
+    return t[4] * ((dz - t[5]) - ((x - t[0]) * t[1]) * t[6]);
+}
+__device__ __forceinline__ float4 train_bn_bwd_apply4(float4 d, float4 x, const float *t) {
+    return make_float4(train_bn_bwd_apply(d.x, x.x, t), train_bn_bwd_apply(d.y, x.y, t), train_bn_bwd_apply(d.z, x.z, t), train_bn_bwd_apply(d.w, x.w, t));
+}
+
 __device__ __forceinline__ float train_bn_apply(float v, const float *t) { return relu_keep_nan((v - t[0]) * t[1] + t[2]); }
 __device__ __forceinline__ float4 train_bn_apply4(float4 v, const float *t) {
     return make_float4(train_bn_apply(v.x, t), train_bn_apply(v.y, t), train_bn_apply(v.z, t), train_bn_apply(v.w, t));

@@ -377,8 +377,11 @@ constexpr int PC_CW = 8, PC_XPW = 16 / PC_CW;
 // PRE / POST: see wino3x3_map4_kernel.  The train-mode pair (round 4; ee_fuse.hpp: TrainBn - BatchNorm with BATCH statistics exchanged
 // across the kernel boundary instead of inside a BatchNorm launch): STATS - the output transform also writes, per (channel, image), the
 // plane's (mean, M2) to tb.stats_out [RC][B][2]; PRE 3 - the prologue merges the partials of every reduction channel in a fixed order and
-// the staged input is relu((x - mean) * invstd * gamma + beta).
-template <int MAP, int PRE, bool POST, bool STATS = false>
+// the staged input is relu((x - mean) * invstd * gamma + beta).  The backward pair (input gradient): STATS 2 - this launch is the backward-data
+// of the layer BEHIND the BatchNorm: next to dy it writes per (channel, image) (sum dz, sum dz * xhat), reading the BatchNorm's input
+// tb.part_x and its saved statistics; PRE 4 - the prologue merges those sums, the staged input is the BatchNorm's dx formed from dy
+// (x) and the BatchNorm's input (pre.mask).
+template <int MAP, int PRE, bool POST, int STATS = 0>
 __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(PcGeo<MAP>::WPE, PcGeo<MAP>::WPE))) void wino3x3_pc_kernel(const float *__restrict__ x, const float *__restrict__ u,
                                                                                                      float *__restrict__ y, WinoDims d, FusePre pre, FusePost post,
                                                                                                      TrainBn tb = TrainBn{}) {
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     const int ci_p = MAP == 8 ? (pt & 127) >> 4 : pt >> 6;  // this producer lane's channel inside a round
     // 16x16 with PRE: the plain kernel sits at the 128 registers four wavefronts per SIMD leave; three pixel streams in two prefetch sets
     // spilled (54 registers).  There pixels and filters travel ONE round ahead in one set (a round is ~1.3 us: enough for an L2 hit) instead of two
-    constexpr bool ONE_X = MAP == 16 && (PRE == 1 || PRE == 2);
+    constexpr bool ONE_X = MAP == 16 && (PRE == 1 || PRE == 2 || PRE == 4);
     const bool pre_store = (PRE == 1 || PRE == 2) && pre.store != nullptr && by == 0 && b + ximg < d.B;
 #define PC_FETCH_U(S, round_)                                                                      \
     do {                                                                                           \
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
         const int r_ = (round_) < rounds ? (round_) : rounds - 1;                                  \
         const float *xp_ = xsrc + r_ * xstep;                                                      \
         S##0 = *reinterpret_cast<const float4 *>(xp_);                                             \
-        if constexpr (PRE == 1 || PRE == 2) S##2 = *reinterpret_cast<const float4 *>((pre.mask + r_ * xstep) + xo); \
+        if constexpr (PRE == 1 || PRE == 2 || PRE == 4) S##2 = *reinterpret_cast<const float4 *>((pre.mask + r_ * xstep) + xo); \
         if constexpr (PRE == 2) S##1 = *reinterpret_cast<const float4 *>((pre.add + r_ * xstep) + xo);  \
     } while (0)
 #define PC_STORE_U(buf_, S)                                                                        \
@@ -460,6 +463,8 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     auto pre_px = [&](float4 v, float4 a, float4 m, int round_) {
         if constexpr (PRE == 3)  // train-mode BatchNorm + ReLU of the producing layer, statistics from the table the prologue merged
             return train_bn_apply4(v, wtab + 3 * ((round_ < rounds ? round_ : rounds - 1) * G::CK + ci_p));
+        if constexpr (PRE == 4)  // train-mode BatchNorm + ReLU BACKWARD: v = dy, m = the BatchNorm's input
+            return train_bn_bwd_apply4(v, m, wtab + 7 * ((round_ < rounds ? round_ : rounds - 1) * G::CK + ci_p));
         if constexpr (PRE == 2) v = sum4(v, a);
         v = mask4(v, m);
         if (pre_store && round_ < rounds) *reinterpret_cast<float4 *>((pre.store + round_ * xstep) + xo) = v;
@@ -549,6 +554,7 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     if constexpr (PRE == 1 || PRE == 2)
         for (int c = threadIdx.x; c < d.KC; c += G::NT) wtab[c] = bn_scale(pre.var, pre.gamma, pre.eps, c);
     if constexpr (PRE == 3) train_bn_merge<G::NT>(tb, d.KC, wtab, blockIdx.x == 0);
+    if constexpr (PRE == 4) train_bn_bwd_merge<G::NT>(tb, d.KC, wtab);
     __syncthreads();  // the zero rings
     if (producer) {
         PC_PUT_X(buf0, XA, 0);
@@ -636,6 +642,20 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
     // POST: the lane's channel constants and its residual values are fetched while the accumulators settle in LDS
     PostConst pk{0.0f, 1.0f, 0.0f};
     float2 q0[G::NB], q1[G::NB];
+    float bs_mean = 0.0f, bs_inv = 0.0f, bs_a = 0.0f, bs_b = 0.0f;
+    if constexpr (STATS == 2) {  // the BatchNorm's input at this lane's outputs, and its channel's saved statistics
+        if (threadIdx.x < 512) {
+            const int co = threadIdx.x >> 4, tl = threadIdx.x & 15, c = co0 + co;
+            bs_mean = tb.save_mean[c], bs_inv = tb.save_invstd[c], bs_a = bs_inv * (tb.gamma ? tb.gamma[c] : 1.0f), bs_b = tb.beta ? tb.beta[c] : 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < G::NB; ++nb) {
+                const int t = 16 * nb + tl, img = t / G::TI, ti = t - img * G::TI, ty = ti / G::TX, tx = ti - ty * G::TX;
+                const int bi = b + img < d.B ? b + img : d.B - 1;
+                const float *rp = tb.part + ((static_cast<size_t>(bi) * d.RC + c) * MAP + 2 * ty) * MAP + 2 * tx;
+                q0[nb] = *reinterpret_cast<const float2 *>(rp), q1[nb] = *reinterpret_cast<const float2 *>(rp + MAP);
+            }
+        }
+    }
     if constexpr (POST) {
         if (threadIdx.x < 512) {
             const int co = threadIdx.x >> 4, tl = threadIdx.x & 15;
@@ -656,6 +676,7 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
         const int idx = threadIdx.x;  // (co, tile of a block)
         const int co = idx >> 4, tl = idx & 15;
         float sv[STATS ? G::NB : 1][4];
+        float bsum1 = 0.0f, bsum2 = 0.0f;
 #pragma unroll
         for (int nb = 0; nb < G::NB; ++nb) {
             const int t = 16 * nb + tl, img = t / G::TI, ti = t - img * G::TI, ty = ti / G::TX, tx = ti - ty * G::TX;
@@ -681,9 +702,24 @@ __global__ __launch_bounds__(PcGeo<MAP>::NT) __attribute__((amdgpu_waves_per_eu(
                 *reinterpret_cast<float2 *>(y + oo) = r0;
                 *reinterpret_cast<float2 *>(y + oo + MAP) = r1;
             }
-            if constexpr (STATS) sv[nb][0] = r0.x, sv[nb][1] = r0.y, sv[nb][2] = r1.x, sv[nb][3] = r1.y;  // (past the batch: never written out)
+            if constexpr (STATS == 1) sv[nb][0] = r0.x, sv[nb][1] = r0.y, sv[nb][2] = r1.x, sv[nb][3] = r1.y;  // (past the batch: never written out)
+            if constexpr (STATS == 2) {
+                const float dd[4] = {r0.x, r0.y, r1.x, r1.y}, xx[4] = {q0[nb].x, q0[nb].y, q1[nb].x, q1[nb].y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dz = ((xx[e] - bs_mean) * bs_a + bs_b) > 0.0f ? dd[e] : 0.0f;
+                    bsum1 += dz;
+                    bsum2 += dz * ((xx[e] - bs_mean) * bs_inv);
+                }
+            }
         }
-        if constexpr (STATS) {
+        if constexpr (STATS == 2) {
+            static_assert(STATS != 2 || G::IMG == 1, "backward sums epilogue: one image per workgroup (16x16 maps)");
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) bsum1 += __shfl_xor(bsum1, off, 16), bsum2 += __shfl_xor(bsum2, off, 16);
+            if (tl == 0 && b < d.B) *reinterpret_cast<float2 *>(tb.stats_out + (static_cast<size_t>(co0 + co) * d.B + b) * 2) = make_float2(bsum1, bsum2);
+        }
+        if constexpr (STATS == 1) {
             // the 16 lanes of a channel hold whole planes: N blocks [i * NBI, (i + 1) * NBI) are image i of the workgroup (MAP 16: one image
             // in four blocks; MAP 8: two images, one block each)
             constexpr int NBI = G::NB / G::IMG;
@@ -708,10 +744,10 @@ constexpr int WN_MAX_KC_TRAIN = 256;  // PRE 3: (mean, scale, shift) per reducti
 
 template <int PRE>
 constexpr size_t wino_table_bytes() {
-    return PRE == 3 ? 3 * WN_MAX_KC_TRAIN * sizeof(float) : (PRE ? WN_MAX_KC * sizeof(float) : 0);
+    return PRE == 4 ? 7 * 128 * sizeof(float) : (PRE == 3 ? 3 * WN_MAX_KC_TRAIN * sizeof(float) : (PRE ? WN_MAX_KC * sizeof(float) : 0));
 }
 
-template <int MAP, int PRE, bool POST, bool STATS = false>
+template <int MAP, int PRE, bool POST, int STATS = 0>
 int wino_pc_launch(const float *x, const float *u, float *y, const WinoDims &d, const FusePre &pre, const FusePost &post, hipStream_t st,
                    const TrainBn &tb = TrainBn{}) {
     using G = PcGeo<MAP>;
@@ -739,8 +775,8 @@ int wino_map4_launch(const float *x, const float *u, float *y, const WinoDims &d
 template <int PRE, bool POST, bool STATS = false>
 int wino_dispatch_t(const float *x, const float *u, float *y, const WinoDims &d, int H, const FusePre &pre, const FusePost &post, hipStream_t st, const TrainBn &tb) {
     if (H == 4) return wino_map4_launch<PRE, POST, STATS>(x, u, y, d, pre, post, st, tb);
-    if (H == 8) return wino_pc_launch<8, PRE, POST, STATS>(x, u, y, d, pre, post, st, tb);
-    return wino_pc_launch<16, PRE, POST, STATS>(x, u, y, d, pre, post, st, tb);
+    if (H == 8) return wino_pc_launch<8, PRE, POST, STATS ? 1 : 0>(x, u, y, d, pre, post, st, tb);
+    return wino_pc_launch<16, PRE, POST, STATS ? 1 : 0>(x, u, y, d, pre, post, st, tb);
 }
 
 template <int PRE, bool POST>
@@ -845,6 +881,45 @@ EE_API int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, int S
     const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
     ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
     return wino_dispatch_t<3, false, false>(x, u, y, d, H, FusePre{}, FusePost{}, as_stream(stream), tb);
+}
+
+// The same exchange in the BACKWARD direction (input gradient only; 16x16 maps, channels <= 128):
+//   ee_wino3x3_bwd_sums_f32         dy = conv3x3^T(dc) on the backward filter set (the backward-data of the layer BEHIND the BatchNorm), and per
+//                                   (channel, image) sums [Cin][B][2] = (sum dz, sum dz * xhat), dz = (bn(x) > 0) * dy, from x = the BatchNorm's
+//                                   input [B,Cin,H,H] and its saved statistics
+//   ee_wino3x3_bn_train_bwd_pre_f32 dx = conv3x3^T( gamma * invstd * ((dz - mean(dz)) - xhat * mean(dz * xhat)) ): the BatchNorm's own backward
+//                                   (ee_bn_act_bwd2_f32, training = 1, relu = 1, mask from x) folded into the staging of the layer in FRONT's
+//                                   backward-data convolution; sums as written by ee_wino3x3_bwd_sums_f32
+EE_API int ee_wino3x3_bwd_sums_f32(const float *dc, const float *u_b, const float *x, const float *save_mean, const float *save_invstd, const float *gamma,
+                                   const float *beta, float *dy, float *sums, int B, int Cin, int Cout, int H, void *stream) {
+    const int rc = wino_check(dc, u_b, dy, B, Cout, Cin, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (H != 16) return EE_ERR_UNSUPPORTED;
+    if (!x || !save_mean || !save_invstd || !sums) return EE_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(x) & 7u) || (reinterpret_cast<uintptr_t>(sums) & 7u)) return EE_ERR_ALIGN;
+    TrainBn tb{};
+    tb.stats_out = sums, tb.part = x, tb.gamma = gamma, tb.beta = beta;
+    tb.save_mean = const_cast<float *>(save_mean), tb.save_invstd = const_cast<float *>(save_invstd);  // read only by this launch
+    const WinoDims d{B, Cout, Cin, xcd_weights_local(4.0 * B * Cout * H * H, 64.0 * Cin * Cout, Cin / WN_CO) ? 1 : 0};
+    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
+    return wino_pc_launch<16, 0, false, 2>(dc, u_b, dy, d, FusePre{}, FusePost{}, as_stream(stream), tb);
+}
+
+EE_API int ee_wino3x3_bn_train_bwd_pre_f32(const float *dy, const float *x, const float *sums, int S, int cnt, const float *save_mean, const float *save_invstd,
+                                           const float *gamma, const float *beta, const float *u_b, float *dx, int B, int Cin, int Cout, int H, void *stream) {
+    const int rc = wino_check(dy, u_b, dx, B, Cout, Cin, H);
+    if (rc != EE_OK || B == 0) return rc;
+    if (H != 16 || Cout > 128) return EE_ERR_UNSUPPORTED;
+    if (!x || !sums || !save_mean || !save_invstd) return EE_ERR_NULL;
+    if (S < 1 || cnt < 1) return EE_ERR_SHAPE;
+    if (!aligned16(x) || (reinterpret_cast<uintptr_t>(sums) & 7u)) return EE_ERR_ALIGN;
+    TrainBn tb{};
+    tb.part = sums, tb.S = S, tb.cnt = static_cast<float>(cnt), tb.gamma = gamma, tb.beta = beta;
+    tb.save_mean = const_cast<float *>(save_mean), tb.save_invstd = const_cast<float *>(save_invstd);
+    const FusePre pre{nullptr, x, nullptr, nullptr, nullptr, 0.0f};
+    const WinoDims d{B, Cout, Cin, xcd_weights_local(4.0 * B * Cout * H * H, 64.0 * Cin * Cout, Cin / WN_CO) ? 1 : 0};
+    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
+    return wino_pc_launch<16, 4, false, 0>(dy, u_b, dx, d, pre, FusePost{}, as_stream(stream), tb);
 }
 
 #ifdef EE_WINO_TIMING

@@ -96,6 +96,10 @@ SIGNATURES = {
     "ee_dense2x2_bn_eval_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     # dy, dy2, y, w2t, var, gamma, eps, dres, dx_add, dx, B, Cin, Cout, stream
     "ee_dense2x2_bn_eval_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    # dc, u_b, x, save_mean, save_invstd, gamma, beta, dy, sums, B, Cin, Cout, H, stream
+    "ee_wino3x3_bwd_sums_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    # dy, x, sums, S, cnt, save_mean, save_invstd, gamma, beta, u_b, dx, B, Cin, Cout, H, stream
+    "ee_wino3x3_bn_train_bwd_pre_f32": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wrw3x3_workspace_floats": [c_i, c_i, c_i, c_i],
     "ee_wrw3x3_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wrw3x3s2_workspace_floats": [c_i, c_i, c_i, c_i, c_i],

@@ -686,6 +686,9 @@ class EvalDownBlockFn(torch.autograd.Function):
         return (dx,) + none[1:]
 
 
+_TRAIN_BWD_BOUNDARY = os.environ.get("EEADV_TRAIN_BWD_BOUNDARY", "1") == "1"  # 0: the BatchNorm backward launch of round 4's first form (A/B)
+
+
 class TrainConvBnConvFn(torch.autograd.Function):
     """conv2(relu(bn1(conv1(x)))) of a BasicBlock (resnet.py:44-49) in TRAIN mode inside the attack loop, TWO launches forward: conv1's output
     transform also writes per-image moments, conv2's prologue merges them (the batch statistics: a grid-wide exchange through the kernel
@@ -706,6 +709,11 @@ class TrainConvBnConvFn(torch.autograd.Function):
         c1, w1, w2, gamma, beta, sm, si = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
             return (None,) * 9
+        if c1.shape[2] == 16 and c1.shape[1] <= 128 and _TRAIN_BWD_BOUNDARY:
+            # the BatchNorm's backward crosses the kernel boundary too: conv2^T writes the per-image sums of dz and dz * xhat next to its output,
+            # conv1^T merges them and forms the BatchNorm's input gradient while it stages (two launches instead of three)
+            d_a1, sums = ops.wino3x3_bwd_sums(dc2.contiguous(), wino_sets(w2)[1], c1, sm, si, gamma, beta)
+            return (ops.wino3x3_bn_train_bwd_pre(d_a1, c1, sums, 256, sm, si, gamma, beta, wino_sets(w1)[1]),) + (None,) * 8
         d_a1 = ops.wino3x3(dc2.contiguous(), wino_sets(w2)[1])
         d_c1 = ops.bn_act_bwd(d_a1, None, c1, gamma, sm, si, None, None, ctx.eps, True, True, True, False, False, None, beta)[0]
         return (ops.wino3x3(d_c1, wino_sets(w1)[1]),) + (None,) * 8

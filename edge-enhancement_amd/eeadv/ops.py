@@ -881,6 +881,33 @@ def wino3x3_bn_train_pre(x, stats, cnt, gamma, beta, eps, momentum, running_mean
     return y, sm, si
 
 
+def wino3x3_bwd_sums(dc, u_b, x, save_mean, save_invstd, gamma, beta):
+    """dy = conv3x3^T(dc) (the backward-data of the layer behind a train-mode BatchNorm) plus, per (channel, image), (sum dz, sum dz * xhat) with
+    dz = (bn(x) > 0) * dy: (dy, sums [Cin, B, 2]) - the producer half of the BatchNorm backward across the kernel boundary (16x16 maps)"""
+    B, Cout, H = dc.shape[0], dc.shape[1], dc.shape[2]
+    Cin = u_b.shape[2]
+    dy = torch.empty((B, Cin, H, H), dtype=torch.float32, device=dc.device)
+    sums = torch.empty((Cin, B, 2), dtype=torch.float32, device=dc.device)
+    N.check(N.lib.ee_wino3x3_bwd_sums_f32(_chk(dc, torch.float32, "dc", (B, Cout, H, H)), _chk(u_b, torch.float32, "u_b", (16, Cout, Cin)),
+                                          _chk(x, torch.float32, "x", (B, Cin, H, H)), _chk(save_mean, torch.float32, "save_mean", (Cin,)),
+                                          _chk(save_invstd, torch.float32, "save_invstd", (Cin,)), _optf(gamma, "gamma", (Cin,)), _optf(beta, "beta", (Cin,)),
+                                          dy.data_ptr(), sums.data_ptr(), B, Cin, Cout, H, _stream()), "ee_wino3x3_bwd_sums_f32")
+    return dy, sums
+
+
+def wino3x3_bn_train_bwd_pre(dy, x, sums, cnt, save_mean, save_invstd, gamma, beta, u_b):
+    """dx = conv3x3^T(batch_norm_relu_backward(dy; x)) in TRAIN mode, the batch means of dz and dz * xhat merged from `sums` [Cout, S, 2]"""
+    B, Cout, H = dy.shape[0], dy.shape[1], dy.shape[2]
+    Cin = u_b.shape[2]
+    dx = torch.empty((B, Cin, H, H), dtype=torch.float32, device=dy.device)
+    N.check(N.lib.ee_wino3x3_bn_train_bwd_pre_f32(_chk(dy, torch.float32, "dy", (B, Cout, H, H)), _chk(x, torch.float32, "x", (B, Cout, H, H)),
+                                                  _chk(sums, torch.float32, "sums", (Cout, sums.shape[1], 2)), sums.shape[1], int(cnt),
+                                                  _chk(save_mean, torch.float32, "save_mean", (Cout,)), _chk(save_invstd, torch.float32, "save_invstd", (Cout,)),
+                                                  _optf(gamma, "gamma", (Cout,)), _optf(beta, "beta", (Cout,)), _chk(u_b, torch.float32, "u_b", (16, Cout, Cin)),
+                                                  dx.data_ptr(), B, Cin, Cout, H, _stream()), "ee_wino3x3_bn_train_bwd_pre_f32")
+    return dx
+
+
 def conv3x3s2_pair_stats_fwd(x, w10, cout):
     """conv3x3s2_pair_fwd plus the statistics of y3 for the train-mode BatchNorm behind it: (y3, y1, stats [Cout, S, 2], cnt)"""
     B, Cin, H = x.shape[0], x.shape[1], x.shape[2]

@@ -399,6 +399,16 @@ int ee_wino3x3_stats_f32(const float *x, const float *u, float *y, float *stats,
 int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, int S, int cnt, const float *gamma, const float *beta, float eps, float momentum,
                                 float *running_mean, float *running_var, float *save_mean, float *save_invstd, const float *u, float *y, int B, int KC,
                                 int RC, int H, void *stream);
+/* The same exchange in the BACKWARD direction (input gradient only; 16x16 maps, <= 128 channels): ee_wino3x3_bwd_sums_f32 is the backward-data
+ * convolution of the layer BEHIND the BatchNorm (dy = conv3x3^T(dc) on the backward filter set u_b [16][Cout][Cin]) that also writes per (channel,
+ * image) sums [Cin][B][2] = (sum dz, sum dz * xhat), dz = (bn(x) > 0) * dy, from x = the BatchNorm's INPUT and its saved statistics;
+ * ee_wino3x3_bn_train_bwd_pre_f32 is the backward-data convolution of the layer in FRONT with the BatchNorm's own backward
+ * (gamma * invstd * ((dz - mean dz) - xhat * mean(dz xhat)): ee_bn_act_bwd2_f32 with training = 1, relu = 1 and the mask taken from x)
+ * folded into its input staging, the means merged from `sums` (S partials of cnt values) in its prologue. */
+int ee_wino3x3_bwd_sums_f32(const float *dc, const float *u_b, const float *x, const float *save_mean, const float *save_invstd, const float *gamma,
+                            const float *beta, float *dy, float *sums, int B, int Cin, int Cout, int H, void *stream);
+int ee_wino3x3_bn_train_bwd_pre_f32(const float *dy, const float *x, const float *sums, int S, int cnt, const float *save_mean, const float *save_invstd,
+                                    const float *gamma, const float *beta, const float *u_b, float *dx, int B, int Cin, int Cout, int H, void *stream);
 
 /* Conv2d(3x3, stride 1, padding 1, bias=False) on a 2x2 map (ResNet-18's layer4 at 64x64 inputs, resnet.py:26-31) as ONE dense product on the
  * f32 matrix cores: every input pixel reaches every output pixel, y[n][(co,p)] = sum x[n][(ci,q)] * w2[(ci,q)][(co,p)], w2 [4 Cin][4 Cout] =

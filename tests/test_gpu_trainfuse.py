@@ -63,6 +63,38 @@ def test_conv_bn_relu_conv_across_the_kernel_boundary(ops, B, C, H):
     ops.wino3x3_bn_train_pre(c1b, stats, H * H, None, None, 1e-5, 0.1, None, None, u2)
 
 
+@pytest.mark.parametrize("B,C", [(100, 64), (5, 64), (3, 32), (9, 128)])
+def test_batchnorm_backward_across_the_kernel_boundary(ops, B, C):
+    """conv2^T -> BatchNorm / ReLU backward (train mode, mask from x) -> conv1^T on 16x16 maps: the sums epilogue + merge / apply prologue
+    against ee_wino3x3_f32 | ee_bn_act_bwd2_f32(training = 1) | ee_wino3x3_f32 - the convolutions' raw outputs bit-equal, the rest within
+    rounding (the batch sums are taken in another order), bit-reproducible."""
+    from eeadv import functional as Fn
+    H = 16
+    gen = torch.Generator().manual_seed(B + C)
+    c1 = torch.randn(B, C, H, H, generator=gen).to(DEV)   # the BatchNorm's input (conv1's raw output)
+    dc2 = torch.randn(B, C, H, H, generator=gen).to(DEV)  # the gradient of conv2's output
+    w1 = (torch.randn(C, C, 3, 3, generator=gen) * (2.0 / (9 * C)) ** 0.5).to(DEV)
+    w2 = (torch.randn(C, C, 3, 3, generator=gen) * (2.0 / (9 * C)) ** 0.5).to(DEV)
+    gamma, beta = (torch.rand(C, generator=gen) + 0.5).to(DEV), (torch.randn(C, generator=gen) * 0.2).to(DEV)
+    sm = c1.mean((0, 2, 3)).contiguous()
+    si = (1.0 / torch.sqrt(c1.var((0, 2, 3), unbiased=False) + 1e-5)).contiguous()
+    u1b, u2b = Fn.wino_sets(w1)[1], Fn.wino_sets(w2)[1]
+    d_a1 = ops.wino3x3(dc2, u2b)
+    d_c1 = ops.bn_act_bwd(d_a1, None, c1, gamma, sm, si, None, None, 1e-5, True, True, True, False, False, None, beta)[0]
+    want = ops.wino3x3(d_c1, u1b)
+    d_a1b, sums = ops.wino3x3_bwd_sums(dc2, u2b, c1, sm, si, gamma, beta)
+    assert torch.equal(d_a1b, d_a1)
+    shape = (1, C, 1, 1)
+    dz = torch.where(((c1 - sm.view(shape)) * (si * gamma).view(shape) + beta.view(shape)) > 0, d_a1, torch.zeros_like(d_a1)).double()
+    xhat = ((c1 - sm.view(shape)) * si.view(shape)).double()
+    _close(sums[:, :, 0], dz.sum((2, 3)).t(), 1e-5, "per-image sums of dz")
+    _close(sums[:, :, 1], (dz * xhat).sum((2, 3)).t(), 1e-5, "per-image sums of dz * xhat")
+    got = ops.wino3x3_bn_train_bwd_pre(d_a1b, c1, sums, H * H, sm, si, gamma, beta, u1b)
+    _close(got, want, 2e-5, "conv1^T(bn_relu_backward(conv2^T dc2))")
+    again_d, again_s = ops.wino3x3_bwd_sums(dc2, u2b, c1, sm, si, gamma, beta)
+    assert torch.equal(again_s, sums) and torch.equal(ops.wino3x3_bn_train_bwd_pre(again_d, c1, again_s, H * H, sm, si, gamma, beta, u1b), got)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H", [(100, 64, 128, 16), (5, 64, 128, 16), (7, 128, 256, 8), (2, 128, 256, 8)])
 @pytest.mark.parametrize("mt", ["222111", "111222"])
 def test_pair_statistics_feed_the_consumer(ops, B, Cin, Cout, H, mt, monkeypatch):
