@@ -14,6 +14,11 @@
 // wavefront order (bit-reproducible).  LDS strides 68 / 48 put the 64 lanes of an operand read on 64 distinct banks.
 // A float4 of A or of the result lies inside ONE channel (4 pixels of a 2x2 plane), which is what makes the per-channel pre / post maps cheap.
 //
+// Round 4 also tried this kernel as the ONE-launch head backward of MNIST's Net_2 (logits of a tile's rows on MFMA in a prologue, the cross-entropy
+// gradient through fc2^T and the ReLU gate formed while fc1's output is staged, then the product with fc1's weight): correct, and 19.8 us against
+// 16.0 us for ee_fc_ce_grad_f32 + the Tensile product it would replace - each of the 32 column tiles repeats its rows' logits (6.7 us) and forms
+// the gradient while staging (3.7 us).  Not kept: commit 0905c3e holds it, profiles/round4_q_net2_head_one_launch.txt the phase timings.
+//
 // CNN-body glue, not a row of SURVEY.md section 8.
 #include "ee_common.hpp"
 #include "ee_fuse.hpp"
@@ -41,35 +46,11 @@ struct DenseDims {
 // c + res (post.mean null).
 // Rounds of 128 reduction indices; the tiles of the next FOUR rounds are in flight in four register sets (a round's products take
 // ~0.4 us, the weights come from the Infinity Cache at ~1 us), written to the other LDS buffer one round ahead; one barrier per round.
-// PRE 2 / 3 (Net_2's head backward, MNIST/models_mnist/Net2.py:17-19; at most 10 / 16 classes): A = d CrossEntropyLoss(fc2(relu(z1)), labels) / d z1,
-// formed from z1 while it is staged.  The prologue computes the workgroup's 32 rows of logits on MFMA (each wavefront 128 of the 1024 hidden units,
-// the eight partial tiles summed in wavefront order), their softmax minus one-hot times gscale -> dl [32][16] in LDS; a staged element is
-// (z1 <= 0) ? 0 : sum_c dl[row][c] * w2[c][j] (ee_loss.hip: fc_ce_grad_small_kernel's expressions, fc2's weights in LDS) - so that fc2, the loss
-// gradient, fc2^T and fc1^T are ONE launch: c = dz1 . W1.
-__device__ __forceinline__ float4 fma4(float s, float4 w, float4 acc) {
-    return make_float4(fmaf(s, w.x, acc.x), fmaf(s, w.y, acc.y), fmaf(s, w.z, acc.z), fmaf(s, w.w, acc.w));
-}
-// the gradient g where the pre-activation z is positive (or NaN), zero where z <= 0
-__device__ __forceinline__ float4 zero_where_le0(float4 z, float4 g) {
-    return make_float4(z.x <= 0.0f ? 0.0f : g.x, z.y <= 0.0f ? 0.0f : g.y, z.z <= 0.0f ? 0.0f : g.z, z.w <= 0.0f ? 0.0f : g.w);
-}
-struct HeadArgs {
-    const float *w2, *b2;       // fc2 [K][Hd], [K] or null
-    const int64_t *labels;      // [M]
-    float gscale;               // 1 (reduction "sum") or 1 / M ("mean")
-    int K;                      // classes (<= 10: PRE 2, <= 16: PRE 3)
-    float *logits_out;          // [M][K] or null (written by the workgroups of the first column tile)
-};
-#ifndef EE_DENSE_SKIP
-#define EE_DENSE_SKIP 0  // probe builds only (scripts/net2_head_phases.py): 1 no gradient forming while staging, 2 no logits products, 4 no main loop
-#endif
-constexpr int DN_HK = 16, DN_HD = 1024;  // PRE 2: at most 16 classes, exactly 1024 hidden units (Net_2)
-
-template <int PRE, bool POST>
+template <bool PRE, bool POST>
 __global__ __launch_bounds__(DN_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_mfma_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ c, DenseDims d,
-                                                           FusePre pre, FusePost post, HeadArgs hd) {
-    extern __shared__ __align__(16) float lds[];  // two buffers of {A tile, B tile}; afterwards the partial-tile exchange; PRE 2: fc2's weights + dl behind them
-    __shared__ float wtab[PRE == 1 ? DN_MAX_C : 1];
+                                                           FusePre pre, FusePost post) {
+    extern __shared__ __align__(16) float lds[];  // two buffers of {A tile, B tile}; afterwards the partial-tile exchange
+    __shared__ float wtab[PRE ? DN_MAX_C : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
     const bool producer = wave >= 4;   // wavefronts 0-3 multiply, 4-7 keep four rounds of loads in flight and write the next round's tiles to LDS:
     const int tid = threadIdx.x & 255; // a wavefront issues in order, so with do-everything wavefronts load latency, staging and products add up
@@ -78,12 +59,9 @@ __global__ __launch_bounds__(DN_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int nt = blockIdx.x / mtiles, mt = blockIdx.x - nt * mtiles;
     const int m0 = mt * DN_TM, n0 = nt * DN_TN;
     const int rounds = d.K / DN_KU;  // a multiple of DN_DEPTH (dense_check)
-    if constexpr (PRE == 1) {
+    if constexpr (PRE) {
         for (int ch = threadIdx.x; ch < d.K / 4; ch += DN_NT) wtab[ch] = bn_scale(pre.var, pre.gamma, pre.eps, ch);
     }
-    constexpr int HK = PRE == 2 ? 10 : DN_HK;    // class rows of fc2 kept in LDS (rows past hd.K are zero)
-    float *w2s = lds + 2 * (DN_ABUF + DN_BBUF);  // PRE 2/3: [HK][1024]
-    float *dls = w2s + DN_HK * DN_HD;            // PRE 2/3: [32 rows][16]
     // staging roles: A tile 32 rows x 32 float4: thread t takes (row (t >> 5) + 8 j, float4 t & 31); B tile 128 k-rows x 8 float4: (k row (t >> 3) + 32 j, float4 t & 7)
     const int ar = tid >> 5, af = tid & 31, br = tid >> 3, bf = tid & 7;
     size_t ao[DN_F4];
@@ -92,7 +70,7 @@ __global__ __launch_bounds__(DN_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     for (int j = 0; j < DN_F4; ++j) {
         const int m = m0 + ar + 8 * j;
         ao[j] = static_cast<size_t>(m < d.M ? m : d.M - 1) * d.K + 4 * af;  // past the batch: a valid row, never stored
-        ast[j] = PRE == 1 && pre.store != nullptr && nt == 0 && m < d.M;
+        ast[j] = PRE && pre.store != nullptr && nt == 0 && m < d.M;
     }
     const float *bsrc = b + static_cast<size_t>(br) * d.N + n0 + 4 * bf;
     const size_t bstep32 = static_cast<size_t>(32) * d.N, bround = static_cast<size_t>(DN_KU) * d.N;
@@ -105,7 +83,7 @@ __global__ __launch_bounds__(DN_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #define DN_FETCH_A1(AS, J, ko_)                                                                \
     do {                                                                                       \
         RA##AS##_##J = *reinterpret_cast<const float4 *>(a + ao[J] + (ko_));                   \
-        if constexpr (PRE == 1) RM##AS##_##J = *reinterpret_cast<const float4 *>(pre.mask + ao[J] + (ko_)); \
+        if constexpr (PRE) RM##AS##_##J = *reinterpret_cast<const float4 *>(pre.mask + ao[J] + (ko_)); \
     } while (0)
 #define DN_FETCH_A(AS, round_)                                                                 \
     do {                                                                                       \
@@ -126,7 +104,7 @@ __global__ __launch_bounds__(DN_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #define DN_STAGE1(buf_, AS, BS, J, round_)                                                     \
     do {                                                                                       \
         float4 v_ = RA##AS##_##J;                                                              \
-        if constexpr (PRE == 1) {                                                              \
+        if constexpr (PRE) {                                                                   \
             const size_t ko_ = static_cast<size_t>(round_) * DN_KU;                            \
             /* two gradient pieces: rare, fetched here */                                      \
             if (pre.add) v_ = sum4(v_, *reinterpret_cast<const float4 *>(pre.add + ao[J] + ko_)); \
@@ -139,17 +117,6 @@ __global__ __launch_bounds__(DN_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     } while (0)
 #define DN_STAGE(buf_, AS, BS, round_)                                                         \
     do {                                                                                       \
-        if constexpr (PRE >= 2 && !(EE_DENSE_SKIP & 1)) { /* the four rows of this lane share fc2's columns */ \
-            float4 h0_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f), h1_ = h0_, h2_ = h0_, h3_ = h0_;  \
-            const float *wc_ = w2s + (round_) * DN_KU + 4 * af, *dl_ = dls + ar * DN_HK;        \
-            _Pragma("unroll") for (int k_ = 0; k_ < HK; ++k_) {                                 \
-                const float4 w_ = *reinterpret_cast<const float4 *>(wc_ + k_ * DN_HD);          \
-                h0_ = fma4(dl_[k_], w_, h0_), h1_ = fma4(dl_[8 * DN_HK + k_], w_, h1_);          \
-                h2_ = fma4(dl_[16 * DN_HK + k_], w_, h2_), h3_ = fma4(dl_[24 * DN_HK + k_], w_, h3_); \
-            }                                                                                  \
-            RA##AS##_0 = zero_where_le0(RA##AS##_0, h0_), RA##AS##_1 = zero_where_le0(RA##AS##_1, h1_); \
-            RA##AS##_2 = zero_where_le0(RA##AS##_2, h2_), RA##AS##_3 = zero_where_le0(RA##AS##_3, h3_); \
-        }                                                                                      \
         DN_STAGE1(buf_, AS, BS, 0, round_);                                                    \
         DN_STAGE1(buf_, AS, BS, 1, round_);                                                    \
         DN_STAGE1(buf_, AS, BS, 2, round_);                                                    \
@@ -178,28 +145,6 @@ __global__ __launch_bounds__(DN_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     };
     constexpr int BUF = DN_ABUF + DN_BBUF;
     static_assert(DN_DEPTH == 4, "four named register sets");
-    // PRE 2/3: the prologue's own loads go out BEFORE the producers' first fetches of fc1's weight rows (loads return in order: behind those fetches
-    // the logits would wait for the furthest memory); their use comes after
-    constexpr int W2N = PRE >= 2 ? HK * (DN_HD / 4) / DN_NT : 1;  // float4 per lane of fc2's weights
-    static_assert(PRE < 2 || HK * (DN_HD / 4) % DN_NT == 0, "whole float4 per lane");
-    float4 w2r[W2N], za[8], zb[8], wv[8];
-    if constexpr (PRE >= 2) {
-        // logits: rows l15 (+ 16) of the tile, classes l15; MFMA step (s, e) reduces over hidden units 128 wave + 16 s + 4 lq + e (one float4 per lane and s)
-        const int r0 = m0 + l15 < d.M ? m0 + l15 : d.M - 1, r1 = m0 + 16 + l15 < d.M ? m0 + 16 + l15 : d.M - 1;
-        const float *z0 = a + static_cast<size_t>(r0) * DN_HD + 128 * wave + 4 * lq, *z1 = a + static_cast<size_t>(r1) * DN_HD + 128 * wave + 4 * lq;
-        const float *wr = hd.w2 + static_cast<size_t>(l15 < hd.K ? l15 : 0) * DN_HD + 128 * wave + 4 * lq;
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-            za[s2] = *reinterpret_cast<const float4 *>(z0 + 16 * s2);
-            zb[s2] = *reinterpret_cast<const float4 *>(z1 + 16 * s2);
-            wv[s2] = *reinterpret_cast<const float4 *>(wr + 16 * s2);
-        }
-#pragma unroll
-        for (int i = 0; i < W2N; ++i) {
-            const int f = threadIdx.x + i * DN_NT;
-            w2r[i] = f < hd.K * (DN_HD / 4) ? reinterpret_cast<const float4 *>(hd.w2)[f] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-    }
     if (producer) {
         DN_FETCH_A(0, 0);
         DN_FETCH_A(1, 1);
@@ -208,50 +153,7 @@ __global__ __launch_bounds__(DN_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         DN_FETCH_B(2, 2);
         DN_FETCH_B(3, 3);
     }
-    if constexpr (PRE >= 2) {
-        {
-            f32x4 l0 = {0.0f, 0.0f, 0.0f, 0.0f}, l1 = {0.0f, 0.0f, 0.0f, 0.0f};
-            const bool wk = l15 < hd.K;
-#pragma unroll
-            for (int s2 = 0; s2 < ((EE_DENSE_SKIP & 2) ? 0 : 8); ++s2) {
-                const float ae[4] = {relu_keep_nan(za[s2].x), relu_keep_nan(za[s2].y), relu_keep_nan(za[s2].z), relu_keep_nan(za[s2].w)};
-                const float be[4] = {relu_keep_nan(zb[s2].x), relu_keep_nan(zb[s2].y), relu_keep_nan(zb[s2].z), relu_keep_nan(zb[s2].w)};
-                const float we[4] = {wk ? wv[s2].x : 0.0f, wk ? wv[s2].y : 0.0f, wk ? wv[s2].z : 0.0f, wk ? wv[s2].w : 0.0f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    l0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], we[e], l0, 0, 0, 0);
-                    l1 = __builtin_amdgcn_mfma_f32_16x16x4f32(be[e], we[e], l1, 0, 0, 0);
-                }
-            }
-            float *part = lds + wave * (DN_TM * DN_HK);  // [wave][32 rows][16 classes] in the staging buffers, before their first use
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[(4 * lq + r) * DN_HK + l15] = l0[r], part[(16 + 4 * lq + r) * DN_HK + l15] = l1[r];
-        }
-#pragma unroll
-        for (int i = 0; i < W2N; ++i) reinterpret_cast<float4 *>(w2s)[threadIdx.x + i * DN_NT] = w2r[i];
-        __syncthreads();
-        {
-            const int row = threadIdx.x >> 4, k = threadIdx.x & 15;  // 512 lanes = 32 rows x 16 classes
-            float lg = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) lg += lds[w * (DN_TM * DN_HK) + row * DN_HK + k];
-            const bool live = k < hd.K;
-            lg = live ? lg + (hd.b2 ? hd.b2[k] : 0.0f) : -INFINITY;
-            float mx = lg;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
-            float se = live ? expf(lg - mx) : 0.0f;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) se += __shfl_xor(se, off, 16);
-            const float lse = logf(se);
-            const int mrow = m0 + row < d.M ? m0 + row : d.M - 1;
-            const int y = static_cast<int>(hd.labels[mrow]);
-            dls[row * DN_HK + k] = live ? (expf((lg - mx) - lse) - (k == y ? 1.0f : 0.0f)) * hd.gscale : 0.0f;
-            if (hd.logits_out && nt == 0 && live && m0 + row < d.M) hd.logits_out[static_cast<size_t>(m0 + row) * hd.K + k] = lg;
-        }
-        __syncthreads();
-    }
-    if constexpr (PRE == 1) __syncthreads();  // the scale table
+    if constexpr (PRE) __syncthreads();  // the scale table
     if (producer) {
         DN_STAGE(lds, 0, 0, 0);
         DN_FETCH_A(0, 2);
@@ -271,7 +173,7 @@ __global__ __launch_bounds__(DN_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }                                                                                      \
         __syncthreads();                                                                       \
     } while (0)
-    for (int r0 = 0; r0 < ((EE_DENSE_SKIP & 4) ? 0 : rounds); r0 += 4) {
+    for (int r0 = 0; r0 < rounds; r0 += 4) {
         DN_STEP(0, 1, 1);
         DN_STEP(1, 2, 0);
         DN_STEP(2, 3, 1);
@@ -332,15 +234,14 @@ int dense_check(const void *a, const void *b, const void *c, int B, int Cin, int
     return EE_OK;
 }
 
-template <int PRE, bool POST>
-int dense_launch(const float *a, const float *b, float *c, const DenseDims &d, const FusePre &pre, const FusePost &post, hipStream_t st, const HeadArgs &hd = HeadArgs{}) {
+template <bool PRE, bool POST>
+int dense_launch(const float *a, const float *b, float *c, const DenseDims &d, const FusePre &pre, const FusePost &post, hipStream_t st) {
     const unsigned grid = static_cast<unsigned>((d.M + DN_TM - 1) / DN_TM) * static_cast<unsigned>(d.N / DN_TN);
-    constexpr size_t bytes = (2 * (DN_ABUF + DN_BBUF) + (PRE >= 2 ? DN_HK * DN_HD + DN_TM * DN_HK : 0)) * sizeof(float);  // 83 KB (+ 66 KB): above the static limit
-    static_assert(bytes <= 160 * 1024, "fits the LDS of a CU");
+    constexpr size_t bytes = 2 * (DN_ABUF + DN_BBUF) * sizeof(float);  // 83 KB: above the static limit
     static int ok = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_mfma_kernel<PRE, POST>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(bytes)) == hipSuccess;
     if (!ok) return EE_ERR_UNSUPPORTED;
-    EE_LAUNCH((dense_mfma_kernel<PRE, POST>), dim3(grid), dim3(DN_NT), bytes, st, a, b, c, d, pre, post, hd);
+    EE_LAUNCH((dense_mfma_kernel<PRE, POST>), dim3(grid), dim3(DN_NT), bytes, st, a, b, c, d, pre, post);
     return launch_status();
 }
 
@@ -351,7 +252,7 @@ int dense_launch(const float *a, const float *b, float *c, const DenseDims &d, c
 EE_API int ee_dense2x2_f32(const float *x, const float *w2, float *y, int B, int Cin, int Cout, void *stream) {
     const int rc = dense_check(x, w2, y, B, Cin, Cout);
     if (rc != EE_OK || B == 0) return rc;
-    return dense_launch<0, false>(x, w2, y, DenseDims{B, 4 * Cin, 4 * Cout}, FusePre{}, FusePost{}, as_stream(stream));
+    return dense_launch<false, false>(x, w2, y, DenseDims{B, 4 * Cin, 4 * Cout}, FusePre{}, FusePost{}, as_stream(stream));
 }
 
 // ... with the eval-mode BatchNorm (running statistics), the block's residual and the ReLU in the epilogue (see ee_wino3x3_bn_eval_fwd_f32)
@@ -363,7 +264,7 @@ EE_API int ee_dense2x2_bn_eval_fwd_f32(const float *x, const float *w2, const fl
     if (!mean || !var) return EE_ERR_NULL;
     const int pc = check_post(post);
     if (pc != EE_OK) return pc;
-    return dense_launch<0, true>(x, w2, y, DenseDims{B, 4 * Cin, 4 * Cout}, FusePre{}, post, as_stream(stream));
+    return dense_launch<false, true>(x, w2, y, DenseDims{B, 4 * Cin, 4 * Cout}, FusePre{}, post, as_stream(stream));
 }
 
 // ... and its backward-data: dz = (y > 0) * (dy [+ dy2]); dres <- dz; dx = (gamma / sqrt(var + eps) * dz) . w2t [+ dx_add]
@@ -380,23 +281,7 @@ EE_API int ee_dense2x2_bn_eval_bwd_f32(const float *dy, const float *dy2, const 
     const DenseDims d{B, 4 * Cout, 4 * Cin};
     if (dx_add) {
         if (!aligned16(dx_add)) return EE_ERR_ALIGN;
-        return dense_launch<1, true>(dy, w2t, dx, d, pre, FusePost{nullptr, nullptr, nullptr, nullptr, 0.0f, dx_add, 0}, as_stream(stream));
+        return dense_launch<true, true>(dy, w2t, dx, d, pre, FusePost{nullptr, nullptr, nullptr, nullptr, 0.0f, dx_add, 0}, as_stream(stream));
     }
-    return dense_launch<1, false>(dy, w2t, dx, d, pre, FusePost{}, as_stream(stream));
-}
-
-// Net_2's head backward in ONE launch (MNIST/models_mnist/Net2.py:17-19; utils/attacks.py:23): from z1 = fc1's output [B][1024], fc2 (w2 [K][1024],
-// b2 [K] or NULL, K <= 16), the labels and gscale (1: reduction "sum", 1 / B: "mean") to d loss / d (fc1's INPUT) = dz1 . w1 [B][Hin], w1 [1024][Hin]
-// = fc1's weight as it lies (Hin a multiple of 32).  logits_out [B][K] (optional) receives fc2(relu(z1)).  Replaces ee_fc_ce_grad_f32 + the
-// product with fc1's weight (two launches).
-EE_API int ee_net2_head_bwd_f32(const float *z1, const float *w2, const float *b2, const int64_t *labels, float gscale, const float *w1, float *dx,
-                                float *logits_out, int B, int Hin, int K, void *stream) {
-    if (B < 0 || K < 1 || Hin < 1) return EE_ERR_SHAPE;
-    if (K > DN_HK || Hin % DN_TN != 0) return EE_ERR_UNSUPPORTED;
-    if (B == 0) return EE_OK;
-    if (!z1 || !w2 || !labels || !w1 || !dx) return EE_ERR_NULL;
-    if (!aligned16(z1) || !aligned16(w2) || !aligned16(w1) || !aligned16(dx)) return EE_ERR_ALIGN;
-    const HeadArgs hd{w2, b2, labels, gscale, K, logits_out};
-    if (K <= 10) return dense_launch<2, false>(z1, w1, dx, DenseDims{B, DN_HD, Hin}, FusePre{}, FusePost{}, as_stream(stream), hd);
-    return dense_launch<3, false>(z1, w1, dx, DenseDims{B, DN_HD, Hin}, FusePre{}, FusePost{}, as_stream(stream), hd);
+    return dense_launch<true, false>(dy, w2t, dx, d, pre, FusePost{}, as_stream(stream));
 }

@@ -48,7 +48,6 @@ SIGNATURES = {
     "ee_pgd_step_bcast_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_f, c_f, c_f, c_f, c_i, c_p],
     "ee_ce_f32": [c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p],
     "ee_fc_ce_grad_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
-    "ee_net2_head_bwd_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "ee_kl_f32": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
     "ee_softce_f64": [c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p],
     "ee_mse_f32": [c_p, c_p, c_l, c_f, c_p, c_p, c_p],

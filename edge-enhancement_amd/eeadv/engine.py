@@ -52,16 +52,6 @@ def _body_input_grad(model, x_in, spec, through_body):
     `body_pre` / `head_grad` / `head_from_pre` and whose head_grad answers (models.Net_2: from fc1's output on) get the rest of the classifier,
     the cross-entropy and the way back as ONE launch (ops.fc_ce_grad) instead of five; the ResNets' head_grad declines (measured slower)."""
     pre = getattr(model, "body_pre", None) if _FC_HEAD and (through_body or not hasattr(model, "front_chain")) else None
-    if pre is not None and spec.kind in (CE_SUM, CE_MEAN) and x_in.is_cuda and hasattr(model, "head_grad_deep"):
-        # one layer further back (models.Net_2): autograd sees the convolution halves only
-        with torch.enable_grad(), attack_forward():
-            a = model.body_conv(x_in)
-        da = model.head_grad_deep(a.detach(), spec.payload, "mean" if spec.kind == CE_MEAN else "sum")
-        if da is not None:
-            with input_grad_only(), torch.autograd.set_multithreading_enabled(_MT_BACKWARD):
-                (g,) = torch.autograd.grad(a, [x_in], grad_outputs=da)
-            return g
-        pre = None  # (declined: the stock sequence below)
     if pre is not None and spec.kind in (CE_SUM, CE_MEAN) and x_in.is_cuda and hasattr(model, "head_grad"):
         with torch.enable_grad(), attack_forward():
             z = pre(x_in)

@@ -378,9 +378,6 @@ class _EEFrontMixin:
 
 
 # ---- MNIST ---------------------------------------------------------------------------------------------------
-_HEAD_DEEP = os.environ.get("EEADV_NET2_HEAD_DEEP", "1") != "0"  # the attack loop's head backward from fc1's input on as one launch
-
-
 class Net_2(nn.Module):
     def __init__(self):
         super(Net_2, self).__init__()
@@ -402,25 +399,9 @@ class Net_2(nn.Module):
             return ops.fc_ce_grad(z1.contiguous(), self.fc2.weight.detach().contiguous(), None if self.fc2.bias is None else self.fc2.bias.detach(), labels, reduction)
         return None
 
-    def head_grad_deep(self, a2, labels, reduction):
-        """d CrossEntropyLoss(body(.), labels) / d a2 for a2 = body_conv's output: fc1 forward (one GEMM, outside autograd), then fc2, the loss
-        gradient, fc2^T and fc1^T as ONE launch (ops.net2_head_bwd); None where that kernel does not apply"""
-        w1, w2 = self.fc1.weight, self.fc2.weight
-        if not (_HEAD_DEEP and type(self.fc1) is nn.Linear and type(self.fc2) is nn.Linear and a2.is_cuda and a2.dtype == torch.float32
-                and w1.dtype == torch.float32 and w2.dtype == torch.float32 and w1.is_contiguous() and w2.is_contiguous() and a2.dim() == 2
-                and a2.shape[1] == w1.shape[1] and ops.net2_head_bwd_supported(a2.new_empty((0, w1.shape[0])), w2, w1)):
-            return None
-        with torch.no_grad():
-            z1 = F.linear(a2, w1, self.fc1.bias)
-        return ops.net2_head_bwd(z1, w2.detach(), None if self.fc2.bias is None else self.fc2.bias.detach(), labels, w1.detach(), reduction)
-
     def body_pre(self, x):
         """fc1's output, i.e. the body without `fc2(relu(.))`: engine fuses those two layers with the cross-entropy gradient
         (ops.fc_ce_grad) inside the attack loop"""
-        return self.fc1(self.body_conv(x))
-
-    def body_conv(self, x):
-        """the two convolution + pool + ReLU halves, flattened [B, 1024]: what fc1 reads"""
         if ("net2" not in _STOCK and _dense_f32(x) and type(self.conv1) is nn.Conv2d and type(self.conv2) is nn.Conv2d
                 and ops.net2_conv_supported(x, self.conv1.weight, self.conv2.weight) and self.conv1.weight.is_contiguous()
                 and self.conv2.weight.is_contiguous()):
@@ -442,7 +423,8 @@ class Net_2(nn.Module):
             _route(self.conv1, "miopen"), _route(self.conv2, "miopen")
             x = F.relu(F.max_pool2d(self.conv1(x), 2))
             x = F.relu(F.max_pool2d(self.conv2_drop(self.conv2(x)), 2))
-        return x.view(-1, 4 * 4 * 64)
+        x = x.view(-1, 4 * 4 * 64)
+        return self.fc1(x)
 
     def forward(self, x):
         return self.body(x)

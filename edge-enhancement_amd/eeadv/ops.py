@@ -361,24 +361,6 @@ def fc_ce_grad(z1, w2, b2, labels, reduction="sum", want_logits=False):
     return (dz, lg) if want_logits else dz
 
 
-def net2_head_bwd_supported(z1, w2, w1):
-    return (z1.dim() == 2 and z1.shape[1] == 1024 and w2.dim() == 2 and w2.shape[1] == 1024 and w2.shape[0] <= 16 and w1.dim() == 2
-            and w1.shape[0] == 1024 and w1.shape[1] % 32 == 0)
-
-
-def net2_head_bwd(z1, w2, b2, labels, w1, reduction="sum", want_logits=False):
-    """d CrossEntropyLoss(fc2(relu(z1)), labels) / d (fc1's input) in one launch (ee_dense.hip, PRE 2): z1 [B,1024] = fc1's output,
-    w2 [K,1024], b2 [K] or None, w1 [1024,Hin] = fc1's weight.  Returns dx [B,Hin], or (dx, logits)."""
-    B, K, Hin = z1.shape[0], w2.shape[0], w1.shape[1]
-    dx = torch.empty((B, Hin), dtype=torch.float32, device=z1.device)
-    lg = torch.empty((B, K), dtype=torch.float32, device=z1.device) if want_logits else None
-    N.check(N.lib.ee_net2_head_bwd_f32(_chk(z1, torch.float32, "z1", (B, 1024)), _chk(w2, torch.float32, "w2", (K, 1024)), _opt(b2, torch.float32, "b2"),
-                                       _chk(labels, torch.int64, "labels", (B,)), _inv(B) if reduction == "mean" else 1.0,
-                                       _chk(w1, torch.float32, "w1", (1024, Hin)), dx.data_ptr(), _opt(lg, torch.float32, "logits"), B, Hin, K,
-                                       _stream()), "ee_net2_head_bwd_f32")
-    return (dx, lg) if want_logits else dx
-
-
 def kl_batchmean(zq, zp, want_loss=True, want_dq=True, want_dp=False):
     B, K = zq.shape
     pq = _chk(zq, torch.float32, "zq")

@@ -184,12 +184,6 @@ int ee_ce_f32(const float *logits, const int64_t *labels, int B, int K, float sm
 int ee_fc_ce_grad_f32(const float *z1, const float *w2, const float *b2, const int64_t *labels, float *dz1, float *logits_out, int B, int Hd,
                       int K, float gscale, void *stream);
 
-/* The same from one layer further back (MNIST/models_mnist/Net2.py:17-19, :26-28): z1 [B,1024] = fc1's output -> d loss / d (fc1's INPUT)
- * dx [B,Hin] = dz1 . w1 with w1 [1024,Hin] = fc1's weight as it lies; dz1 never reaches memory (ee_dense.hip, one launch instead of
- * ee_fc_ce_grad_f32 + a GEMM).  K <= 16, the hidden width is 1024, Hin a multiple of 32; else EE_ERR_UNSUPPORTED. */
-int ee_net2_head_bwd_f32(const float *z1, const float *w2, const float *b2, const int64_t *labels, float gscale, const float *w1, float *dx,
-                         float *logits_out, int B, int Hin, int K, void *stream);
-
 /* nn.KLDivLoss('batchmean')(log_softmax(zq), softmax(zp))  (attacks.py:375, :412, :426):
  *     row_loss_b = sum_k p(log p - log q);  dzq = gscale*(q - p);  dzp = gscale*p*((log p - log q) - row_loss_b)
  * dzq / dzp nullable. */

@@ -1061,61 +1061,6 @@ def test_fc_ce_grad_matches_autograd(ops, B, Hd, K, reduction):
     assert float(dzn[0, closed].abs().max()) == 0.0  # closed gates stay closed next to the NaN
 
 
-@pytest.mark.parametrize("B,Hin,K,reduction", [(50, 1024, 10, "sum"), (512, 1024, 10, "sum"), (7, 1024, 10, "mean"), (33, 64, 16, "sum"), (1, 32, 2, "mean"), (65, 96, 11, "mean")])
-def test_net2_head_backward_in_one_launch_matches_autograd(ops, B, Hin, K, reduction):
-    """fc2(relu(z1)) + CrossEntropyLoss + fc2^T + ReLU gate + fc1^T as one launch (ee_dense.hip PRE 2/3) against float64 autograd through
-    z1 -> loss taken to fc1's input; logits too; closed gates contribute exactly nothing; a NaN stays in its own row."""
-    import torch.nn.functional as F
-    g = torch.Generator(device="cpu").manual_seed(B * Hin + K)
-    z1 = torch.randn(B, 1024, generator=g)
-    z1[0, :5] = 0.0
-    w1 = torch.randn(1024, Hin, generator=g) / Hin ** 0.5
-    w2 = torch.randn(K, 1024, generator=g) / 32
-    b2 = torch.randn(K, generator=g)
-    y = torch.randint(0, K, (B,), generator=g)
-    for bias in (b2, None):
-        z64 = z1.double().requires_grad_(True)
-        loss = F.cross_entropy(F.linear(F.relu(z64), w2.double(), None if bias is None else bias.double()), y, reduction=reduction)
-        (dz,) = torch.autograd.grad(loss, [z64])
-        want = dz @ w1.double()
-        dx, lg = ops.net2_head_bwd(z1.to(DEV), w2.to(DEV), None if bias is None else bias.to(DEV), y.to(DEV), w1.to(DEV), reduction, want_logits=True)
-        assert dx.shape == (B, Hin)
-        assert float((dx.cpu().double() - want).abs().max()) < 3e-6 * max(float(want.abs().max()), 1e-3)
-        torch.testing.assert_close(lg.cpu().double(), F.linear(F.relu(z1.double()), w2.double(), None if bias is None else bias.double()), rtol=1e-5, atol=1e-5)
-        # the two-launch sequence it replaces
-        two = ops.fc_ce_grad(z1.to(DEV), w2.to(DEV), None if bias is None else bias.to(DEV), y.to(DEV), reduction) @ w1.to(DEV)
-        assert float((dx - two).abs().max()) < 3e-6 * max(float(want.abs().max()), 1e-3)
-    if B > 1:
-        zn = z1.clone()
-        zn[0, 7] = float("nan")
-        dxn = ops.net2_head_bwd(zn.to(DEV), w2.to(DEV), b2.to(DEV), y.to(DEV), w1.to(DEV), reduction).cpu()
-        assert bool(torch.isnan(dxn[0]).all()) and bool(torch.isfinite(dxn[1:]).all())
-    # unsupported shapes are refused, not mangled
-    with pytest.raises(Exception):
-        ops.net2_head_bwd(z1.to(DEV), torch.zeros(17, 1024, device=DEV), None, y.to(DEV), w1.to(DEV), reduction)
-
-
-def test_net2_attack_gradient_with_and_without_the_one_launch_head(ops, monkeypatch):
-    """engine's input gradient of Net_2 through head_grad_deep (conv halves under autograd, head as one launch) against the route through
-    head_grad (fc1 under autograd) and against plain autograd"""
-    from eeadv import engine, models
-    torch.manual_seed(3)
-    net = models.Net_2().to(DEV).eval()
-    x = torch.rand(37, 1, 28, 28, device=DEV)
-    y = torch.randint(0, 10, (37,), device=DEV)
-    spec = engine.LossSpec(engine.CE_SUM, y)
-    outs = []
-    for deep in (True, False):
-        monkeypatch.setattr(models, "_HEAD_DEEP", deep)
-        xi = x.clone().requires_grad_(True)
-        outs.append(engine.input_gradient(net, xi, spec).clone())
-    xi = x.clone().requires_grad_(True)
-    (ref,) = torch.autograd.grad(torch.nn.functional.cross_entropy(net(xi), y, reduction="sum"), [xi])
-    scale = float(ref.abs().max())
-    assert float((outs[0] - outs[1]).abs().max()) < 1e-5 * scale
-    assert float((outs[0] - ref).abs().max()) < 1e-4 * scale
-
-
 @pytest.mark.parametrize("co,ci", [(64, 32), (32, 96), (128, 128)])
 def test_weight_preparation_kernels_match_their_torch_restatement(ops, monkeypatch, co, ci):
     """ee_wprep.hip (one launch per weight and kind) against functional._rearranged's torch expressions: the permutation kinds bit for bit,
