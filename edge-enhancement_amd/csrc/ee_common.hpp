@@ -38,6 +38,17 @@ __device__ __forceinline__ bool xcd_decode(int id, int ncb, int nimg, bool weigh
     return bx < nimg;
 }
 
+// compute units of the current device (persistent kernels size their grids by it); 256 on MI355X, which is also the answer when the query fails
+static inline int device_cus() {
+    static int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 

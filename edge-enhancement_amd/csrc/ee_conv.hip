@@ -302,35 +302,74 @@ EE_API int ee_stem7x7s2_bwd_data_f32(const float *dy, const float *weight, float
 }
 
 // =====================================================================================================================
-// Forward of the stem convolution Conv2d(3, 64k, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113), round 2.
+// Forward of the stem convolution Conv2d(3, 64k, kernel_size=7, stride=2, padding=3, bias=False) (resnet.py:112-113).
 // MIOpen's best solver (Winograd f3x2_stride2) takes 52 us un-profiled for [100,3,64,64] -> [100,64,32,32], the most expensive
 // single launch of a PGD iteration's forward pass.  Implicit GEMM on v_mfma_f32_32x32x2_f32:
-//   D[co][p] = sum_{(ci, ky, kx)} W[co][ci][ky][kx] * x[n, ci, 2 oy + ky - 3, 2 ox + kx - 3],     K = 3 * 7 * 8 (kx padded to 8, W = 0 there)
-// One MFMA step takes the taps (kx, kx + 1) of one (ci, ky) on the two lane halves: the B operand of lane (i, half) is the frame
-// element at column 2 i + kx + half - even and odd columns on disjoint LDS banks, one ds_read_b32 with an immediate offset per
-// MFMA and tile, no index arithmetic in the loop.  A workgroup (4 wavefronts = 2 channel halves x 2 row pairs) owns 64 output
-// channels x 4 output rows x 32 columns; its 13 x 72 x 3 input frame sits in LDS (zero outside the image) and the 84 A operands
-// of a lane stay in REGISTERS for both of its tiles (weights pass through LDS once, in their natural layout, 16-B global loads).
+//   D[co][p] = sum_{(ci, ky, kx)} W[co][ci][ky][kx] * x[n, ci, 2 oy + ky - 3, 2 ox + kx - 3],     K = 3 * 7 * 7 = 147 (+ 1)
+// Round 2 padded kx to 8 (84 steps, the B operand of lane (i, half) at column 2 i + kx + half: one immediate offset per step); round 4
+// walks the 147 taps flat, two per step (74 steps = 12 % fewer products; the half's frame offset is a select of two constants).
+// Round 4: PERSISTENT workgroups.  Round 2's kernel (one workgroup = one 4-row tile: weights through LDS into registers, frame, 168
+// products, stores, moments - one after the other; 800 workgroups for 768 slots) measured 8.8 us without its products and 32.5 with
+// them: the phases added up (scripts/stem_phases.py at commit 0905c3e+2).  Now a workgroup (4 wavefronts = 2 channel halves x 2 output
+// rows) loads its 84 A operands per lane ONCE and walks over units of 64 channels x 2 rows x 32 columns (unit = blockIdx.x, += gridDim.x):
+// the next unit's 9 x 72 x 3 input frame travels global -> registers while the current one is multiplied out of LDS (two frame buffers),
+// the result stores are fire-and-forget, one barrier per unit (two with the BatchNorm moments).
 // =====================================================================================================================
 namespace {
 
-constexpr int SF_ROWS = 4, SF_FH = 2 * SF_ROWS + 5, SF_FW = 72, SF_K = 147, SF_WS = 149, SF_STEPS = 3 * 7 * 4;
+#ifndef EE_STEM_SKIP
+#define EE_STEM_SKIP 0  // probe builds only (scripts/stem_phases.py): 1 no products, 2 no result stores, 8 products without their LDS operand reads
+#endif
+constexpr int SF_ROWS = 2, SF_FH = 2 * SF_ROWS + 5, SF_FW = 72, SF_K = 147, SF_WS = 149, SF_STEPS = (SF_K + 1) / 2;
+constexpr int SF_FR = 3 * SF_FH * SF_FW, SF_FPT = (SF_FR + 255) / 256;  // frame floats, per lane
+constexpr int SF_CS = SF_ROWS * 32 + 4, SF_NV = SF_ROWS * 8;            // moments exchange: channel stride (conflict-free), values per lane
+constexpr int SF_WG_PER_CU = 2;
+static_assert(2 * SF_FR + 64 * SF_CS <= 64 * SF_WS, "both frame buffers and the moments exchange live where the weights were staged");
 
-__global__ __launch_bounds__(256, 3) void stem_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
-                                                               float *__restrict__ stats, int K, int H, int W, int tiles_r, int tiles_c) {
-    __shared__ float fr[3 * SF_FH * SF_FW];
-    __shared__ __align__(16) float wn[64 * SF_WS];
+struct StemUnit {
+    int n, oy0, ox0;
+};
+__device__ __forceinline__ StemUnit stem_unit(int u, int tiles_r, int tiles_c) {
+    const int tc = u % tiles_c;
+    u /= tiles_c;
+    const int tr = u % tiles_r;
+    return StemUnit{u / tiles_r, tr * SF_ROWS, tc * 32};
+}
+// this lane's share of a unit's input frame: loads on clamped addresses (all in flight together), validity as a bit mask
+__device__ __forceinline__ void stem_frame_load(const float *__restrict__ x, const StemUnit &t, int H, int W, float (&fv)[SF_FPT], unsigned &fok) {
+    const int iy0 = 2 * t.oy0 - 3, ix0 = 2 * t.ox0 - 3;
+    const float *xn = x + static_cast<size_t>(t.n) * 3 * H * W;
+    fok = 0;
+#pragma unroll
+    for (int j = 0; j < SF_FPT; ++j) {
+        const int idx = static_cast<int>(threadIdx.x) + j * 256;
+        const int c = idx % SF_FW, q = idx / SF_FW;
+        const int r = q % SF_FH, ci = idx < SF_FR ? q / SF_FH : 0;
+        const int iy = iy0 + r, ix = ix0 + c;
+        const bool ok = idx < SF_FR && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        fok |= ok ? 1u << j : 0u;
+        fv[j] = xn[ok ? static_cast<unsigned>((ci * H + iy) * W + ix) : 0u];  // uniform base + 32-bit lane offset
+    }
+}
+__device__ __forceinline__ void stem_frame_store(float *fr, const float (&fv)[SF_FPT], unsigned fok) {
+#pragma unroll
+    for (int j = 0; j < SF_FPT; ++j)
+        if (static_cast<int>(threadIdx.x) + j * 256 < SF_FR) fr[threadIdx.x + j * 256] = (fok >> j) & 1u ? fv[j] : 0.0f;
+}
+
+__global__ __launch_bounds__(256, SF_WG_PER_CU) void stem_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
+                                                                          float *__restrict__ stats, int K, int H, int W, int tiles_r, int tiles_c,
+                                                                          int units) {
+    __shared__ __align__(16) float lds[64 * SF_WS];
+    float *wn = lds, *fr = lds, *ex = lds + 2 * SF_FR;  // the weight rows are dead once every lane holds its A operands
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
     const int mt = wave >> 1, nt = wave & 1;
     const int OH = H / 2, OW = W / 2;
-    int t = static_cast<int>(blockIdx.x);
-    const int tc = t % tiles_c;
-    t /= tiles_c;
-    const int tr = t % tiles_r, n = t / tiles_r;
-    const int oy0 = tr * SF_ROWS, ox0 = tc * 32;
     const int cb = static_cast<int>(blockIdx.y) * 64;
-    // ---- all global loads first (clamped addresses, masked afterwards) ----------------------------------------------------------
-    constexpr int WV4 = 64 * SF_K / 4, WPT = (WV4 + 255) / 256, FTOT = 3 * SF_FH * SF_FW, FPT = (FTOT + 255) / 256;
+    int u = static_cast<int>(blockIdx.x);
+    StemUnit t = stem_unit(u, tiles_r, tiles_c);
+    // ---- all global loads first (clamped addresses, masked afterwards): the weights and the first frame ----------------------------------
+    constexpr int WV4 = 64 * SF_K / 4, WPT = (WV4 + 255) / 256;
     float4 wv[WPT];
     const float4 *wsrc = reinterpret_cast<const float4 *>(w + static_cast<size_t>(cb) * SF_K);
 #pragma unroll
@@ -338,112 +377,105 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_mfma_kernel(const float *__re
         const int e = threadIdx.x + j * 256;
         wv[j] = wsrc[e < WV4 ? e : WV4 - 1];
     }
-    float fv[FPT];
-    bool fok[FPT];
-    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-#pragma unroll
-    for (int j = 0; j < FPT; ++j) {
-        const int idx = threadIdx.x + j * 256;
-        const int c = idx % SF_FW, q = idx / SF_FW;
-        const int r = q % SF_FH, ci = idx < FTOT ? q / SF_FH : 0;
-        const int iy = iy0 + r, ix = ix0 + c;
-        fok[j] = idx < FTOT && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        fv[j] = x[((static_cast<size_t>(n) * 3 + ci) * H + (fok[j] ? iy : 0)) * W + (fok[j] ? ix : 0)];
-    }
+    float fv[SF_FPT];
+    unsigned fok;
+    stem_frame_load(x, t, H, W, fv, fok);
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
         const int e = threadIdx.x + j * 256;
         if (e < WV4) {
             const float v4[4] = {wv[j].x, wv[j].y, wv[j].z, wv[j].w};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = 4 * e + u, co = f / SF_K, k = f - co * SF_K;
-                wn[co * SF_WS + k] = v4[u];
+            for (int q = 0; q < 4; ++q) {
+                const int f = 4 * e + q, co = f / SF_K, k = f - co * SF_K;
+                wn[co * SF_WS + k] = v4[q];
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < FPT; ++j)
-        if (static_cast<int>(threadIdx.x) + j * 256 < FTOT) fr[threadIdx.x + j * 256] = fok[j] ? fv[j] : 0.0f;
     __syncthreads();
-    // ---- this lane's 84 A operands: W[cb + mt*32 + i][ci][ky][2 kxp + kk], zero for the padded tap ---------------------------------
+    // ---- this lane's 74 A operands: W[cb + mt*32 + i][k] for the flat tap index k = 2 s + kk = (ci * 7 + ky) * 7 + kx, zero for k = 147 ---------
     float a[SF_STEPS];
     const float *wrow = wn + (mt * 32 + i) * SF_WS + kk;
 #pragma unroll
     for (int s = 0; s < SF_STEPS; ++s) {
-        const int kxp = s & 3, cy = s >> 2;  // cy = ci * 7 + ky
-        const float v = wrow[cy * 7 + 2 * kxp];  // for (kxp 3, kk 1) this is the next row's first tap (or the pad column): finite, dropped
-        a[s] = (kxp == 3 && kk) ? 0.0f : v;
+        const float v = wrow[2 * s];  // (k = 147: the pad column of the row - finite, dropped)
+        a[s] = (2 * s + 1 >= SF_K && kk) ? 0.0f : v;
     }
-#pragma unroll
-    for (int s = 0; s < SF_STEPS; ++s) asm volatile("" : "+v"(a[s]));  // keep them in registers: the compiler would re-read LDS per MFMA
-    // ---- two tiles (output rows 2 nt, 2 nt + 1 of the workgroup's four), 84 MFMAs each, interleaved ---------------------------------
-    f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
-    const float *b0 = fr + (2 * (2 * nt)) * SF_FW + 2 * i + kk;  // frame row 2 r + ky, column 2 i + 2 kxp + kk
-    const float *b1 = b0 + 2 * SF_FW;
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-            for (int kxp = 0; kxp < 4; ++kxp) {
-                const int off = (ci * SF_FH + ky) * SF_FW + 2 * kxp;
-                const float av = a[(ci * 7 + ky) * 4 + kxp];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[off], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[off], acc1, 0, 0, 0);
-            }
-    // ---- store: lane (i, kk) holds column ox0 + i of rows acc_row(r, lane) ------------------------------------------------------------
-    const size_t plane = static_cast<size_t>(OH) * OW;
-    const int oy = oy0 + 2 * nt;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = cb + mt * 32 + acc_row(r, lane);
-        float *o = y + (static_cast<size_t>(n) * K + co) * plane + static_cast<size_t>(oy) * OW + ox0 + i;
-        if (oy < OH) o[0] = acc0[r];
-        if (oy + 1 < OH) o[OW] = acc1[r];
-    }
-    // ---- optional: this workgroup's share of the BatchNorm statistics that follow the stem (resnet.py:113) - per output channel
-    // (sum, M2 about the tile's own mean, count) of its <= 4 x 32 values, so that bn1 does not have to read y twice for them:
-    // stats[(co * S + workgroup) * 3 + {0,1,2}], S = gridDim.x; merged by ee_bn.hip (bn_stats_finalize_kernel, Chan's update) -------
-    if (!stats) return;
-    // Through LDS, not through lane shuffles (a butterfly over 32 lanes for 2 x 16 registers is 160 dependent ds_bpermute: +13 us):
-    // the tile goes to LDS as [64 channels][4 rows x 32 columns] (channel stride 132: conflict-free), then four lanes per channel
-    // take 32 values each (two passes on registers: sum, then M2 about the tile mean) and meet through two quad exchanges.
-    constexpr int CS = 132;
-    __syncthreads();  // the weight rows in LDS are dead (every lane holds its A operands in registers): reuse them
-    float *ex = wn;
-    static_assert(64 * CS <= 64 * SF_WS, "the tile fits where the weights were");
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float *e = ex + (mt * 32 + acc_row(r, lane)) * CS + (2 * nt) * 32 + i;
-        e[0] = acc0[r];
-        e[32] = acc1[r];
-    }
+    __syncthreads();  // every lane has read its weight rows (they stay in registers): the frames take their place
+    stem_frame_store(fr, fv, fok);
     __syncthreads();
-    const int c = threadIdx.x >> 2, q = threadIdx.x & 3;
-    const int rows = OH - oy0 < SF_ROWS ? OH - oy0 : SF_ROWS;  // valid output rows of this tile (>= 1)
-    float v[32];
+    const size_t plane = static_cast<size_t>(OH) * OW;
+    const int stride = static_cast<int>(gridDim.x);
+    int cur = 0;
+    for (; u < units; u += stride) {
+        const bool more = u + stride < units;  // (uniform)
+        StemUnit tn = t;
+        if (more) {
+            tn = stem_unit(u + stride, tiles_r, tiles_c);
+            stem_frame_load(x, tn, H, W, fv, fok);  // in flight behind the products
+        }
+        // ---- one tile per wavefront (output row nt of the unit's two), 74 MFMAs: step s takes the taps k = 2 s, 2 s + 1 on the two lane halves;
+        // the B operand of lane (i, kk) is the frame element at row 2 nt + ky(k), column 2 i + kx(k) - an offset known at compile time per half
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const float *b0 = fr + cur * SF_FR + (2 * nt) * SF_FW + 2 * i;
+        // the second half's tap is one column further (p1), or - after kx = 6 - at the start of the next row (pr) / of the next plane (pc);
+        // the pad tap reads the first half's element (pz): four lane bases, every step an immediate offset
+        const float *p1 = b0 + kk, *pr = b0 + kk * (SF_FW - 6), *pc = b0 + kk * ((SF_FH - 6) * SF_FW - 6), *pz = b0;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) v[j] = ex[c * CS + q + 4 * j];  // element q + 4j: row j / 8
-    float sum = 0.0f;
+        for (int s2 = 0; s2 < ((EE_STEM_SKIP & 1) ? 0 : SF_STEPS); ++s2) {
+            const int k0 = 2 * s2, k1 = k0 + 1;
+            const int f0 = ((k0 / 49) * SF_FH + (k0 % 49) / 7) * SF_FW + k0 % 7;
+            const float *pb = k1 >= SF_K ? pz : (k0 % 7 != 6 ? p1 : (k0 % 49 != 48 ? pr : pc));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], (EE_STEM_SKIP & 8) ? fv[s2 & 3] : pb[f0], acc, 0, 0, 0);
+        }
+        // ---- store: lane (i, kk) holds column ox0 + i of rows acc_row(r, lane) -------------------------------------------------------------
+        const int oy = t.oy0 + nt;
+        if (oy < OH && (!(EE_STEM_SKIP & 2) || acc[0] == 123.456f)) {
+            float *yb = y + (static_cast<size_t>(t.n) * K + cb) * plane + static_cast<size_t>(t.oy0) * OW + t.ox0;  // uniform base + 32-bit lane offsets
+            const unsigned lo = static_cast<unsigned>(mt * 32 + 4 * kk) * static_cast<unsigned>(plane) + static_cast<unsigned>(nt * OW + i);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) sum += (j / 8 < rows) ? v[j] : 0.0f;
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
-    const float cnt = 32.0f * static_cast<float>(rows), mean = sum / cnt;
-    float m2 = 0.0f;
+            for (int r = 0; r < 16; ++r) yb[lo + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * static_cast<unsigned>(plane)] = acc[r];  // acc_row(r, lane)
+        }
+        // ---- optional: this unit's share of the BatchNorm statistics that follow the stem (resnet.py:113) - per output channel
+        // (sum, M2 about the unit's own mean, count) of its <= 2 x 32 values, so that bn1 does not have to read y twice for them:
+        // stats[(co * S + unit) * 3 + {0,1,2}], S = units; merged by ee_bn.hip (bn_stats_finalize_kernel, Chan's update) ------------------
+        // Through LDS, not through lane shuffles (a butterfly over 32 lanes for 16 registers is 80 dependent ds_bpermute): the tile goes
+        // to LDS as [64 channels][2 rows x 32 columns] (channel stride 68: conflict-free), then four lanes per channel take 16 values
+        // each (two passes on registers: sum, then M2 about the tile mean) and meet through two quad exchanges.
+        if (stats) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const float d = v[j] - mean;
-        m2 += (j / 8 < rows) ? d * d : 0.0f;
-    }
-    m2 += __shfl_xor(m2, 1);
-    m2 += __shfl_xor(m2, 2);
-    if (q == 0) {
-        float *o = stats + (static_cast<size_t>(cb + c) * gridDim.x + blockIdx.x) * 3;
-        o[0] = sum;
-        o[1] = m2;
-        o[2] = cnt;
+            for (int r = 0; r < 16; ++r) ex[(mt * 32 + acc_row(r, lane)) * SF_CS + nt * 32 + i] = acc[r];
+            __syncthreads();
+            const int c = threadIdx.x >> 2, q = threadIdx.x & 3;
+            const int rows = OH - t.oy0 < SF_ROWS ? OH - t.oy0 : SF_ROWS;  // valid output rows of this unit (>= 1)
+            float v[SF_NV];
+#pragma unroll
+            for (int j = 0; j < SF_NV; ++j) v[j] = ex[c * SF_CS + q + 4 * j];  // element q + 4j: row j / 8
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < SF_NV; ++j) sum += (j / 8 < rows) ? v[j] : 0.0f;
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            const float cnt = 32.0f * static_cast<float>(rows), mean = sum / cnt;
+            float m2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < SF_NV; ++j) {
+                const float d = v[j] - mean;
+                m2 += (j / 8 < rows) ? d * d : 0.0f;
+            }
+            m2 += __shfl_xor(m2, 1);
+            m2 += __shfl_xor(m2, 2);
+            if (q == 0) {
+                float *o = stats + (static_cast<size_t>(cb + c) * units + u) * 3;
+                o[0] = sum;
+                o[1] = m2;
+                o[2] = cnt;
+            }
+        }
+        if (more) stem_frame_store(fr + (cur ^ 1) * SF_FR, fv, fok);
+        __syncthreads();  // the next frame is complete; the moments exchange has been read
+        cur ^= 1;
+        t = tn;
     }
 }
 
@@ -451,9 +483,9 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_mfma_kernel(const float *__re
 
 EE_API int ee_stem7x7s2_fwd_stats_floats(int B, int K, int H, int W) {
     if (B < 1 || K < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || (W / 2) % 32 != 0 || K % 64 != 0) return 0;
-    const int64_t grid = static_cast<int64_t>(B) * ((H / 2 + SF_ROWS - 1) / SF_ROWS) * (W / 2 / 32);
-    if (grid * K * 3 > 0x7fffffffLL) return 0;
-    return static_cast<int>(grid * K * 3);
+    const int64_t units = static_cast<int64_t>(B) * ((H / 2 + SF_ROWS - 1) / SF_ROWS) * (W / 2 / 32);
+    if (units * K * 3 > 0x7fffffffLL) return 0;
+    return static_cast<int>(units * K * 3);
 }
 
 EE_API int ee_stem7x7s2_fwd_f32(const float *x, const float *weight, float *y, int B, int K, int H, int W, void *stream) {
@@ -468,9 +500,12 @@ EE_API int ee_stem7x7s2_fwd_stats_f32(const float *x, const float *weight, float
     if (reinterpret_cast<uintptr_t>(weight) & 15u) return EE_ERR_ALIGN;
     const int OH = H / 2, OW = W / 2;
     const int tiles_r = (OH + SF_ROWS - 1) / SF_ROWS, tiles_c = OW / 32;
-    const int64_t grid = static_cast<int64_t>(B) * tiles_r * tiles_c;
-    if (grid > 0x7fffffffLL || static_cast<int64_t>(B) * K * OH * OW > 0x7fffffffLL * 4LL) return EE_ERR_SHAPE;
+    const int64_t units = static_cast<int64_t>(B) * tiles_r * tiles_c;
+    if (units > 0x7fffffffLL / 3 / K || static_cast<int64_t>(B) * K * OH * OW > 0x7fffffffLL * 4LL) return EE_ERR_SHAPE;
+    // persistent workgroups: as many as the chip holds at once (per 64-channel slab), each walking units blockIdx.x, + gridDim.x, ...
+    const int64_t slots = static_cast<int64_t>(device_cus()) * SF_WG_PER_CU / (K / 64);
+    const int64_t grid = units < slots ? units : (slots > 0 ? slots : 1);
     EE_LAUNCH(stem_fwd_mfma_kernel, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(K / 64)), dim3(256), 0, as_stream(stream), x, weight, y,
-              stats, K, H, W, tiles_r, tiles_c);
+              stats, K, H, W, tiles_r, tiles_c, static_cast<int>(units));
     return launch_status();
 }
