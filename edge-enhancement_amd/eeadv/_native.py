@@ -92,8 +92,6 @@ SIGNATURES = {
     # x, stats, S, cnt, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, u, y, B, KC, RC, H, stream
     "ee_wino3x3_bn_train_pre_f32": [c_p, c_p, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_dense2x2_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
-    "ee_split_bf16x3_f32": [c_p, c_l, c_p, c_p, c_p, c_p],
-    "ee_gemm_bf16x3_nt_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     # x, w2, mean, var, gamma, beta, eps, res, relu, y, B, Cin, Cout, stream
     "ee_dense2x2_bn_eval_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     # dy, dy2, y, w2t, var, gamma, eps, dres, dx_add, dx, B, Cin, Cout, stream

@@ -934,26 +934,6 @@ def dense2x2(x, w2):
     return y
 
 
-def split_bf16x3(x):
-    """x (f32, contiguous) -> (hi, mid, lo) bfloat16 tensors of x's shape with x == hi + mid + lo exactly (round 4 pilot, ee_bf16x3.hip)"""
-    out = tuple(torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) for _ in range(3))
-    N.check(N.lib.ee_split_bf16x3_f32(_chk(x, torch.float32, "x"), x.numel(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()), "ee_split_bf16x3_f32")
-    return out
-
-
-def gemm_bf16x3_nt(a3, b3):
-    """C [M,N] f32 = A [M,K] . B [N,K]^T from the bf16 piece triples of split_bf16x3 (six bf16 MFMAs per product block, f32 accumulation)"""
-    M, K = a3[0].shape
-    Nn = b3[0].shape[0]
-    for t in tuple(a3) + tuple(b3):
-        if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.shape[1] != K:
-            raise ValueError("gemm_bf16x3_nt: contiguous bfloat16 pieces [rows, K] expected")
-    c = torch.empty((M, Nn), dtype=torch.float32, device=a3[0].device)
-    N.check(N.lib.ee_gemm_bf16x3_nt_f32(a3[0].data_ptr(), a3[1].data_ptr(), a3[2].data_ptr(), b3[0].data_ptr(), b3[1].data_ptr(), b3[2].data_ptr(),
-                                        c.data_ptr(), M, Nn, K, _stream()), "ee_gemm_bf16x3_nt_f32")
-    return c
-
-
 def dense2x2_bn_eval_fwd(x, w2, bn, res, relu):
     """[relu]( bn(conv3x3(x)) [+ res] ) on a 2x2 map with bn in eval mode, ONE launch: bn = (mean, var, gamma, beta, eps)"""
     B, Cin = x.shape[0], x.shape[1]

@@ -421,16 +421,6 @@ int ee_dense2x2_bn_eval_fwd_f32(const float *x, const float *w2, const float *me
 int ee_dense2x2_bn_eval_bwd_f32(const float *dy, const float *dy2, const float *y, const float *w2t, const float *var, const float *gamma, float eps,
                                 float *dres, const float *dx_add, float *dx, int B, int Cin, int Cout, void *stream);
 
-/* ROUND 4 PILOT (opt-in, not on the default path): f32 matrix products on the BF16 matrix cores.  Every f32 value is the exact sum of three bf16
- * pieces (hi + mid + lo, 8 significant bits each); a product keeps the six piece products of weight >= 2^-16 and accumulates them in f32
- * (v_mfma_f32_16x16x32_bf16): f32 ACCURACY (error of the order of one f32 rounding per product), not the bits of an f32 fma chain.
- * ee_split_bf16x3_f32: x [n] -> hi, mid, lo [n] (bf16 bit patterns).  ee_gemm_bf16x3_nt_f32: C [M][N] = A [M][K] . B [N][K]^T from the pieces;
- * K a multiple of 128, N of 32, pieces 16-byte aligned.  The shape behind it: layer4's 2x2-map convolutions (resnet.py:26-31) as ee_dense2x2_f32
- * runs them, [B x 4 Cin] . [4 Cin x 4 Cout]. */
-int ee_split_bf16x3_f32(const float *x, int64_t n, uint16_t *hi, uint16_t *mid, uint16_t *lo, void *stream);
-int ee_gemm_bf16x3_nt_f32(const uint16_t *a_hi, const uint16_t *a_mid, const uint16_t *a_lo, const uint16_t *b_hi, const uint16_t *b_mid,
-                          const uint16_t *b_lo, float *c, int M, int N, int K, void *stream);
-
 /* The WEIGHT gradient of the same convolution (`loss.backward()` of the training step, experiments_tinyimagenet.py:304-306; resnet.py:26-31) on
  * H x H maps, H = 2, 4, 8 or 16, as Winograd F(3x3, 2x2) around the f32 matrix cores: x [B,Cin,H,H] (the layer's input), dy [B,Cout,H,H] (the
  * gradient of its output) -> dw [Cout,Cin,3,3] (overwritten).  The sum over images and tiles is split over ~256 workgroups whose partial results

@@ -339,6 +339,46 @@ def test_ee_model_forward_and_input_gradient(square, c, n, r, alpha, low, high):
     assert agree > 0.999
 
 
+@pytest.mark.parametrize("square", [True, False])
+def test_ee_front_end_vjp_at_imagenet_resolution_against_the_oracle(square):
+    """The EE front end ALONE at 224 x 224 (configs_imagenet/ee_at_bpda3_square.yml: r 16, thresholds 38 / 76, alpha 0;
+    models_imagenet/resnet_EE_square.py:169-184): forward and the vector-Jacobian product for ONE fixed upstream gradient, HIP against the
+    oracle's front end - no classifier in between, so no ReLU branch of the CNN can differ and the tolerance is the front end's own
+    (test_free_at_repeat_vs_oracle's floors for resnet18_EE are wide because they include the CNN).  Both ways the
+    attack loop differentiates it: autograd through `front`, and the explicit kernel chain `front_manual` / `front_manual_backward`."""
+    m, ref = _ee_pair(square, n=224, r=16)
+    torch.manual_seed(21)
+    B = 2
+    x = torch.rand(B, 3, 224, 224)
+    x[1, :, 40:90, 100:200] = 0.25  # flat patch: zero magnitude -> NaN gradients (SURVEY H1)
+    g_up = torch.randn(B, 3, 224, 224)
+    draws = ref.front.add_square.draw(B) if square else None
+    ddev = None if draws is None else {"stripe": draws["stripe"].to(DEV), "sq_pos": draws["sq_pos"].to(DEV), "sq_sign": draws["sq_sign"].reshape(1, 3).to(DEV)}
+    xr = x.clone().requires_grad_(True)
+    xin_ref = ref.front(xr, draws)
+    xin_ref.backward(g_up)
+    gr = xr.grad.numpy()
+    xd = x.to(DEV).requires_grad_(True)
+    xin = m.front(xd, ddev)
+    d = (xin.detach().cpu() - xin_ref.detach()).abs()
+    assert float((d > 1e-5).float().mean()) == 0.0, "front-end outputs differ (an edge bit flipped?)"
+    xin.backward(g_up.to(DEV))
+    g_auto = xd.grad.cpu().numpy()
+    # the explicit chain of the attack loop: its two gradient pieces add up to the same vector-Jacobian product
+    with torch.no_grad():
+        x_in2, ctx = m.front_manual(x.to(DEV), ddev)
+        g_lp, g_edge = m.front_manual_backward(g_up.to(DEV).contiguous(), ctx)
+    assert torch.equal(x_in2, xin.detach())
+    g_manual = (g_lp + g_edge).cpu().numpy()
+    assert np.isnan(gr).sum() > 0
+    fin = ~np.isnan(gr)
+    scale = np.abs(gr[fin]).max()
+    for name, g in (("autograd", g_auto), ("manual chain", g_manual)):
+        assert np.array_equal(np.isnan(g), np.isnan(gr)), name
+        err = np.abs(g[fin] - gr[fin]).max()
+        assert err < 5e-6 * scale, (name, err, scale)  # (the oracle's low-pass is an FFT, ours the banded operator)
+
+
 def test_pgd_on_ee_model_matches_oracle(A):
     m, ref = _ee_pair(False)
     torch.manual_seed(6)
