@@ -1360,31 +1360,6 @@ EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, 
     return launch_status();
 }
 
-// Pass 1 of ee_bn_relu_pool_bwd_f32 ALONE (training mode): workspace[(c * G + g) * 2 + {0, 1}] = (sum dz, sum dz * xhat) of image group g, G =
-// the return value of ee_bn_relu_pool_bwd_groups.  ee_stem_bn_pool_bwd_data_f32 (ee_stem.hip) merges them and applies the rest of the
-// BatchNorm backward while it stages the stem convolution's backward-data operand: the full-resolution gradient never reaches memory.
-EE_API int ee_bn_relu_pool_bwd_groups(int B, int C, int H, int W) {
-    PoolShape p;
-    return pool_shape(B, C, H, W, p) ? p.G : 0;
-}
-
-EE_API int ee_bn_relu_pool_bwd_sums_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *gamma, const float *beta,
-                                        const float *save_mean, const float *save_invstd, float eps, float *workspace, int B, int C, int H, int W,
-                                        void *stream) {
-    if (B < 0 || C < 1 || H < 1 || W < 1) return EE_ERR_SHAPE;
-    if (B == 0) return EE_OK;
-    PoolShape p;
-    if (!pool_shape(B, C, H, W, p)) return EE_ERR_UNSUPPORTED;
-    if (!dy_pool || !code || !x || !workspace || !save_mean || !save_invstd) return EE_ERR_NULL;
-    if (!aligned16(x)) return EE_ERR_ALIGN;
-    const dim3 grid(static_cast<unsigned>(C), static_cast<unsigned>(p.G)), block(SPLIT_NT);
-    const size_t lds = (static_cast<size_t>(p.OH) * p.OW * 5 + 15) / 16 * 16;
-    EE_LAUNCH((bn_pool_bwd_kernel<false>), grid, block, lds, as_stream(stream), dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd,
-              static_cast<const float *>(nullptr), static_cast<const float *>(nullptr), eps, 1, static_cast<float *>(nullptr), static_cast<float *>(nullptr),
-              static_cast<float *>(nullptr), workspace, p);
-    return launch_status();
-}
-
 // 1 when relu(bn_a(xa) + bn_b(xb)) runs as one launch each way (the register-cached variants with 256-lane workgroups), else 0
 EE_API int ee_bn_dual_supported(int B, int C, int HW) {
     if (B < 1 || C < 1 || HW < 1 || HW % 4) return 0;

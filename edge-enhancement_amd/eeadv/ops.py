@@ -739,37 +739,6 @@ def bn_relu_pool_bwd(dy_pool, code, x, gamma, beta, save_mean, save_invstd, runn
     return dx, dg, db
 
 
-def stem_bn_pool_bwd_data_supported(x, weight):
-    """x: the stem convolution's output [B,64,H/2,32]"""
-    return (x.dim() == 4 and x.shape[1] == 64 and x.shape[3] == 32 and x.shape[2] % 2 == 0 and tuple(weight.shape) == (64, 3, 7, 7)
-            and N.lib.ee_bn_relu_pool_bwd_groups(x.shape[0], 64, x.shape[2], 32) > 0)
-
-
-def stem_bn_pool_bwd_data(dy_pool, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, training, weight, want_dparams=False,
-                          dy_pool2=None):
-    """d loss / d image from the gradient of the stem's pooled activation, ONE launch in eval mode, the sums pass + one in training mode
-    (ee_stem.hip; resnet.py:112-117 backwards).  Returns (dx_image [B,3,2H,2W], dgamma, dbeta) - the last two None unless want_dparams (training)."""
-    B, C, H, W = x.shape
-    ptr = lambda t: None if t is None else t.data_ptr()
-    p1 = _chk(dy_pool, torch.float32, "dy_pool", code.shape)
-    p2 = None if dy_pool2 is None else _chk(dy_pool2, torch.float32, "dy_pool2", code.shape)
-    pc, px = _chk(code, torch.uint8, "code"), _chk(x, torch.float32, "x")
-    ws, G = None, 0
-    if training:
-        G = N.lib.ee_bn_relu_pool_bwd_groups(B, C, H, W)
-        ws = _pool_workspace(x)
-        N.check(N.lib.ee_bn_relu_pool_bwd_sums_f32(p1, p2, pc, px, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), float(eps), ws.data_ptr(),
-                                                   B, C, H, W, _stream()), "ee_bn_relu_pool_bwd_sums_f32")
-    dx = torch.empty((B, 3, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
-    dg = torch.empty(C, dtype=torch.float32, device=x.device) if (want_dparams and training) else None
-    db = torch.empty(C, dtype=torch.float32, device=x.device) if (want_dparams and training) else None
-    N.check(N.lib.ee_stem_bn_pool_bwd_data_f32(p1, p2, pc, px, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(running_mean), ptr(running_var),
-                                               float(eps), 1 if training else 0, ptr(ws), G, ptr(dg), ptr(db),
-                                               _chk(weight, torch.float32, "weight", (C, 3, 7, 7)), dx.data_ptr(), B, C, 2 * H, 2 * W, _stream()),
-            "ee_stem_bn_pool_bwd_data_f32")
-    return dx, dg, db
-
-
 # ---- stem max-pool and classifier head -----------------------------------------------------------------------------------
 def maxpool3s2_fwd(x):
     """MaxPool2d(3, 2, 1) of x [B,C,H,W] -> (y, code uint8) (resnet.py:117)."""

@@ -342,24 +342,6 @@ int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, const u
                             const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
                             float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
                             int W, void *stream);
-/* The last launch of an attack iteration's backward pass (resnet.py:112-117 backwards: maxpool, relu, bn1, conv1): from the gradient of the stem's
- * POOLED activation straight to d loss / d image, the [B,64,H/2,W/2] gradient in between never reaching memory (ee_stem.hip).
- *   ee_bn_relu_pool_bwd_sums_f32   training mode only: pass 1 of ee_bn_relu_pool_bwd_f32 alone - workspace[(c * G + g) * 2 + {0,1}] = (sum dz,
- *                                  sum dz * xhat) of image group g, G = ee_bn_relu_pool_bwd_groups(B, C, H, W) (0 = unsupported shape); here H, W
- *                                  are x's (the convolution output's) sizes
- *   ee_stem_bn_pool_bwd_data_f32   dy_pool (+ dy_pool2) [B,64,H/4,W/4], code, x [B,64,H/2,W/2], bn1's gamma / beta and statistics (training:
- *                                  save_mean / save_invstd, sums = the workspace above with its G; eval: running_mean / running_var, sums NULL),
- *                                  weight [64,3,7,7] -> dx [B,3,H,W] with H, W the IMAGE's sizes; dgamma / dbeta [64] nullable (training).
- * Bit-identical to ee_bn_relu_pool_bwd_f32 followed by ee_stem7x7s2_bwd_data_f32.  K = 64 channels, W = 64, H a multiple of 4 (the
- * Tiny-ImageNet stem); else EE_ERR_UNSUPPORTED: use the two calls. */
-int ee_bn_relu_pool_bwd_groups(int B, int C, int H, int W);
-int ee_bn_relu_pool_bwd_sums_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *gamma, const float *beta,
-                                 const float *save_mean, const float *save_invstd, float eps, float *workspace, int B, int C, int H, int W,
-                                 void *stream);
-int ee_stem_bn_pool_bwd_data_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *gamma, const float *beta,
-                                 const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var, float eps,
-                                 int training, const float *sums, int G, float *dgamma, float *dbeta, const float *weight, float *dx, int B,
-                                 int K, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The stem's MaxPool2d(3, stride 2, padding 1) (Tiny_ImageNet/models_tinyimagenet/resnet.py:117), bit-identical to ATen's

@@ -58,10 +58,3 @@ for name, fn in rows:
 print("%-50s %8.1f us" % ("stem conv fwd + BatchNorm moments in the epilogue", timeit(lambda: ops.stem7x7s2_fwd(img, w, True))), flush=True)
 _, st = ops.stem7x7s2_fwd(img, w, True)
 print("%-50s %8.1f us" % ("bn+relu+pool fwd, fused, moments from the conv", timeit(lambda: ops.bn_relu_pool_fwd(x, gamma, beta, rm, rv, 0.1, 1e-5, True, st))), flush=True)
-rm2, rv2 = torch.zeros(64, device=dev), torch.ones(64, device=dev)
-for training in (True, False):
-    two = lambda: ops.stem7x7s2_bwd_data(ops.bn_relu_pool_bwd(dyp, code, x, gamma, beta, sm, si, rm2, rv2, 1e-5, training, True, False)[0], w, 64, 64)
-    one = lambda: ops.stem_bn_pool_bwd_data(dyp, code, x, gamma, beta, sm, si, rm2, rv2, 1e-5, training, w)
-    mode = "training" if training else "eval"
-    print("%-50s %8.1f us" % ("pooled gradient -> image gradient, %s, separate" % mode, timeit(two)), flush=True)
-    print("%-50s %8.1f us" % ("  ... ee_stem.hip (sums pass + one launch)" if training else "  ... ee_stem.hip (one launch)", timeit(one)), flush=True)

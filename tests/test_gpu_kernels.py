@@ -1061,41 +1061,6 @@ def test_fc_ce_grad_matches_autograd(ops, B, Hd, K, reduction):
     assert float(dzn[0, closed].abs().max()) == 0.0  # closed gates stay closed next to the NaN
 
 
-@pytest.mark.parametrize("B,H,training,two", [(3, 64, True, True), (1, 64, False, False), (100, 64, True, False), (7, 32, False, True), (5, 128, True, True)])
-def test_stem_backward_from_the_pooled_gradient_in_one_launch(ops, B, H, training, two):
-    """ee_stem.hip: maxpool / relu / bn1 / conv1 backwards (resnet.py:112-117) from the pooled gradient to the image gradient without the
-    full-resolution gradient in memory - bit-identical to ee_bn_relu_pool_bwd_f32 followed by ee_stem7x7s2_bwd_data_f32 (same expressions while
-    staging, same products in the same order), training and eval mode, one or two gradient pieces, dgamma / dbeta too."""
-    g = torch.Generator(device="cpu").manual_seed(B * H + training)
-    img = torch.rand(B, 3, H, 64, generator=g).to(DEV)
-    w = (torch.randn(64, 3, 7, 7, generator=g) / 12).to(DEV)
-    x = ops.stem7x7s2_fwd(img, w)
-    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), torch.randn(64, generator=g).to(DEV)
-    rm, rv = (torch.randn(64, generator=g) * 0.1).to(DEV), (torch.rand(64, generator=g) + 0.5).to(DEV)
-    assert ops.stem_bn_pool_bwd_data_supported(x, w)
-    y, code, sm, si = ops.bn_relu_pool_fwd(x, gamma, beta, rm.clone(), rv.clone(), 0.1, 1e-5, training)
-    dyp = torch.randn(y.shape, generator=g).to(DEV)
-    dyp2 = torch.randn(y.shape, generator=g).to(DEV) if two else None
-    dx_bn, dg, db = ops.bn_relu_pool_bwd(dyp, code, x, gamma, beta, sm, si, rm, rv, 1e-5, training, True, training, dyp2)
-    want = ops.stem7x7s2_bwd_data(dx_bn, w, H, 64)
-    got, dg2, db2 = ops.stem_bn_pool_bwd_data(dyp, code, x, gamma, beta, sm, si, rm, rv, 1e-5, training, w, training, dyp2)
-    assert got.shape == (B, 3, H, 64)
-    assert torch.equal(got, want), float((got - want).abs().max())
-    if training:
-        assert torch.equal(dg, dg2) and torch.equal(db, db2)
-    else:
-        assert dg2 is None and db2 is None
-    # a NaN in the convolution output stays where the two-launch sequence puts it
-    xn = x.clone()
-    xn[0, 5, 3, 7] = float("nan")
-    dx_bn, _, _ = ops.bn_relu_pool_bwd(dyp, code, xn, gamma, beta, sm, si, rm, rv, 1e-5, training, True, False, dyp2)
-    want = ops.stem7x7s2_bwd_data(dx_bn, w, H, 64)
-    got, _, _ = ops.stem_bn_pool_bwd_data(dyp, code, xn, gamma, beta, sm, si, rm, rv, 1e-5, training, w, False, dyp2)
-    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
-    with pytest.raises(Exception):  # another width: refused, the two calls remain
-        ops.stem_bn_pool_bwd_data(dyp[..., :8], code[..., :8], x[..., :16].contiguous(), gamma, beta, sm, si, rm, rv, 1e-5, training, w)
-
-
 @pytest.mark.parametrize("co,ci", [(64, 32), (32, 96), (128, 128)])
 def test_weight_preparation_kernels_match_their_torch_restatement(ops, monkeypatch, co, ci):
     """ee_wprep.hip (one launch per weight and kind) against functional._rearranged's torch expressions: the permutation kinds bit for bit,
