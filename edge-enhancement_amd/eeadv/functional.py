@@ -498,10 +498,10 @@ def rebuild_dense_weights(model=None):
     """Unconditional in-place rebuild of the rearranged matrices - capturable: a captured optimiser step ends with it, because
     replaying a graph updates the weights without moving their Python-side version counters.  `model`: only ITS weights - a
     captured graph must not bake in copies into the buffers of another live model (tests, A/B scripts), which would write
-    freed memory once that model is gone.  One ee_wprep.hip launch per (weight, kind): ~30 back-to-back launches of a few us inside the
-    replayed graph before round 4; now ONE launch whose descriptors travel in the kernel arguments (ee_conv_weight_prep_batch_f32: the
-    captured update of ResNet-18 ended with 19 launches, 125 us; round 2's mixed launch read its table from device memory and had measured
-    no faster).  Returns the cache keys it rebuilt."""
+    freed memory once that model is gone.  Round 4: ONE ee_wprep.hip launch for all (weight, kind) items of the model, their descriptors in a
+    device-resident table (ee_conv_weight_prep_batch_f32) where the captured update of ResNet-18 used to end with 19 launches - measured the
+    SAME 120 us either way: the gathers (16 MB of rearranged filters written per update), not the launches, are what this costs.
+    Returns the cache keys it rebuilt."""
     own = None if model is None else {id(p) for p in model.parameters()}
     rebuilt, batch = set(), []
     with torch.no_grad():
