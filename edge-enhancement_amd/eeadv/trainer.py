@@ -343,11 +343,11 @@ class _GraphedPredsUpdate:
             # the loss spans two forward passes: one backward per pass and one multi-tensor add instead of 62 AccumulateGrad launches
             logits_adv = getattr(self.criterion, "last_logits_adv", None) if self.args.method_name == 'TRADES' else output
             two_branch_backward(loss, preds, logits_adv, [p for g in optimizer.param_groups for p in g['params']])
-            if self.args.method_name == 'TRADES':
-                self.criterion.last_logits_adv = None
         else:
             self.sync.zero_()  # .loss() called optimizer.zero_grad() (attacks.py:265-266, :422-423): the views go back in
             loss.backward()
+        if self.args.method_name == 'TRADES':
+            self.criterion.last_logits_adv = None  # it holds the second forward's autograd graph (inside a capture: tensors of the graph's pool)
         return loss.detach(), output.detach()
 
     def _step(self):

@@ -119,3 +119,20 @@ def test_free_at_repeat_with_its_collectives_in_one_graph():
                        timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "eager vs graphed: max |parameter difference| 0.000e+00" in r.stdout, r.stdout[-1500:]
+
+
+@pytest.mark.gpu
+def test_multi_rank_updates_rehearsed_with_one_rccl_rank():
+    """The N > 1 forms of the training step - AT with the one-piece and the segmented gradient exchange, TRADES as three graphs around its
+    all-reduce (experiments_tinyimagenet.py:250-306) - with ONE rank over RCCL and every collective forced on (scripts/ddp_same_gpu.py asserts
+    equal parameters, captured graphs, finite statistics).  Regression: round 4's `Trades.last_logits_adv` stayed alive behind the captured
+    backward of the multi-rank path (it holds tensors of the graph's memory pool) and the process died with SIGSEGV at the next capture."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 200),
+               DDP_BACKEND="nccl", EEADV_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "ddp_same_gpu.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "TRADES segmented=True" in r.stdout and "graphs g1 g2 g3: [True, True, True]" in r.stdout, r.stdout[-1500:]
