@@ -453,12 +453,18 @@ def main():
         return dry_launch(world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    share = os.environ.get("EEADV_SHARE_GPU", "0") == "1"  # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo between them
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     torch.backends.cudnn.benchmark = not a.no_miopen_benchmark
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group(os.environ.get("EEADV_DIST_BACKEND") or "gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from eeadv import engine, ops, runtime, trainer, _native as N
 
