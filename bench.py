@@ -537,10 +537,13 @@ def main():
                                  "GBps": round(nbytes / us / 1e3, 1), "share_of_timed_us": None}
         # matrix-core families (the residual blocks' 3x3 convolutions, ee_wino.hip / ee_s2.hip): the library sums the floating-point
         # operations its timed launches declared (2 * 9 * Cin * Cout * B * H * W each), so mixed shapes average correctly
-        mfma_fams = {"ee_wino3x3": N.K_WINO, "ee_conv3x3s2_small_fwd": N.K_CONV3S2_FWD, "ee_conv3x3s2_small_bwd_data": N.K_CONV3S2_BWD}
+        # (ee_wino3x3_fused: the same Winograd products with a BatchNorm's work folded into the launch - eval-mode fold, train-mode exchange
+        # across the kernel boundary; its flops count the convolution only, so its fraction is NOT comparable with the plain kernels')
+        mfma_fams = {"ee_wino3x3": N.K_WINO, "ee_wino3x3_fused": N.K_WINO_FUSED, "ee_conv3x3s2_small_fwd": N.K_CONV3S2_FWD,
+                     "ee_conv3x3s2_small_bwd_data": N.K_CONV3S2_BWD}
         # Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile where the convolution has 36: `flops` stays the convolution's
         # algorithmic count, `executed_flops` = 4/9 of it is what the matrix cores actually do
-        executed_share = {"ee_wino3x3": 4.0 / 9.0}
+        executed_share = {"ee_wino3x3": 4.0 / 9.0, "ee_wino3x3_fused": 4.0 / 9.0}
         for name, kid in mfma_fams.items():
             ms, cnt = ops.prof_read(kid)
             if cnt:

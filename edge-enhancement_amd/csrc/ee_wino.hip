@@ -821,7 +821,7 @@ EE_API int ee_wino3x3_bn_eval_fwd_f32(const float *x, const float *u, const floa
     const int pc = check_post(post);
     if (pc != EE_OK) return pc;
     const WinoDims d{B, Cin, Cout, xcd_weights_local(4.0 * B * Cin * H * H, 64.0 * Cin * Cout, Cout / WN_CO) ? 1 : 0};
-    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
+    ProfScope prof(EE_K_WINO_FUSED, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
     return wino_dispatch<0, true>(x, u, y, d, H, FusePre{}, post, as_stream(stream));
 }
 
@@ -841,7 +841,7 @@ EE_API int ee_wino3x3_bn_eval_bwd_f32(const float *dy, const float *dy2, const f
     const int pc = check_pre(pre);
     if (pc != EE_OK) return pc;
     const WinoDims d{B, Cout, Cin, xcd_weights_local(4.0 * B * Cout * H * H, 64.0 * Cin * Cout, Cin / WN_CO) ? 1 : 0};
-    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
+    ProfScope prof(EE_K_WINO_FUSED, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
     if (dx_add) {
         const FusePost post{nullptr, nullptr, nullptr, nullptr, 0.0f, dx_add, 0};
         if (!aligned16(dx_add)) return EE_ERR_ALIGN;
@@ -862,7 +862,7 @@ EE_API int ee_wino3x3_stats_f32(const float *x, const float *u, float *y, float 
     if (rc != EE_OK || B == 0) return rc;
     if (!stats) return EE_ERR_NULL;
     const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
-    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
+    ProfScope prof(EE_K_WINO_FUSED, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
     TrainBn tb{};
     tb.stats_out = stats;
     return wino_dispatch_t<0, false, true>(x, u, y, d, H, FusePre{}, FusePost{}, as_stream(stream), tb);
@@ -879,7 +879,7 @@ EE_API int ee_wino3x3_bn_train_pre_f32(const float *x, const float *stats, int S
     if (reinterpret_cast<uintptr_t>(stats) & 7u) return EE_ERR_ALIGN;
     const TrainBn tb{nullptr, stats, S, static_cast<float>(cnt), gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd};
     const WinoDims d{B, KC, RC, xcd_weights_local(4.0 * B * KC * H * H, 64.0 * KC * RC, RC / WN_CO) ? 1 : 0};
-    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
+    ProfScope prof(EE_K_WINO_FUSED, as_stream(stream), 2.0 * 9.0 * KC * RC * static_cast<double>(B) * H * H);
     return wino_dispatch_t<3, false, false>(x, u, y, d, H, FusePre{}, FusePost{}, as_stream(stream), tb);
 }
 
@@ -901,7 +901,7 @@ EE_API int ee_wino3x3_bwd_sums_f32(const float *dc, const float *u_b, const floa
     tb.stats_out = sums, tb.part = x, tb.gamma = gamma, tb.beta = beta;
     tb.save_mean = const_cast<float *>(save_mean), tb.save_invstd = const_cast<float *>(save_invstd);  // read only by this launch
     const WinoDims d{B, Cout, Cin, xcd_weights_local(4.0 * B * Cout * H * H, 64.0 * Cin * Cout, Cin / WN_CO) ? 1 : 0};
-    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
+    ProfScope prof(EE_K_WINO_FUSED, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
     return wino_pc_launch<16, 0, false, 2>(dc, u_b, dy, d, FusePre{}, FusePost{}, as_stream(stream), tb);
 }
 
@@ -918,7 +918,7 @@ EE_API int ee_wino3x3_bn_train_bwd_pre_f32(const float *dy, const float *x, cons
     tb.save_mean = const_cast<float *>(save_mean), tb.save_invstd = const_cast<float *>(save_invstd);
     const FusePre pre{nullptr, x, nullptr, nullptr, nullptr, 0.0f};
     const WinoDims d{B, Cout, Cin, xcd_weights_local(4.0 * B * Cout * H * H, 64.0 * Cin * Cout, Cin / WN_CO) ? 1 : 0};
-    ProfScope prof(EE_K_WINO, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
+    ProfScope prof(EE_K_WINO_FUSED, as_stream(stream), 2.0 * 9.0 * Cin * Cout * static_cast<double>(B) * H * H);
     return wino_pc_launch<16, 4, false, 0>(dy, u_b, dx, d, pre, FusePost{}, as_stream(stream), tb);
 }
 

@@ -144,7 +144,7 @@ _RESTYPE = {"ee_strerror": ctypes.c_char_p, "ee_device_name": ctypes.c_char_p, "
 # kernel-family ids of include/eeadv.h (ee_prof_*)
 (K_PGD_STEP, K_FRONTEND_FWD, K_FRONTEND_BWD, K_EDGE_FWD, K_EDGE_BWD, K_CE, K_PGD_STEP_BCAST, K_EMPTY, K_HFS, K_CHAIN_FWD, K_CHAIN_BWD,
  K_HFS_SQ_FWD, K_HFS_SQ_BWD, K_SQUARE_DRAW) = range(14)
-K_WINO, K_CONV3S2_FWD, K_CONV3S2_BWD = 18, 19, 20  # 14 - 17: the direct 3x3 kernels removed in round 3
+K_WINO, K_CONV3S2_FWD, K_CONV3S2_BWD, K_WINO_FUSED = 18, 19, 20, 21  # 14 - 17: the direct 3x3 kernels removed in round 3
 
 
 class EEError(RuntimeError):

@@ -606,7 +606,9 @@ int ee_chain_bwd_f32(const float *g_in, const uint8_t *gate, const float *gx, co
 #define EE_K_WINO 18        /* ee_wino3x3_f32 (forward and backward-data are the same kernel); work = the convolution's algorithmic flops */
 #define EE_K_CONV3S2_FWD 19 /* ee_conv3x3s2_small_fwd_f32; work = flops */
 #define EE_K_CONV3S2_BWD 20 /* ee_conv3x3s2_small_bwd_data_f32 */
-#define EE_K_COUNT 21
+#define EE_K_WINO_FUSED 21  /* ee_wino3x3_bn_eval_*, ee_wino3x3_stats_f32, ee_wino3x3_bn_train_*, ee_wino3x3_bwd_sums_f32: the same products with the
+                             * BatchNorm work of the layer folded into the staging / output stage; work = the convolution's flops only */
+#define EE_K_COUNT 22
 int ee_prof_enable(int on);
 /* records one empty start/stop bracket on `stream` (family EE_K_EMPTY): callers subtract its mean from the other
  * families' means, because a HIP event pair costs ~4-5 us on gfx950 - comparable to the kernels being timed */
