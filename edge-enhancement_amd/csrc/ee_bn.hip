@@ -258,6 +258,11 @@ __global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restri
                                                            float *__restrict__ save_invstd, BnShape s) {
     __shared__ float scratch[3 * (NT / 64)];
     const int c = blockIdx.x;
+    // gridDim.y = P workgroups per channel (round 4; few-channel layers: 64 channels fill 64 of 256 CUs).  Every one of them reads the whole
+    // channel and forms the SAME statistics in the same order (the same bits); part p then normalises, adds the residual for and stores only
+    // the register slots j with j * P / MAXV == p - a quarter of the residual reads and of the stores per CU; part 0 owns the statistics' side
+    // effects
+    const int P = static_cast<int>(gridDim.y), part = static_cast<int>(blockIdx.y);
     const int per = s.HW / 4, total = s.B * per;
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
@@ -274,7 +279,14 @@ __global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restri
         const int b = e / per, q = e - b * per;
         off[j] = static_cast<unsigned>(b * s.C + c) * static_cast<unsigned>(per) + static_cast<unsigned>(q);
         xv[j] = x4[off[j]];
-        if (RES) rv[j] = r4[off[j]];  // needed only by the last pass: its latency hides behind the statistics
+    }
+    if (RES) {  // needed only by the last pass: its latency hides behind the statistics.  Slots of other parts: a load of this part's first slot
+        const int jf = (part * MAXV + P - 1) / P;  // (smallest j with j * P / MAXV == part)
+        unsigned of = off[0];
+#pragma unroll
+        for (int j = 1; j < MAXV; ++j) of = j == jf ? off[j] : of;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) rv[j] = r4[(j * P / MAXV == part) ? off[j] : of];
     }
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
@@ -293,7 +305,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restri
             }
         var = block_sum<NT>(var, scratch) / n;
         invstd = 1.0f / sqrtf(var + eps);
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && part == 0) {
             save_mean[c] = mean;
             save_invstd[c] = invstd;
             if (running_mean) {
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_cached_kernel(const float *__restri
     float4 *y4 = reinterpret_cast<float4 *>(y);
 #pragma unroll
     for (int j = 0; j < MAXV; ++j)
-        if (static_cast<int>(threadIdx.x) + j * NT < total) {
+        if (static_cast<int>(threadIdx.x) + j * NT < total && j * P / MAXV == part) {
             const float4 v = xv[j];
             float4 r = make_float4((v.x - mean) * a + b0, (v.y - mean) * a + b0, (v.z - mean) * a + b0, (v.w - mean) * a + b0);
             if (RES) {
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
                                                            float *__restrict__ dbeta, BnShape s) {
     __shared__ float scratch[3 * (NT / 64)];
     const int c = blockIdx.x;
+    const int P = static_cast<int>(gridDim.y), part = static_cast<int>(blockIdx.y);  // as in bn_fwd_cached_kernel: the sums by every part, the stores split
     const int per = s.HW / 4, total = s.B * per;
     const float n = static_cast<float>(s.B) * static_cast<float>(s.HW);
     const float mean = training ? save_mean[c] : running_mean[c];
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
         block_sums<NT, 2>(two, scratch);
         sdz = two[0], sdzx = two[1];
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && part == 0) {
         if (dgamma) dgamma[c] = sdzx;
         if (dbeta) dbeta[c] = sdz;
     }
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_cached_kernel(const float *__restri
     float4 *dx4 = reinterpret_cast<float4 *>(dx), *dr4 = reinterpret_cast<float4 *>(dres);
 #pragma unroll
     for (int j = 0; j < MAXV; ++j)
-        if (static_cast<int>(threadIdx.x) + j * NT < total) {
+        if (static_cast<int>(threadIdx.x) + j * NT < total && j * P / MAXV == part) {
             const float4 g = gv[j], h = hv[j];
             if (dres) dr4[off[j]] = g;
             if (dx) dx4[off[j]] = make_float4(w * ((g.x - m1) - h.x * m2), w * ((g.y - m1) - h.y * m2), w * ((g.z - m1) - h.z * m2),
@@ -561,10 +574,21 @@ __global__ __launch_bounds__(NT) void bn_dual_bwd_cached_kernel(const float *__r
         }
 }
 
+// workgroups per channel of the register-cached kernels: as many as keep the grid within the chip (layer1's 64 channels: 4; 128: 2), at most one
+// per register slot
+inline int cached_parts(int C, int maxv) {
+    static const int off = [] { const char *e = getenv("EEADV_BN_PARTS"); return (e && e[0] == '0') ? 1 : 0; }();
+    if (off) return 1;
+    int p = device_cus() / (C > 0 ? C : 1);
+    p = p > 4 ? 4 : p;
+    p = p > maxv ? maxv : p;
+    return p < 1 ? 1 : p;
+}
+
 template <int NT, int MAXV>
 void launch_fwd_cached(bool relu, bool has_res, hipStream_t st, const float *x, const float *res, const float *gamma, const float *beta, float *rm,
                        float *rv, float momentum, float eps, int training, float *y, float *sm, float *si, BnShape s) {
-    const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
+    const dim3 grid(static_cast<unsigned>(s.C), static_cast<unsigned>(cached_parts(s.C, MAXV))), block(NT);
     if (relu && has_res)
         EE_LAUNCH((bn_fwd_cached_kernel<NT, MAXV, true, true>), grid, block, 0, st, x, res, gamma, beta, rm, rv, momentum, eps, training, y, sm, si, s);
     else if (relu)
@@ -579,7 +603,7 @@ template <int NT, int MAXV>
 void launch_bwd_cached(bool relu, hipStream_t st, const float *dy, const float *dy2, const float *y, const float *x, const float *beta, const float *gamma, const float *sm,
                        const float *si, const float *rm, const float *rv, float eps, int training, float *dx, float *dres, float *dgamma,
                        float *dbeta, BnShape s) {
-    const dim3 grid(static_cast<unsigned>(s.C)), block(NT);
+    const dim3 grid(static_cast<unsigned>(s.C), static_cast<unsigned>(cached_parts(s.C, MAXV))), block(NT);
     if (relu)
         EE_LAUNCH((bn_bwd_cached_kernel<NT, MAXV, true>), grid, block, 0, st, dy, dy2, y, x, beta, gamma, sm, si, rm, rv, eps, training, dx, dres, dgamma, dbeta, s);
     else
