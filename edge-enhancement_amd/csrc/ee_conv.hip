@@ -407,6 +407,7 @@ __global__ __launch_bounds__(256, SF_WG_PER_CU) void stem_fwd_mfma_kernel(const 
     const size_t plane = static_cast<size_t>(OH) * OW;
     const int stride = static_cast<int>(gridDim.x);
     int cur = 0;
+    float run_sum = 0.0f, run_m2 = 0.0f, run_n = 0.0f;  // lanes 4 c: channel c's moments over this workgroup's units
     for (; u < units; u += stride) {
         const bool more = u + stride < units;  // (uniform)
         StemUnit tn = t;
@@ -437,8 +438,8 @@ __global__ __launch_bounds__(256, SF_WG_PER_CU) void stem_fwd_mfma_kernel(const 
             for (int r = 0; r < 16; ++r) yb[lo + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * static_cast<unsigned>(plane)] = acc[r];  // acc_row(r, lane)
         }
         // ---- optional: this unit's share of the BatchNorm statistics that follow the stem (resnet.py:113) - per output channel
-        // (sum, M2 about the unit's own mean, count) of its <= 2 x 32 values, so that bn1 does not have to read y twice for them:
-        // stats[(co * S + unit) * 3 + {0,1,2}], S = units; merged by ee_bn.hip (bn_stats_finalize_kernel, Chan's update) ------------------
+        // (sum, M2 about the unit's own mean, count) of its <= 2 x 32 values, so that bn1 does not have to read y twice for them;
+        // accumulated over the workgroup's units and written once at the end; merged by ee_bn.hip (bn_pool_fwd_kernel) -------------------
         // Through LDS, not through lane shuffles (a butterfly over 32 lanes for 16 registers is 80 dependent ds_bpermute): the tile goes
         // to LDS as [64 channels][2 rows x 32 columns] (channel stride 68: conflict-free), then four lanes per channel take 16 values
         // each (two passes on registers: sum, then M2 about the tile mean) and meet through two quad exchanges.
@@ -465,27 +466,38 @@ __global__ __launch_bounds__(256, SF_WG_PER_CU) void stem_fwd_mfma_kernel(const 
             }
             m2 += __shfl_xor(m2, 1);
             m2 += __shfl_xor(m2, 2);
-            if (q == 0) {
-                float *o = stats + (static_cast<size_t>(cb + c) * units + u) * 3;
-                o[0] = sum;
-                o[1] = m2;
-                o[2] = cnt;
-            }
+            // this workgroup's units met so far and this one (Chan's update; a workgroup walks its units in a fixed order)
+            const float n2 = run_n + cnt, d = mean - (run_n > 0.0f ? run_sum / run_n : 0.0f);
+            run_m2 = (run_m2 + m2) + d * d * (run_n * cnt / n2);
+            run_sum += sum;
+            run_n = n2;
         }
         if (more) stem_frame_store(fr + (cur ^ 1) * SF_FR, fv, fok);
         __syncthreads();  // the next frame is complete; the moments exchange has been read
         cur ^= 1;
         t = tn;
     }
+    if (stats && (threadIdx.x & 3) == 0) {  // ONE slot per workgroup and channel: stats[(co * S + workgroup) * 3 + {0,1,2}], S = gridDim.x
+        float *o = stats + (static_cast<size_t>(cb + (threadIdx.x >> 2)) * gridDim.x + blockIdx.x) * 3;
+        o[0] = run_sum;
+        o[1] = run_m2;
+        o[2] = run_n;
+    }
 }
 
 }  // namespace
 
+// persistent workgroups: as many as the chip holds at once (per 64-channel slab), each walking units blockIdx.x, + gridDim.x, ...
+static int64_t stem_fwd_grid(int64_t units, int K) {
+    const int64_t slots = static_cast<int64_t>(device_cus()) * SF_WG_PER_CU / (K / 64);
+    return units < slots ? units : (slots > 0 ? slots : 1);
+}
+
 EE_API int ee_stem7x7s2_fwd_stats_floats(int B, int K, int H, int W) {
     if (B < 1 || K < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || (W / 2) % 32 != 0 || K % 64 != 0) return 0;
     const int64_t units = static_cast<int64_t>(B) * ((H / 2 + SF_ROWS - 1) / SF_ROWS) * (W / 2 / 32);
-    if (units * K * 3 > 0x7fffffffLL) return 0;
-    return static_cast<int>(units * K * 3);
+    if (units > 0x7fffffffLL / 3 / K) return 0;
+    return static_cast<int>(stem_fwd_grid(units, K) * K * 3);  // one slot per workgroup and channel
 }
 
 EE_API int ee_stem7x7s2_fwd_f32(const float *x, const float *weight, float *y, int B, int K, int H, int W, void *stream) {
@@ -502,9 +514,7 @@ EE_API int ee_stem7x7s2_fwd_stats_f32(const float *x, const float *weight, float
     const int tiles_r = (OH + SF_ROWS - 1) / SF_ROWS, tiles_c = OW / 32;
     const int64_t units = static_cast<int64_t>(B) * tiles_r * tiles_c;
     if (units > 0x7fffffffLL / 3 / K || static_cast<int64_t>(B) * K * OH * OW > 0x7fffffffLL * 4LL) return EE_ERR_SHAPE;
-    // persistent workgroups: as many as the chip holds at once (per 64-channel slab), each walking units blockIdx.x, + gridDim.x, ...
-    const int64_t slots = static_cast<int64_t>(device_cus()) * SF_WG_PER_CU / (K / 64);
-    const int64_t grid = units < slots ? units : (slots > 0 ? slots : 1);
+    const int64_t grid = stem_fwd_grid(units, K);
     EE_LAUNCH(stem_fwd_mfma_kernel, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(K / 64)), dim3(256), 0, as_stream(stream), x, weight, y,
               stats, K, H, W, tiles_r, tiles_c, static_cast<int>(units));
     return launch_status();
