@@ -187,3 +187,43 @@ def test_model_zoo_matches_reference_initialisation(golden):
     assert any(k.startswith("canny.weight_") for k in n2.state_dict())  # CannyFilter registers its weights
     with pytest.raises(NotImplementedError):
         Net2_EE_square(type_canny="nope")
+
+
+def test_two_branch_backward_equals_one_backward():
+    """trainer.two_branch_backward (the TRADES / ALP update without autograd's per-parameter accumulation, utils/attacks.py:264-272, :421-429):
+    a loss over TWO forward passes through the same parameters, backpropagated pass by pass and joined by one multi-tensor add, gives the
+    gradients of loss.backward() - including parameters only ONE of the passes reaches, and the fall-backs (one branch missing / detached)."""
+    import torch.nn.functional as F
+    from eeadv.trainer import two_branch_backward
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 4)).double()
+    extra = torch.nn.Parameter(torch.randn(4, dtype=torch.float64))  # reached by the natural pass only
+    params = list(net.parameters()) + [extra]
+    x, xa, y = torch.randn(5, 6, dtype=torch.float64), torch.randn(5, 6, dtype=torch.float64), torch.randint(0, 4, (5,))
+
+    def losses():
+        nat, adv = net(x) + extra, net(xa)
+        return F.cross_entropy(nat, y) + 6.0 * F.kl_div(F.log_softmax(adv, 1), F.softmax(nat, 1), reduction="batchmean"), nat, adv
+
+    for p in params:
+        p.grad = None
+    losses()[0].backward()
+    want = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = torch.full_like(p, 7.0)  # stale gradients must not leak into the result
+    loss, nat, adv = losses()
+    two_branch_backward(loss, nat, adv, params)
+    for p, w in zip(params, want):
+        assert torch.allclose(p.grad, w, rtol=1e-12, atol=1e-14)
+    # fall-backs: a missing or detached branch is an ordinary backward (which ACCUMULATES, as loss.backward() does)
+    for p in params:
+        p.grad = None
+    loss, nat, adv = losses()
+    two_branch_backward(loss, nat, None, params)
+    for p, w in zip(params, want):
+        assert torch.allclose(p.grad, w, rtol=1e-12, atol=1e-14)
+    for p in params:
+        p.grad = None
+    nat2 = net(x) + extra
+    two_branch_backward(F.cross_entropy(nat2, y), nat2, net(xa).detach(), params)
+    assert all(p.grad is not None for p in params)
