@@ -227,3 +227,38 @@ def test_two_branch_backward_equals_one_backward():
     nat2 = net(x) + extra
     two_branch_backward(F.cross_entropy(nat2, y), nat2, net(xa).detach(), params)
     assert all(p.grad is not None for p in params)
+
+
+def test_attack_forward_context_and_route_report(monkeypatch):
+    """Host logic of round 4: functional.attack_forward() marks the forward passes of the attack loop (the fused eval / train blocks are chosen
+    there only), input_only_forward() also holds under no_grad; models.fallback_report lists the convolutions whose last forward went to a
+    vendor library; trainer.graph_collectives_enabled needs the switch AND an RCCL process group."""
+    from eeadv import functional as EF, models as M, trainer
+    assert not EF.attack_forward_active() and not EF.input_only_forward()
+    with torch.no_grad():
+        assert EF.input_only_forward() and not EF.attack_forward_active()
+    with EF.attack_forward():
+        assert EF.attack_forward_active() and EF.input_only_forward()
+        with EF.attack_forward():  # nests
+            assert EF.attack_forward_active()
+        assert EF.attack_forward_active()
+    assert not EF.attack_forward_active()
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 4, 1), torch.nn.Conv2d(4, 2, 1))
+    assert M.fallback_report(net) == {"count": 0, "of": 0, "layers": []}  # nothing ran yet
+    M._route(net[0], "miopen")
+    M._route(net[1], "ee_wino")
+    rep = M.fallback_report(net)
+    assert rep["of"] == 2 and rep["count"] == 1 and rep["layers"] == ["0:miopen"]
+    monkeypatch.setenv("EEADV_GRAPH_COLLECTIVES", "1")
+    assert trainer.graph_collectives_enabled() is False  # no process group here
+    monkeypatch.setenv("EEADV_GRAPH_COLLECTIVES", "0")
+    assert trainer.graph_collectives_enabled() is False
+
+
+def test_miopen_db_match_report(tmp_path):
+    """runtime.shipped_miopen_db_matched: None without a private copy, False when the device / MIOpen build cannot be named (no ROCm device
+    here) - bench.py prints it as config.miopen_db_matched, so a silent fall-back to MIOpen's search shows on the line"""
+    from eeadv import runtime
+    assert runtime.shipped_miopen_db_matched(None) is None
+    assert runtime.shipped_miopen_db_matched(str(tmp_path / "missing")) is None
+    assert runtime.shipped_miopen_db_matched(str(tmp_path)) is False
