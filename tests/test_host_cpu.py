@@ -261,4 +261,5 @@ def test_miopen_db_match_report(tmp_path):
     from eeadv import runtime
     assert runtime.shipped_miopen_db_matched(None) is None
     assert runtime.shipped_miopen_db_matched(str(tmp_path / "missing")) is None
+    (tmp_path / "gfx000ff.HIP.9_9_9_deadbeef.ufdb.txt").write_text("")  # a find-db of ANOTHER build / device appeared: MIOpen did not take ours
     assert runtime.shipped_miopen_db_matched(str(tmp_path)) is False
