@@ -921,7 +921,8 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_pool_fwd_kernel(const float *__re
                                                                const float *__restrict__ beta, float *running_mean, float *running_var,
                                                                float momentum, float eps, int training, float *__restrict__ yp,
                                                                uint8_t *__restrict__ code, float *__restrict__ save_mean,
-                                                               float *__restrict__ save_invstd, const float *__restrict__ ws, PoolShape p, int S) {
+                                                               float *__restrict__ save_invstd, const float *__restrict__ ws, PoolShape p, int S,
+                                                               float *__restrict__ xa) {
     extern __shared__ __align__(16) float plane[];  // y = relu(bn(x)) of one image plane
     __shared__ float parts[2 * SPLIT_MAX];
     const int c = blockIdx.x, g = blockIdx.y;
@@ -1014,8 +1015,55 @@ __global__ __launch_bounds__(SPLIT_NT) void bn_pool_fwd_kernel(const float *__re
                 }
             yp[pl * OHW + o] = best;
             code[pl * OHW + o] = static_cast<uint8_t>(bc);
+            // x at the window's argmax (optional): the backward's batch sums then need the pooled tensors only (bn_pool_bwd_sums_pooled_kernel)
+            if (xa) xa[pl * OHW + o] = x[pl * HW + (h0 + bc / 3) * p.W + (w0 + bc % 3)];
         }
         __syncthreads();
+    }
+}
+
+// pass 1 of the backward from POOLED tensors (round 4): a position's masked gradient dz is the sum of the pooled gradients of the windows
+// whose argmax it is, so  sum dz = sum over windows (pre > 0 ? g : 0)  and  sum dz * xhat = sum over windows (pre > 0 ? g * xhat : 0)  with
+// pre / xhat taken from x at the window's argmax (xa, written by the forward): 13-20 MB read instead of the 26 MB map + pooled gradient +
+// codes.  Same partition and workspace as bn_pool_bwd_kernel<false>; the sums are taken in another order (rounding-level difference).
+__global__ __launch_bounds__(SPLIT_NT) void bn_pool_bwd_sums_pooled_kernel(const float *__restrict__ dyp, const float *__restrict__ dyp2, const float *__restrict__ xa,
+                                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                           const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+                                                                           float *__restrict__ ws, PoolShape p) {
+    __shared__ float scratch[3 * (SPLIT_NT / 64)];
+    const int c = blockIdx.x, g = blockIdx.y;
+    const int OHW = p.OH * p.OW;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float a = invstd * (gamma ? gamma[c] : 1.0f), b0 = beta ? beta[c] : 0.0f;
+    const int b_end = (g + 1) * p.IPW < p.B ? (g + 1) * p.IPW : p.B;
+    float sdz = 0.0f, sdzx = 0.0f;
+    for (int b = g * p.IPW; b < b_end; ++b) {
+        const size_t pl = (static_cast<size_t>(b) * p.C + c) * OHW;
+        for (int o0 = threadIdx.x; o0 < OHW; o0 += 4 * SPLIT_NT) {
+            float gv[4], g2[4], xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // all loads first (clamped), then the arithmetic
+                const int o = o0 + u * SPLIT_NT < OHW ? o0 + u * SPLIT_NT : OHW - 1;
+                gv[u] = dyp[pl + o];
+                g2[u] = dyp2 ? dyp2[pl + o] : 0.0f;
+                xv[u] = xa[pl + o];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (o0 + u * SPLIT_NT < OHW) {
+                    const float gg = dyp2 ? gv[u] + g2[u] : gv[u];
+                    const float pre = (xv[u] - mean) * a + b0;
+                    const float dz = pre > 0.0f ? gg : 0.0f;
+                    sdz += dz;
+                    sdzx += dz * ((xv[u] - mean) * invstd);
+                }
+        }
+    }
+    float two[2] = {sdz, sdzx};
+    block_sums<SPLIT_NT, 2>(two, scratch);
+    if (threadIdx.x == 0) {
+        ws[(static_cast<size_t>(c) * p.G + g) * 2 + 0] = two[0];
+        ws[(static_cast<size_t>(c) * p.G + g) * 2 + 1] = two[1];
     }
 }
 
@@ -1370,10 +1418,10 @@ EE_API int ee_bn_relu_pool_workspace_floats(int B, int C, int H, int W) {
     return C * SPLIT_MAX * 2;
 }
 
-EE_API int ee_bn_relu_pool_fwd_f32(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
-                                   float momentum, float eps, int training, float *y_pool, uint8_t *code, float *save_mean,
-                                   float *save_invstd, float *workspace, const float *conv_stats, int conv_stats_slices, int B, int C, int H,
-                                   int W, void *stream) {
+static int bn_relu_pool_fwd_impl(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                 float momentum, float eps, int training, float *y_pool, uint8_t *code, float *x_argmax, float *save_mean,
+                                 float *save_invstd, float *workspace, const float *conv_stats, int conv_stats_slices, int B, int C, int H,
+                                 int W, void *stream) {
     if (B < 0 || C < 1 || H < 1 || W < 1) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
     PoolShape p;
@@ -1398,14 +1446,33 @@ EE_API int ee_bn_relu_pool_fwd_f32(const float *x, const float *gamma, const flo
         EE_LAUNCH(bn_split_stats_kernel, dim3(static_cast<unsigned>(C), static_cast<unsigned>(S)), dim3(SPLIT_NT), 0, st, x, workspace, s, S);
     }
     EE_LAUNCH(bn_pool_fwd_kernel, dim3(static_cast<unsigned>(C), static_cast<unsigned>(p.G)), dim3(SPLIT_NT), static_cast<size_t>(H) * W * sizeof(float), st,
-              x, gamma, beta, running_mean, running_var, momentum, eps, mode, y_pool, code, save_mean, save_invstd, wsk, p, Sk);
+              x, gamma, beta, running_mean, running_var, momentum, eps, mode, y_pool, code, save_mean, save_invstd, wsk, p, Sk, x_argmax);
     return launch_status();
 }
 
-EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *gamma, const float *beta,
-                                   const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
-                                   float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
+EE_API int ee_bn_relu_pool_fwd_f32(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                   float momentum, float eps, int training, float *y_pool, uint8_t *code, float *save_mean,
+                                   float *save_invstd, float *workspace, const float *conv_stats, int conv_stats_slices, int B, int C, int H,
                                    int W, void *stream) {
+    return bn_relu_pool_fwd_impl(x, gamma, beta, running_mean, running_var, momentum, eps, training, y_pool, code, nullptr, save_mean, save_invstd, workspace,
+                                 conv_stats, conv_stats_slices, B, C, H, W, stream);
+}
+
+// ... also writing x_argmax [B,C,OH,OW] = x at every window's argmax: ee_bn_relu_pool_bwd_xa_f32 then takes its batch sums from the pooled
+// tensors alone (training mode: one pass over the 26 MB map less)
+EE_API int ee_bn_relu_pool_fwd_xa_f32(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                      float momentum, float eps, int training, float *y_pool, uint8_t *code, float *x_argmax, float *save_mean,
+                                      float *save_invstd, float *workspace, const float *conv_stats, int conv_stats_slices, int B, int C, int H,
+                                      int W, void *stream) {
+    if (B > 0 && !x_argmax) return EE_ERR_NULL;
+    return bn_relu_pool_fwd_impl(x, gamma, beta, running_mean, running_var, momentum, eps, training, y_pool, code, x_argmax, save_mean, save_invstd, workspace,
+                                 conv_stats, conv_stats_slices, B, C, H, W, stream);
+}
+
+static int bn_relu_pool_bwd_impl(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *x_argmax, const float *gamma,
+                                 const float *beta, const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
+                                 float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
+                                 int W, void *stream) {
     if (B < 0 || C < 1 || H < 1 || W < 1) return EE_ERR_SHAPE;
     if (B == 0) return EE_OK;
     PoolShape p;
@@ -1420,12 +1487,31 @@ EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, 
     // eval mode (running statistics) and no parameter gradients wanted - every iteration of an eval-mode attack: dx = a * dz needs no sums
     p.nosums = (!training && !dgamma && !dbeta) ? 1 : 0;
     if (p.nosums && !dx) return EE_OK;
-    if (!p.nosums)
+    if (!p.nosums && training && x_argmax)
+        EE_LAUNCH(bn_pool_bwd_sums_pooled_kernel, grid, block, 0, st, dy_pool, dy_pool2, x_argmax, gamma, beta, save_mean, save_invstd, workspace, p);
+    else if (!p.nosums)
         EE_LAUNCH((bn_pool_bwd_kernel<false>), grid, block, lds, st, dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
                   training, dx, dgamma, dbeta, workspace, p);
     EE_LAUNCH((bn_pool_bwd_kernel<true>), grid, block, lds, st, dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps,
               training, dx, dgamma, dbeta, workspace, p);
     return launch_status();
+}
+
+EE_API int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *gamma, const float *beta,
+                                   const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
+                                   float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
+                                   int W, void *stream) {
+    return bn_relu_pool_bwd_impl(dy_pool, dy_pool2, code, x, nullptr, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dgamma,
+                                 dbeta, workspace, B, C, H, W, stream);
+}
+
+// ... with x_argmax (ee_bn_relu_pool_fwd_xa_f32; nullable = the form above): training mode takes the batch sums from dy_pool and x_argmax
+EE_API int ee_bn_relu_pool_bwd_xa_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *x_argmax, const float *gamma,
+                                      const float *beta, const float *save_mean, const float *save_invstd, const float *running_mean,
+                                      const float *running_var, float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B,
+                                      int C, int H, int W, void *stream) {
+    return bn_relu_pool_bwd_impl(dy_pool, dy_pool2, code, x, x_argmax, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, training, dx, dgamma,
+                                 dbeta, workspace, B, C, H, W, stream);
 }
 
 // 1 when relu(bn_a(xa) + bn_b(xb)) runs as one launch each way (the register-cached variants with 256-lane workgroups), else 0

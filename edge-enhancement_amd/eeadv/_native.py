@@ -83,6 +83,8 @@ SIGNATURES = {
     "ee_bn_relu_pool_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     # dy_pool, dy_pool2, code, x, gamma, beta, save_mean, save_invstd, rm, rv, eps, training, dx, dgamma, dbeta, workspace, B, C, H, W, stream
     "ee_bn_relu_pool_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "ee_bn_relu_pool_fwd_xa_f32": [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "ee_bn_relu_pool_bwd_xa_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_wino3x3_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     # x, u, mean, var, gamma, beta, eps, res, relu, y, B, Cin, Cout, H, stream
     "ee_wino3x3_bn_eval_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],

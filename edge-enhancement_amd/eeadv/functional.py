@@ -255,6 +255,9 @@ class BnDualFn(torch.autograd.Function):
         return (dxa, dxb, keep(dga, 2), keep(dba, 3), None, None, None, None, keep(dgb, 8), keep(dbb, 9)) + none[10:]
 
 
+_POOL_XA = os.environ.get("EEADV_POOL_XA", "1") != "0"  # the stem's BatchNorm backward sums from pooled tensors (A/B switch)
+
+
 class BnReluPoolFn(torch.autograd.Function):
     """maxpool3s2(relu(batch_norm(x))) - the ResNet stem (resnet.py:113-117) - in one pass each way: the full-resolution activation and its
     gradient never exist (ee_bn.hip: bn_pool_*)."""
@@ -263,21 +266,25 @@ class BnReluPoolFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, fork=False, conv_stats=None):
         if conv_stats is not None and conv_stats.numel() == 0:
             conv_stats = None
-        y, code, sm, si = ops.bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, conv_stats)
-        ctx.save_for_backward(x, code, gamma, beta, sm, si, None if training else running_mean, None if training else running_var)
+        xa = None
+        if training and _POOL_XA:  # x at every window's argmax: the backward's batch sums then come from the pooled tensors (one pass over x less)
+            y, code, sm, si, xa = ops.bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, conv_stats, True)
+        else:
+            y, code, sm, si = ops.bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, conv_stats)
+        ctx.save_for_backward(x, code, gamma, beta, sm, si, None if training else running_mean, None if training else running_var, xa)
         ctx.cfg = (eps, training)
         ctx.set_materialize_grads(False)
         return (y, y.view_as(y)) if fork else y  # fork: see BnActFn
 
     @staticmethod
     def backward(ctx, *grads):
-        x, code, gamma, beta, sm, si, rm, rv = ctx.saved_tensors
+        x, code, gamma, beta, sm, si, rm, rv, xa = ctx.saved_tensors
         eps, training = ctx.cfg
         want_params = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRAD_ONLY
         dy, dy2 = _two_pieces(grads)
         if dy is None or (not ctx.needs_input_grad[0] and not want_params):
             return (None,) * 10
-        dx, dg, db = ops.bn_relu_pool_bwd(dy, code, x, gamma, beta, sm, si, rm, rv, eps, training, ctx.needs_input_grad[0], want_params, dy2)
+        dx, dg, db = ops.bn_relu_pool_bwd(dy, code, x, gamma, beta, sm, si, rm, rv, eps, training, ctx.needs_input_grad[0], want_params, dy2, xa)
         return (dx, (dg if ctx.needs_input_grad[1] and want_params else None), (db if ctx.needs_input_grad[2] and want_params else None)) + (None,) * 7
 
 

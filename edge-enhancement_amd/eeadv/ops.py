@@ -702,9 +702,10 @@ def _pool_workspace(x):
     return torch.empty(n, dtype=torch.float32, device=x.device)
 
 
-def bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, conv_stats=None):
+def bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, conv_stats=None, want_x_argmax=False):
     """maxpool3s2(relu(bn(x))) -> (y_pool, code uint8, save_mean, save_invstd) (resnet.py:113-117); the saves are None in eval mode.
-    conv_stats [C,S,3]: the producing convolution's per-workgroup moments of x (stem7x7s2_fwd(want_stats=True)): no statistics pass over x."""
+    conv_stats [C,S,3]: the producing convolution's per-workgroup moments of x (stem7x7s2_fwd(want_stats=True)): no statistics pass over x.
+    want_x_argmax: a fifth result, x at every window's argmax [B,C,OH,OW] - bn_relu_pool_bwd(x_argmax=...) then needs one pass over x less."""
     B, C, H, W = x.shape
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
@@ -715,16 +716,24 @@ def bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, t
         si = torch.empty(C, dtype=torch.float32, device=x.device)
     ptr = lambda t: None if t is None else t.data_ptr()
     ws = _pool_workspace(x)
+    cs = None if conv_stats is None else _chk(conv_stats, torch.float32, "conv_stats")
+    ncs = 0 if conv_stats is None else conv_stats.shape[1]
+    if want_x_argmax:
+        xa = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+        N.check(N.lib.ee_bn_relu_pool_fwd_xa_f32(_chk(x, torch.float32, "x"), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
+                                                 float(eps), 1 if training else 0, y.data_ptr(), code.data_ptr(), xa.data_ptr(), ptr(sm), ptr(si),
+                                                 ws.data_ptr(), cs, ncs, B, C, H, W, _stream()), "ee_bn_relu_pool_fwd_xa_f32")
+        return y, code, sm, si, xa
     N.check(N.lib.ee_bn_relu_pool_fwd_f32(_chk(x, torch.float32, "x"), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
                                           float(eps), 1 if training else 0, y.data_ptr(), code.data_ptr(), ptr(sm), ptr(si), ws.data_ptr(),
-                                          None if conv_stats is None else _chk(conv_stats, torch.float32, "conv_stats"),
-                                          0 if conv_stats is None else conv_stats.shape[1], B, C, H, W, _stream()), "ee_bn_relu_pool_fwd_f32")
+                                          cs, ncs, B, C, H, W, _stream()), "ee_bn_relu_pool_fwd_f32")
     return y, code, sm, si
 
 
 def bn_relu_pool_bwd(dy_pool, code, x, gamma, beta, save_mean, save_invstd, running_mean, running_var, eps, training, want_dx=True,
-                     want_dparams=True, dy_pool2=None):
-    """Backward of bn_relu_pool_fwd: (dx, dgamma, dbeta), None where not wanted; `dy_pool2` = a second piece of the gradient."""
+                     want_dparams=True, dy_pool2=None, x_argmax=None):
+    """Backward of bn_relu_pool_fwd: (dx, dgamma, dbeta), None where not wanted; `dy_pool2` = a second piece of the gradient;
+    `x_argmax` (bn_relu_pool_fwd(want_x_argmax=True)): training mode then takes its batch sums from the pooled tensors."""
     B, C, H, W = x.shape
     dx = torch.empty_like(x) if want_dx else None
     dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_dparams else None
@@ -732,6 +741,12 @@ def bn_relu_pool_bwd(dy_pool, code, x, gamma, beta, save_mean, save_invstd, runn
     ptr = lambda t: None if t is None else t.data_ptr()
     ws = _pool_workspace(x)
     p2 = None if dy_pool2 is None else _chk(dy_pool2, torch.float32, "dy_pool2", code.shape)
+    if x_argmax is not None:
+        N.check(N.lib.ee_bn_relu_pool_bwd_xa_f32(_chk(dy_pool, torch.float32, "dy_pool", code.shape), p2, _chk(code, torch.uint8, "code"),
+                                                 _chk(x, torch.float32, "x"), _chk(x_argmax, torch.float32, "x_argmax", code.shape), ptr(gamma), ptr(beta),
+                                                 ptr(save_mean), ptr(save_invstd), ptr(running_mean), ptr(running_var), float(eps), 1 if training else 0,
+                                                 ptr(dx), ptr(dg), ptr(db), ws.data_ptr(), B, C, H, W, _stream()), "ee_bn_relu_pool_bwd_xa_f32")
+        return dx, dg, db
     N.check(N.lib.ee_bn_relu_pool_bwd_f32(_chk(dy_pool, torch.float32, "dy_pool", code.shape), p2, _chk(code, torch.uint8, "code"),
                                           _chk(x, torch.float32, "x"), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(running_mean),
                                           ptr(running_var), float(eps), 1 if training else 0, ptr(dx), ptr(dg), ptr(db), ws.data_ptr(),

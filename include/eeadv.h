@@ -342,6 +342,18 @@ int ee_bn_relu_pool_bwd_f32(const float *dy_pool, const float *dy_pool2, const u
                             const float *save_mean, const float *save_invstd, const float *running_mean, const float *running_var,
                             float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, int H,
                             int W, void *stream);
+/* The same pair with one more tensor between them (round 4): the forward also writes x_argmax [B,C,OH,OW] = x at every window's argmax, and
+ * the training-mode backward takes its two batch sums from dy_pool and x_argmax alone (a position's masked gradient is the sum of the pooled
+ * gradients of the windows whose argmax it is) - one pass over the full-resolution map less.  x_argmax NULL in the backward = the form above.
+ * Sums in another order: dgamma / dbeta / dx agree with the form above to rounding. */
+int ee_bn_relu_pool_fwd_xa_f32(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                               float momentum, float eps, int training, float *y_pool, uint8_t *code, float *x_argmax, float *save_mean,
+                               float *save_invstd, float *workspace, const float *conv_stats, int conv_stats_slices, int B, int C, int H,
+                               int W, void *stream);
+int ee_bn_relu_pool_bwd_xa_f32(const float *dy_pool, const float *dy_pool2, const uint8_t *code, const float *x, const float *x_argmax, const float *gamma,
+                               const float *beta, const float *save_mean, const float *save_invstd, const float *running_mean,
+                               const float *running_var, float eps, int training, float *dx, float *dgamma, float *dbeta, float *workspace, int B,
+                               int C, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The stem's MaxPool2d(3, stride 2, padding 1) (Tiny_ImageNet/models_tinyimagenet/resnet.py:117), bit-identical to ATen's

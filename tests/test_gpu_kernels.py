@@ -1061,6 +1061,37 @@ def test_fc_ce_grad_matches_autograd(ops, B, Hd, K, reduction):
     assert float(dzn[0, closed].abs().max()) == 0.0  # closed gates stay closed next to the NaN
 
 
+@pytest.mark.parametrize("B,C,H,W,two", [(100, 64, 32, 32, True), (3, 64, 32, 32, False), (5, 16, 14, 20, True), (2, 8, 7, 12, False)])
+def test_stem_batchnorm_backward_sums_from_the_pooled_tensors(ops, B, C, H, W, two):
+    """ee_bn_relu_pool_fwd_xa_f32 / _bwd_xa_f32 (resnet.py:113-117 backwards, training mode): x at every window's argmax is what the forward
+    recorded, and the backward's batch sums taken from the pooled gradient and that tensor alone give the dx / dgamma / dbeta of the form that
+    reads the full-resolution map twice - to rounding (the sums run in another order), with a NaN input gradient staying where it was."""
+    g = torch.Generator(device="cpu").manual_seed(B * C + H)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y, code, sm, si, xa = ops.bn_relu_pool_fwd(x, gamma, beta, rm.clone(), rv.clone(), 0.1, 1e-5, True, None, True)
+    y0, code0, sm0, si0 = ops.bn_relu_pool_fwd(x, gamma, beta, rm.clone(), rv.clone(), 0.1, 1e-5, True)
+    assert torch.equal(y, y0) and torch.equal(code, code0) and torch.equal(sm, sm0) and torch.equal(si, si0)
+    # x_argmax is x at the position the code names
+    OH, OW = y.shape[2], y.shape[3]
+    oh, ow = torch.meshgrid(torch.arange(OH, device=DEV), torch.arange(OW, device=DEV), indexing="ij")
+    hh = (2 * oh - 1)[None, None] + (code.long() // 3)
+    ww = (2 * ow - 1)[None, None] + (code.long() % 3)
+    assert torch.equal(xa, x.flatten(2).gather(2, (hh * W + ww).flatten(2)).view_as(xa))
+    dyp = torch.randn(y.shape, generator=g).to(DEV)
+    dyp2 = torch.randn(y.shape, generator=g).to(DEV) if two else None
+    want = ops.bn_relu_pool_bwd(dyp, code, x, gamma, beta, sm, si, rm, rv, 1e-5, True, True, True, dyp2)
+    got = ops.bn_relu_pool_bwd(dyp, code, x, gamma, beta, sm, si, rm, rv, 1e-5, True, True, True, dyp2, xa)
+    for a_, b_, name in zip(got, want, ("dx", "dgamma", "dbeta")):
+        scale = float(b_.abs().max())
+        assert float((a_ - b_).abs().max()) <= 2e-5 * scale + 1e-6, name
+    # eval mode takes no sums: the same bits with or without x_argmax
+    e0 = ops.bn_relu_pool_bwd(dyp, code, x, gamma, beta, None, None, rm, rv, 1e-5, False, True, False, dyp2)
+    e1 = ops.bn_relu_pool_bwd(dyp, code, x, gamma, beta, None, None, rm, rv, 1e-5, False, True, False, dyp2, xa)
+    assert torch.equal(e0[0], e1[0])
+
+
 @pytest.mark.parametrize("co,ci", [(64, 32), (32, 96), (128, 128)])
 def test_weight_preparation_kernels_match_their_torch_restatement(ops, monkeypatch, co, ci):
     """ee_wprep.hip (one launch per weight and kind) against functional._rearranged's torch expressions: the permutation kinds bit for bit,
