@@ -137,6 +137,50 @@ __global__ __launch_bounds__(HEAD_NT) void pool_linear_bwd_kernel(const float *_
     for (int i = 0; i < HW; ++i) d[i] = acc;
 }
 
+// The cross-entropy gradient AND the head's backward in one launch (round 4): d CrossEntropyLoss(logits, labels) / d feat.  Every workgroup of
+// an image (ceil(C / 256) of them) forms the row's softmax itself - wavefront 0 with ee_loss.hip's row_stats expressions (row maximum, the
+// exponentials' sum carried in float64 through the same butterfly, its logarithm), then dl[k] = (exp((z_k - mx) - lse) - [k == y]) * gscale as
+// ce_kernel writes it - and goes on as pool_linear_bwd_kernel does: the same bits as the two launches, one launch (5 us) less per iteration.
+__global__ __launch_bounds__(HEAD_NT) void ce_pool_linear_bwd_kernel(const float *__restrict__ logits, const int64_t *__restrict__ labels, float gscale,
+                                                                     const float *__restrict__ w, float *__restrict__ dfeat, int C, int HW, int K) {
+    extern __shared__ float dl[];
+    __shared__ float stats[2];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const float *z = logits + static_cast<size_t>(b) * K;
+    if (threadIdx.x < 64) {
+        float m = -INFINITY;
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, z[k]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        double sum = 0.0;
+        for (int k = lane; k < K; k += 64) sum += static_cast<double>(expf(z[k] - m));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane == 0) stats[0] = m, stats[1] = logf(static_cast<float>(sum));
+    }
+    __syncthreads();
+    const float mx = stats[0], lse = stats[1];
+    const int y = static_cast<int>(labels[b]);
+    for (int k = threadIdx.x; k < K; k += HEAD_NT) dl[k] = (expf((z[k] - mx) - lse) - (k == y ? 1.0f : 0.0f)) * gscale;
+    __syncthreads();
+    const int c = blockIdx.y * HEAD_NT + threadIdx.x;
+    if (c >= C) return;
+    const float inv = 1.0f / static_cast<float>(HW);
+    float acc = 0.0f;
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+        float wv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wv[i] = w[static_cast<size_t>(k + i) * C + c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = fmaf(dl[k + i], wv[i], acc);
+    }
+    for (; k < K; ++k) acc = fmaf(dl[k], w[static_cast<size_t>(k) * C + c], acc);
+    acc *= inv;
+    float *d = dfeat + (static_cast<size_t>(b) * C + c) * HW;
+    for (int i = 0; i < HW; ++i) d[i] = acc;
+}
+
 }  // namespace
 
 EE_API int ee_pool_linear_fwd_f32(const float *feat, const float *weight, const float *bias, float *pooled, float *logits, int B, int C,
@@ -157,5 +201,19 @@ EE_API int ee_pool_linear_bwd_f32(const float *dlogits, const float *weight, flo
     if (!dlogits || !weight || !dfeat) return EE_ERR_NULL;
     EE_LAUNCH(pool_linear_bwd_kernel, dim3(static_cast<unsigned>(B), static_cast<unsigned>((C + HEAD_NT - 1) / HEAD_NT)), dim3(HEAD_NT), static_cast<size_t>(K) * sizeof(float), as_stream(stream),
               dlogits, weight, dfeat, C, HW, K);
+    return launch_status();
+}
+
+// d CrossEntropyLoss(logits, labels) / d feat for logits = fc(global_avgpool(feat)) (resnet.py:157-160 + attacks.py:23 / :255), the loss
+// gradient formed inside the head's backward launch: logits [B,K] (ee_pool_linear_fwd_f32), labels [B], gscale = 1 ("sum") or 1 / B ("mean"),
+// weight [K,C] -> dfeat [B,C,HW].  The same bits as ee_ce_f32 (smoothing 0) followed by ee_pool_linear_bwd_f32.
+EE_API int ee_ce_pool_linear_bwd_f32(const float *logits, const int64_t *labels, float gscale, const float *weight, float *dfeat, int B, int C, int HW,
+                                     int K, void *stream) {
+    if (B < 0 || C < 1 || HW < 1 || K < 1) return EE_ERR_SHAPE;
+    if (K > 8192) return EE_ERR_UNSUPPORTED;
+    if (B == 0) return EE_OK;
+    if (!logits || !labels || !weight || !dfeat) return EE_ERR_NULL;
+    EE_LAUNCH(ce_pool_linear_bwd_kernel, dim3(static_cast<unsigned>(B), static_cast<unsigned>((C + HEAD_NT - 1) / HEAD_NT)), dim3(HEAD_NT),
+              static_cast<size_t>(K) * sizeof(float), as_stream(stream), logits, labels, gscale, weight, dfeat, C, HW, K);
     return launch_status();
 }

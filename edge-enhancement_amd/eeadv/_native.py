@@ -135,6 +135,7 @@ SIGNATURES = {
     "ee_stem7x7s2_fwd_stats_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_pool_linear_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_pool_linear_bwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "ee_ce_pool_linear_bwd_f32": [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "ee_prof_enable": [c_i],
     "ee_prof_mark_empty": [c_p],
     "ee_prof_read": [c_i, c_p, c_p],

@@ -50,7 +50,8 @@ _FC_HEAD = True  # models that offer head_grad (Net_2) get head + loss + way bac
 def _body_input_grad(model, x_in, spec, through_body):
     """d loss / d x_in through model.body (through_body) or the whole model: logits -> loss gradient -> autograd.  Models that expose
     `body_pre` / `head_grad` / `head_from_pre` and whose head_grad answers (models.Net_2: from fc1's output on) get the rest of the classifier,
-    the cross-entropy and the way back as ONE launch (ops.fc_ce_grad) instead of five; the ResNets' head_grad declines (measured slower)."""
+    the cross-entropy and the way back as ONE launch (ops.fc_ce_grad) instead of five; the ResNets': the head's forward, then the loss gradient inside the
+    head's backward launch (ops.ce_pool_linear_bwd) - two launches instead of three, the same bits."""
     pre = getattr(model, "body_pre", None) if _FC_HEAD and (through_body or not hasattr(model, "front_chain")) else None
     if pre is not None and spec.kind in (CE_SUM, CE_MEAN) and x_in.is_cuda and hasattr(model, "head_grad"):
         with torch.enable_grad(), attack_forward():

@@ -128,13 +128,21 @@ def stem_pool(pool, x):
     return pool(x)
 
 
-def head(avgpool, fc, x):
-    """x = avgpool(x); x = x.view(B, -1); x = fc(x) (resnet.py:157-160): ONE launch each way (ee_head.hip) when the pool
-    is global (AdaptiveAvgPool2d(1), or AvgPool2d(7) on a 7x7 map) and the tensors are dense fp32 ROCm."""
+def _head_is_fused(avgpool, fc, x):
     is_global = (isinstance(avgpool, nn.AdaptiveAvgPool2d) and avgpool.output_size in (1, (1, 1))) or (
         isinstance(avgpool, nn.AvgPool2d) and avgpool.kernel_size in (x.shape[2], (x.shape[2], x.shape[3])) and x.shape[2] == x.shape[3]
         and avgpool.padding == 0)
-    if "head" not in _STOCK and is_global and type(fc) is nn.Linear and _dense_f32(x) and x.shape[1] <= 4096 and fc.out_features <= 8192 and fc.weight.is_cuda:
+    return ("head" not in _STOCK and is_global and type(fc) is nn.Linear and _dense_f32(x) and x.shape[1] <= 4096 and fc.out_features <= 8192
+            and fc.weight.is_cuda and fc.weight.dtype == torch.float32 and fc.weight.is_contiguous())
+
+
+_HEAD_CE = os.environ.get("EEADV_HEAD_CE", "1") != "0"  # the attack loop's loss gradient inside the head's backward launch
+
+
+def head(avgpool, fc, x):
+    """x = avgpool(x); x = x.view(B, -1); x = fc(x) (resnet.py:157-160): ONE launch each way (ee_head.hip) when the pool
+    is global (AdaptiveAvgPool2d(1), or AvgPool2d(7) on a 7x7 map) and the tensors are dense fp32 ROCm."""
+    if _head_is_fused(avgpool, fc, x):
         return PoolLinearFn.apply(x, fc.weight, fc.bias)
     x = avgpool(x)
     return fc(x.view(x.size(0), -1))
@@ -689,10 +697,15 @@ class ResNet(nn.Module):
         return head(self.avgpool, self.fc, feat)
 
     def head_grad(self, feat, labels, reduction):
-        """no fused head for the ResNets: pool + fc + cross-entropy + both backward steps as ONE launch (one workgroup per image, 100 workgroups)
-        was built and measured 1.5 % SLOWER end to end than ee_head.hip's forward, the loss kernel and ee_head.hip's backward (400 / 25 / 200
-        workgroups, 21 us together) - engine falls back to head_from_pre"""
-        return None
+        """d CrossEntropyLoss(head(feat), labels) / d feat in TWO launches instead of three: ee_head.hip's forward (outside autograd), then the
+        loss gradient formed inside the head's backward launch (ops.ce_pool_linear_bwd: the same bits).  (Pool + fc + cross-entropy + both
+        backward steps as ONE launch - one workgroup per image, 100 workgroups - was built in round 2 and measured 1.5 % SLOWER end to end.)
+        None where ee_head.hip does not take the head: engine falls back to head_from_pre."""
+        if not _HEAD_CE or not _head_is_fused(self.avgpool, self.fc, feat):
+            return None
+        feat = feat.contiguous()
+        logits, _ = ops.pool_linear_fwd(feat, self.fc.weight.detach(), None if self.fc.bias is None else self.fc.bias.detach())
+        return ops.ce_pool_linear_bwd(logits, labels, self.fc.weight.detach(), tuple(feat.shape), reduction)
 
     def forward(self, x):
         return self.body(x)

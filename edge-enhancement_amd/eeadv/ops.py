@@ -1184,6 +1184,21 @@ def pool_linear_bwd(dlogits, weight, feat_shape):
     return dfeat
 
 
+def ce_pool_linear_bwd(logits, labels, weight, feat_shape, reduction="sum"):
+    """d CrossEntropyLoss(logits, labels) / d feat for logits = fc(global_avgpool(feat)): the loss gradient is formed inside the head's backward
+    launch (ee_head.hip) - the bits of ce(...) followed by pool_linear_bwd(...), one launch less"""
+    B, C = feat_shape[0], feat_shape[1]
+    HW = 1
+    for d in feat_shape[2:]:
+        HW *= d
+    K = weight.shape[0]
+    dfeat = torch.empty(feat_shape, dtype=torch.float32, device=logits.device)
+    N.check(N.lib.ee_ce_pool_linear_bwd_f32(_chk(logits, torch.float32, "logits", (B, K)), _chk(labels, torch.int64, "labels", (B,)),
+                                            _inv(B) if reduction == "mean" else 1.0, _chk(weight, torch.float32, "weight", (K, C)),
+                                            _chk(dfeat, torch.float32, "dfeat"), B, C, HW, K, _stream()), "ee_ce_pool_linear_bwd_f32")
+    return dfeat
+
+
 # ---- Net_2's convolutional half (MNIST) -------------------------------------------------------------------------------------------
 def net2_conv_supported(x, w1, w2):
     return (x.dim() == 4 and tuple(x.shape[1:]) == (1, 28, 28) and tuple(w1.shape) == (32, 1, 5, 5) and tuple(w2.shape) == (64, 32, 5, 5)

@@ -554,6 +554,10 @@ int ee_net2_conv_wrw_f32(const float *x, const float *a1, const uint8_t *code1, 
 int ee_pool_linear_fwd_f32(const float *feat, const float *weight, const float *bias, float *pooled, float *logits, int B,
                            int C, int HW, int K, void *stream);
 int ee_pool_linear_bwd_f32(const float *dlogits, const float *weight, float *dfeat, int B, int C, int HW, int K, void *stream);
+/* ... with the cross-entropy gradient formed inside the same launch (the attack loop: attacks.py:23 sum, :255 mean): logits [B,K] as
+ * ee_pool_linear_fwd_f32 wrote them, labels [B], gscale = 1 or 1 / B -> dfeat [B,C,HW]; the bits of ee_ce_f32 + ee_pool_linear_bwd_f32. */
+int ee_ce_pool_linear_bwd_f32(const float *logits, const int64_t *labels, float gscale, const float *weight, float *dfeat, int B, int C, int HW,
+                              int K, void *stream);
 
 /* HighFreqSuppress for planes up to 256 x 256 (ImageNet 224 x 224, r = 16: utils/core.py:15-55 with cize 224) on the f32 matrix
  * cores, one workgroup per plane, one wavefront per 16-row band (csrc/ee_hfs_mfma.hip).  Same operator, same sq_mode fusions and

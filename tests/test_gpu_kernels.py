@@ -1092,6 +1092,45 @@ def test_stem_batchnorm_backward_sums_from_the_pooled_tensors(ops, B, C, H, W, t
     assert torch.equal(e0[0], e1[0])
 
 
+@pytest.mark.parametrize("B,C,HW,K,reduction", [(100, 512, 4, 200, "sum"), (3, 2048, 49, 1000, "mean"), (1, 64, 1, 10, "sum"), (7, 300, 4, 33, "mean")])
+def test_cross_entropy_gradient_inside_the_head_backward(ops, B, C, HW, K, reduction):
+    """ee_ce_pool_linear_bwd_f32 (resnet.py:157-160 + attacks.py:23 / :255): the loss gradient formed inside the head's backward launch gives the
+    bits of ee_ce_f32 followed by ee_pool_linear_bwd_f32; a NaN logit stays in its own image."""
+    g = torch.Generator(device="cpu").manual_seed(B * C + K)
+    side = int(HW ** 0.5)
+    feat = torch.randn(B, C, side, side, generator=g).to(DEV)
+    w = (torch.randn(K, C, generator=g) / C ** 0.5).to(DEV)
+    bias = torch.randn(K, generator=g).to(DEV)
+    y = torch.randint(0, K, (B,), generator=g).to(DEV)
+    logits, _ = ops.pool_linear_fwd(feat, w, bias)
+    _, d = ops.ce(logits, y, reduction, 0.0, False, True)
+    want = ops.pool_linear_bwd(d, w, tuple(feat.shape))
+    got = ops.ce_pool_linear_bwd(logits, y, w, tuple(feat.shape), reduction)
+    assert torch.equal(got, want)
+    if B > 1:
+        ln = logits.clone()
+        ln[0, 0] = float("nan")
+        gn = ops.ce_pool_linear_bwd(ln, y, w, tuple(feat.shape), reduction)
+        assert bool(torch.isnan(gn[0]).all()) and torch.equal(gn[1:], want[1:])
+
+
+def test_resnet_attack_gradient_with_the_loss_gradient_inside_the_head(ops, monkeypatch):
+    """engine's input gradient of ResNet-18 (64 x 64) with models.ResNet.head_grad on (two head launches) and off (three): the same bits"""
+    from eeadv import engine, models
+    torch.manual_seed(4)
+    net = models.make_resnet(18, "tiny").to(DEV).eval()
+    x = torch.rand(6, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 200, (6,), device=DEV)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(models, "_HEAD_CE", on)
+        for kind in (engine.CE_SUM, engine.CE_MEAN):
+            xi = x.clone().requires_grad_(True)
+            outs.append(engine.input_gradient(net, xi, engine.LossSpec(kind, y)).clone())
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    assert float(outs[0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("co,ci", [(64, 32), (32, 96), (128, 128)])
 def test_weight_preparation_kernels_match_their_torch_restatement(ops, monkeypatch, co, ci):
     """ee_wprep.hip (one launch per weight and kind) against functional._rearranged's torch expressions: the permutation kinds bit for bit,
